@@ -1,0 +1,25 @@
+# Builds libbuctd_hip.so (gfx950 only) and the C oracle helpers.
+HIPCC ?= /opt/rocm/bin/hipcc
+ARCH  ?= gfx950
+CSRC  := buctd_amd/csrc
+OUT   := buctd_amd/lib/libbuctd_hip.so
+HIPFLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -ffp-contract=off -Wno-unused-result
+OBJS := $(CSRC)/conv.o $(CSRC)/matmul.o $(CSRC)/bn.o $(CSRC)/elementwise.o $(CSRC)/attention.o \
+        $(CSRC)/loss_decode.o $(CSRC)/error.o
+
+all: $(OUT)
+
+$(CSRC)/%.o: $(CSRC)/%.hip $(CSRC)/common.h $(CSRC)/gemm_core.h include/buctd_hip.h
+	$(HIPCC) $(HIPFLAGS) -x hip -c $< -o $@
+
+$(CSRC)/error.o: $(CSRC)/error.cpp
+	$(HIPCC) -O2 -std=c++17 -fPIC -c $< -o $@
+
+$(OUT): $(OBJS)
+	@mkdir -p buctd_amd/lib
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(OBJS)
+
+clean:
+	rm -f $(CSRC)/*.o $(OUT)
+
+.PHONY: all clean

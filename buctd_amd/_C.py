@@ -1,0 +1,131 @@
+"""ctypes binding of libbuctd_hip.so (the C ABI declared in include/buctd_hip.h).
+
+The library is the only compute back end of the package: there is no CPU or eager
+PyTorch fallback.  Importing this module without the built library, or calling an op
+with tensors that are not on a ROCm device, raises.
+
+torch is imported first on purpose: the shared object depends on libamdhip64.so.7 by
+SONAME, and the dynamic loader then binds it to the HIP runtime PyTorch already loaded,
+so device pointers and streams are shared with the caching allocator.
+"""
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libbuctd_hip.so")
+
+
+class ConvDesc(C.Structure):
+    _fields_ = [(n, C.c_int) for n in ("N", "H", "W", "Ci", "Co", "R", "S", "stride", "pad", "Ho", "Wo")]
+
+
+class MatmulDesc(C.Structure):
+    _fields_ = [
+        ("batch", C.c_int), ("M", C.c_int), ("N", C.c_int), ("K", C.c_int),
+        ("a_layout", C.c_int), ("b_layout", C.c_int),
+        ("lda", C.c_int), ("ldb", C.c_int), ("ldc", C.c_int),
+        ("stride_a", C.c_long), ("stride_b", C.c_long), ("stride_c", C.c_long),
+        ("Kc", C.c_int), ("group_stride_a", C.c_long), ("group_stride_bk", C.c_long),
+        ("Nc", C.c_int), ("group_stride_bn", C.c_long), ("group_stride_c", C.c_long),
+        ("alpha", C.c_float), ("bias_axis", C.c_int),
+    ]
+
+
+_P = C.c_void_p
+_I = C.c_int
+_L = C.c_long
+_F = C.c_float
+_U64 = C.c_uint64
+_SZ = C.c_size_t
+_PD = C.POINTER(ConvDesc)
+_PM = C.POINTER(MatmulDesc)
+_PI = C.POINTER(C.c_int)
+
+# name -> (restype, argtypes); mirrors include/buctd_hip.h one to one
+SIGNATURES = {
+    "buctd_version": (_I, []),
+    "buctd_last_error": (C.c_char_p, []),
+    "buctd_conv2d_fwd": (_I, [_PD, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P]),
+    "buctd_conv2d_dgrad": (_I, [_PD, _P, _P, _P, _P, _P, _P]),
+    "buctd_conv2d_stats_groups": (_I, [_PD, _I, _PI, _PI]),
+    "buctd_conv2d_wgrad_workspace": (_SZ, [_PD]),
+    "buctd_conv2d_wgrad": (_I, [_PD, _P, _P, _P, _I, _P, _SZ, _P]),
+    "buctd_matmul_workspace": (_SZ, [_PM]),
+    "buctd_matmul": (_I, [_PM, _P, _P, _P, _P, _P, _SZ, _P]),
+    "buctd_bn_finalize": (_I, [_P, _I, _I, _L, _I, _F, _F, _P, _P, _P, _P, _P]),
+    "buctd_bn_stats": (_I, [_P, _L, _I, _P, _PI, _PI, _P]),
+    "buctd_bn_stats_groups": (_I, [_L, _I, _PI, _PI]),
+    "buctd_bn_apply": (_I, [_P, _P, _P, _P, _P, _P, _I, _P, _L, _I, _P]),
+    "buctd_bn_bwd_workspace": (_SZ, [_L, _I]),
+    "buctd_bn_bwd": (_I, [_P, _P, _P, _P, _P, _P, _I, _L, _I, _P, _P, _P, _P, _I, _P, _SZ, _P]),
+    "buctd_bn_fold": (_I, [_P, _P, _P, _P, _F, _I, _P, _P, _P]),
+    "buctd_add": (_I, [_P, _P, _P, _L, _I, _P]),
+    "buctd_scale": (_I, [_P, _P, _F, _P, _L, _P]),
+    "buctd_relu_bwd": (_I, [_P, _P, _P, _L, _P]),
+    "buctd_colsum_workspace": (_SZ, [_L, _I]),
+    "buctd_colsum": (_I, [_P, _L, _I, _P, _I, _P, _SZ, _P]),
+    "buctd_nchw_to_nhwc": (_I, [_P, _I, _I, _I, _I, _I, _I, _P, _P]),
+    "buctd_nhwc_to_nchw": (_I, [_P, _I, _I, _I, _I, _P, _P]),
+    "buctd_fuse_sum": (_I, [C.POINTER(_P), _PI, _I, _I, _I, _I, _I, _I, _P, _P]),
+    "buctd_fuse_sum_bwd": (_I, [_P, _P, _I, _I, _I, _I, _I, _P, _P]),
+    "buctd_resize_bilinear": (_I, [_P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P]),
+    "buctd_maxpool3x3s2_fwd": (_I, [_P, _I, _I, _I, _I, _P, _P, _P]),
+    "buctd_maxpool3x3s2_bwd": (_I, [_P, _P, _I, _I, _I, _I, _P, _P]),
+    "buctd_softmax_dropout_fwd": (_I, [_P, _L, _I, _F, _F, _U64, _P, _P, _P]),
+    "buctd_softmax_dropout_bwd": (_I, [_P, _P, _L, _I, _F, _F, _U64, _P, _P]),
+    "buctd_dropout": (_I, [_P, _P, _L, _F, _U64, _P]),
+    "buctd_layernorm_fwd": (_I, [_P, _P, _P, _L, _I, _F, _P, _P, _P, _P]),
+    "buctd_layernorm_bwd_workspace": (_SZ, [_L, _I]),
+    "buctd_layernorm_bwd": (_I, [_P, _P, _P, _P, _P, _L, _I, _P, _P, _P, _I, _P, _SZ, _P]),
+    "buctd_joints_mse": (_I, [_P, _P, _P, _I, _I, _I, _P, _P, _F, _P, _SZ, _P]),
+    "buctd_argmax_decode": (_I, [_P, _I, _I, _I, _P, _P, _P, _P]),
+    "buctd_gaussian_target": (_I, [_P, _P, _I, _I, _I, _I, _F, _F, _F, _P, _P, _P]),
+    "buctd_cond_render_workspace": (_SZ, [_I, _I, _I, _I]),
+    "buctd_cond_render": (_I, [_P, _I, _P, _I, _I, _I, _I, _I, _I, _P, _P, _SZ, _P]),
+    "buctd_flipback_avg": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P, _P]),
+    "buctd_adam_step": (_I, [_P, _P, _P, _P, _L, _F, _F, _F, _F, _I, _F, _P]),
+}
+
+_lib = None
+
+
+class BuctdHipError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load (once) and return the shared library; raises if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.isfile(LIB_PATH):
+            raise BuctdHipError(
+                f"{LIB_PATH} is missing - build it with `make` (or __graft_entry__.build()); "
+                "buctd_amd has no CPU / eager fallback")
+        handle = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(handle, name)  # AttributeError if the symbol is not exported
+            fn.restype = res
+            fn.argtypes = args
+        _lib = handle
+    return _lib
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = lib().buctd_last_error()
+        raise BuctdHipError(f"{what} failed ({rc}): {msg.decode() if msg else ''}")
+
+
+def stream_ptr():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr(t):
+    """Device pointer of a contiguous fp32 (or int32) ROCm tensor, None -> NULL."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise BuctdHipError("buctd_amd ops need tensors on the ROCm device (no CPU path)")
+    return C.c_void_p(t.data_ptr())

@@ -1,0 +1,369 @@
+// Train / eval BatchNorm2d pieces for NHWC tensors viewed as [rows][C]
+// (reference: nn.BatchNorm2d(momentum=0.1, eps=1e-5) in lib/models/pose_hrnet.py:37-56).
+//
+// Forward statistics come either from the conv epilogue (conv.hip) or from
+// bn_stats_kernel as Welford partials (mean, M2) per (row group, channel);
+// bn_finalize_kernel merges them in fp64 with Chan's formula - one wave64 per
+// channel, shuffle tree - so the batch variance never suffers the E[x^2]-E[x]^2
+// cancellation.  All streaming kernels are HBM-bound: float4 per lane, rows
+// tiled so that a wave reads whole 64B+ segments.
+#include "common.h"
+#include "../../include/buctd_hip.h"
+
+#define STAT_ROWS 64  // rows per Welford group for bn_stats_kernel
+
+// ---------------------------------------------------------------- stats ----
+// grid.x = row groups of STAT_ROWS rows; thread t handles channel c = t (looping by 256)
+__global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__ z, long rows, int C,
+                                                       float* __restrict__ part) {
+  const long r0 = (long)blockIdx.x * STAT_ROWS;
+  long r1 = r0 + STAT_ROWS;
+  if (r1 > rows) r1 = rows;
+  const int cnt = (int)(r1 - r0);
+  for (int c = threadIdx.x; c < C; c += 256) {
+    float s = 0.f;
+    for (long r = r0; r < r1; ++r) s += z[r * C + c];
+    const float mean = cnt > 0 ? s / (float)cnt : 0.f;
+    float m2 = 0.f;
+    for (long r = r0; r < r1; ++r) {
+      const float d = z[r * C + c] - mean;
+      m2 += d * d;
+    }
+    part[((long)blockIdx.x * C + c) * 2 + 0] = mean;
+    part[((long)blockIdx.x * C + c) * 2 + 1] = m2;
+  }
+}
+
+struct Wf {
+  double n, mean, m2;
+};
+__device__ __forceinline__ Wf wf_merge(Wf a, Wf b) {
+  const double n = a.n + b.n;
+  if (n == 0.0) return a;
+  const double d = b.mean - a.mean;
+  Wf r;
+  r.n = n;
+  r.mean = a.mean + d * (b.n / n);
+  r.m2 = a.m2 + b.m2 + d * d * (a.n * b.n / n);
+  return r;
+}
+__device__ __forceinline__ double shfl_xor_d(double v, int o) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __shfl_xor(lo, o, 64);
+  hi = __shfl_xor(hi, o, 64);
+  return __hiloint2double(hi, lo);
+}
+
+// one wave per channel
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ part, int ngroups, int rpg,
+                                                          long rows, int C, float eps, float momentum,
+                                                          float* __restrict__ mean, float* __restrict__ invstd,
+                                                          float* __restrict__ rmean, float* __restrict__ rvar) {
+  const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (c >= C) return;
+  Wf a = {0.0, 0.0, 0.0};
+  for (int g = lane; g < ngroups; g += 64) {
+    long n = rows - (long)g * rpg;
+    n = n < 0 ? 0 : (n > rpg ? rpg : n);
+    if (n > 0) {
+      Wf b = {(double)n, (double)part[((long)g * C + c) * 2], (double)part[((long)g * C + c) * 2 + 1]};
+      a = wf_merge(a, b);
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    Wf b = {shfl_xor_d(a.n, o), shfl_xor_d(a.mean, o), shfl_xor_d(a.m2, o)};
+    a = wf_merge(a, b);
+  }
+  if (lane == 0) {
+    const double var = a.n > 0 ? a.m2 / a.n : 0.0;
+    mean[c] = (float)a.mean;
+    invstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+    if (rmean) {
+      const double unb = a.n > 1 ? a.m2 / (a.n - 1.0) : var;
+      rmean[c] = (float)((1.0 - momentum) * rmean[c] + momentum * a.mean);
+      rvar[c] = (float)((1.0 - momentum) * rvar[c] + momentum * unb);
+    }
+  }
+}
+
+// ---------------------------------------------------------------- apply ----
+template <bool VEC>
+__global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__ z, const float* __restrict__ mean,
+                                                       const float* __restrict__ invstd,
+                                                       const float* __restrict__ gamma,
+                                                       const float* __restrict__ beta, const float* __restrict__ res,
+                                                       int relu, float* __restrict__ y, long total, int C) {
+  if (VEC) {
+    const long n4 = total >> 2;
+    const long step = (long)gridDim.x * 256;
+    const int dc = (int)((step * 4) % C);
+    int c = (int)((((long)blockIdx.x * 256 + threadIdx.x) * 4) % C) - dc;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += step) {
+      c += dc;
+      if (c >= C) c -= C;
+      const f32x4 v = reinterpret_cast<const f32x4*>(z)[i];
+      f32x4 o;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float sc = invstd[c + j] * gamma[c + j];
+        o[j] = (v[j] - mean[c + j]) * sc + beta[c + j];
+      }
+      if (res) {
+        const f32x4 r = reinterpret_cast<const f32x4*>(res)[i];
+        o += r;
+      }
+      if (relu) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = fmaxf(o[j], 0.f);
+      }
+      reinterpret_cast<f32x4*>(y)[i] = o;
+    }
+  } else {
+    const long step = (long)gridDim.x * 256;
+    const int dc = (int)(step % C);
+    int c = (int)(((long)blockIdx.x * 256 + threadIdx.x) % C) - dc;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += step) {
+      c += dc;
+      if (c >= C) c -= C;
+      float o = (z[i] - mean[c]) * (invstd[c] * gamma[c]) + beta[c];
+      if (res) o += res[i];
+      if (relu) o = fmaxf(o, 0.f);
+      y[i] = o;
+    }
+  }
+}
+
+// -------------------------------------------------------------- backward ----
+// pass 1: per row-chunk partial sums  s1 = sum g,  s2 = sum g * zhat   (g = dy * relu-mask)
+// block = 256 threads laid out as (rows 256/CT) x (CT column threads), CT = min(C,64) rounded;
+// simple layout: thread handles channel c = t % CW, row lane = t / CW.
+#define BWD_ROWS 64
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restrict__ dy, const float* __restrict__ y,
+                                                            const float* __restrict__ z,
+                                                            const float* __restrict__ mean,
+                                                            const float* __restrict__ invstd, int relu, long rows,
+                                                            int C, float* __restrict__ part) {
+  __shared__ float sm[2][256];
+  const int cw = C < 256 ? C : 256;        // channels handled per sweep
+  const int rl = 256 / cw;                  // row lanes
+  const int tc = threadIdx.x % cw, tr = threadIdx.x / cw;
+  const long r0 = (long)blockIdx.x * BWD_ROWS;
+  long r1 = r0 + BWD_ROWS;
+  if (r1 > rows) r1 = rows;
+  for (int cb = 0; cb < C; cb += cw) {
+    const int c = cb + tc;
+    float s1 = 0.f, s2 = 0.f;
+    if (c < C && tr < rl) {
+      const float mu = mean[c], is = invstd[c];
+      for (long r = r0 + tr; r < r1; r += rl) {
+        float g = dy[r * C + c];
+        if (relu && !(y[r * C + c] > 0.f)) g = 0.f;
+        s1 += g;
+        s2 += g * (z[r * C + c] - mu) * is;
+      }
+    }
+    sm[0][threadIdx.x] = s1;
+    sm[1][threadIdx.x] = s2;
+    __syncthreads();
+    if (tr == 0 && c < C) {
+      for (int k = 1; k < rl; ++k) {
+        s1 += sm[0][k * cw + tc];
+        s2 += sm[1][k * cw + tc];
+      }
+      part[((long)blockIdx.x * 2 + 0) * C + c] = s1;
+      part[((long)blockIdx.x * 2 + 1) * C + c] = s2;
+    }
+    __syncthreads();
+  }
+}
+
+// pass 2: one wave per channel sums the chunk partials (fp64), writes s[2][C] and dgamma/dbeta
+__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __restrict__ part, int nchunks, int C,
+                                                              float* __restrict__ s, float* __restrict__ dgamma,
+                                                              float* __restrict__ dbeta, int accumulate) {
+  const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (c >= C) return;
+  double s1 = 0.0, s2 = 0.0;
+  for (int k = lane; k < nchunks; k += 64) {
+    s1 += (double)part[((long)k * 2 + 0) * C + c];
+    s2 += (double)part[((long)k * 2 + 1) * C + c];
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    s1 += shfl_xor_d(s1, o);
+    s2 += shfl_xor_d(s2, o);
+  }
+  if (lane == 0) {
+    s[c] = (float)s1;
+    s[C + c] = (float)s2;
+    if (dbeta) dbeta[c] = accumulate ? dbeta[c] + (float)s1 : (float)s1;
+    if (dgamma) dgamma[c] = accumulate ? dgamma[c] + (float)s2 : (float)s2;
+  }
+}
+
+// pass 3: dz = gamma*invstd*(g - s1/M - zhat*s2/M);  dres = g
+template <bool VEC>
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ dy, const float* __restrict__ y,
+                                                           const float* __restrict__ z,
+                                                           const float* __restrict__ mean,
+                                                           const float* __restrict__ invstd,
+                                                           const float* __restrict__ gamma,
+                                                           const float* __restrict__ s, int relu, long total, int C,
+                                                           float inv_rows, float* __restrict__ dz,
+                                                           float* __restrict__ dres) {
+  if (VEC) {
+    const long n4 = total >> 2;
+    const long step = (long)gridDim.x * 256;
+    const int dc = (int)((step * 4) % C);
+    int c = (int)((((long)blockIdx.x * 256 + threadIdx.x) * 4) % C) - dc;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += step) {
+      c += dc;
+      if (c >= C) c -= C;
+      f32x4 g = reinterpret_cast<const f32x4*>(dy)[i];
+      const f32x4 zz = reinterpret_cast<const f32x4*>(z)[i];
+      if (relu) {
+        const f32x4 yy = reinterpret_cast<const f32x4*>(y)[i];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (!(yy[j] > 0.f)) g[j] = 0.f;
+      }
+      f32x4 o;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float is = invstd[c + j];
+        const float zh = (zz[j] - mean[c + j]) * is;
+        o[j] = gamma[c + j] * is * (g[j] - s[c + j] * inv_rows - zh * s[C + c + j] * inv_rows);
+      }
+      reinterpret_cast<f32x4*>(dz)[i] = o;
+      if (dres) reinterpret_cast<f32x4*>(dres)[i] = g;
+    }
+  } else {
+    const long step = (long)gridDim.x * 256;
+    const int dc = (int)(step % C);
+    int c = (int)(((long)blockIdx.x * 256 + threadIdx.x) % C) - dc;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += step) {
+      c += dc;
+      if (c >= C) c -= C;
+      float g = dy[i];
+      if (relu && !(y[i] > 0.f)) g = 0.f;
+      const float is = invstd[c];
+      const float zh = (z[i] - mean[c]) * is;
+      dz[i] = gamma[c] * is * (g - s[c] * inv_rows - zh * s[C + c] * inv_rows);
+      if (dres) dres[i] = g;
+    }
+  }
+}
+
+__global__ void bn_fold_kernel(const float* gamma, const float* beta, const float* rm, const float* rv, float eps,
+                               int C, float* scale, float* shift) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c < C) {
+    const float sc = gamma[c] / sqrtf(rv[c] + eps);
+    scale[c] = sc;
+    shift[c] = beta[c] - rm[c] * sc;
+  }
+}
+
+// ------------------------------------------------------------------ host ----
+static int stream_grid(long work_items) {
+  long b = (work_items + 255) / 256;
+  if (b > 4096) b = 4096;
+  if (b < 1) b = 1;
+  return (int)b;
+}
+
+extern "C" int buctd_bn_stats_groups(long rows, int C, int* ngroups, int* rows_per_group) {
+  BUCTD_CHECK_ARG(rows > 0 && C > 0 && ngroups && rows_per_group, "buctd_bn_stats_groups: bad argument");
+  *rows_per_group = STAT_ROWS;
+  *ngroups = ceil_div(rows, STAT_ROWS);
+  return BUCTD_OK;
+}
+
+extern "C" int buctd_bn_stats(const float* z, long rows, int C, float* partials, int* ngroups, int* rows_per_group,
+                              void* stream) {
+  BUCTD_CHECK_ARG(z && partials && rows > 0 && C > 0, "buctd_bn_stats: bad argument");
+  const int ng = ceil_div(rows, STAT_ROWS);
+  if (ngroups) *ngroups = ng;
+  if (rows_per_group) *rows_per_group = STAT_ROWS;
+  hipLaunchKernelGGL(bn_stats_kernel, dim3(ng), dim3(256), 0, (hipStream_t)stream, z, rows, C, partials);
+  BUCTD_CHECK_LAUNCH("buctd_bn_stats");
+  return BUCTD_OK;
+}
+
+extern "C" int buctd_bn_finalize(const float* partials, int ngroups, int rows_per_group, long rows, int C, float eps,
+                                 float momentum, float* mean, float* invstd, float* running_mean,
+                                 float* running_var, void* stream) {
+  BUCTD_CHECK_ARG(partials && mean && invstd && ngroups > 0 && rows_per_group > 0 && rows > 0 && C > 0,
+                  "buctd_bn_finalize: bad argument");
+  BUCTD_CHECK_ARG((running_mean == nullptr) == (running_var == nullptr),
+                  "buctd_bn_finalize: running_mean/var go together");
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(ceil_div(C, 4)), dim3(256), 0, (hipStream_t)stream, partials, ngroups,
+                     rows_per_group, rows, C, eps, momentum, mean, invstd, running_mean, running_var);
+  BUCTD_CHECK_LAUNCH("buctd_bn_finalize");
+  return BUCTD_OK;
+}
+
+extern "C" int buctd_bn_apply(const float* z, const float* mean, const float* invstd, const float* gamma,
+                              const float* beta, const float* residual, int relu, float* y, long rows, int C,
+                              void* stream) {
+  BUCTD_CHECK_ARG(z && mean && invstd && gamma && beta && y && rows > 0 && C > 0, "buctd_bn_apply: bad argument");
+  const long total = rows * C;
+  if (C % 4 == 0)
+    hipLaunchKernelGGL(bn_apply_kernel<true>, dim3(stream_grid(total / 4)), dim3(256), 0, (hipStream_t)stream, z, mean,
+                       invstd, gamma, beta, residual, relu, y, total, C);
+  else
+    hipLaunchKernelGGL(bn_apply_kernel<false>, dim3(stream_grid(total)), dim3(256), 0, (hipStream_t)stream, z, mean,
+                       invstd, gamma, beta, residual, relu, y, total, C);
+  BUCTD_CHECK_LAUNCH("buctd_bn_apply");
+  return BUCTD_OK;
+}
+
+extern "C" size_t buctd_bn_bwd_workspace(long rows, int C) {
+  const long nchunks = (rows + BWD_ROWS - 1) / BWD_ROWS;
+  return (size_t)(nchunks * 2 * C + 2 * C) * sizeof(float);
+}
+
+extern "C" int buctd_bn_bwd(const float* dy, const float* y, const float* z, const float* mean, const float* invstd,
+                            const float* gamma, int relu, long rows, int C, float* dz, float* dres, float* dgamma,
+                            float* dbeta, int accumulate, void* workspace, size_t workspace_bytes, void* stream) {
+  BUCTD_CHECK_ARG(dy && z && mean && invstd && gamma && dz && rows > 0 && C > 0, "buctd_bn_bwd: bad argument");
+  BUCTD_CHECK_ARG(!relu || y, "buctd_bn_bwd: relu backward needs the forward output");
+  const size_t need = buctd_bn_bwd_workspace(rows, C);
+  if (!workspace || workspace_bytes < need) {
+    buctd_set_error("buctd_bn_bwd: workspace %zu bytes < required %zu", workspace_bytes, need);
+    return BUCTD_EWORKSPACE;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  const int nchunks = ceil_div(rows, BWD_ROWS);
+  float* part = (float*)workspace;
+  float* s = part + (long)nchunks * 2 * C;
+  hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(nchunks), dim3(256), 0, st, dy, y, z, mean, invstd, relu, rows, C,
+                     part);
+  BUCTD_CHECK_LAUNCH("buctd_bn_bwd(reduce)");
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(ceil_div(C, 4)), dim3(256), 0, st, (const float*)part, nchunks, C, s,
+                     dgamma, dbeta, accumulate);
+  BUCTD_CHECK_LAUNCH("buctd_bn_bwd(finalize)");
+  const long total = rows * C;
+  const float inv_rows = 1.0f / (float)rows;
+  if (C % 4 == 0)
+    hipLaunchKernelGGL(bn_bwd_apply_kernel<true>, dim3(stream_grid(total / 4)), dim3(256), 0, st, dy, y, z, mean,
+                       invstd, gamma, (const float*)s, relu, total, C, inv_rows, dz, dres);
+  else
+    hipLaunchKernelGGL(bn_bwd_apply_kernel<false>, dim3(stream_grid(total)), dim3(256), 0, st, dy, y, z, mean, invstd,
+                       gamma, (const float*)s, relu, total, C, inv_rows, dz, dres);
+  BUCTD_CHECK_LAUNCH("buctd_bn_bwd(apply)");
+  return BUCTD_OK;
+}
+
+extern "C" int buctd_bn_fold(const float* gamma, const float* beta, const float* running_mean,
+                             const float* running_var, float eps, int C, float* scale, float* shift, void* stream) {
+  BUCTD_CHECK_ARG(gamma && beta && running_mean && running_var && scale && shift && C > 0,
+                  "buctd_bn_fold: bad argument");
+  hipLaunchKernelGGL(bn_fold_kernel, dim3(ceil_div(C, 256)), dim3(256), 0, (hipStream_t)stream, gamma, beta,
+                     running_mean, running_var, eps, C, scale, shift);
+  BUCTD_CHECK_LAUNCH("buctd_bn_fold");
+  return BUCTD_OK;
+}

@@ -1,0 +1,66 @@
+// Shared helpers for libbuctd_hip.so (gfx950 / MI355X only).
+// Every exported entry point returns 0 on success and a negative code on
+// failure; the message is retrievable through buctd_last_error().
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#define BUCTD_OK 0
+#define BUCTD_EINVAL (-1)
+#define BUCTD_ELAUNCH (-2)
+#define BUCTD_EWORKSPACE (-3)
+
+void buctd_set_error(const char* fmt, ...);
+
+#define BUCTD_CHECK_ARG(cond, ...)            \
+  do {                                        \
+    if (!(cond)) {                            \
+      buctd_set_error(__VA_ARGS__);           \
+      return BUCTD_EINVAL;                    \
+    }                                         \
+  } while (0)
+
+#define BUCTD_CHECK_LAUNCH(name)                                                   \
+  do {                                                                             \
+    hipError_t e__ = hipGetLastError();                                            \
+    if (e__ != hipSuccess) {                                                       \
+      buctd_set_error("%s: launch failed: %s", name, hipGetErrorString(e__));      \
+      return BUCTD_ELAUNCH;                                                        \
+    }                                                                              \
+  } while (0)
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+static inline int ceil_div(long a, long b) { return (int)((a + b - 1) / b); }
+
+// wave64 butterfly sum
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// Block-wide sum for 256-thread blocks (4 waves); result valid in all threads.
+__device__ __forceinline__ float block_sum_256(float v, float* sm /* >=4 floats */) {
+  v = wave_sum(v);
+  const int w = threadIdx.x >> 6;
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) sm[w] = v;
+  __syncthreads();
+  return sm[0] + sm[1] + sm[2] + sm[3];
+}
+__device__ __forceinline__ float block_max_256(float v, float* sm) {
+  v = wave_max(v);
+  const int w = threadIdx.x >> 6;
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) sm[w] = v;
+  __syncthreads();
+  return fmaxf(fmaxf(sm[0], sm[1]), fmaxf(sm[2], sm[3]));
+}

@@ -1,0 +1,604 @@
+// NHWC implicit-GEMM convolution for gfx950: forward, data-gradient and
+// weight-gradient, all on the fp32 MFMA tile engine of gemm_core.h.
+//
+// Replaces the cuDNN calls behind nn.Conv2d / nn.ConvTranspose2d / nn.Linear in
+//   reference lib/models/pose_hrnet.py:28-98 (BasicBlock / Bottleneck convs),
+//   lib/models/pose_hrnet_coam.py:635-641,666-670 (CoAM convs),
+//   lib/models/self_attention.py:31-37 (fc_q/k/v/o as 1x1 convs over tokens).
+//
+// Layouts: activations [N][H][W][C] fp32, weights [Co][R][S][Ci] fp32 (the
+// physical layout of a torch channels_last OIHW tensor).
+//
+//   forward : out[m=(n,ho,wo)][co] = sum_{r,s,ci} x[n][ho*st-p+r][wo*st-p+s][ci] * w[co][r][s][ci]
+//   dgrad   : dx[m=(n,hi,wi)][ci] = sum_{r,s,co} dy[n][(hi+p-r)/st][(wi+p-s)/st][co] * w[co][r][s][ci]
+//   wgrad   : dw[co][(r,s,ci)]    = sum_{pix}    dy[pix][co] * x[src(pix,r,s)][ci]      (split over pixels)
+//
+// A operand = gathered rows of the source tensor (row image, 16 channels of one
+// filter tap per stage); B operand = weights (row image for forward, col image
+// for dgrad).  HBM->register loads for stage t+1 are issued before the MFMAs of
+// stage t and written to the other LDS buffer afterwards (one barrier / stage).
+#include "gemm_core.h"
+#include "../../include/buctd_hip.h"
+
+struct ConvArgs {
+  const float* src;
+  const float* w;
+  float* out;
+  const float* bias;
+  const float* scale;
+  const float* shift;
+  const float* res;
+  float* stats;
+  int N, SH, SW, SC;  // source tensor dims (fwd: x, dgrad: dy)
+  int RH, RW;         // row space (fwd: Ho,Wo ; dgrad: H,W)
+  int OC;             // output channels (fwd: Co ; dgrad: Ci)
+  int R, S, stride, pad;
+  int M, K;           // M = N*RH*RW, K = R*S*SC
+  int wRSCi, wCi;     // weight strides: R*S*Ci and Ci
+  int relu;
+};
+
+template <class T, bool DGRAD, bool VEC>
+__global__ __launch_bounds__(256) void conv_gemm_kernel(ConvArgs p) {
+  constexpr int BM = T::BM, BN = T::BN;
+  constexpr bool BCOL = DGRAD;
+  using AImg = OperandImage<BM, false>;
+  using BImg = OperandImage<BN, BCOL>;
+  constexpr int PA = BM / 64;
+  constexpr int PB = (BN + 63) / 64;            // row-image passes for B
+  constexpr int NB4 = BN / 4;
+  constexpr int PBK = (GK * NB4 + 255) / 256;   // col-image passes for B
+  static_assert(BM % 64 == 0, "BM multiple of 64");
+
+  __shared__ __attribute__((aligned(16))) float lds[2 * (AImg::SIZE + BImg::SIZE)];
+  constexpr int STAGE = AImg::SIZE + BImg::SIZE;
+
+
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int wm = wave / T::WN, wn = wave % T::WN;
+  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+  const int arow = t >> 2, chunk = t & 3;
+
+  // per-pass row decode for the A gather
+  int r_img[PA], r_a[PA], r_b[PA];
+  bool r_ok[PA];
+#pragma unroll
+  for (int q = 0; q < PA; ++q) {
+    const int m = m0 + arow + 64 * q;
+    r_ok[q] = m < p.M;
+    const int mm = r_ok[q] ? m : 0;
+    const int img = mm / (p.RH * p.RW);
+    const int rem = mm - img * (p.RH * p.RW);
+    r_a[q] = rem / p.RW;
+    r_b[q] = rem - r_a[q] * p.RW;
+    r_img[q] = img * p.SH * p.SW * p.SC;
+  }
+
+  auto src_offset = [&](int q, int r, int s, bool& ok) -> int {
+    int sh, sw;
+    if (!DGRAD) {
+      sh = r_a[q] * p.stride - p.pad + r;
+      sw = r_b[q] * p.stride - p.pad + s;
+      ok = r_ok[q] && (unsigned)sh < (unsigned)p.SH && (unsigned)sw < (unsigned)p.SW;
+    } else {
+      const int th = r_a[q] + p.pad - r, tw = r_b[q] + p.pad - s;
+      if (p.stride == 1) { sh = th; sw = tw; }
+      else if (p.stride == 2) { sh = th >> 1; sw = tw >> 1; }
+      else { sh = th / p.stride; sw = tw / p.stride; }
+      ok = r_ok[q] && th >= 0 && tw >= 0 && sh * p.stride == th && sw * p.stride == tw && sh < p.SH && sw < p.SW;
+    }
+    return r_img[q] + (sh * p.SW + sw) * p.SC;
+  };
+
+  f32x4 areg[PA];
+  f32x4 breg[BCOL ? PBK : PB];
+
+  auto load_stage = [&](int k0) {
+    // ---- A: gathered source rows --------------------------------------
+    if (VEC) {
+      const int tap = k0 / p.SC, c0 = k0 - tap * p.SC;
+      const int r = tap / p.S, s = tap - r * p.S;
+#pragma unroll
+      for (int q = 0; q < PA; ++q) {
+        bool ok;
+        const int off = src_offset(q, r, s, ok);
+        areg[q] = ok ? *reinterpret_cast<const f32x4*>(p.src + off + c0 + chunk * 4) : (f32x4){0.f, 0.f, 0.f, 0.f};
+      }
+    } else {
+#pragma unroll
+      for (int q = 0; q < PA; ++q) {
+        float v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int k = k0 + chunk * 4 + j;
+          v[j] = 0.f;
+          if (k < p.K) {
+            const int tap = k / p.SC, c = k - tap * p.SC;
+            const int r = tap / p.S, s = tap - r * p.S;
+            bool ok;
+            const int off = src_offset(q, r, s, ok);
+            if (ok) v[j] = p.src[off + c];
+          }
+        }
+        areg[q] = (f32x4){v[0], v[1], v[2], v[3]};
+      }
+    }
+    // ---- B: weights ------------------------------------------------------
+    if (!BCOL) {
+#pragma unroll
+      for (int q = 0; q < PB; ++q) {
+        const int nl = arow + 64 * q;
+        const int n = n0 + nl;
+        f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (nl < BN && n < p.OC) {
+          const float* wp = p.w + (long)n * p.K + k0 + chunk * 4;
+          if (VEC) {
+            v = *reinterpret_cast<const f32x4*>(wp);
+          } else {
+            const int kb = k0 + chunk * 4;
+            if (kb + 0 < p.K) v.x = wp[0];
+            if (kb + 1 < p.K) v.y = wp[1];
+            if (kb + 2 < p.K) v.z = wp[2];
+            if (kb + 3 < p.K) v.w = wp[3];
+          }
+        }
+        breg[q] = v;
+      }
+    } else {
+      // B(k=(tap,co), n=ci) = w[co][tap][ci]
+#pragma unroll
+      for (int q = 0; q < PBK; ++q) {
+        const int idx = t + 256 * q;
+        const int krow = idx / NB4, n4 = idx - krow * NB4;
+        const int k = k0 + krow, n = n0 + n4 * 4;
+        f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (krow < GK && k < p.K && n < p.OC) {
+          const int tap = k / p.SC, co = k - tap * p.SC;
+          const float* wp = p.w + (long)co * p.wRSCi + tap * p.wCi + n;
+          if (VEC) {
+            v = *reinterpret_cast<const f32x4*>(wp);
+          } else {
+            v.x = wp[0];
+            if (n + 1 < p.OC) v.y = wp[1];
+            if (n + 2 < p.OC) v.z = wp[2];
+            if (n + 3 < p.OC) v.w = wp[3];
+          }
+        }
+        breg[q] = v;
+      }
+    }
+  };
+
+  auto store_stage = [&](int buf) {
+#pragma unroll
+    for (int q = 0; q < PA; ++q)
+      *reinterpret_cast<f32x4*>((lds + buf * STAGE) + (arow + 64 * q) * AImg::LD + chunk * 4) = areg[q];
+    if (!BCOL) {
+#pragma unroll
+      for (int q = 0; q < PB; ++q) {
+        const int nl = arow + 64 * q;
+        if (nl < BN) *reinterpret_cast<f32x4*>((lds + buf * STAGE + AImg::SIZE) + nl * BImg::LD + chunk * 4) = breg[q];
+      }
+    } else {
+#pragma unroll
+      for (int q = 0; q < PBK; ++q) {
+        const int idx = t + 256 * q;
+        const int krow = idx / NB4, n4 = idx - krow * NB4;
+        if (krow < GK) *reinterpret_cast<f32x4*>((lds + buf * STAGE + AImg::SIZE) + krow * BImg::LD + n4 * 4) = breg[q];
+      }
+    }
+  };
+
+  f32x4 acc[T::MF][T::NF];
+  zero_acc<T>(acc);
+
+  const int nk = (p.K + GK - 1) / GK;
+  load_stage(0);
+  store_stage(0);
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    const int cur = kt & 1;
+    if (kt + 1 < nk) load_stage((kt + 1) * GK);
+    mma_stage<T, false, BCOL>(lds + cur * STAGE, lds + cur * STAGE + AImg::SIZE, acc, wm, wn, lane);
+    if (kt + 1 < nk) store_stage(cur ^ 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue -----------------------------------------------------------
+  const bool do_stats = p.stats != nullptr;
+#pragma unroll
+  for (int nf = 0; nf < T::NF; ++nf) {
+    const int n = n0 + acc_col<T>(wn, nf, lane);
+    const bool nok = n < p.OC;
+    const float bv = (p.bias && nok) ? p.bias[n] : 0.f;
+    if (do_stats) {
+      // Welford partial of this wave's MF*16 rows for column n:
+      // (mean, M2) over the valid rows; bn_finalize combines the groups.
+      const int g = blockIdx.x * T::WM + wm;
+      const int row0 = m0 + wm * T::MF * 16;
+      int cnt = p.M - row0;
+      cnt = cnt < 0 ? 0 : (cnt > T::MF * 16 ? T::MF * 16 : cnt);
+      float s1 = 0.f;
+#pragma unroll
+      for (int mf = 0; mf < T::MF; ++mf)
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) {
+          const int m = m0 + acc_row<T>(wm, mf, lane, rg);
+          if (m < p.M) s1 += acc[mf][nf][rg] + bv;
+        }
+      s1 += __shfl_xor(s1, 16, 64);
+      s1 += __shfl_xor(s1, 32, 64);
+      const float mean = cnt > 0 ? s1 / (float)cnt : 0.f;
+      float s2 = 0.f;
+#pragma unroll
+      for (int mf = 0; mf < T::MF; ++mf)
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) {
+          const int m = m0 + acc_row<T>(wm, mf, lane, rg);
+          if (m < p.M) {
+            const float d = acc[mf][nf][rg] + bv - mean;
+            s2 += d * d;
+          }
+        }
+      s2 += __shfl_xor(s2, 16, 64);
+      s2 += __shfl_xor(s2, 32, 64);
+      if (nok && (lane >> 4) == 0) {
+        p.stats[((long)g * p.OC + n) * 2 + 0] = mean;
+        p.stats[((long)g * p.OC + n) * 2 + 1] = s2;
+      }
+    }
+    if (nok) {
+      const float sc = p.scale ? p.scale[n] : 1.f;
+      const float sh = p.shift ? p.shift[n] : 0.f;
+#pragma unroll
+      for (int mf = 0; mf < T::MF; ++mf)
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) {
+          const int m = m0 + acc_row<T>(wm, mf, lane, rg);
+          if (m < p.M) {
+            float v = (acc[mf][nf][rg] + bv) * sc + sh;
+            const long o = (long)m * p.OC + n;
+            if (p.res) v += p.res[o];
+            if (p.relu) v = fmaxf(v, 0.f);
+            p.out[o] = v;
+          }
+        }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// wgrad: dw[co][(r,s,ci)] = sum_pix dy[pix][co] * x[src(pix,r,s)][ci]
+// GEMM view: M' = Co (col image of dy), N' = R*S*Ci (col image gathered from
+// x), K' = output pixels.  grid.z splits the pixel range; partial products go
+// to a workspace slab per split and wgrad_reduce_kernel sums them.
+// ---------------------------------------------------------------------------
+struct WgradArgs {
+  const float* x;
+  const float* dy;
+  float* part;  // [nsplit][Co][R*S*Ci]
+  int N, H, W, Ci, Ho, Wo, Co, R, S, stride, pad;
+  int Mpix, Ncols, pix_per_split;
+};
+
+template <class T, bool VEC>
+__global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs p) {
+  constexpr int BM = T::BM, BN = T::BN;
+  using AImg = OperandImage<BM, true>;
+  using BImg = OperandImage<BN, true>;
+  constexpr int NA4 = BM / 4, NB4 = BN / 4;
+  constexpr int PAK = (GK * NA4 + 255) / 256;
+  constexpr int PBK = (GK * NB4 + 255) / 256;
+
+  __shared__ __attribute__((aligned(16))) float lds[2 * (AImg::SIZE + BImg::SIZE)];
+  constexpr int STAGE = AImg::SIZE + BImg::SIZE;
+
+
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int wm = wave / T::WN, wn = wave % T::WN;
+  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+  const int pix_begin = blockIdx.z * p.pix_per_split;
+  int pix_end = pix_begin + p.pix_per_split;
+  if (pix_end > p.Mpix) pix_end = p.Mpix;
+
+  // fixed per-thread column decode for the gathered B operand
+  int b_krow[PBK], b_col[PBK], b_r[PBK], b_s[PBK], b_ci[PBK];
+#pragma unroll
+  for (int q = 0; q < PBK; ++q) {
+    const int idx = t + 256 * q;
+    b_krow[q] = idx / NB4;
+    const int n4 = idx - b_krow[q] * NB4;
+    b_col[q] = n4 * 4;
+    const int n = n0 + n4 * 4;
+    const int tap = n / p.Ci;
+    b_ci[q] = n - tap * p.Ci;
+    b_r[q] = tap / p.S;
+    b_s[q] = tap - b_r[q] * p.S;
+  }
+
+  f32x4 areg[PAK], breg[PBK];
+  const int HoWo = p.Ho * p.Wo;
+
+  auto load_stage = [&](int pix0) {
+#pragma unroll
+    for (int q = 0; q < PAK; ++q) {
+      const int idx = t + 256 * q;
+      const int krow = idx / NA4, m4 = idx - krow * NA4;
+      const int pix = pix0 + krow, m = m0 + m4 * 4;
+      f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
+      if (krow < GK && pix < pix_end && m < p.Co) {
+        const float* dp = p.dy + (long)pix * p.Co + m;
+        if (VEC) {
+          v = *reinterpret_cast<const f32x4*>(dp);
+        } else {
+          v.x = dp[0];
+          if (m + 1 < p.Co) v.y = dp[1];
+          if (m + 2 < p.Co) v.z = dp[2];
+          if (m + 3 < p.Co) v.w = dp[3];
+        }
+      }
+      areg[q] = v;
+    }
+#pragma unroll
+    for (int q = 0; q < PBK; ++q) {
+      const int pix = pix0 + b_krow[q];
+      f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
+      if (b_krow[q] < GK && pix < pix_end) {
+        const int img = pix / HoWo;
+        const int rem = pix - img * HoWo;
+        const int ho = rem / p.Wo, wo = rem - ho * p.Wo;
+        if (VEC) {
+          const int hi = ho * p.stride - p.pad + b_r[q], wi = wo * p.stride - p.pad + b_s[q];
+          if (n0 + b_col[q] < p.Ncols && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W)
+            v = *reinterpret_cast<const f32x4*>(p.x + ((long)(img * p.H + hi) * p.W + wi) * p.Ci + b_ci[q]);
+        } else {
+          float e[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            e[j] = 0.f;
+            const int n = n0 + b_col[q] + j;
+            if (n < p.Ncols) {
+              const int tap = n / p.Ci, ci = n - tap * p.Ci;
+              const int r = tap / p.S, s = tap - r * p.S;
+              const int hi = ho * p.stride - p.pad + r, wi = wo * p.stride - p.pad + s;
+              if ((unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W)
+                e[j] = p.x[((long)(img * p.H + hi) * p.W + wi) * p.Ci + ci];
+            }
+          }
+          v = (f32x4){e[0], e[1], e[2], e[3]};
+        }
+      }
+      breg[q] = v;
+    }
+  };
+  auto store_stage = [&](int buf) {
+#pragma unroll
+    for (int q = 0; q < PAK; ++q) {
+      const int idx = t + 256 * q;
+      const int krow = idx / NA4, m4 = idx - krow * NA4;
+      if (krow < GK) *reinterpret_cast<f32x4*>((lds + buf * STAGE) + krow * AImg::LD + m4 * 4) = areg[q];
+    }
+#pragma unroll
+    for (int q = 0; q < PBK; ++q)
+      if (b_krow[q] < GK) *reinterpret_cast<f32x4*>((lds + buf * STAGE + AImg::SIZE) + b_krow[q] * BImg::LD + b_col[q]) = breg[q];
+  };
+
+  f32x4 acc[T::MF][T::NF];
+  zero_acc<T>(acc);
+  const int nk = (pix_end - pix_begin + GK - 1) / GK;
+  if (nk > 0) {
+    load_stage(pix_begin);
+    store_stage(0);
+  }
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    const int cur = kt & 1;
+    if (kt + 1 < nk) load_stage(pix_begin + (kt + 1) * GK);
+    mma_stage<T, true, true>(lds + cur * STAGE, lds + cur * STAGE + AImg::SIZE, acc, wm, wn, lane);
+    if (kt + 1 < nk) store_stage(cur ^ 1);
+    __syncthreads();
+  }
+  float* outp = p.part + (long)blockIdx.z * p.Co * p.Ncols;
+#pragma unroll
+  for (int nf = 0; nf < T::NF; ++nf) {
+    const int n = n0 + acc_col<T>(wn, nf, lane);
+    if (n < p.Ncols) {
+#pragma unroll
+      for (int mf = 0; mf < T::MF; ++mf)
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) {
+          const int m = m0 + acc_row<T>(wm, mf, lane, rg);
+          if (m < p.Co) outp[(long)m * p.Ncols + n] = acc[mf][nf][rg];
+        }
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ part, float* __restrict__ out,
+                                                            long n, int nsplit, int accumulate, float alpha) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    float s = 0.f;
+    for (int z = 0; z < nsplit; ++z) s += part[(long)z * n + i];
+    s *= alpha;
+    out[i] = accumulate ? out[i] + s : s;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------
+static int check_desc(const buctd_conv_desc* d, const char* who) {
+  BUCTD_CHECK_ARG(d != nullptr, "%s: null descriptor", who);
+  BUCTD_CHECK_ARG(d->N > 0 && d->H > 0 && d->W > 0 && d->Ci > 0 && d->Co > 0 && d->R > 0 && d->S > 0,
+                  "%s: non-positive dimension", who);
+  BUCTD_CHECK_ARG(d->stride >= 1 && d->pad >= 0, "%s: bad stride/pad", who);
+  BUCTD_CHECK_ARG(d->R * d->S <= 64, "%s: filter larger than 8x8 unsupported", who);
+  const int ho = (d->H + 2 * d->pad - d->R) / d->stride + 1;
+  const int wo = (d->W + 2 * d->pad - d->S) / d->stride + 1;
+  BUCTD_CHECK_ARG(ho == d->Ho && wo == d->Wo, "%s: Ho/Wo (%d,%d) inconsistent with input (expect %d,%d)", who,
+                  d->Ho, d->Wo, ho, wo);
+  BUCTD_CHECK_ARG((long)d->N * d->H * d->W * d->Ci < 2147483647L && (long)d->N * d->Ho * d->Wo * d->Co < 2147483647L,
+                  "%s: tensor exceeds 2^31 elements", who);
+  return BUCTD_OK;
+}
+
+template <class T, bool DGRAD, bool VEC>
+static void launch_conv(const ConvArgs& a, hipStream_t st) {
+  dim3 grid(ceil_div(a.M, T::BM), ceil_div(a.OC, T::BN));
+  hipLaunchKernelGGL((conv_gemm_kernel<T, DGRAD, VEC>), grid, dim3(256), 0, st, a);
+}
+
+// Tile choice: BN follows the output-channel count (48*2^b HRNet widths, 64 /
+// 128 / 256 stem + W32 widths); BM drops to 64 when a 128-row grid would leave
+// most of the 256 CUs idle (low-resolution branches).
+struct ConvTileSel { int id, BM, WM, MF; };
+static ConvTileSel conv_tile_select(int oc, long M, bool vec) {
+  if (!vec) return {0, 128, 4, 2};                             // 128x64 generic
+  const bool small_m = (long)ceil_div(M, 128) * ceil_div(oc, 96) < 384;
+  if (oc <= 16) return {1, 256, 4, 4};                         // 256x16
+  if (oc <= 32) return {2, 128, 4, 2};                         // 128x32
+  if (oc <= 48) return small_m ? ConvTileSel{3, 64, 4, 1} : ConvTileSel{4, 128, 4, 2};    // 64x48 / 128x48
+  if (oc <= 64) return small_m ? ConvTileSel{5, 64, 4, 1} : ConvTileSel{6, 128, 4, 2};    // 64x64 / 128x64
+  if (oc % 96 == 0 || (oc % 128 != 0 && oc <= 96))
+    return small_m ? ConvTileSel{7, 64, 2, 2} : ConvTileSel{8, 128, 2, 4};                // 64x96 / 128x96
+  return small_m ? ConvTileSel{9, 64, 2, 2} : ConvTileSel{10, 128, 2, 4};                 // 64x128 / 128x128
+}
+
+template <bool DGRAD>
+static void dispatch_conv(const ConvArgs& a, bool vec, hipStream_t st) {
+  switch (conv_tile_select(a.OC, a.M, vec).id) {
+    case 0: launch_conv<TileCfg<4, 1, 2, 4>, DGRAD, false>(a, st); break;
+    case 1: launch_conv<TileCfg<4, 1, 4, 1>, DGRAD, true>(a, st); break;
+    case 2: launch_conv<TileCfg<4, 1, 2, 2>, DGRAD, true>(a, st); break;
+    case 3: launch_conv<TileCfg<4, 1, 1, 3>, DGRAD, true>(a, st); break;
+    case 4: launch_conv<TileCfg<4, 1, 2, 3>, DGRAD, true>(a, st); break;
+    case 5: launch_conv<TileCfg<4, 1, 1, 4>, DGRAD, true>(a, st); break;
+    case 6: launch_conv<TileCfg<4, 1, 2, 4>, DGRAD, true>(a, st); break;
+    case 7: launch_conv<TileCfg<2, 2, 2, 3>, DGRAD, true>(a, st); break;
+    case 8: launch_conv<TileCfg<2, 2, 4, 3>, DGRAD, true>(a, st); break;
+    case 9: launch_conv<TileCfg<2, 2, 2, 4>, DGRAD, true>(a, st); break;
+    default: launch_conv<TileCfg<2, 2, 4, 4>, DGRAD, true>(a, st); break;
+  }
+}
+
+static bool fwd_vec_ok(const buctd_conv_desc* d) { return d->Ci % 16 == 0; }
+static bool dgrad_vec_ok(const buctd_conv_desc* d) { return d->Co % 16 == 0 && d->Ci % 4 == 0; }
+
+extern "C" int buctd_conv2d_stats_groups(const buctd_conv_desc* d, int transposed, int* ngroups,
+                                         int* rows_per_group) {
+  int rc = check_desc(d, "buctd_conv2d_stats_groups");
+  if (rc) return rc;
+  BUCTD_CHECK_ARG(ngroups && rows_per_group, "buctd_conv2d_stats_groups: null output");
+  const long M = transposed ? (long)d->N * d->H * d->W : (long)d->N * d->Ho * d->Wo;
+  const int oc = transposed ? d->Ci : d->Co;
+  const ConvTileSel ts = conv_tile_select(oc, M, transposed ? dgrad_vec_ok(d) : fwd_vec_ok(d));
+  *rows_per_group = ts.MF * 16;
+  *ngroups = ceil_div(M, ts.BM) * ts.WM;
+  return BUCTD_OK;
+}
+
+extern "C" int buctd_conv2d_fwd(const buctd_conv_desc* d, const float* x, const float* w, const float* bias,
+                                const float* scale, const float* shift, const float* residual, int relu, float* y,
+                                float* stats_partials, void* stream) {
+  int rc = check_desc(d, "buctd_conv2d_fwd");
+  if (rc) return rc;
+  BUCTD_CHECK_ARG(x && w && y, "buctd_conv2d_fwd: null tensor pointer");
+  BUCTD_CHECK_ARG((scale == nullptr) == (shift == nullptr), "buctd_conv2d_fwd: scale and shift go together");
+  ConvArgs a;
+  a.src = x; a.w = w; a.out = y; a.bias = bias; a.scale = scale; a.shift = shift; a.res = residual;
+  a.stats = stats_partials;
+  a.N = d->N; a.SH = d->H; a.SW = d->W; a.SC = d->Ci;
+  a.RH = d->Ho; a.RW = d->Wo; a.OC = d->Co;
+  a.R = d->R; a.S = d->S; a.stride = d->stride; a.pad = d->pad;
+  a.M = d->N * d->Ho * d->Wo; a.K = d->R * d->S * d->Ci;
+  a.wRSCi = d->R * d->S * d->Ci; a.wCi = d->Ci;
+  a.relu = relu;
+  dispatch_conv<false>(a, fwd_vec_ok(d), (hipStream_t)stream);
+  BUCTD_CHECK_LAUNCH("buctd_conv2d_fwd");
+  return BUCTD_OK;
+}
+
+extern "C" int buctd_conv2d_dgrad(const buctd_conv_desc* d, const float* dy, const float* w, const float* bias,
+                                  float* dx, float* stats_partials, void* stream) {
+  int rc = check_desc(d, "buctd_conv2d_dgrad");
+  if (rc) return rc;
+  BUCTD_CHECK_ARG(dy && w && dx, "buctd_conv2d_dgrad: null tensor pointer");
+  ConvArgs a;
+  a.src = dy; a.w = w; a.out = dx; a.bias = bias; a.scale = nullptr; a.shift = nullptr; a.res = nullptr;
+  a.stats = stats_partials;
+  a.N = d->N; a.SH = d->Ho; a.SW = d->Wo; a.SC = d->Co;
+  a.RH = d->H; a.RW = d->W; a.OC = d->Ci;
+  a.R = d->R; a.S = d->S; a.stride = d->stride; a.pad = d->pad;
+  a.M = d->N * d->H * d->W; a.K = d->R * d->S * d->Co;
+  a.wRSCi = d->R * d->S * d->Ci; a.wCi = d->Ci;
+  a.relu = 0;
+  dispatch_conv<true>(a, dgrad_vec_ok(d), (hipStream_t)stream);
+  BUCTD_CHECK_LAUNCH("buctd_conv2d_dgrad");
+  return BUCTD_OK;
+}
+
+// ---- wgrad ------------------------------------------------------------------
+static void wgrad_plan(const buctd_conv_desc* d, int* bm, int* bn, int* nsplit, int* pps) {
+  const int co = d->Co;
+  *bm = (co <= 48) ? 48 : (co % 96 == 0 ? 96 : (co <= 64 ? 64 : 128));
+  *bn = 64;
+  const int ncols = d->R * d->S * d->Ci;
+  const long tiles = (long)ceil_div(co, *bm) * ceil_div(ncols, *bn);
+  const long Mpix = (long)d->N * d->Ho * d->Wo;
+  long want = (1536 + tiles - 1) / tiles;  // ~6 workgroups per CU in total
+  long maxsplit = (Mpix + 255) / 256;      // at least 256 pixels per split
+  if (want > maxsplit) want = maxsplit;
+  if (want < 1) want = 1;
+  if (want > 512) want = 512;
+  long per = (Mpix + want - 1) / want;
+  per = ((per + GK - 1) / GK) * GK;
+  *pps = (int)per;
+  *nsplit = (int)((Mpix + per - 1) / per);
+}
+
+extern "C" size_t buctd_conv2d_wgrad_workspace(const buctd_conv_desc* d) {
+  if (check_desc(d, "buctd_conv2d_wgrad_workspace")) return 0;
+  int bm, bn, ns, pps;
+  wgrad_plan(d, &bm, &bn, &ns, &pps);
+  return (size_t)ns * d->Co * d->R * d->S * d->Ci * sizeof(float);
+}
+
+template <class T, bool VEC>
+static void launch_wgrad(const WgradArgs& a, int nsplit, hipStream_t st) {
+  dim3 grid(ceil_div(a.Co, T::BM), ceil_div(a.Ncols, T::BN), nsplit);
+  hipLaunchKernelGGL((conv_wgrad_kernel<T, VEC>), grid, dim3(256), 0, st, a);
+}
+
+extern "C" int buctd_conv2d_wgrad(const buctd_conv_desc* d, const float* x, const float* dy, float* dw,
+                                  int accumulate, void* workspace, size_t workspace_bytes, void* stream) {
+  int rc = check_desc(d, "buctd_conv2d_wgrad");
+  if (rc) return rc;
+  BUCTD_CHECK_ARG(x && dy && dw, "buctd_conv2d_wgrad: null tensor pointer");
+  int bm, bn, ns, pps;
+  wgrad_plan(d, &bm, &bn, &ns, &pps);
+  const size_t need = (size_t)ns * d->Co * d->R * d->S * d->Ci * sizeof(float);
+  if (workspace == nullptr || workspace_bytes < need) {
+    buctd_set_error("buctd_conv2d_wgrad: workspace %zu bytes < required %zu", workspace_bytes, need);
+    return BUCTD_EWORKSPACE;
+  }
+  WgradArgs a;
+  a.x = x; a.dy = dy; a.part = (float*)workspace;
+  a.N = d->N; a.H = d->H; a.W = d->W; a.Ci = d->Ci; a.Ho = d->Ho; a.Wo = d->Wo; a.Co = d->Co;
+  a.R = d->R; a.S = d->S; a.stride = d->stride; a.pad = d->pad;
+  a.Mpix = d->N * d->Ho * d->Wo; a.Ncols = d->R * d->S * d->Ci; a.pix_per_split = pps;
+  hipStream_t st = (hipStream_t)stream;
+  const bool vec = (d->Ci % 4 == 0) && (d->Co % 4 == 0);
+  if (!vec) launch_wgrad<TileCfg<2, 2, 2, 2>, false>(a, ns, st);          // 64x64 generic
+  else if (bm == 48) launch_wgrad<TileCfg<1, 4, 3, 1>, true>(a, ns, st);  // 48x64
+  else if (bm == 96) launch_wgrad<TileCfg<2, 2, 3, 2>, true>(a, ns, st);  // 96x64
+  else if (bm == 64) launch_wgrad<TileCfg<2, 2, 2, 2>, true>(a, ns, st);  // 64x64
+  else launch_wgrad<TileCfg<2, 2, 4, 2>, true>(a, ns, st);                // 128x64
+  BUCTD_CHECK_LAUNCH("buctd_conv2d_wgrad");
+  const long n = (long)d->Co * a.Ncols;
+  int blocks = ceil_div(n, 256);
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, (const float*)workspace, dw, n, ns,
+                     accumulate, 1.0f);
+  BUCTD_CHECK_LAUNCH("buctd_conv2d_wgrad(reduce)");
+  return BUCTD_OK;
+}

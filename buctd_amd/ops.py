@@ -1,0 +1,745 @@
+"""Tensor-level wrappers over the C ABI (buctd_amd/_C.py) plus the autograd Functions the
+model mirror is written with.
+
+Internal layout: activations are contiguous fp32 NHWC tensors ``[N, H, W, C]`` (token tensors
+``[B, T, C]`` are the same memory), conv weights are logical OIHW Parameters stored
+channels_last (= physical ``[Co][R][S][Ci]``), Linear weights ``[out, in]``.
+
+Nothing here falls back to eager PyTorch arithmetic: every numeric op is a libbuctd_hip.so
+kernel; torch is used for allocation (caching allocator), streams and autograd bookkeeping.
+Parameter gradients are written by the kernels straight into ``param.grad`` (allocated from a
+flat arena when one is registered, see buctd_amd/engine.py) instead of being returned to
+autograd, so no AccumulateGrad add kernels run.
+"""
+import ctypes as C
+import math
+
+import torch
+
+from . import _C
+from ._C import ConvDesc, MatmulDesc, check, lib, ptr, stream_ptr
+
+# --------------------------------------------------------------------------------------
+# workspace + RNG seed bookkeeping
+# --------------------------------------------------------------------------------------
+_workspaces = {}
+
+
+def workspace(nbytes, device):
+    """Grow-only scratch buffer per (device, stream); ops on one stream run in order, so
+    sharing it between consecutive ops is safe."""
+    key = (device.index, torch.cuda.current_stream(device).cuda_stream)
+    buf = _workspaces.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
+        _workspaces[key] = buf
+    return buf
+
+
+_seed_state = {"seed": 0x5EEDBC7D, "counter": 0}
+
+
+def manual_seed(seed):
+    _seed_state["seed"] = int(seed) & 0xFFFFFFFFFFFFFFFF
+    _seed_state["counter"] = 0
+
+
+def next_seed():
+    _seed_state["counter"] += 1
+    return (_seed_state["seed"] * 0x9E3779B97F4A7C15 + _seed_state["counter"] * 0xD1B54A32D192ED03) & 0xFFFFFFFFFFFFFFFF
+
+
+def _f32(t, name="tensor"):
+    if t.dtype != torch.float32:
+        raise _C.BuctdHipError(f"{name}: fp32 expected, got {t.dtype}")
+    if not t.is_contiguous():
+        raise _C.BuctdHipError(f"{name}: contiguous tensor expected")
+    return t
+
+
+def weight_rsc(w):
+    """Check that the weight memory is [Co][R][S][Ci]: a channels_last OIHW conv weight, or a
+    2-d [out][in] Linear weight (== [out][1][1][in])."""
+    if w.dim() == 2:
+        if not w.is_contiguous():
+            raise _C.BuctdHipError("Linear weight must be contiguous")
+    elif w.dim() != 4:
+        raise _C.BuctdHipError("conv weight must be 4-d OIHW or 2-d [out,in]")
+    elif not w.is_contiguous(memory_format=torch.channels_last):
+        raise _C.BuctdHipError("conv weight must be stored channels_last (call buctd_amd.nn.prepare_module)")
+    return w
+
+
+def _wshape(w):
+    return tuple(w.shape) if w.dim() == 4 else (w.shape[0], w.shape[1], 1, 1)
+
+
+def _new_like_weight(w):
+    return torch.empty_like(w, memory_format=torch.preserve_format)
+
+
+# --------------------------------------------------------------------------------------
+# parameter-gradient sink
+# --------------------------------------------------------------------------------------
+_grad_arena = None
+
+
+def set_grad_arena(arena):
+    """arena(param) -> preallocated grad view (or None). Installed by engine.FlatParams."""
+    global _grad_arena
+    _grad_arena = arena
+
+
+def grad_target(p):
+    """Returns (tensor to write the gradient into, accumulate flag)."""
+    if p.grad is not None:
+        return p.grad, 1
+    g = _grad_arena(p) if _grad_arena is not None else None
+    if g is None:
+        g = torch.empty_like(p, memory_format=torch.preserve_format)
+    p.grad = g
+    return g, 0
+
+
+# --------------------------------------------------------------------------------------
+# raw ops
+# --------------------------------------------------------------------------------------
+def conv_desc(x_shape, w_shape, stride, pad):
+    N, H, W, Ci = x_shape
+    Co, Ci2, R, S = w_shape
+    if Ci2 != Ci:
+        raise _C.BuctdHipError(f"conv: input has {Ci} channels, weight expects {Ci2}")
+    Ho = (H + 2 * pad - R) // stride + 1
+    Wo = (W + 2 * pad - S) // stride + 1
+    return ConvDesc(N, H, W, Ci, Co, R, S, stride, pad, Ho, Wo)
+
+
+def conv_fwd(x, w, bias=None, stride=1, pad=0, scale=None, shift=None, residual=None, relu=False, stats=False):
+    _f32(x, "conv input")
+    weight_rsc(w)
+    d = conv_desc(x.shape, _wshape(w), stride, pad)
+    y = torch.empty((d.N, d.Ho, d.Wo, d.Co), dtype=torch.float32, device=x.device)
+    part = None
+    info = None
+    if stats:
+        ng, rpg = C.c_int(), C.c_int()
+        check(lib().buctd_conv2d_stats_groups(C.byref(d), 0, C.byref(ng), C.byref(rpg)), "conv2d_stats_groups")
+        part = torch.empty((ng.value, d.Co, 2), dtype=torch.float32, device=x.device)
+        info = (ng.value, rpg.value)
+    check(lib().buctd_conv2d_fwd(C.byref(d), ptr(x), ptr(w), ptr(bias), ptr(scale), ptr(shift), ptr(residual),
+                                 int(bool(relu)), ptr(y), ptr(part), stream_ptr()), "conv2d_fwd")
+    return (y, part, info) if stats else y
+
+
+def conv_dgrad(dy, w, x_shape, stride=1, pad=0, bias=None, stats=False):
+    """dx of a convolution == forward of a transposed convolution."""
+    _f32(dy, "conv dgrad input")
+    weight_rsc(w)
+    d = conv_desc(x_shape, _wshape(w), stride, pad)
+    if tuple(dy.shape) != (d.N, d.Ho, d.Wo, d.Co):
+        raise _C.BuctdHipError(f"conv_dgrad: dy shape {tuple(dy.shape)} != {(d.N, d.Ho, d.Wo, d.Co)}")
+    dx = torch.empty(tuple(x_shape), dtype=torch.float32, device=dy.device)
+    part = None
+    info = None
+    if stats:
+        ng, rpg = C.c_int(), C.c_int()
+        check(lib().buctd_conv2d_stats_groups(C.byref(d), 1, C.byref(ng), C.byref(rpg)), "conv2d_stats_groups")
+        part = torch.empty((ng.value, d.Ci, 2), dtype=torch.float32, device=dy.device)
+        info = (ng.value, rpg.value)
+    check(lib().buctd_conv2d_dgrad(C.byref(d), ptr(dy), ptr(w), ptr(bias), ptr(dx), ptr(part), stream_ptr()),
+          "conv2d_dgrad")
+    return (dx, part, info) if stats else dx
+
+
+def conv_wgrad(x, dy, w_like, stride=1, pad=0, out=None, accumulate=0):
+    _f32(x, "conv wgrad x")
+    _f32(dy, "conv wgrad dy")
+    d = conv_desc(x.shape, _wshape(w_like), stride, pad)
+    if out is None:
+        out = _new_like_weight(w_like)
+        accumulate = 0
+    weight_rsc(out)
+    need = lib().buctd_conv2d_wgrad_workspace(C.byref(d))
+    ws = workspace(need, x.device)
+    check(lib().buctd_conv2d_wgrad(C.byref(d), ptr(x), ptr(dy), ptr(out), int(accumulate), ptr(ws), ws.numel(),
+                                   stream_ptr()), "conv2d_wgrad")
+    return out
+
+
+def matmul(A, B, Cout, *, batch, M, N, K, a_layout, b_layout, lda, ldb, ldc, stride_a=0, stride_b=0, stride_c=0,
+           Kc=None, gsa=0, gsbk=0, Nc=None, gsbn=0, gsc=0, alpha=1.0, bias=None, bias_axis=0,
+           a_off=0, b_off=0, c_off=0):
+    d = MatmulDesc(batch, M, N, K, a_layout, b_layout, lda, ldb, ldc, stride_a, stride_b, stride_c,
+                   K if Kc is None else Kc, gsa, gsbk, N if Nc is None else Nc, gsbn, gsc, alpha, bias_axis)
+    need = lib().buctd_matmul_workspace(C.byref(d))
+    ws = workspace(need, A.device) if need else None
+    pa = C.c_void_p(A.data_ptr() + 4 * a_off)
+    pb = C.c_void_p(B.data_ptr() + 4 * b_off)
+    pc = C.c_void_p(Cout.data_ptr() + 4 * c_off)
+    check(lib().buctd_matmul(C.byref(d), pa, pb, ptr(bias), pc, ptr(ws), ws.numel() if ws is not None else 0,
+                             stream_ptr()), "matmul")
+    return Cout
+
+
+def bn_finalize(part, info, rows, Cn, eps, momentum, running_mean, running_var):
+    mean = torch.empty(Cn, dtype=torch.float32, device=part.device)
+    invstd = torch.empty(Cn, dtype=torch.float32, device=part.device)
+    check(lib().buctd_bn_finalize(ptr(part), info[0], info[1], rows, Cn, eps, momentum, ptr(mean), ptr(invstd),
+                                  ptr(running_mean), ptr(running_var), stream_ptr()), "bn_finalize")
+    return mean, invstd
+
+
+def bn_stats(z):
+    Cn = z.shape[-1]
+    rows = z.numel() // Cn
+    ng, rpg = C.c_int(), C.c_int()
+    check(lib().buctd_bn_stats_groups(rows, Cn, C.byref(ng), C.byref(rpg)), "bn_stats_groups")
+    part = torch.empty((ng.value, Cn, 2), dtype=torch.float32, device=z.device)
+    check(lib().buctd_bn_stats(ptr(z), rows, Cn, ptr(part), None, None, stream_ptr()), "bn_stats")
+    return part, (ng.value, rpg.value)
+
+
+def bn_apply(z, mean, invstd, gamma, beta, residual=None, relu=False):
+    Cn = z.shape[-1]
+    y = torch.empty_like(z)
+    check(lib().buctd_bn_apply(ptr(z), ptr(mean), ptr(invstd), ptr(gamma), ptr(beta), ptr(residual), int(bool(relu)),
+                               ptr(y), z.numel() // Cn, Cn, stream_ptr()), "bn_apply")
+    return y
+
+
+def bn_bwd(dy, y, z, mean, invstd, gamma, relu, want_dres, dgamma, dbeta, accumulate):
+    Cn = z.shape[-1]
+    rows = z.numel() // Cn
+    dz = torch.empty_like(z)
+    dres = torch.empty_like(z) if want_dres else None
+    need = lib().buctd_bn_bwd_workspace(rows, Cn)
+    ws = workspace(need, z.device)
+    check(lib().buctd_bn_bwd(ptr(dy), ptr(y) if relu else None, ptr(z), ptr(mean), ptr(invstd), ptr(gamma),
+                             int(bool(relu)), rows, Cn, ptr(dz), ptr(dres), ptr(dgamma), ptr(dbeta), int(accumulate),
+                             ptr(ws), ws.numel(), stream_ptr()), "bn_bwd")
+    return dz, dres
+
+
+def bn_fold(gamma, beta, rm, rv, eps):
+    Cn = gamma.numel()
+    scale = torch.empty(Cn, dtype=torch.float32, device=gamma.device)
+    shift = torch.empty(Cn, dtype=torch.float32, device=gamma.device)
+    check(lib().buctd_bn_fold(ptr(gamma), ptr(beta), ptr(rm), ptr(rv), eps, Cn, ptr(scale), ptr(shift), stream_ptr()),
+          "bn_fold")
+    return scale, shift
+
+
+def add(a, b=None, relu=False, out=None):
+    if out is None:
+        out = torch.empty_like(a)
+    check(lib().buctd_add(ptr(a), ptr(b), ptr(out), a.numel(), int(bool(relu)), stream_ptr()), "add")
+    return out
+
+
+def scale(x, dev_scalar=None, alpha=1.0, out=None):
+    if out is None:
+        out = torch.empty_like(x)
+    check(lib().buctd_scale(ptr(x), ptr(dev_scalar), alpha, ptr(out), x.numel(), stream_ptr()), "scale")
+    return out
+
+
+def relu_bwd(dy, y):
+    dx = torch.empty_like(dy)
+    check(lib().buctd_relu_bwd(ptr(dy), ptr(y), ptr(dx), dy.numel(), stream_ptr()), "relu_bwd")
+    return dx
+
+
+def colsum(x2d_like, Cn, out, accumulate):
+    rows = x2d_like.numel() // Cn
+    need = lib().buctd_colsum_workspace(rows, Cn)
+    ws = workspace(need, x2d_like.device)
+    check(lib().buctd_colsum(ptr(x2d_like), rows, Cn, ptr(out), int(accumulate), ptr(ws), ws.numel(), stream_ptr()),
+          "colsum")
+    return out
+
+
+def nchw_to_nhwc(x, c0=0, cc=None):
+    _f32(x, "nchw input")
+    N, Ct, H, W = x.shape
+    cc = Ct - c0 if cc is None else cc
+    y = torch.empty((N, H, W, cc), dtype=torch.float32, device=x.device)
+    check(lib().buctd_nchw_to_nhwc(ptr(x), N, Ct, c0, cc, H, W, ptr(y), stream_ptr()), "nchw_to_nhwc")
+    return y
+
+
+def nhwc_to_nchw(x):
+    _f32(x, "nhwc input")
+    N, H, W, Cn = x.shape
+    y = torch.empty((N, Cn, H, W), dtype=torch.float32, device=x.device)
+    check(lib().buctd_nhwc_to_nchw(ptr(x), N, Cn, H, W, ptr(y), stream_ptr()), "nhwc_to_nchw")
+    return y
+
+
+def fuse_sum(terms, shifts, relu=True):
+    """terms[j]: [N, H>>s_j, W>>s_j, C]; output resolution = that of the shift-0 term."""
+    base = terms[shifts.index(0)]
+    N, H, W, Cn = base.shape
+    out = torch.empty_like(base)
+    n = len(terms)
+    arr = (C.c_void_p * n)(*[t.data_ptr() for t in terms])
+    sh = (C.c_int * n)(*shifts)
+    check(lib().buctd_fuse_sum(arr, sh, n, N, H, W, Cn, int(bool(relu)), ptr(out), stream_ptr()), "fuse_sum")
+    return out
+
+
+def fuse_sum_bwd(dy, y, shift):
+    N, H, W, Cn = dy.shape
+    g = torch.empty((N, H >> shift, W >> shift, Cn), dtype=torch.float32, device=dy.device)
+    check(lib().buctd_fuse_sum_bwd(ptr(dy), ptr(y), shift, N, H, W, Cn, ptr(g), stream_ptr()), "fuse_sum_bwd")
+    return g
+
+
+def resize_bilinear_from_nchw(x, c0, cc, Ho, Wo):
+    _f32(x, "resize input")
+    N, Ct, H, W = x.shape
+    y = torch.empty((N, Ho, Wo, cc), dtype=torch.float32, device=x.device)
+    check(lib().buctd_resize_bilinear(ptr(x), N, Ct, c0, cc, H, W, Ho, Wo, ptr(y), stream_ptr()), "resize_bilinear")
+    return y
+
+
+def softmax_dropout_fwd(s, L, scale, p_drop, seed, inplace=True):
+    rows = s.numel() // L
+    p = s if inplace else torch.empty_like(s)
+    pd = torch.empty_like(s) if p_drop > 0 else p
+    check(lib().buctd_softmax_dropout_fwd(ptr(s), rows, L, scale, p_drop, seed, ptr(p), ptr(pd), stream_ptr()),
+          "softmax_dropout_fwd")
+    return p, pd
+
+
+def softmax_dropout_bwd(dpd, p, L, scale, p_drop, seed, inplace=True):
+    rows = p.numel() // L
+    ds = dpd if inplace else torch.empty_like(dpd)
+    check(lib().buctd_softmax_dropout_bwd(ptr(dpd), ptr(p), rows, L, scale, p_drop, seed, ptr(ds), stream_ptr()),
+          "softmax_dropout_bwd")
+    return ds
+
+
+def joints_mse(pred, gt, w, want_grad, gscale=1.0):
+    N, K = pred.shape[0], pred.shape[1]
+    HW = pred.numel() // (N * K)
+    loss = torch.empty((), dtype=torch.float32, device=pred.device)
+    grad = torch.empty_like(pred) if want_grad else None
+    ws = workspace(N * K * 4, pred.device)
+    check(lib().buctd_joints_mse(ptr(pred), ptr(gt), ptr(w), N, K, HW, ptr(loss), ptr(grad), gscale, ptr(ws),
+                                 ws.numel(), stream_ptr()), "joints_mse")
+    return loss, grad
+
+
+def argmax_decode(hm):
+    N, K, H, W = hm.shape
+    preds = torch.empty((N, K, 2), dtype=torch.float32, device=hm.device)
+    maxvals = torch.empty((N, K, 1), dtype=torch.float32, device=hm.device)
+    idx = torch.empty((N, K), dtype=torch.int32, device=hm.device)
+    check(lib().buctd_argmax_decode(ptr(hm), N * K, H, W, ptr(preds), ptr(maxvals), ptr(idx), stream_ptr()),
+          "argmax_decode")
+    return preds, maxvals, idx
+
+
+def gaussian_target(joints, vis, heatmap_size, image_size, sigma):
+    """joints [B,K,3] (crop pixels), vis [B,K]; sizes are (W, H) like the reference cfg."""
+    B, K = joints.shape[0], joints.shape[1]
+    Wh, Hh = int(heatmap_size[0]), int(heatmap_size[1])
+    target = torch.empty((B, K, Hh, Wh), dtype=torch.float32, device=joints.device)
+    weight = torch.empty((B, K, 1), dtype=torch.float32, device=joints.device)
+    check(lib().buctd_gaussian_target(ptr(joints), ptr(vis), B, K, Hh, Wh, image_size[0] / heatmap_size[0],
+                                      image_size[1] / heatmap_size[1], float(sigma), ptr(target), ptr(weight),
+                                      stream_ptr()), "gaussian_target")
+    return target, weight
+
+
+def cond_render(joints, colors, H, W, truncate=False):
+    """joints [B,K,>=2] crop pixels; colors [K,Cc] or None (mono 255) -> [B,Cc,H,W] in [0,255]."""
+    B, K, js = joints.shape
+    Cc = 1 if colors is None else colors.shape[1]
+    cond = torch.empty((B, Cc, H, W), dtype=torch.float32, device=joints.device)
+    need = lib().buctd_cond_render_workspace(B, Cc, H, W)
+    ws = workspace(need, joints.device)
+    check(lib().buctd_cond_render(ptr(joints), js, ptr(colors), B, K, Cc, H, W, int(bool(truncate)), ptr(cond),
+                                  ptr(ws), ws.numel(), stream_ptr()), "cond_render")
+    return cond
+
+
+def flipback_avg(a, b, perm, shift):
+    N, K, H, W = a.shape
+    out = torch.empty_like(a)
+    check(lib().buctd_flipback_avg(ptr(a), ptr(b), ptr(perm), N, K, H, W, int(bool(shift)), ptr(out), stream_ptr()),
+          "flipback_avg")
+    return out
+
+
+def adam_step(p, g, m, v, lr, beta1, beta2, eps, step, gscale=1.0):
+    check(lib().buctd_adam_step(ptr(p), ptr(g), ptr(m), ptr(v), p.numel(), lr, beta1, beta2, eps, step, gscale,
+                                stream_ptr()), "adam_step")
+
+
+def layernorm_fwd(x, gamma, beta, eps):
+    Cn = x.shape[-1]
+    rows = x.numel() // Cn
+    y = torch.empty_like(x)
+    mean = torch.empty(rows, dtype=torch.float32, device=x.device)
+    invstd = torch.empty(rows, dtype=torch.float32, device=x.device)
+    check(lib().buctd_layernorm_fwd(ptr(x), ptr(gamma), ptr(beta), rows, Cn, eps, ptr(y), ptr(mean), ptr(invstd),
+                                    stream_ptr()), "layernorm_fwd")
+    return y, mean, invstd
+
+
+def layernorm_bwd(dy, x, mean, invstd, gamma, dgamma, dbeta, accumulate):
+    Cn = x.shape[-1]
+    rows = x.numel() // Cn
+    dx = torch.empty_like(x)
+    need = lib().buctd_layernorm_bwd_workspace(rows, Cn)
+    ws = workspace(need, x.device)
+    check(lib().buctd_layernorm_bwd(ptr(dy), ptr(x), ptr(mean), ptr(invstd), ptr(gamma), rows, Cn, ptr(dx),
+                                    ptr(dgamma), ptr(dbeta), int(accumulate), ptr(ws), ws.numel(), stream_ptr()),
+          "layernorm_bwd")
+    return dx
+
+
+def dropout(x, p_drop, seed):
+    y = torch.empty_like(x)
+    check(lib().buctd_dropout(ptr(x), ptr(y), x.numel(), p_drop, seed, stream_ptr()), "dropout")
+    return y
+
+
+def maxpool3x3s2_fwd(x):
+    N, H, W, Cn = x.shape
+    Ho, Wo = (H + 2 - 3) // 2 + 1, (W + 2 - 3) // 2 + 1
+    y = torch.empty((N, Ho, Wo, Cn), dtype=torch.float32, device=x.device)
+    idx = torch.empty((N, Ho, Wo, Cn), dtype=torch.int32, device=x.device)
+    check(lib().buctd_maxpool3x3s2_fwd(ptr(x), N, H, W, Cn, ptr(y), ptr(idx), stream_ptr()), "maxpool_fwd")
+    return y, idx
+
+
+def maxpool3x3s2_bwd(dy, idx, x_shape):
+    N, H, W, Cn = x_shape
+    dx = torch.empty(tuple(x_shape), dtype=torch.float32, device=dy.device)
+    check(lib().buctd_maxpool3x3s2_bwd(ptr(dy), ptr(idx), N, H, W, Cn, ptr(dx), stream_ptr()), "maxpool_bwd")
+    return dx
+
+
+# --------------------------------------------------------------------------------------
+# autograd Functions
+# --------------------------------------------------------------------------------------
+def _contig(g):
+    return g if g.is_contiguous() else g.contiguous()
+
+
+class ConvBnAct(torch.autograd.Function):
+    """conv (+bias) -> BatchNorm2d -> (+residual) -> (ReLU), train or eval mode.
+
+    Mirrors the conv/bn/relu triplets of reference lib/models/pose_hrnet.py:44-57 (BasicBlock),
+    81-99 (Bottleneck) and the nn.Sequential(conv, bn[, relu]) groups of 201-242, 404-432.
+    """
+
+    @staticmethod
+    def forward(ctx, x, conv_w, conv_b, bn, residual, relu, stride, pad, training, transposed_shape):
+        gamma, beta = bn.weight, bn.bias
+        eps = bn.eps
+        ctx.meta = (bn, conv_w, conv_b, relu, stride, pad, training, transposed_shape, tuple(x.shape))
+        if training or bn.running_mean is None:
+            momentum = 0.1 if bn.momentum is None else bn.momentum
+            if transposed_shape is None:
+                z, part, info = conv_fwd(x, conv_w, conv_b, stride, pad, stats=True)
+            else:
+                z, part, info = conv_dgrad(x, conv_w, transposed_shape, stride, pad, bias=conv_b, stats=True)
+            Cn = z.shape[-1]
+            rows = z.numel() // Cn
+            track = bn.track_running_stats and training
+            mean, invstd = bn_finalize(part, info, rows, Cn, eps, momentum,
+                                       bn.running_mean if track else None, bn.running_var if track else None)
+            if track and bn.num_batches_tracked is not None:
+                bn.num_batches_tracked += 1
+            y = bn_apply(z, mean, invstd, gamma, beta, residual, relu)
+            ctx.save_for_backward(x, z, mean, invstd, y if relu else None)
+            ctx.has_res = residual is not None
+            return y
+        scale, shift = bn_fold(gamma, beta, bn.running_mean, bn.running_var, eps)
+        if transposed_shape is None:
+            y = conv_fwd(x, conv_w, conv_b, stride, pad, scale=scale, shift=shift, residual=residual, relu=relu)
+        else:
+            z = conv_dgrad(x, conv_w, transposed_shape, stride, pad, bias=conv_b)
+            Cn = z.shape[-1]
+            zero = torch.zeros(Cn, dtype=torch.float32, device=z.device)
+            y = bn_apply(z, zero, scale, torch.ones_like(zero), shift, residual, relu)
+        ctx.save_for_backward()
+        ctx.eval_mode = True
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        if getattr(ctx, "eval_mode", False):
+            raise _C.BuctdHipError("backward through eval-mode BatchNorm is not on the BUCTD path")
+        bn, conv_w, conv_b, relu, stride, pad, training, transposed_shape, x_shape = ctx.meta
+        x, z, mean, invstd, y = ctx.saved_tensors
+        dy = _contig(dy)
+        dgamma, acc_g = grad_target(bn.weight)
+        dbeta, acc_b = grad_target(bn.bias)
+        assert acc_g == acc_b
+        dz, dres = bn_bwd(dy, y, z, mean, invstd, bn.weight, relu, ctx.has_res and relu, dgamma, dbeta, acc_g)
+        if ctx.has_res and not relu:
+            dres = dy
+        dx = None
+        if transposed_shape is None:
+            if ctx.needs_input_grad[0]:
+                dx = conv_dgrad(dz, conv_w, x_shape, stride, pad)
+            dw, acc_w = grad_target(conv_w)
+            conv_wgrad(x, dz, conv_w, stride, pad, out=dw, accumulate=acc_w)
+        else:
+            # forward was a transposed conv: its data gradient is a plain conv, its weight gradient
+            # swaps the roles of input and output gradient
+            if ctx.needs_input_grad[0]:
+                dx = conv_fwd(dz, conv_w, None, stride, pad)
+            dw, acc_w = grad_target(conv_w)
+            conv_wgrad(dz, x, conv_w, stride, pad, out=dw, accumulate=acc_w)
+        if conv_b is not None:
+            db, acc = grad_target(conv_b)
+            colsum(dz, dz.shape[-1], db, acc)
+        return dx, None, None, None, dres, None, None, None, None, None
+
+
+class Conv(torch.autograd.Function):
+    """conv / Linear-as-1x1-conv with bias, optional fused residual + ReLU (no BatchNorm)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, stride, pad, relu):
+        y = conv_fwd(x, w, b, stride, pad, relu=relu)
+        ctx.meta = (w, b, stride, pad, relu, tuple(x.shape))
+        ctx.save_for_backward(x, y if relu else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        w, b, stride, pad, relu, x_shape = ctx.meta
+        x, y = ctx.saved_tensors
+        dy = _contig(dy)
+        if relu:
+            dy = relu_bwd(dy, y)
+        dx = conv_dgrad(dy, w, x_shape, stride, pad) if ctx.needs_input_grad[0] else None
+        if w.requires_grad:
+            dw, acc = grad_target(w)
+            conv_wgrad(x, dy, w, stride, pad, out=dw, accumulate=acc)
+        if b is not None and b.requires_grad:
+            db, acc = grad_target(b)
+            colsum(dy, dy.shape[-1], db, acc)
+        return dx, None, None, None, None, None
+
+
+class FuseSum(torch.autograd.Function):
+    """relu(sum_j nearest_upsample(term_j)) - reference lib/models/pose_hrnet.py:257-265."""
+
+    @staticmethod
+    def forward(ctx, shifts, relu, *terms):
+        out = fuse_sum(list(terms), list(shifts), relu)
+        ctx.shifts, ctx.relu = shifts, relu
+        ctx.save_for_backward(out if relu else None)
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        (y,) = ctx.saved_tensors
+        dy = _contig(dy)
+        cache = {}
+        grads = []
+        for j, s in enumerate(ctx.shifts):
+            if not ctx.needs_input_grad[2 + j]:
+                grads.append(None)
+                continue
+            if s not in cache:
+                cache[s] = fuse_sum_bwd(dy, y, s) if (s > 0 or ctx.relu) else dy
+            grads.append(cache[s])
+        return (None, None, *grads)
+
+
+class AddN(torch.autograd.Function):
+    """out = a + b (+ c), used for DAModule's input + (p_out + c_out) (pose_hrnet_coam.py:724)."""
+
+    @staticmethod
+    def forward(ctx, a, b, c):
+        out = add(a, b)
+        if c is not None:
+            out = add(out, c, out=out)
+        ctx.n = 3 if c is not None else 2
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        return dy, dy, (dy if ctx.n == 3 else None)
+
+
+class ToNCHW(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        return nhwc_to_nchw(x)
+
+    @staticmethod
+    def backward(ctx, dy):
+        return nchw_to_nhwc(_contig(dy))
+
+
+class PositionAttention(torch.autograd.Function):
+    """softmax(q k^T / sqrt(dk)) -> dropout -> . v for h heads (self_attention.py:74-86).
+    q [B,Tq,h*dk], k [B,Tk,h*dk], v [B,Tk,h*dv] -> [B,Tq,h*dv]."""
+
+    @staticmethod
+    def forward(ctx, q, k, v, h, p_drop, training):
+        B, Tq, hdk = q.shape
+        Tk = k.shape[1]
+        dk, dv = hdk // h, v.shape[2] // h
+        scale = 1.0 / math.sqrt(dk)
+        p_eff = p_drop if training else 0.0
+        seed = next_seed()
+        S = torch.empty((B, h, Tq, Tk), dtype=torch.float32, device=q.device)
+        for i in range(h):
+            matmul(q, k, S, batch=B, M=Tq, N=Tk, K=dk, a_layout=0, b_layout=0, lda=hdk, ldb=hdk, ldc=Tk,
+                   stride_a=Tq * hdk, stride_b=Tk * hdk, stride_c=h * Tq * Tk, a_off=i * dk, b_off=i * dk,
+                   c_off=i * Tq * Tk)
+        P, Pd = softmax_dropout_fwd(S, Tk, scale, p_eff, seed)
+        O = torch.empty((B, Tq, h * dv), dtype=torch.float32, device=q.device)
+        for i in range(h):
+            matmul(Pd, v, O, batch=B, M=Tq, N=dv, K=Tk, a_layout=0, b_layout=1, lda=Tk, ldb=h * dv, ldc=h * dv,
+                   stride_a=h * Tq * Tk, stride_b=Tk * h * dv, stride_c=Tq * h * dv, a_off=i * Tq * Tk,
+                   b_off=i * dv, c_off=i * dv)
+        ctx.meta = (h, dk, dv, scale, p_eff, seed)
+        ctx.save_for_backward(q, k, v, P, Pd if p_eff > 0 else None)
+        return O
+
+    @staticmethod
+    def backward(ctx, dO):
+        h, dk, dv, scale, p_eff, seed = ctx.meta
+        q, k, v, P, Pd = ctx.saved_tensors
+        if Pd is None:
+            Pd = P
+        dO = _contig(dO)
+        B, Tq, hdk = q.shape
+        Tk = k.shape[1]
+        hdv = h * dv
+        dq, dkk, dvv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+        dP = torch.empty_like(P)
+        for i in range(h):
+            # dV = Pd^T dO
+            matmul(Pd, dO, dvv, batch=B, M=Tk, N=dv, K=Tq, a_layout=1, b_layout=1, lda=Tk, ldb=hdv, ldc=hdv,
+                   stride_a=h * Tq * Tk, stride_b=Tq * hdv, stride_c=Tk * hdv, a_off=i * Tq * Tk, b_off=i * dv,
+                   c_off=i * dv)
+            # dPd = dO V^T
+            matmul(dO, v, dP, batch=B, M=Tq, N=Tk, K=dv, a_layout=0, b_layout=0, lda=hdv, ldb=hdv, ldc=Tk,
+                   stride_a=Tq * hdv, stride_b=Tk * hdv, stride_c=h * Tq * Tk, a_off=i * dv, b_off=i * dv,
+                   c_off=i * Tq * Tk)
+        dS = softmax_dropout_bwd(dP, P, Tk, scale, p_eff, seed)
+        for i in range(h):
+            # dq = dS k ; dk = dS^T q
+            matmul(dS, k, dq, batch=B, M=Tq, N=dk, K=Tk, a_layout=0, b_layout=1, lda=Tk, ldb=hdk, ldc=hdk,
+                   stride_a=h * Tq * Tk, stride_b=Tk * hdk, stride_c=Tq * hdk, a_off=i * Tq * Tk, b_off=i * dk,
+                   c_off=i * dk)
+            matmul(dS, q, dkk, batch=B, M=Tk, N=dk, K=Tq, a_layout=1, b_layout=1, lda=Tk, ldb=hdk, ldc=hdk,
+                   stride_a=h * Tq * Tk, stride_b=Tq * hdk, stride_c=Tk * hdk, a_off=i * Tq * Tk, b_off=i * dk,
+                   c_off=i * dk)
+        return dq, dkk, dvv, None, None, None
+
+
+class ChannelAttention(torch.autograd.Function):
+    """SimplifiedScaledDotProductAttention + fc_o on channel-major queries (self_attention.py:146-159)
+    evaluated on NHWC token tensors: qn [B,T,C] (condition features), yn [B,T,C] (keys = values).
+    Logits are [B,h,C,C] with the reduction over the T/h tokens of each head; fc_o = Linear(T,T)."""
+
+    @staticmethod
+    def forward(ctx, qn, yn, fc_w, fc_b, h, p_drop, training):
+        B, T, Cn = yn.shape
+        dk = T // h
+        scale = 1.0 / math.sqrt(dk)
+        p_eff = p_drop if training else 0.0
+        seed = next_seed()
+        Lg = torch.empty((B, h, Cn, Cn), dtype=torch.float32, device=yn.device)
+        for i in range(h):
+            # L[c1][c2] = sum_t qn[t][c1] yn[t][c2]
+            matmul(qn, yn, Lg, batch=B, M=Cn, N=Cn, K=dk, a_layout=1, b_layout=1, lda=Cn, ldb=Cn, ldc=Cn,
+                   stride_a=T * Cn, stride_b=T * Cn, stride_c=h * Cn * Cn, a_off=i * dk * Cn, b_off=i * dk * Cn,
+                   c_off=i * Cn * Cn)
+        A, Ad = softmax_dropout_fwd(Lg, Cn, scale, p_eff, seed)
+        on = torch.empty((B, T, Cn), dtype=torch.float32, device=yn.device)
+        for i in range(h):
+            # on[t][c1] = sum_c2 yn[t][c2] Ad[c1][c2]   (tokens of head i)
+            matmul(yn, Ad, on, batch=B, M=dk, N=Cn, K=Cn, a_layout=0, b_layout=0, lda=Cn, ldb=Cn, ldc=Cn,
+                   stride_a=T * Cn, stride_b=h * Cn * Cn, stride_c=T * Cn, a_off=i * dk * Cn, b_off=i * Cn * Cn,
+                   c_off=i * dk * Cn)
+        # fc_o over the token axis for all images at once: out[b][t'][c] = sum_t W[t'][t] on[b][t][c] + bias[t']
+        out = torch.empty_like(on)
+        matmul(fc_w, on, out, batch=1, M=T, N=B * Cn, K=T, a_layout=0, b_layout=1, lda=T, ldb=Cn, ldc=Cn,
+               Nc=Cn, gsbn=T * Cn, gsc=T * Cn, bias=fc_b, bias_axis=1)
+        ctx.meta = (fc_w, fc_b, h, dk, scale, p_eff, seed)
+        ctx.save_for_backward(qn, yn, A, Ad if p_eff > 0 else None, on)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        fc_w, fc_b, h, dk, scale, p_eff, seed = ctx.meta
+        qn, yn, A, Ad, on = ctx.saved_tensors
+        if Ad is None:
+            Ad = A
+        dout = _contig(dout)
+        B, T, Cn = yn.shape
+        dev = yn.device
+        # fc_o parameter gradients
+        if fc_w.requires_grad:
+            dw, acc = grad_target(fc_w)
+            tgt = dw if not acc else torch.empty_like(dw)
+            matmul(dout, on, tgt, batch=1, M=T, N=T, K=B * Cn, a_layout=0, b_layout=0, lda=Cn, ldb=Cn, ldc=T,
+                   Kc=Cn, gsa=T * Cn, gsbk=T * Cn)
+            if acc:
+                add(dw, tgt, out=dw)
+        if fc_b is not None and fc_b.requires_grad:
+            db, acc = grad_target(fc_b)
+            ones = torch.ones(B * Cn, dtype=torch.float32, device=dev)
+            tgt = db if not acc else torch.empty_like(db)
+            matmul(dout, ones, tgt, batch=1, M=T, N=1, K=B * Cn, a_layout=0, b_layout=0, lda=Cn, ldb=B * Cn, ldc=1,
+                   Kc=Cn, gsa=T * Cn, gsbk=Cn)
+            if acc:
+                add(db, tgt, out=db)
+        # d_on[b][t][c] = sum_t' W[t'][t] dout[b][t'][c]
+        don = torch.empty_like(on)
+        matmul(fc_w, dout, don, batch=1, M=T, N=B * Cn, K=T, a_layout=1, b_layout=1, lda=T, ldb=Cn, ldc=Cn,
+               Nc=Cn, gsbn=T * Cn, gsc=T * Cn)
+        dAd = torch.empty_like(A)
+        dyn_v = torch.empty_like(yn)
+        for i in range(h):
+            # dAd[c1][c2] = sum_t don[t][c1] yn[t][c2]
+            matmul(don, yn, dAd, batch=B, M=Cn, N=Cn, K=dk, a_layout=1, b_layout=1, lda=Cn, ldb=Cn, ldc=Cn,
+                   stride_a=T * Cn, stride_b=T * Cn, stride_c=h * Cn * Cn, a_off=i * dk * Cn, b_off=i * dk * Cn,
+                   c_off=i * Cn * Cn)
+            # dV[t][c2] = sum_c1 don[t][c1] Ad[c1][c2]
+            matmul(don, Ad, dyn_v, batch=B, M=dk, N=Cn, K=Cn, a_layout=0, b_layout=1, lda=Cn, ldb=Cn, ldc=Cn,
+                   stride_a=T * Cn, stride_b=h * Cn * Cn, stride_c=T * Cn, a_off=i * dk * Cn, b_off=i * Cn * Cn,
+                   c_off=i * dk * Cn)
+        dL = softmax_dropout_bwd(dAd, A, Cn, scale, p_eff, seed)
+        dqn = torch.empty_like(qn)
+        dyn_k = torch.empty_like(yn)
+        for i in range(h):
+            # dq[t][c1] = sum_c2 yn[t][c2] dL[c1][c2] ; dK[t][c2] = sum_c1 qn[t][c1] dL[c1][c2]
+            matmul(yn, dL, dqn, batch=B, M=dk, N=Cn, K=Cn, a_layout=0, b_layout=0, lda=Cn, ldb=Cn, ldc=Cn,
+                   stride_a=T * Cn, stride_b=h * Cn * Cn, stride_c=T * Cn, a_off=i * dk * Cn, b_off=i * Cn * Cn,
+                   c_off=i * dk * Cn)
+            matmul(qn, dL, dyn_k, batch=B, M=dk, N=Cn, K=Cn, a_layout=0, b_layout=1, lda=Cn, ldb=Cn, ldc=Cn,
+                   stride_a=T * Cn, stride_b=h * Cn * Cn, stride_c=T * Cn, a_off=i * dk * Cn, b_off=i * Cn * Cn,
+                   c_off=i * dk * Cn)
+        dyn = add(dyn_v, dyn_k, out=dyn_v)
+        return dqn, dyn, None, None, None, None, None
+
+
+class JointsMSE(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, pred, gt, w):
+        loss, grad = joints_mse(pred, gt, w, want_grad=pred.requires_grad)
+        ctx.save_for_backward(grad)
+        return loss
+
+    @staticmethod
+    def backward(ctx, dl):
+        (grad,) = ctx.saved_tensors
+        # chain rule through the scalar loss, on device (no host sync)
+        if grad is None:
+            return None, None, None
+        return scale(grad, dl.reshape(1).contiguous()), None, None

@@ -1,0 +1,187 @@
+/* libbuctd_hip.so - C ABI of the MI355X (gfx950) BUCTD hot path.
+ *
+ * The reference (amathislab/BUCTD) has no FFI on this path: every device op is
+ * a torch.nn module call that lands in cuDNN / cuBLAS / ATen.  Each entry point
+ * below names the reference call site it stands in for (file:line relative to
+ * the reference root).  INTEGRATION.md shows the ctypes binding the Python host
+ * (buctd_amd/_C.py) uses.
+ *
+ * Conventions
+ *  - every function returns 0 on success, <0 on error (buctd_last_error());
+ *  - no allocation, no ownership transfer, no synchronisation: the caller owns
+ *    all buffers (device pointers), passes a hipStream_t as `void* stream`, and
+ *    kernels are only enqueued on that stream;
+ *  - activations are fp32 NHWC  [N][H][W][C]; conv weights are fp32
+ *    [Co][R][S][Ci] (physical layout of a torch channels_last OIHW tensor);
+ *    Linear weights are [out][in]; token tensors are [B][T][C];
+ *  - "rows" = product of all leading dims, "C" = innermost (channel) dim.
+ */
+#ifndef BUCTD_HIP_H
+#define BUCTD_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+int buctd_version(void);
+const char* buctd_last_error(void);
+
+/* ------------------------------------------------------------------ conv --- */
+typedef struct {
+  int N, H, W, Ci; /* input  [N][H][W][Ci]            */
+  int Co, R, S;    /* filter [Co][R][S][Ci]           */
+  int stride, pad; /* symmetric                       */
+  int Ho, Wo;      /* output [N][Ho][Wo][Co]          */
+} buctd_conv_desc;
+
+/* y = conv(x,w) (+bias) ; then, in this order and each optional:
+ *   stats_partials != NULL : per-(row-group, channel) Welford partials (mean, M2) of the
+ *                            biased conv output for train-mode BatchNorm (see buctd_bn_finalize);
+ *   scale/shift   != NULL  : y = y*scale[c] + shift[c]   (eval-mode BatchNorm folded);
+ *   residual      != NULL  : y += residual ; relu != 0 : y = max(y,0).
+ * Replaces nn.Conv2d(+BatchNorm2d+ReLU+residual): pose_hrnet.py:28-98, pose_hrnet_coam.py:44-60,
+ * nn.Linear on token tensors (R=S=1): self_attention.py:74-76,87. */
+int buctd_conv2d_fwd(const buctd_conv_desc* d, const float* x, const float* w, const float* bias,
+                     const float* scale, const float* shift, const float* residual, int relu, float* y,
+                     float* stats_partials, void* stream);
+/* dx = conv_transpose(dy, w) (+bias, + Welford partials over dx): the data gradient of
+ * buctd_conv2d_fwd, and the forward of nn.ConvTranspose2d (pose_resnet.py:197-205). */
+int buctd_conv2d_dgrad(const buctd_conv_desc* d, const float* dy, const float* w, const float* bias, float* dx,
+                       float* stats_partials, void* stream);
+/* number / height of the Welford row groups written by fwd (transposed=0, channels=Co, rows=N*Ho*Wo)
+ * or dgrad (transposed=1, channels=Ci, rows=N*H*W); partial buffer = ngroups*channels*2 floats. */
+int buctd_conv2d_stats_groups(const buctd_conv_desc* d, int transposed, int* ngroups, int* rows_per_group);
+/* dw (+)= sum over pixels dy (x) x ; split over pixels through `workspace`. */
+size_t buctd_conv2d_wgrad_workspace(const buctd_conv_desc* d);
+int buctd_conv2d_wgrad(const buctd_conv_desc* d, const float* x, const float* dy, float* dw, int accumulate,
+                       void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---------------------------------------------------------------- matmul --- */
+typedef struct {
+  int batch, M, N, K;
+  int a_layout;            /* 0: A(m,k)=A[m*lda + (k/Kc)*group_stride_a + k%Kc] ; 1: A(m,k)=A[k*lda+m]   */
+  int b_layout;            /* 0: B(k,n)=B[n*ldb + (k/Kc)*group_stride_bk + k%Kc] ;
+                              1: B(k,n)=B[k*ldb + (n/Nc)*group_stride_bn + n%Nc]                          */
+  int lda, ldb, ldc;       /* C(m,n)=C[m*ldc + (n/Nc)*group_stride_c + n%Nc]                              */
+  long stride_a, stride_b, stride_c; /* per-batch element strides (0 = shared operand) */
+  int Kc; long group_stride_a, group_stride_bk;
+  int Nc; long group_stride_bn, group_stride_c;
+  float alpha;
+  int bias_axis;           /* 0: bias[n], 1: bias[m] (only read when bias != NULL) */
+} buctd_matmul_desc;
+/* C = alpha*A*B (+bias). Replaces torch.matmul / nn.Linear in self_attention.py:78,86,150,158-159. */
+size_t buctd_matmul_workspace(const buctd_matmul_desc* d);
+int buctd_matmul(const buctd_matmul_desc* d, const float* A, const float* B, const float* bias, float* C,
+                 void* workspace, size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------- batchnorm --- */
+/* Combine Welford partials -> mean, invstd (biased var, eps) and update running stats
+ * (momentum, unbiased var) exactly like nn.BatchNorm2d in train mode (pose_hrnet.py:37). */
+int buctd_bn_finalize(const float* partials, int ngroups, int rows_per_group, long rows, int C, float eps,
+                      float momentum, float* mean, float* invstd, float* running_mean, float* running_var,
+                      void* stream);
+/* Welford partials of a plain [rows][C] tensor (when the producer was not a conv epilogue). */
+int buctd_bn_stats(const float* z, long rows, int C, float* partials, int* ngroups, int* rows_per_group,
+                   void* stream);
+int buctd_bn_stats_groups(long rows, int C, int* ngroups, int* rows_per_group);
+/* y = act((z-mean)*invstd*gamma+beta (+residual)) */
+int buctd_bn_apply(const float* z, const float* mean, const float* invstd, const float* gamma, const float* beta,
+                   const float* residual, int relu, float* y, long rows, int C, void* stream);
+/* Backward of bn_apply in train mode. y is the forward output (ReLU mask), may be NULL when relu==0.
+ * Writes dz; dres (NULL ok) receives the masked upstream gradient (gradient of the residual input);
+ * dgamma/dbeta are overwritten (accumulate=0) or added to. workspace: buctd_bn_bwd_workspace bytes. */
+size_t buctd_bn_bwd_workspace(long rows, int C);
+int buctd_bn_bwd(const float* dy, const float* y, const float* z, const float* mean, const float* invstd,
+                 const float* gamma, int relu, long rows, int C, float* dz, float* dres, float* dgamma,
+                 float* dbeta, int accumulate, void* workspace, size_t workspace_bytes, void* stream);
+/* eval-mode helpers: scale = gamma/sqrt(var+eps), shift = beta - mean*scale */
+int buctd_bn_fold(const float* gamma, const float* beta, const float* running_mean, const float* running_var,
+                  float eps, int C, float* scale, float* shift, void* stream);
+
+/* ----------------------------------------------------------- elementwise --- */
+/* out[i] = a[i] + b[i] (b may be NULL -> copy); relu optional */
+int buctd_add(const float* a, const float* b, float* out, long n, int relu, void* stream);
+/* out[i] = x[i] * alpha * (*dev_scalar) ; dev_scalar is a device pointer or NULL (chain rule through
+ * the scalar loss without a host sync: loss.backward() hands d(loss) over as a device scalar) */
+int buctd_scale(const float* x, const float* dev_scalar, float alpha, float* out, long n, void* stream);
+/* dx = dy * (y > 0) */
+int buctd_relu_bwd(const float* dy, const float* y, float* dx, long n, void* stream);
+/* column sums of [rows][C] (bias gradients); db overwritten or accumulated */
+size_t buctd_colsum_workspace(long rows, int C);
+int buctd_colsum(const float* x, long rows, int C, float* out, int accumulate, void* workspace,
+                 size_t workspace_bytes, void* stream);
+/* NCHW channel slice [c0, c0+Cc) of x[N][Ctot][H][W]  ->  NHWC [N][H][W][Cc], and back (full tensor). */
+int buctd_nchw_to_nhwc(const float* x, int N, int Ctot, int c0, int Cc, int H, int W, float* y, void* stream);
+int buctd_nhwc_to_nchw(const float* x, int N, int C, int H, int W, float* y, void* stream);
+/* HighResolutionModule fuse (pose_hrnet.py:250-265): out = relu(sum_j upsample_nearest(term_j, 2^shift_j)).
+ * terms[j] is [N][H>>shift_j][W>>shift_j][C]; up to 4 terms. */
+int buctd_fuse_sum(const float* const* terms, const int* shifts, int nterms, int N, int H, int W, int C, int relu,
+                   float* out, void* stream);
+/* gradient of one fuse term: g[n][h][w][c] = sum over its 2^shift x 2^shift block of dy*(y>0) (y NULL: no mask) */
+int buctd_fuse_sum_bwd(const float* dy, const float* y, int shift, int N, int H, int W, int C, float* g,
+                       void* stream);
+/* torchvision TF.resize (bilinear, align_corners=False, no antialias; pose_hrnet_coam.py:755) of the NCHW
+ * channel slice [c0, c0+Cc) of x -> NHWC [N][Ho][Wo][Cc] */
+int buctd_resize_bilinear(const float* x, int N, int Ctot, int c0, int Cc, int H, int W, int Ho, int Wo, float* y,
+                          void* stream);
+/* MaxPool2d(3, stride 2, pad 1) NHWC (pose_resnet.py:122) forward (argmax index saved) / backward */
+int buctd_maxpool3x3s2_fwd(const float* x, int N, int H, int W, int C, float* y, int32_t* idx, void* stream);
+int buctd_maxpool3x3s2_bwd(const float* dy, const int32_t* idx, int N, int H, int W, int C, float* dx,
+                           void* stream);
+
+/* ------------------------------------------------------------- attention --- */
+/* Row softmax with fused scale and inverted dropout (self_attention.py:78-84):
+ *   p = softmax(scale * s) over the last dim (length L);  pd = p * keep / (1-p_drop),
+ *   keep drawn from a counter-based generator keyed by (seed, row, col) so the backward can rebuild it.
+ * p (pre-dropout) and pd may alias when p_drop == 0. */
+int buctd_softmax_dropout_fwd(const float* s, long rows, int L, float scale, float p_drop, uint64_t seed, float* p,
+                              float* pd, void* stream);
+/* ds = scale * p * (g - sum_j g_j p_j), g = dpd * keep/(1-p_drop) */
+int buctd_softmax_dropout_bwd(const float* dpd, const float* p, long rows, int L, float scale, float p_drop,
+                              uint64_t seed, float* ds, void* stream);
+/* elementwise inverted dropout (transpose_h.py:180-183), mask rebuilt from (seed, index) */
+int buctd_dropout(const float* x, float* y, long n, float p_drop, uint64_t seed, void* stream);
+/* LayerNorm over the last dim (transpose_h.py:178-179) */
+int buctd_layernorm_fwd(const float* x, const float* gamma, const float* beta, long rows, int C, float eps, float* y,
+                        float* mean, float* invstd, void* stream);
+size_t buctd_layernorm_bwd_workspace(long rows, int C);
+int buctd_layernorm_bwd(const float* dy, const float* x, const float* mean, const float* invstd, const float* gamma,
+                        long rows, int C, float* dx, float* dgamma, float* dbeta, int accumulate, void* workspace,
+                        size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------- loss / target / decode --- */
+/* JointsMSELoss (core/loss.py:23-41): loss = 0.5/(K*N*HW) * sum w^2 (p-g)^2 ; grad (NULL ok) = dloss/dp * gscale.
+ * pred/gt are [N][K][HW] (NCHW heatmaps), w is [N][K] (NULL: weights 1). workspace: N*K floats. */
+int buctd_joints_mse(const float* pred, const float* gt, const float* w, int N, int K, int HW, float* loss,
+                     float* grad, float gscale, void* workspace, size_t workspace_bytes, void* stream);
+/* get_max_preds (core/inference.py:19-47): first-index argmax per [N*K] row of length H*W;
+ * preds[row] = (x, y) zeroed where maxval <= 0. */
+int buctd_argmax_decode(const float* hm, int rows, int H, int W, float* preds, float* maxvals, int32_t* idx,
+                        void* stream);
+/* generate_target (dataset/JointsDataset.py:397-453): joints [B][K][3] (crop px), vis [B][K] ->
+ * target [B][K][Hh][Wh], weight [B][K]. */
+int buctd_gaussian_target(const float* joints, const float* vis, int B, int K, int Hh, int Wh, float stride_x,
+                          float stride_y, float sigma, float* target, float* weight, void* stream);
+/* get_condition_image(_colored) (dataset/JointsDataset.py:500-543): joints [B][K][2+] (row stride js floats),
+ * colors [K][Cc] (NULL: 255 mono) -> cond [B][Cc][H][W] in [0,255]; 15x15 Gaussian blur sigma 2.6 (reflect-101),
+ * peak-normalised to 255 per image; truncate != 0 applies the mono path's .astype(int). workspace: B*Cc*H*W floats + B floats. */
+size_t buctd_cond_render_workspace(int B, int Cc, int H, int W);
+int buctd_cond_render(const float* joints, int js, const float* colors, int B, int K, int Cc, int H, int W,
+                      int truncate, float* cond, void* workspace, size_t workspace_bytes, void* stream);
+/* flip-test merge (core/function.py:226-236): out = 0.5*(a + shift(flip_back(b))) on [N][K][H][W];
+ * perm[k] = source channel after the left/right swap; shift != 0 applies the 1-px SHIFT_HEATMAP. */
+int buctd_flipback_avg(const float* a, const float* b, const int32_t* perm, int N, int K, int H, int W, int shift,
+                       float* out, void* stream);
+
+/* -------------------------------------------------------------- optimizer --- */
+/* torch.optim.Adam step (utils/utils.py:268-272: betas .9/.999, eps 1e-8, no weight decay, no amsgrad)
+ * on flat fp32 buffers; gscale multiplies the gradient first (1/world for averaged all-reduce). */
+int buctd_adam_step(float* p, const float* g, float* m, float* v, long n, float lr, float beta1, float beta2,
+                    float eps, int step, float gscale, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
