@@ -1,0 +1,262 @@
+"""TEST INFRASTRUCTURE - pins the oracle against the real reference and writes tests/golden/*.npz.
+
+Runs ONLY in the build container (needs /root/reference, read-only).  It imports the reference's
+own Python modules (lib/models, lib/core, lib/utils/transforms) with the stub set of SURVEY 8c
+for packages this image lacks (torchvision, cv2, yacs), drives them and the oracle with the same
+seeded state_dict + inputs, asserts agreement, and stores the REFERENCE's outputs as golden
+vectors.  Nothing from the reference's sources is copied; only inputs/outputs (data) are kept.
+
+    python -m oracle.make_golden            # all cases
+    python -m oracle.make_golden --fast     # skip the full-size W48 / W32 cases
+"""
+import argparse
+import hashlib
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+REF = "/root/reference"
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+OUT = os.path.join(ROOT, "tests", "golden")
+
+
+def install_stubs():
+    """Stand-ins for packages missing from this image - used by this script only."""
+    tv = types.ModuleType("torchvision")
+    tvt = types.ModuleType("torchvision.transforms")
+    tvf = types.ModuleType("torchvision.transforms.functional")
+    tvu = types.ModuleType("torchvision.utils")
+
+    def resize(img, size, *a, **k):  # torchvision 0.9 tensor resize: bilinear, no antialias
+        return F.interpolate(img, size=tuple(size), mode="bilinear", align_corners=False)
+
+    tvf.resize = resize
+    tvt.functional = tvf
+    tvt.Normalize = lambda *a, **k: None
+    tv.transforms, tv.utils = tvt, tvu
+    sys.modules.update({"torchvision": tv, "torchvision.transforms": tvt,
+                        "torchvision.transforms.functional": tvf, "torchvision.utils": tvu})
+    cv2 = types.ModuleType("cv2")
+
+    def get_affine(src, dst):
+        A = np.concatenate([np.asarray(src, np.float64), np.ones((3, 1))], 1)
+        return np.linalg.solve(A, np.asarray(dst, np.float64)).T
+
+    cv2.getAffineTransform = get_affine
+    cv2.INTER_LINEAR = 1
+    sys.modules["cv2"] = cv2
+    torch.Tensor.cuda = lambda self, *a, **k: self  # reference forwards call x.cuda()
+
+
+def sha(t):
+    return hashlib.sha256(np.ascontiguousarray(t.detach().cpu().numpy()).tobytes()).hexdigest()[:16]
+
+
+def state_digest(model):
+    h = hashlib.sha256()
+    for k, v in model.state_dict().items():
+        h.update(k.encode())
+        h.update(np.ascontiguousarray(v.detach().cpu().numpy()).tobytes())
+    return h.hexdigest()[:16]
+
+
+def close(a, b, tol, what):
+    err = (a - b).abs().max().item()
+    assert err <= tol, f"{what}: reference vs oracle max abs diff {err:.3e} > {tol}"
+    return err
+
+
+def ref_model_for(name, cfg):
+    import models  # reference lib/models
+    mod = {"pose_hrnet": models.pose_hrnet, "pose_hrnet_coam": models.pose_hrnet_coam,
+           "transpose_h": models.transpose_h, "pose_resnet": models.pose_resnet}[cfg.MODEL.NAME]
+    return mod.get_pose_net(cfg, is_train=False)
+
+
+def model_case(name, train):
+    from oracle import recipes, core as ocore
+    cfg, omodel, x, joints = recipes.build(name)
+    rmodel = ref_model_for(name, cfg)
+    # identical keys / shapes: strict load of the oracle's state into the reference
+    rmodel.load_state_dict(omodel.state_dict(), strict=True)
+    assert list(rmodel.state_dict().keys()) == list(omodel.state_dict().keys()), name + ": key order differs"
+    rmodel.eval()
+    with torch.no_grad():
+        y_ref = rmodel(x)
+        y_orc = omodel(x)
+    err = close(y_ref, y_orc, 1e-5, name + " eval forward")
+    rec = {"out": y_ref.numpy(), "x_sha": sha(x), "state_sha": state_digest(omodel)}
+    flat = y_ref.reshape(y_ref.shape[0], y_ref.shape[1], -1)
+    rec["argmax"] = flat.argmax(2).numpy().astype(np.int32)
+    print(f"  {name}: eval fwd ok (ref-oracle diff {err:.2e}), out |max| {y_ref.abs().max():.3f}")
+    if train:
+        # one training forward/backward with dropout disabled (SURVEY 8c train-step protocol)
+        tgt, wt = recipes.make_targets(cfg, joints, 77)
+        crit_ref = __import__("core.loss", fromlist=["JointsMSELoss"]).JointsMSELoss(True)
+        outs = {}
+        for tag, m in (("ref", rmodel), ("orc", omodel)):
+            m.train()
+            recipes.set_dropout(m, 0.0)
+            m.zero_grad()
+            y = m(x)
+            loss = crit_ref(y, tgt, wt) if tag == "ref" else ocore.JointsMSELoss(True)(y, tgt, wt)
+            loss.backward()
+            outs[tag] = (y.detach(), loss.detach(),
+                         {k: p.grad.detach().clone() for k, p in m.named_parameters() if p.grad is not None},
+                         {k: b.detach().clone() for k, b in m.named_buffers()})
+        close(outs["ref"][0], outs["orc"][0], 1e-5, name + " train forward")
+        close(outs["ref"][1], outs["orc"][1], 1e-7, name + " loss")
+        for k, gref in outs["ref"][2].items():
+            close(gref, outs["orc"][2][k], 1e-5 * max(1.0, gref.abs().max().item()), name + " grad " + k)
+        for k, bref in outs["ref"][3].items():
+            close(bref.float(), outs["orc"][3][k].float(), 1e-5, name + " buffer " + k)
+        y, loss, grads, bufs = outs["ref"]
+        rec["train_out"] = y.numpy()
+        rec["loss"] = loss.numpy()
+        names = sorted(grads)
+        rec["grad_names"] = np.array(names)
+        rec["grad_norms"] = np.array([grads[k].norm().item() for k in names], np.float64)
+        rec["grad_sums"] = np.array([grads[k].double().sum().item() for k in names], np.float64)
+        for k in ("final_layer.weight", "conv1.weight"):
+            if k in grads:
+                rec["grad::" + k] = grads[k].numpy()
+        bnames = sorted(k for k in bufs if k.endswith("running_mean") or k.endswith("running_var"))
+        rec["buf_names"] = np.array(bnames)
+        rec["buf_norms"] = np.array([bufs[k].norm().item() for k in bnames], np.float64)
+        rec["target_sha"] = sha(tgt)
+        print(f"  {name}: train fwd/bwd ok, loss {loss.item():.6f}, {len(names)} grads pinned")
+    np.savez_compressed(os.path.join(OUT, f"model_{name}.npz"), **rec)
+
+
+def core_cases():
+    """loss / decode / accuracy / flip / affine: reference functions vs oracle on seeded inputs."""
+    from core.loss import JointsMSELoss as RefLoss
+    from core.inference import get_max_preds as ref_gmp, get_final_preds as ref_gfp
+    from core.evaluate import accuracy as ref_acc
+    from utils.transforms import flip_back as ref_flip_back, fliplr_joints as ref_fliplr
+    from oracle import core as oc
+    g = torch.Generator().manual_seed(2024)
+    N, K, H, W = 6, 14, 24, 18
+    pred = torch.randn(N, K, H, W, generator=g)
+    gt = torch.rand(N, K, H, W, generator=g)
+    wt = (torch.rand(N, K, 1, generator=g) > 0.25).float() * (0.5 + torch.rand(N, K, 1, generator=g))
+    p1 = pred.clone().requires_grad_(True)
+    l_ref = RefLoss(True)(p1, gt, wt)
+    l_ref.backward()
+    p2 = pred.clone().requires_grad_(True)
+    l_orc = oc.JointsMSELoss(True)(p2, gt, wt)
+    l_orc.backward()
+    close(l_ref.detach(), l_orc.detach(), 1e-8, "loss")
+    close(p1.grad, p2.grad, 1e-9, "loss grad")
+    close(l_ref.detach(), oc.joints_mse_closed_form(pred, gt, wt), 1e-7, "loss closed form")
+    # decode incl. ties / non-positive maxima / borders
+    hm = pred.numpy().copy()
+    hm[0, 0] = 0.25
+    hm[0, 0, 3, 4] = 2.0
+    hm[0, 0, 10, 2] = 2.0
+    hm[1, 1] = -1.0
+    hm[2, 2] = 0.0
+    hm[3, 3, 0, 0] = 9.0
+    hm[3, 4, H - 1, W - 1] = 9.0
+    hm[3, 5, 1, 1] = 9.0
+    hm[3, 6, 2, 2] = 9.0
+    pr, mv = ref_gmp(hm)
+    po, mo = oc.get_max_preds(hm)
+    assert np.array_equal(pr, po) and np.array_equal(mv, mo)
+    center = (torch.rand(N, 2, generator=g) * 200 + 50).numpy()
+    scale = (torch.rand(N, 2, generator=g) * 1.5 + 0.5).numpy()
+
+    class C:
+        class TEST:
+            POST_PROCESS = True
+    fr, fm = ref_gfp(C, hm.copy(), center, scale)
+    fo, fmo = oc.get_final_preds(True, hm.copy(), center, scale)
+    assert np.allclose(fr, fo, atol=1e-9) and np.array_equal(fm, fmo)
+    ar = ref_acc(hm, gt.numpy())
+    ao = oc.accuracy(hm, gt.numpy())
+    assert np.allclose(ar[0], ao[0]) and ar[1] == ao[1] and ar[2] == ao[2] and np.array_equal(ar[3], ao[3])
+    fb_r = ref_flip_back(hm.copy(), oc.CROWDPOSE_FLIP_PAIRS)
+    fb_o = oc.flip_back(hm.copy(), oc.CROWDPOSE_FLIP_PAIRS)
+    assert np.array_equal(fb_r, fb_o)
+    j = (torch.rand(K, 3, generator=g) * 40).numpy()
+    jv = (torch.rand(K, 3, generator=g) > 0.3).float().numpy()
+    jr, jvr = ref_fliplr(j.copy(), jv.copy(), 48, oc.CROWDPOSE_FLIP_PAIRS)
+    jo, jvo = oc.fliplr_joints(j, jv, 48, oc.CROWDPOSE_FLIP_PAIRS)
+    assert np.array_equal(jr, jo) and np.array_equal(jvr, jvo)
+    np.savez_compressed(os.path.join(OUT, "core.npz"), pred=pred.numpy(), gt=gt.numpy(), wt=wt.numpy(),
+                        loss=l_ref.detach().numpy(), loss_grad=p1.grad.numpy(), hm=hm, preds=pr, maxvals=mv,
+                        center=center, scale=scale, final_preds=fr, acc=ar[0], avg_acc=ar[1], cnt=ar[2],
+                        flip_back=fb_r, merged=oc.flip_test_merge(hm, hm[::-1].copy(), oc.CROWDPOSE_FLIP_PAIRS, True))
+    print("  core: loss / decode / final_preds / accuracy / flip_back match the reference")
+
+
+def target_case():
+    """generate_target: executes the reference function body (JointsDataset.py:397-453) with a dummy self
+    (lib/dataset cannot be imported: cv2 / pycocotools / np.float), compares with the oracle."""
+    import ast
+    import textwrap
+    from oracle import core as oc
+    src = open(os.path.join(REF, "lib/dataset/JointsDataset.py")).read()
+    fn = next(n for n in ast.walk(ast.parse(src)) if isinstance(n, ast.FunctionDef) and n.name == "generate_target")
+    code = textwrap.dedent("\n".join(src.splitlines()[fn.lineno - 1:fn.end_lineno]))
+    ns = {"np": np}
+    exec(compile(code, "generate_target", "exec"), ns)
+
+    class Self:
+        pass
+
+    recs = {}
+    for tag, (hw, iw, sig, k) in {"crowdpose": ((72, 96), (288, 384), 3, 14), "coco256": ((64, 96), (192, 256), 2, 17)}.items():
+        s = Self()
+        s.num_joints, s.heatmap_size, s.image_size = k, np.array(hw), np.array(iw)
+        s.sigma, s.target_type, s.use_different_joints_weight = sig, "gaussian", False
+        g = torch.Generator().manual_seed(5 + k)
+        joints = torch.rand(k, 3, generator=g).numpy() * np.array([iw[0] * 1.4, iw[1] * 1.4, 0]) - \
+            np.array([iw[0] * 0.2, iw[1] * 0.2, 0])
+        joints[0, :2] = [-40.0, 10.0]      # fully outside (left)
+        joints[1, :2] = [iw[0] + 60.0, 5]  # fully outside (right)
+        joints[2, :2] = [-3.0, -3.0]       # partially outside, negative coords (int() truncation)
+        joints[3, :2] = [iw[0] - 1.0, iw[1] - 1.0]
+        vis = (torch.rand(k, 1, generator=g) > 0.2).float().repeat(1, 3).numpy()
+        vis[2] = 1.0
+        t_ref, w_ref = ns["generate_target"](s, joints.copy(), vis.copy())
+        t_orc, w_orc = oc.generate_target(joints, vis, k, hw, iw, sig)
+        assert np.array_equal(t_ref, t_orc) and np.array_equal(w_ref, w_orc), tag
+        recs.update({f"{tag}_joints": joints, f"{tag}_vis": vis, f"{tag}_target": t_ref, f"{tag}_weight": w_ref,
+                     f"{tag}_meta": np.array([hw[0], hw[1], iw[0], iw[1], sig, k])})
+    np.savez_compressed(os.path.join(OUT, "target.npz"), **recs)
+    print("  target: generate_target (executed reference body) == oracle, incl. out-of-bounds joints")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--fast", action="store_true")
+    ap.add_argument("--only", default="")
+    args = ap.parse_args()
+    assert os.path.isdir(REF), "the reference checkout is required (build container only)"
+    os.makedirs(OUT, exist_ok=True)
+    install_stubs()
+    sys.path.insert(0, os.path.join(REF, "lib"))
+    sys.path.insert(0, ROOT)
+    torch.set_num_threads(8)
+    from oracle import recipes
+    print("pinning oracle against", REF)
+    if not args.only:
+        core_cases()
+        target_case()
+    small = ["prenet_w16_96x64", "coam_w16_96x64_colored", "coam_w16_96x64_mono_default_att",
+             "coam_w16_96x64_stacked_2heads", "transpose_w16_96x64", "resnet18_96x64"]
+    full = ["coam_w48_384x288", "prenet_w32_256x192"]
+    for name in small + ([] if args.fast else full):
+        if args.only and args.only != name:
+            continue
+        model_case(name, train=name in small)
+    print("golden vectors written to", OUT)
+
+
+if __name__ == "__main__":
+    main()

@@ -315,6 +315,7 @@ class PositionAttentionModule(nn.Module):  # pose_hrnet_coam.py:631-660
         pad = (kernel_size - 1) // 2
         self.cnn = nn.Conv2d(d_model, d_model, kernel_size, padding=pad)
         self.self_att = self_att
+        self.register_module("pa", None)  # slot registered before cnn_cond, like the reference module order
         if self_att:
             self.pa = ScaledDotProductAttention(d_model, d_model, d_model, d_model, n_heads)
         else:
