@@ -1,0 +1,254 @@
+"""HRNet building blocks of the MI355X engine (NHWC, fused conv+BN+ReLU kernels).
+
+Module / attribute names and construction order follow the reference so that state_dict keys are
+identical (reference lib/models/pose_hrnet.py:28-98 BasicBlock/Bottleneck, 101-265
+HighResolutionModule, 355-444 transition/stage builders); the forward passes are re-expressed
+on the fused ops: a BasicBlock is two ConvBnAct launches, a fuse row is one FuseSum launch.
+"""
+import logging
+import os
+
+import torch
+
+from .. import nn
+from .. import ops
+
+BN_MOMENTUM = 0.1
+logger = logging.getLogger(__name__)
+
+
+def conv3x3(in_planes, out_planes, stride=1):
+    return nn.Conv2d(in_planes, out_planes, kernel_size=3, stride=stride, padding=1, bias=False)
+
+
+class BasicBlock(nn.Module):
+    expansion = 1
+
+    def __init__(self, inplanes, planes, stride=1, downsample=None):
+        super().__init__()
+        self.conv1 = conv3x3(inplanes, planes, stride)
+        self.bn1 = nn.BatchNorm2d(planes, momentum=BN_MOMENTUM)
+        self.relu = nn.ReLU(inplace=True)
+        self.conv2 = conv3x3(planes, planes)
+        self.bn2 = nn.BatchNorm2d(planes, momentum=BN_MOMENTUM)
+        self.downsample = downsample
+        self.stride = stride
+
+    def forward(self, x):
+        residual = x if self.downsample is None else self.downsample(x)
+        out = nn.conv_bn_act(x, self.conv1, self.bn1, relu=True)
+        return nn.conv_bn_act(out, self.conv2, self.bn2, relu=True, residual=residual)
+
+
+class Bottleneck(nn.Module):
+    expansion = 4
+
+    def __init__(self, inplanes, planes, stride=1, downsample=None):
+        super().__init__()
+        self.conv1 = nn.Conv2d(inplanes, planes, kernel_size=1, bias=False)
+        self.bn1 = nn.BatchNorm2d(planes, momentum=BN_MOMENTUM)
+        self.conv2 = nn.Conv2d(planes, planes, kernel_size=3, stride=stride, padding=1, bias=False)
+        self.bn2 = nn.BatchNorm2d(planes, momentum=BN_MOMENTUM)
+        self.conv3 = nn.Conv2d(planes, planes * self.expansion, kernel_size=1, bias=False)
+        self.bn3 = nn.BatchNorm2d(planes * self.expansion, momentum=BN_MOMENTUM)
+        self.relu = nn.ReLU(inplace=True)
+        self.downsample = downsample
+        self.stride = stride
+
+    def forward(self, x):
+        residual = x if self.downsample is None else self.downsample(x)
+        out = nn.conv_bn_act(x, self.conv1, self.bn1, relu=True)
+        out = nn.conv_bn_act(out, self.conv2, self.bn2, relu=True)
+        return nn.conv_bn_act(out, self.conv3, self.bn3, relu=True, residual=residual)
+
+
+blocks_dict = {"BASIC": BasicBlock, "BOTTLENECK": Bottleneck}
+
+
+def make_residual_layer(block, inplanes, planes, blocks, stride=1):
+    """-> (nn.Chain of blocks, output channels)."""
+    downsample = None
+    if stride != 1 or inplanes != planes * block.expansion:
+        downsample = nn.ConvBN(
+            nn.Conv2d(inplanes, planes * block.expansion, kernel_size=1, stride=stride, bias=False),
+            nn.BatchNorm2d(planes * block.expansion, momentum=BN_MOMENTUM))
+    layers = [block(inplanes, planes, stride, downsample)]
+    inplanes = planes * block.expansion
+    for _ in range(1, blocks):
+        layers.append(block(inplanes, planes))
+    return nn.Chain(*layers), inplanes
+
+
+class HighResolutionModule(nn.Module):
+    def __init__(self, num_branches, blocks, num_blocks, num_inchannels, num_channels, fuse_method,
+                 multi_scale_output=True):
+        super().__init__()
+        self._check_branches(num_branches, blocks, num_blocks, num_inchannels, num_channels)
+        self.num_inchannels = num_inchannels
+        self.fuse_method = fuse_method
+        self.num_branches = num_branches
+        self.multi_scale_output = multi_scale_output
+        self.branches = self._make_branches(num_branches, blocks, num_blocks, num_channels)
+        self.fuse_layers = self._make_fuse_layers()
+        self.relu = nn.ReLU(True)
+
+    def _check_branches(self, num_branches, blocks, num_blocks, num_inchannels, num_channels):
+        for what, lst in (("NUM_BLOCKS", num_blocks), ("NUM_CHANNELS", num_channels),
+                          ("NUM_INCHANNELS", num_inchannels)):
+            if num_branches != len(lst):
+                msg = "NUM_BRANCHES({}) <> {}({})".format(num_branches, what, len(lst))
+                logger.error(msg)
+                raise ValueError(msg)
+
+    def _make_branches(self, num_branches, block, num_blocks, num_channels):
+        branches = []
+        for i in range(num_branches):
+            chain, cout = make_residual_layer(block, self.num_inchannels[i], num_channels[i], num_blocks[i])
+            self.num_inchannels[i] = cout
+            branches.append(chain)
+        return nn.ModuleList(branches)
+
+    def _make_fuse_layers(self):
+        if self.num_branches == 1:
+            return None
+        ch = self.num_inchannels
+        rows = []
+        for i in range(self.num_branches if self.multi_scale_output else 1):
+            row = []
+            for j in range(self.num_branches):
+                if j > i:
+                    row.append(nn.ConvBN(nn.Conv2d(ch[j], ch[i], 1, 1, 0, bias=False), nn.BatchNorm2d(ch[i]),
+                                         nn.Upsample(scale_factor=2 ** (j - i), mode="nearest")))
+                elif j == i:
+                    row.append(None)
+                else:
+                    steps = []
+                    for k in range(i - j):
+                        last = k == i - j - 1
+                        cout = ch[i] if last else ch[j]
+                        steps.append(nn.ConvBN(nn.Conv2d(ch[j], cout, 3, 2, 1, bias=False), nn.BatchNorm2d(cout),
+                                               None if last else nn.ReLU(True)))
+                    row.append(nn.Chain(*steps))
+            rows.append(nn.ModuleList(row))
+        return nn.ModuleList(rows)
+
+    def get_num_inchannels(self):
+        return self.num_inchannels
+
+    def forward(self, x):
+        if self.num_branches == 1:
+            return [self.branches[0](x[0])]
+        xs = [self.branches[i](x[i]) for i in range(self.num_branches)]
+        outs = []
+        for i, row in enumerate(self.fuse_layers):
+            terms, shifts = [], []
+            for j in range(self.num_branches):
+                if j == i:
+                    terms.append(xs[j])
+                    shifts.append(0)
+                elif j > i:
+                    terms.append(row[j](xs[j]))   # 1x1 conv + BN at the low resolution
+                    shifts.append(j - i)          # nearest up-sampling happens inside the fuse kernel
+                else:
+                    terms.append(row[j](xs[j]))
+                    shifts.append(0)
+            outs.append(ops.FuseSum.apply(tuple(shifts), True, *terms))
+        return outs
+
+
+def make_transition_layer(pre, cur):
+    layers = []
+    for i in range(len(cur)):
+        if i < len(pre):
+            if cur[i] != pre[i]:
+                layers.append(nn.ConvBN(nn.Conv2d(pre[i], cur[i], 3, 1, 1, bias=False), nn.BatchNorm2d(cur[i]),
+                                        nn.ReLU(inplace=True)))
+            else:
+                layers.append(None)
+        else:
+            steps = []
+            for j in range(i + 1 - len(pre)):
+                cin = pre[-1]
+                cout = cur[i] if j == i - len(pre) else cin
+                steps.append(nn.ConvBN(nn.Conv2d(cin, cout, 3, 2, 1, bias=False), nn.BatchNorm2d(cout),
+                                       nn.ReLU(inplace=True)))
+            layers.append(nn.Chain(*steps))
+    return nn.ModuleList(layers)
+
+
+def make_stage(layer_config, num_inchannels, multi_scale_output=True):
+    block = blocks_dict[layer_config["BLOCK"]]
+    modules = []
+    for i in range(layer_config["NUM_MODULES"]):
+        mso = multi_scale_output or i != layer_config["NUM_MODULES"] - 1
+        modules.append(HighResolutionModule(layer_config["NUM_BRANCHES"], block, layer_config["NUM_BLOCKS"],
+                                            num_inchannels, layer_config["NUM_CHANNELS"],
+                                            layer_config["FUSE_METHOD"], mso))
+        num_inchannels = modules[-1].get_num_inchannels()
+    return nn.Chain(*modules), num_inchannels
+
+
+class HRNetTrunk(nn.Module):
+    """stem + layer1 + stage2..N; subclasses add heads.  All tensors below the API boundary are NHWC."""
+
+    def build_trunk(self, extra, last_stage=4):
+        self.conv1 = nn.Conv2d(3, 64, kernel_size=3, stride=2, padding=1, bias=False)
+        self.bn1 = nn.BatchNorm2d(64, momentum=BN_MOMENTUM)
+        self.conv2 = nn.Conv2d(64, 64, kernel_size=3, stride=2, padding=1, bias=False)
+        self.bn2 = nn.BatchNorm2d(64, momentum=BN_MOMENTUM)
+        self.relu = nn.ReLU(inplace=True)
+        self.layer1, c = make_residual_layer(Bottleneck, 64, 64, 4)
+        pre = [c]
+        for s in range(2, last_stage + 1):
+            scfg = extra["STAGE%d" % s]
+            setattr(self, "stage%d_cfg" % s, scfg)
+            block = blocks_dict[scfg["BLOCK"]]
+            ch = [c * block.expansion for c in scfg["NUM_CHANNELS"]]
+            setattr(self, "transition%d" % (s - 1), make_transition_layer(pre, ch))
+            stage, pre = make_stage(scfg, ch, multi_scale_output=(s != last_stage))
+            setattr(self, "stage%d" % s, stage)
+        return pre
+
+    def stem(self, x_nhwc):
+        x = nn.conv_bn_act(x_nhwc, self.conv1, self.bn1, relu=True)
+        x = nn.conv_bn_act(x, self.conv2, self.bn2, relu=True)
+        return self.layer1(x)
+
+    def enter_stage(self, s, prev, first=False):
+        trans = getattr(self, "transition%d" % (s - 1))
+        n = getattr(self, "stage%d_cfg" % s)["NUM_BRANCHES"]
+        if first:
+            return [trans[i](prev) if trans[i] is not None else prev for i in range(n)]
+        return [trans[i](prev[-1]) if trans[i] is not None else prev[i] for i in range(n)]
+
+
+def to_device_input(x):
+    """The reference forwards call x.cuda() themselves (pose_hrnet_coam.py:495): CPU inputs are accepted."""
+    if not x.is_cuda:
+        x = x.cuda()
+    if x.dtype != torch.float32:
+        x = x.float()
+    return x.contiguous()
+
+
+def init_weights_hrnet(model, pretrained="", linear=False):
+    """normal(std=0.001) conv (+Linear for the CoAM variant) weights, zero biases, BN 1/0, then the
+    non-strict filtered load of ImageNet weights (pose_hrnet.py:578-614, pose_hrnet_coam.py:574-609)."""
+    logger.info("=> init weights from normal distribution")
+    for m in model.modules():
+        if isinstance(m, (torch.nn.Conv2d, torch.nn.ConvTranspose2d)) or (linear and isinstance(m, torch.nn.Linear)):
+            torch.nn.init.normal_(m.weight, std=0.001)
+            if m.bias is not None:
+                torch.nn.init.constant_(m.bias, 0)
+        elif isinstance(m, torch.nn.BatchNorm2d):
+            torch.nn.init.constant_(m.weight, 1)
+            torch.nn.init.constant_(m.bias, 0)
+    if os.path.isfile(pretrained):
+        state = torch.load(pretrained, map_location="cpu")
+        logger.info("=> loading pretrained model {}".format(pretrained))
+        keep = {k: v for k, v in state.items()
+                if k.split(".")[0] in model.pretrained_layers or model.pretrained_layers[0] == "*"}
+        model.load_state_dict(keep, strict=False)
+    elif pretrained:
+        logger.error("=> please download pre-trained models first!")
+        raise ValueError("{} is not exist!".format(pretrained))

@@ -1,0 +1,87 @@
+"""Tight train-mode parity of the building blocks (conv+BN+ReLU fusions, BasicBlock / Bottleneck chains,
+HighResolutionModule with its fuse rows): forward, input gradient and every parameter gradient of the HIP path
+against an fp64 CPU evaluation of the oracle block, bar 5e-6 relative (fp32 round-off level) and never worse than
+4x the fp32 CPU oracle's own distance to fp64."""
+import copy
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _e(a, b):
+    return ((a.double().cpu() - b).norm() / b.norm().clamp_min(1e-30)).item()
+
+
+def _check(name, e_hip, e_cpu):
+    assert e_hip <= max(5e-6, 4 * e_cpu), f"{name}: rel err vs fp64 {e_hip:.2e} (fp32 CPU {e_cpu:.2e})"
+
+
+def _run(dev, name, omod, pmod, xs):
+    pmod.load_state_dict(omod.state_dict(), strict=True)
+    pmod = pmod.to(dev).train()
+    single = not isinstance(xs, list)
+    xs = [xs] if single else xs
+    ref = {}
+    for dt in (torch.float64, torch.float32):
+        m = copy.deepcopy(omod).to(dt).train()
+        xi = [x.to(dt).clone().requires_grad_(True) for x in xs]
+        ys = m(xi[0]) if single else m(list(xi))
+        ys = [ys] if not isinstance(ys, (list, tuple)) else list(ys)
+        ws = [torch.linspace(-1, 1, y.numel(), dtype=dt).view(y.shape) for y in ys]
+        sum((y * w).sum() for y, w in zip(ys, ws)).backward()
+        ref[dt] = ([y.detach() for y in ys], [x.grad for x in xi], {k: p.grad for k, p in m.named_parameters()})
+    xd = [x.permute(0, 2, 3, 1).contiguous().to(dev).requires_grad_(True) for x in xs]
+    yd = pmod(xd[0]) if single else pmod(list(xd))
+    yd = [yd] if not isinstance(yd, (list, tuple)) else list(yd)
+    for y, y64 in zip(yd, ref[torch.float64][0]):
+        w = torch.linspace(-1, 1, y64.numel()).view(y64.shape).permute(0, 2, 3, 1).contiguous().to(dev)
+        y.backward(w, retain_graph=True)
+    y64, gx64, gp64 = ref[torch.float64]
+    y32, gx32, gp32 = ref[torch.float32]
+    for i in range(len(yd)):
+        _check(f"{name} out{i}", _e(yd[i].detach().permute(0, 3, 1, 2), y64[i]), _e(y32[i], y64[i]))
+    for i in range(len(xd)):
+        _check(f"{name} dx{i}", _e(xd[i].grad.permute(0, 3, 1, 2), gx64[i]), _e(gx32[i], gx64[i]))
+    for k, p in pmod.named_parameters():
+        assert p.grad is not None, f"{name}: {k} got no gradient"
+        _check(f"{name} d{k}", _e(p.grad, gp64[k]), _e(gp32[k], gp64[k]))
+
+
+@pytest.mark.parametrize("shape", [(3, 24, 16, 16, 16, 3, 1, True), (3, 3, 2, 128, 128, 3, 1, True),
+                                   (3, 6, 4, 64, 128, 3, 2, False), (3, 12, 8, 64, 16, 1, 1, False),
+                                   (32, 12, 9, 384, 384, 3, 1, True), (2, 16, 12, 3, 64, 3, 2, True)])
+def test_conv_bn_act(dev, shape):
+    from oracle import models as om
+    from buctd_amd import nn as bnn
+    N, H, W, ci, co, k, st, relu = shape
+    torch.manual_seed(1)
+    o = om.cbr(ci, co, k, st, relu)
+    p = bnn.ConvBN(bnn.Conv2d(ci, co, k, st, (k - 1) // 2, bias=False), bnn.BatchNorm2d(co),
+                   bnn.ReLU(True) if relu else None)
+    _run(dev, f"convbn{shape}", o, p, torch.randn(N, ci, H, W))
+
+
+def test_residual_chains(dev):
+    from oracle import models as om
+    from buctd_amd.models import hrnet_common as hc
+    torch.manual_seed(2)
+    _run(dev, "basicblock", om.BasicBlock(16, 16), hc.BasicBlock(16, 16), torch.randn(3, 16, 24, 16))
+    o, _ = om.make_layer(om.BasicBlock, 32, 32, 4)
+    p, _ = hc.make_residual_layer(hc.BasicBlock, 32, 32, 4)
+    _run(dev, "4 basic blocks", o, p, torch.randn(3, 32, 12, 8))
+    o, _ = om.make_layer(om.Bottleneck, 64, 64, 2)
+    p, _ = hc.make_residual_layer(hc.Bottleneck, 64, 64, 2)
+    _run(dev, "2 bottlenecks (layer1 head)", o, p, torch.randn(2, 64, 12, 8))
+
+
+@pytest.mark.parametrize("nb,mso", [(2, True), (3, True), (4, True), (4, False)])
+def test_high_resolution_module(dev, nb, mso):
+    from oracle import models as om
+    from buctd_amd.models import hrnet_common as hc
+    torch.manual_seed(3)
+    ch = [16 * 2 ** i for i in range(nb)]
+    o = om.HighResolutionModule(nb, om.BasicBlock, [1] * nb, list(ch), list(ch), "SUM", mso)
+    p = hc.HighResolutionModule(nb, hc.BasicBlock, [1] * nb, list(ch), list(ch), "SUM", mso)
+    _run(dev, f"hr{nb}", o, p, [torch.randn(3, ch[i], 24 >> i, 16 >> i) for i in range(nb)])
