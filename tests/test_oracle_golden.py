@@ -1,0 +1,79 @@
+"""CPU suite (no GPU): the oracle against the golden vectors the REFERENCE produced (tests/golden/, made by
+oracle/make_golden.py in the build container where /root/reference exists)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def test_core_functions_match_reference_golden():
+    from oracle import core as oc
+    g = np.load(os.path.join(GOLD, "core.npz"))
+    pred, gt, wt = (torch.from_numpy(g[k]) for k in ("pred", "gt", "wt"))
+    p = pred.clone().requires_grad_(True)
+    loss = oc.JointsMSELoss(True)(p, gt, wt)
+    loss.backward()
+    assert abs(loss.item() - float(g["loss"])) <= 1e-7
+    assert np.abs(p.grad.numpy() - g["loss_grad"]).max() <= 1e-9
+    assert abs(oc.joints_mse_closed_form(pred, gt, wt).item() - float(g["loss"])) <= 1e-6
+    preds, maxvals = oc.get_max_preds(g["hm"])
+    assert np.array_equal(preds, g["preds"]) and np.array_equal(maxvals, g["maxvals"])
+    fp, _ = oc.get_final_preds(True, g["hm"].copy(), g["center"], g["scale"])
+    assert np.allclose(fp, g["final_preds"], atol=1e-9)
+    acc, avg, cnt, _ = oc.accuracy(g["hm"], g["gt"])
+    assert np.allclose(acc, g["acc"]) and avg == float(g["avg_acc"]) and cnt == int(g["cnt"])
+    assert np.array_equal(oc.flip_back(g["hm"].copy(), oc.CROWDPOSE_FLIP_PAIRS), g["flip_back"])
+
+
+def test_generate_target_matches_reference_golden():
+    from oracle import core as oc
+    g = np.load(os.path.join(GOLD, "target.npz"))
+    for tag in ("crowdpose", "coco256"):
+        hw0, hw1, iw0, iw1, sig, k = (int(v) for v in g[f"{tag}_meta"])
+        t, w = oc.generate_target(g[f"{tag}_joints"], g[f"{tag}_vis"], k, (hw0, hw1), (iw0, iw1), sig)
+        assert np.array_equal(t, g[f"{tag}_target"]) and np.array_equal(w, g[f"{tag}_weight"])
+        assert w[1, 0] == 0 and t[1].max() == 0        # joint fully outside the map: weight zeroed, nothing painted
+        assert t[2].max() > 0                           # partially outside (negative coordinates): still painted
+
+
+def test_condition_render_hand_derived():
+    """cv2.GaussianBlur(ksize 15, sigma 0 -> 2.6, BORDER_REFLECT_101) restated; hand-derived properties:
+    a single interior impulse blurs to the outer product of the normalised 1-D kernel, peak-normalised to 255."""
+    from oracle import core as oc
+    k = oc.gaussian_kernel_1d()
+    assert abs(k.sum() - 1) < 1e-12 and abs(0.3 * ((15 - 1) * 0.5 - 1) + 0.8 - 2.6) < 1e-12
+    img = oc.get_condition_image_colored([[21, 31]], (64, 48, 3), [[10, 20, 30]])
+    ref = np.outer(k, k) / k[7] ** 2
+    assert np.allclose(img[30 - 7:30 + 8, 20 - 7:20 + 8, 2], ref * 255.0, atol=1e-9)
+    assert np.allclose(img[:, :, 0] * 3, img[:, :, 2], atol=1e-9)
+    # reflect-101 at the border: for an impulse at column 1, output column 0 sees it through taps -1 and +1
+    # (index -1 folds back onto 1); output column 1 through taps 0 and -2 (index -1 again)
+    z = np.zeros((32, 32)); z[16, 1] = 1.0
+    b = oc.gaussian_blur_reflect101(z)
+    assert np.allclose(b[16, 0], k[7] * (k[6] + k[8]), atol=1e-12) and np.allclose(b[16, 1], k[7] * (k[7] + k[5]), atol=1e-12)
+    mono = oc.get_condition_image([[21, 31], [0, 5], [48, 5]], (64, 48))  # x = 0 and x = W are rejected
+    assert mono.shape == (3, 64, 48) and mono.max() == 255 and mono.dtype.kind == "i"
+
+
+@pytest.mark.parametrize("name", ["prenet_w16_96x64", "coam_w16_96x64_colored", "coam_w16_96x64_mono_default_att",
+                                  "coam_w16_96x64_stacked_2heads", "transpose_w16_96x64", "resnet18_96x64"])
+def test_oracle_models_reproduce_reference_outputs(name):
+    from oracle import recipes
+    torch.set_num_threads(max(1, (os.cpu_count() or 2) // 2))
+    g = np.load(os.path.join(GOLD, f"model_{name}.npz"))
+    cfg, model, x, joints = recipes.build(name)
+    with torch.no_grad():
+        y = model(x).numpy()
+    scale = max(1.0, float(np.abs(g["out"]).max()))
+    assert np.abs(y - g["out"]).max() <= 1e-4 * scale
+    assert np.array_equal(y.reshape(y.shape[0], y.shape[1], -1).argmax(2), g["argmax"])
+    # one train step: loss pinned to the reference's value
+    from oracle import core as oc
+    tgt, wt = recipes.make_targets(cfg, joints, 77)
+    model.train()
+    recipes.set_dropout(model, 0.0)
+    loss = oc.JointsMSELoss(True)(model(x), tgt, wt)
+    assert abs(loss.item() - float(g["loss"])) <= 1e-4 * abs(float(g["loss"]))
