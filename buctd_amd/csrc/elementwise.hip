@@ -64,6 +64,41 @@ extern "C" int buctd_scale(const float* x, const float* dev_scalar, float alpha,
   return BUCTD_OK;
 }
 
+// dst[r][cd0 + c] = src[r][cs0 + c], c < Cc : channel concat / split of NHWC tensors
+__global__ __launch_bounds__(256) void copy_channels_kernel(const float* __restrict__ src, long rows, int Cs, int cs0,
+                                                            float* __restrict__ dst, int Cd, int cd0, int Cc) {
+  const long total = rows * Cc;
+  const long step = (long)gridDim.x * 256;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += step) {
+    const long r = i / Cc;
+    const int c = (int)(i - r * Cc);
+    dst[r * Cd + cd0 + c] = src[r * Cs + cs0 + c];
+  }
+}
+extern "C" int buctd_copy_channels(const float* src, long rows, int Cs, int cs0, float* dst, int Cd, int cd0, int Cc,
+                                   void* stream) {
+  BUCTD_CHECK_ARG(src && dst && rows > 0 && Cc > 0 && cs0 >= 0 && cd0 >= 0 && cs0 + Cc <= Cs && cd0 + Cc <= Cd,
+                  "buctd_copy_channels: bad argument");
+  hipLaunchKernelGGL(copy_channels_kernel, dim3(stream_grid(rows * Cc)), dim3(256), 0, (hipStream_t)stream, src, rows,
+                     Cs, cs0, dst, Cd, cd0, Cc);
+  BUCTD_CHECK_LAUNCH("buctd_copy_channels");
+  return BUCTD_OK;
+}
+
+// out[b][i] = a[b][i] + v[i]  (position embedding added to every image's token tensor)
+__global__ __launch_bounds__(256) void add_bcast_kernel(const float* __restrict__ a, const float* __restrict__ v,
+                                                        float* __restrict__ out, long n, long total) {
+  const long step = (long)gridDim.x * 256;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += step) out[i] = a[i] + v[i % n];
+}
+extern "C" int buctd_add_bcast(const float* a, const float* v, float* out, long batch, long n, void* stream) {
+  BUCTD_CHECK_ARG(a && v && out && batch > 0 && n > 0, "buctd_add_bcast: bad argument");
+  hipLaunchKernelGGL(add_bcast_kernel, dim3(stream_grid(batch * n)), dim3(256), 0, (hipStream_t)stream, a, v, out, n,
+                     batch * n);
+  BUCTD_CHECK_LAUNCH("buctd_add_bcast");
+  return BUCTD_OK;
+}
+
 extern "C" int buctd_add(const float* a, const float* b, float* out, long n, int relu, void* stream) {
   BUCTD_CHECK_ARG(a && out && n > 0, "buctd_add: bad argument");
   hipLaunchKernelGGL(add_kernel, dim3(stream_grid((n + 3) / 4)), dim3(256), 0, (hipStream_t)stream, a, b, out, n, relu);

@@ -1,0 +1,166 @@
+"""BUCTD-TransPose-H on the MI355X engine - drop-in for reference lib/models/transpose_h.py
+(TransformerEncoder 110-150, TransformerEncoderLayer 168-243, TransPoseH 419-714): HRNet stages 1-3 -> 1x1 reduce
+-> (+16 condition channels) -> post-norm Transformer encoder with a sine position embedding -> 1x1 head.
+Same constructor, state_dict keys (incl. self_attn.in_proj_weight / out_proj) and init; tokens are kept
+batch-major [B, T, d] (the flattened NHWC tensor) instead of the reference's [T, B, d] - same math, no transposes.
+"""
+import copy
+import math
+
+import torch
+
+from .. import nn
+from .. import ops
+from .. import ops_seq
+from .hrnet_common import HRNetTrunk, init_weights_hrnet, to_device_input
+
+
+class MultiheadAttention(nn.Module):
+    """Parameter container with nn.MultiheadAttention's names (in_proj_weight, in_proj_bias, out_proj.*)."""
+
+    def __init__(self, embed_dim, num_heads, dropout=0.0):
+        super().__init__()
+        self.embed_dim, self.num_heads, self.dropout = embed_dim, num_heads, dropout
+        self.in_proj_weight = nn.Parameter(torch.empty(3 * embed_dim, embed_dim))
+        self.in_proj_bias = nn.Parameter(torch.empty(3 * embed_dim))
+        self.out_proj = nn.Linear(embed_dim, embed_dim)
+        torch.nn.init.xavier_uniform_(self.in_proj_weight)
+        torch.nn.init.constant_(self.in_proj_bias, 0.0)
+        torch.nn.init.constant_(self.out_proj.bias, 0.0)
+
+    def forward(self, qin, src):
+        """q = k = qin (src + pos), v = src; returns the attention output [B, T, d]."""
+        qk, v = ops_seq.InProjection.apply(qin, src, self.in_proj_weight, self.in_proj_bias)
+        out = ops.PositionAttention.apply(qk, None, v, self.num_heads, float(self.dropout), self.training)
+        return self.out_proj(out)
+
+
+class TransformerEncoderLayer(nn.Module):
+    def __init__(self, d_model, nhead, dim_feedforward=2048, dropout=0.1, activation="relu", normalize_before=False,
+                 return_atten_map=False):
+        super().__init__()
+        if activation != "relu" or normalize_before or return_atten_map:
+            raise NotImplementedError("TransPoseH builds post-norm ReLU layers without attention-map output")
+        self.self_attn = MultiheadAttention(d_model, nhead, dropout=dropout)
+        self.linear1 = nn.Linear(d_model, dim_feedforward)
+        self.dropout = torch.nn.Dropout(dropout)
+        self.linear2 = nn.Linear(dim_feedforward, d_model)
+        self.norm1 = torch.nn.LayerNorm(d_model)
+        self.norm2 = torch.nn.LayerNorm(d_model)
+        self.dropout1 = torch.nn.Dropout(dropout)
+        self.dropout2 = torch.nn.Dropout(dropout)
+
+    def forward(self, src, pos=None):
+        qin = src if pos is None else ops_seq.AddPos.apply(src, pos)
+        src2 = self.self_attn(qin, src)
+        src2 = ops_seq.Dropout.apply(src2, float(self.dropout1.p), self.training)
+        src = ops_seq.AddLayerNorm.apply(src, src2, self.norm1)
+        ff = self.linear1(src, relu=True)
+        ff = ops_seq.Dropout.apply(ff, float(self.dropout.p), self.training)
+        ff = self.linear2(ff)
+        ff = ops_seq.Dropout.apply(ff, float(self.dropout2.p), self.training)
+        return ops_seq.AddLayerNorm.apply(src, ff, self.norm2)
+
+
+class TransformerEncoder(nn.Module):
+    def __init__(self, encoder_layer, num_layers, norm=None, pe_only_at_begin=False, return_atten_map=False):
+        super().__init__()
+        self.layers = nn.ModuleList([copy.deepcopy(encoder_layer) for _ in range(num_layers)])
+        self.num_layers = num_layers
+        self.norm = norm
+        self.pe_only_at_begin = pe_only_at_begin
+        self.return_atten_map = return_atten_map
+        for p in self.parameters():
+            if p.dim() > 1:
+                torch.nn.init.xavier_uniform_(p)
+
+    def forward(self, src, pos=None):
+        for layer in self.layers:
+            src = layer(src, pos=pos)
+            pos = None if self.pe_only_at_begin else pos
+        if self.norm is not None:
+            raise NotImplementedError("TransPoseH never sets a final encoder norm")
+        return src
+
+
+class TransPoseH(HRNetTrunk):
+    def __init__(self, cfg, **kwargs):
+        super().__init__()
+        self.inplanes = 64
+        self.cfg = cfg
+        extra = cfg["MODEL"]["EXTRA"]
+        pre = self.build_trunk(extra, last_stage=3)
+        d_model = cfg.MODEL.DIM_MODEL
+        w, h = cfg.MODEL.IMAGE_SIZE
+        self.reduce = nn.Conv2d(pre[0], d_model, 1, bias=False)
+        if self.cfg.MODEL.EXTRA.USE_ATTENTION:
+            self.trans_cond = nn.Conv2d(3, 16, 1, bias=False)
+            d_model += 16
+        self._make_position_embedding(w, h, d_model, cfg.MODEL.POS_EMBEDDING)
+        layer = TransformerEncoderLayer(d_model=d_model, nhead=cfg.MODEL.N_HEAD,
+                                        dim_feedforward=cfg.MODEL.DIM_FEEDFORWARD, activation="relu")
+        self.global_encoder = TransformerEncoder(layer, cfg.MODEL.ENCODER_LAYERS)
+        k = extra["FINAL_CONV_KERNEL"]
+        self.final_layer = nn.Conv2d(in_channels=d_model, out_channels=cfg["MODEL"]["NUM_JOINTS"], kernel_size=k,
+                                     stride=1, padding=1 if k == 3 else 0)
+        self.pretrained_layers = extra["PRETRAINED_LAYERS"]
+
+    def _make_position_embedding(self, w, h, d_model, pe_type="sine"):
+        assert pe_type in ["none", "learnable", "sine"]
+        if pe_type == "none":
+            self.pos_embedding = None
+            return
+        self.pe_h, self.pe_w = h // 4, w // 4
+        length = self.pe_h * self.pe_w
+        if pe_type == "learnable":
+            self.pos_embedding = nn.Parameter(torch.randn(length, 1, d_model))
+        else:
+            self.pos_embedding = nn.Parameter(self._make_sine_position_embedding(d_model), requires_grad=False)
+
+    def _make_sine_position_embedding(self, d_model, temperature=10000, scale=2 * math.pi):
+        """2-D sine embedding: first half of the channels encodes y, second half x; sin / cos interleaved."""
+        h, w = self.pe_h, self.pe_w
+        half = d_model // 2
+        ys = torch.arange(1, h + 1, dtype=torch.float32).view(h, 1).expand(h, w)
+        xs = torch.arange(1, w + 1, dtype=torch.float32).view(1, w).expand(h, w)
+        eps = 1e-6
+        ys = ys / (float(h) + eps) * scale
+        xs = xs / (float(w) + eps) * scale
+        idx = torch.arange(half, dtype=torch.float32)
+        dim_t = temperature ** (2 * (idx // 2) / half)
+
+        def enc(v):
+            p = v[:, :, None] / dim_t
+            return torch.stack((p[:, :, 0::2].sin(), p[:, :, 1::2].cos()), dim=3).flatten(2)
+
+        pos = torch.cat((enc(ys), enc(xs)), dim=2)  # [h, w, d]
+        return pos.reshape(h * w, 1, -1).contiguous()  # [T, 1, d] like the reference parameter
+
+    def forward(self, x):
+        x = to_device_input(x)
+        use_att = self.cfg.MODEL.EXTRA.USE_ATTENTION
+        if use_att and x.shape[1] - 3 <= 0:
+            raise Exception("condition is empty, please check your dataloader")
+        feat = self.stem(ops.nchw_to_nhwc(x, 0, 3 if use_att else x.shape[1]))
+        y = self.stage2(self.enter_stage(2, feat, first=True))
+        y = self.stage3(self.enter_stage(3, y))
+        t = self.reduce(y[0])
+        b, h, w, c = t.shape
+        if use_att:
+            cond = ops.resize_bilinear_from_nchw(x, 3, 3, h, w)
+            t = ops_seq.ConcatChannels.apply(t, self.trans_cond(cond))
+            c = t.shape[3]
+        tokens = t.view(b, h * w, c)
+        pos = None if self.pos_embedding is None else self.pos_embedding.view(h * w, c)
+        tokens = self.global_encoder(tokens, pos=pos)
+        return ops.ToNCHW.apply(self.final_layer(tokens.view(b, h, w, c)))
+
+    def init_weights(self, pretrained="", print_load_info=False):
+        init_weights_hrnet(self, pretrained)
+
+
+def get_pose_net(cfg, is_train, **kwargs):
+    model = TransPoseH(cfg, **kwargs)
+    if is_train and cfg["MODEL"]["INIT_WEIGHTS"]:
+        model.init_weights(cfg["MODEL"]["PRETRAINED"])
+    return model

@@ -602,20 +602,26 @@ class ToNCHW(torch.autograd.Function):
 
 class PositionAttention(torch.autograd.Function):
     """softmax(q k^T / sqrt(dk)) -> dropout -> . v for h heads (self_attention.py:74-86).
-    q [B,Tq,h*dk], k [B,Tk,h*dk], v [B,Tk,h*dv] -> [B,Tq,h*dv]."""
+    q [B,Tq,h*dk], k [B,Tk,h*dk], v [B,Tk,h*dv] -> [B,Tq,h*dv].
+    Packed form (nn.MultiheadAttention self-attention): k=None and q = [B,T,2*h*dk] holding q | k side by side,
+    as produced by one fused input-projection GEMM; the backward then returns one packed gradient."""
 
     @staticmethod
     def forward(ctx, q, k, v, h, p_drop, training):
-        B, Tq, hdk = q.shape
-        Tk = k.shape[1]
+        packed = k is None
+        B, Tq = q.shape[0], q.shape[1]
+        ldq = q.shape[2]
+        hdk = ldq // 2 if packed else ldq
+        kt, k_off, ldk = (q, hdk, ldq) if packed else (k, 0, k.shape[2])
+        Tk = kt.shape[1]
         dk, dv = hdk // h, v.shape[2] // h
         scale = 1.0 / math.sqrt(dk)
         p_eff = p_drop if training else 0.0
         seed = next_seed()
         S = torch.empty((B, h, Tq, Tk), dtype=torch.float32, device=q.device)
         for i in range(h):
-            matmul(q, k, S, batch=B, M=Tq, N=Tk, K=dk, a_layout=0, b_layout=0, lda=hdk, ldb=hdk, ldc=Tk,
-                   stride_a=Tq * hdk, stride_b=Tk * hdk, stride_c=h * Tq * Tk, a_off=i * dk, b_off=i * dk,
+            matmul(q, kt, S, batch=B, M=Tq, N=Tk, K=dk, a_layout=0, b_layout=0, lda=ldq, ldb=ldk, ldc=Tk,
+                   stride_a=Tq * ldq, stride_b=Tk * ldk, stride_c=h * Tq * Tk, a_off=i * dk, b_off=k_off + i * dk,
                    c_off=i * Tq * Tk)
         P, Pd = softmax_dropout_fwd(S, Tk, scale, p_eff, seed)
         O = torch.empty((B, Tq, h * dv), dtype=torch.float32, device=q.device)
@@ -623,21 +629,25 @@ class PositionAttention(torch.autograd.Function):
             matmul(Pd, v, O, batch=B, M=Tq, N=dv, K=Tk, a_layout=0, b_layout=1, lda=Tk, ldb=h * dv, ldc=h * dv,
                    stride_a=h * Tq * Tk, stride_b=Tk * h * dv, stride_c=Tq * h * dv, a_off=i * Tq * Tk,
                    b_off=i * dv, c_off=i * dv)
-        ctx.meta = (h, dk, dv, scale, p_eff, seed)
+        ctx.meta = (h, dk, dv, scale, p_eff, seed, packed)
         ctx.save_for_backward(q, k, v, P, Pd if p_eff > 0 else None)
         return O
 
     @staticmethod
     def backward(ctx, dO):
-        h, dk, dv, scale, p_eff, seed = ctx.meta
+        h, dk, dv, scale, p_eff, seed, packed = ctx.meta
         q, k, v, P, Pd = ctx.saved_tensors
         if Pd is None:
             Pd = P
         dO = _contig(dO)
-        B, Tq, hdk = q.shape
-        Tk = k.shape[1]
+        B, Tq, ldq = q.shape
+        hdk = h * dk
+        kt, k_off, ldk = (q, hdk, ldq) if packed else (k, 0, k.shape[2])
+        Tk = kt.shape[1]
         hdv = h * dv
-        dq, dkk, dvv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+        dq = torch.empty_like(q)
+        dkk = dq if packed else torch.empty_like(k)
+        dvv = torch.empty_like(v)
         dP = torch.empty_like(P)
         for i in range(h):
             # dV = Pd^T dO
@@ -651,13 +661,13 @@ class PositionAttention(torch.autograd.Function):
         dS = softmax_dropout_bwd(dP, P, Tk, scale, p_eff, seed)
         for i in range(h):
             # dq = dS k ; dk = dS^T q
-            matmul(dS, k, dq, batch=B, M=Tq, N=dk, K=Tk, a_layout=0, b_layout=1, lda=Tk, ldb=hdk, ldc=hdk,
-                   stride_a=h * Tq * Tk, stride_b=Tk * hdk, stride_c=Tq * hdk, a_off=i * Tq * Tk, b_off=i * dk,
+            matmul(dS, kt, dq, batch=B, M=Tq, N=dk, K=Tk, a_layout=0, b_layout=1, lda=Tk, ldb=ldk, ldc=ldq,
+                   stride_a=h * Tq * Tk, stride_b=Tk * ldk, stride_c=Tq * ldq, a_off=i * Tq * Tk, b_off=k_off + i * dk,
                    c_off=i * dk)
-            matmul(dS, q, dkk, batch=B, M=Tk, N=dk, K=Tq, a_layout=1, b_layout=1, lda=Tk, ldb=hdk, ldc=hdk,
-                   stride_a=h * Tq * Tk, stride_b=Tq * hdk, stride_c=Tk * hdk, a_off=i * Tq * Tk, b_off=i * dk,
-                   c_off=i * dk)
-        return dq, dkk, dvv, None, None, None
+            matmul(dS, q, dkk, batch=B, M=Tk, N=dk, K=Tq, a_layout=1, b_layout=1, lda=Tk, ldb=ldq, ldc=ldk,
+                   stride_a=h * Tq * Tk, stride_b=Tq * ldq, stride_c=Tk * ldk, a_off=i * Tq * Tk, b_off=i * dk,
+                   c_off=k_off + i * dk)
+        return dq, (None if packed else dkk), dvv, None, None, None
 
 
 class ChannelAttention(torch.autograd.Function):

@@ -106,6 +106,12 @@ int buctd_add(const float* a, const float* b, float* out, long n, int relu, void
 /* out[i] = x[i] * alpha * (*dev_scalar) ; dev_scalar is a device pointer or NULL (chain rule through
  * the scalar loss without a host sync: loss.backward() hands d(loss) over as a device scalar) */
 int buctd_scale(const float* x, const float* dev_scalar, float alpha, float* out, long n, void* stream);
+/* dst[r][cd0+c] = src[r][cs0+c] for c < Cc: channel concat / split on [rows][C] tensors
+ * (torch.cat((x, x_cond), dim=1), transpose_h.py:672) */
+int buctd_copy_channels(const float* src, long rows, int Cs, int cs0, float* dst, int Cd, int cd0, int Cc,
+                        void* stream);
+/* out[b][i] = a[b][i] + v[i]: position embedding added to each image's tokens (transpose_h.py:189-192) */
+int buctd_add_bcast(const float* a, const float* v, float* out, long batch, long n, void* stream);
 /* dx = dy * (y > 0) */
 int buctd_relu_bwd(const float* dy, const float* y, float* dx, long n, void* stream);
 /* column sums of [rows][C] (bias gradients); db overwritten or accumulated */

@@ -202,5 +202,5 @@ def set_dropout(model, p):
     for m in model.modules():
         if isinstance(m, nn.Dropout):
             m.p = p
-        if isinstance(m, nn.MultiheadAttention):
-            m.dropout = p
+        if isinstance(m, nn.MultiheadAttention) or type(m).__name__ == "MultiheadAttention":
+            m.dropout = p  # torch's module and the engine's parameter container both keep p in .dropout

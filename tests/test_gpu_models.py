@@ -17,7 +17,7 @@ pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 SMALL = ["prenet_w16_96x64", "coam_w16_96x64_colored", "coam_w16_96x64_mono_default_att",
-         "coam_w16_96x64_stacked_2heads"]
+         "coam_w16_96x64_stacked_2heads", "transpose_w16_96x64", "resnet18_96x64"]
 
 
 def product_model(cfg, oracle_model, dev):

@@ -380,3 +380,40 @@ def test_loss_decode_target_adam(dev):
         opt.step()
         ops.adam_step(pd_, gr.to(dev), m, v, 1e-3, 0.9, 0.999, 1e-8, step)
     close(pd_, pr_, 1e-6, "adam")
+
+
+def test_target_and_condition_render_vs_oracle(dev):
+    """Device versions of generate_target (JointsDataset.py:397-453) and the condition renderers (500-543)
+    against the oracle restatements (which are pinned to the reference / hand-derived vectors on the CPU side)."""
+    from buctd_amd import ops
+    from oracle import core as oc
+    g = torch.Generator().manual_seed(21)
+    B, K, W, H = 4, 14, 288, 384
+    joints = torch.rand(B, K, 3, generator=g) * torch.tensor([W * 1.3, H * 1.3, 0.0]) - torch.tensor([W * 0.15, H * 0.15, 0.0])
+    joints[0, 0, :2] = torch.tensor([-40.0, 10.0])
+    joints[0, 1, :2] = torch.tensor([W + 60.0, 5.0])
+    joints[0, 2, :2] = torch.tensor([-3.0, -3.0])
+    vis = (torch.rand(B, K, generator=g) > 0.2).float()
+    target, weight = ops.gaussian_target(joints.to(dev), vis.to(dev), (72, 96), (288, 384), 3)
+    for b in range(B):
+        v3 = vis[b].view(K, 1).repeat(1, 3).numpy()
+        t, w = oc.generate_target(joints[b].numpy(), v3, K, (72, 96), (288, 384), 3)
+        assert np.abs(target[b].cpu().numpy() - t).max() <= 2e-7, "gaussian target"
+        assert np.array_equal(weight[b].cpu().numpy(), w)
+    # colored condition (3 channels, CrowdPose palette) incl. key points on the border and duplicates
+    cj = torch.rand(B, K, 2, generator=g) * torch.tensor([W - 1.0, H - 1.0])
+    cj[1, 0] = torch.tensor([3.0, 4.0])        # reflect-101 corner
+    cj[1, 1] = torch.tensor([W - 2.0, H - 2.0])
+    cj[1, 2] = cj[1, 3]                        # same pixel: later key point overwrites the earlier colour
+    cj[2, 0] = torch.tensor([0.4, 10.0])       # x truncates to 0 -> rejected
+    colors = torch.tensor(oc.CROWDPOSE_KPT_COLORS, dtype=torch.float32)
+    cond = ops.cond_render(cj.to(dev), colors.to(dev), H, W).cpu().numpy()
+    for b in range(B):
+        ref = oc.get_condition_image_colored(cj[b].numpy(), (H, W, 3), oc.CROWDPOSE_KPT_COLORS).transpose(2, 0, 1)
+        assert np.abs(cond[b] - ref).max() <= 2e-3, f"colored condition image {b}: {np.abs(cond[b] - ref).max()}"
+        assert abs(cond[b].max() - 255.0) < 1e-3
+    mono = ops.cond_render(cj.to(dev), None, H, W, truncate=True).cpu().numpy()
+    for b in range(B):
+        ref = oc.get_condition_image(cj[b].numpy(), (H, W))[0:1].astype(np.float64)
+        d = np.abs(mono[b] - ref)
+        assert d.max() <= 1.0 and (d > 0).mean() < 1e-3, "mono condition: only integer-boundary flips allowed"
