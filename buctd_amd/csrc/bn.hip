@@ -54,35 +54,46 @@ __device__ __forceinline__ double shfl_xor_d(double v, int o) {
   return __hiloint2double(hi, lo);
 }
 
-// one wave per channel
+// one 256-thread workgroup per channel; two division-free fp64 passes over the (L2-resident) partials:
+//   mean = sum n_g mean_g / N ;  M2 = sum [ M2_g + n_g (mean_g - mean)^2 ]      (Chan et al., exact)
+__device__ __forceinline__ double block_sum_d(double v, double* sm) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += shfl_xor_d(v, o);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return sm[0] + sm[1] + sm[2] + sm[3];
+}
 __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ part, int ngroups, int rpg,
                                                           long rows, int C, float eps, float momentum,
                                                           float* __restrict__ mean, float* __restrict__ invstd,
                                                           float* __restrict__ rmean, float* __restrict__ rvar) {
-  const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
-  const int lane = threadIdx.x & 63;
-  if (c >= C) return;
-  Wf a = {0.0, 0.0, 0.0};
-  for (int g = lane; g < ngroups; g += 64) {
+  __shared__ double sm[4];
+  const int c = blockIdx.x;
+  double s = 0.0;
+  for (int g = threadIdx.x; g < ngroups; g += 256) {
+    long n = rows - (long)g * rpg;
+    n = n < 0 ? 0 : (n > rpg ? rpg : n);
+    if (n > 0) s += (double)n * (double)part[((long)g * C + c) * 2];
+  }
+  const double mu = block_sum_d(s, sm) / (double)rows;
+  double q = 0.0;
+  for (int g = threadIdx.x; g < ngroups; g += 256) {
     long n = rows - (long)g * rpg;
     n = n < 0 ? 0 : (n > rpg ? rpg : n);
     if (n > 0) {
-      Wf b = {(double)n, (double)part[((long)g * C + c) * 2], (double)part[((long)g * C + c) * 2 + 1]};
-      a = wf_merge(a, b);
+      const double d = (double)part[((long)g * C + c) * 2] - mu;
+      q += (double)part[((long)g * C + c) * 2 + 1] + (double)n * d * d;
     }
   }
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
-    Wf b = {shfl_xor_d(a.n, o), shfl_xor_d(a.mean, o), shfl_xor_d(a.m2, o)};
-    a = wf_merge(a, b);
-  }
-  if (lane == 0) {
-    const double var = a.n > 0 ? a.m2 / a.n : 0.0;
-    mean[c] = (float)a.mean;
+  const double m2 = block_sum_d(q, sm);
+  if (threadIdx.x == 0) {
+    const double var = m2 / (double)rows;
+    mean[c] = (float)mu;
     invstd[c] = (float)(1.0 / sqrt(var + (double)eps));
     if (rmean) {
-      const double unb = a.n > 1 ? a.m2 / (a.n - 1.0) : var;
-      rmean[c] = (float)((1.0 - momentum) * rmean[c] + momentum * a.mean);
+      const double unb = rows > 1 ? m2 / (double)(rows - 1) : var;
+      rmean[c] = (float)((1.0 - momentum) * rmean[c] + momentum * mu);
       rvar[c] = (float)((1.0 - momentum) * rvar[c] + momentum * unb);
     }
   }
@@ -140,6 +151,51 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
 // block = 256 threads laid out as (rows 256/CT) x (CT column threads), CT = min(C,64) rounded;
 // simple layout: thread handles channel c = t % CW, row lane = t / CW.
 #define BWD_ROWS 64
+// Vector path (C % 4 == 0, C/4 <= 256): thread = (row lane, 4-channel group); 16-byte loads of dy, y, z.
+__global__ __launch_bounds__(256) void bn_bwd_reduce_vec_kernel(const float* __restrict__ dy,
+                                                                const float* __restrict__ y,
+                                                                const float* __restrict__ z,
+                                                                const float* __restrict__ mean,
+                                                                const float* __restrict__ invstd, int relu, long rows,
+                                                                int C, float* __restrict__ part) {
+  __shared__ f32x4 sm[2][256];
+  const int c4n = C >> 2;
+  const int rl = 256 / c4n;
+  const int tc = threadIdx.x % c4n, tr = threadIdx.x / c4n;
+  const long r0 = (long)blockIdx.x * BWD_ROWS;
+  long r1 = r0 + BWD_ROWS;
+  if (r1 > rows) r1 = rows;
+  f32x4 s1 = (f32x4){0.f, 0.f, 0.f, 0.f}, s2 = s1;
+  if (tr < rl) {
+    const f32x4 mu = reinterpret_cast<const f32x4*>(mean)[tc];
+    const f32x4 is = reinterpret_cast<const f32x4*>(invstd)[tc];
+    for (long r = r0 + tr; r < r1; r += rl) {
+      const long o = r * c4n + tc;
+      f32x4 g = reinterpret_cast<const f32x4*>(dy)[o];
+      const f32x4 zz = reinterpret_cast<const f32x4*>(z)[o];
+      if (relu) {
+        const f32x4 yy = reinterpret_cast<const f32x4*>(y)[o];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (!(yy[j] > 0.f)) g[j] = 0.f;
+      }
+      s1 += g;
+      s2 += g * (zz - mu) * is;
+    }
+  }
+  sm[0][threadIdx.x] = s1;
+  sm[1][threadIdx.x] = s2;
+  __syncthreads();
+  if (tr == 0) {
+    for (int k = 1; k < rl; ++k) {
+      s1 += sm[0][k * c4n + tc];
+      s2 += sm[1][k * c4n + tc];
+    }
+    reinterpret_cast<f32x4*>(part + ((long)blockIdx.x * 2 + 0) * C)[tc] = s1;
+    reinterpret_cast<f32x4*>(part + ((long)blockIdx.x * 2 + 1) * C)[tc] = s2;
+  }
+}
+
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restrict__ dy, const float* __restrict__ y,
                                                             const float* __restrict__ z,
                                                             const float* __restrict__ mean,
@@ -300,7 +356,7 @@ extern "C" int buctd_bn_finalize(const float* partials, int ngroups, int rows_pe
                   "buctd_bn_finalize: bad argument");
   BUCTD_CHECK_ARG((running_mean == nullptr) == (running_var == nullptr),
                   "buctd_bn_finalize: running_mean/var go together");
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3(ceil_div(C, 4)), dim3(256), 0, (hipStream_t)stream, partials, ngroups,
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, partials, ngroups,
                      rows_per_group, rows, C, eps, momentum, mean, invstd, running_mean, running_var);
   BUCTD_CHECK_LAUNCH("buctd_bn_finalize");
   return BUCTD_OK;
@@ -340,8 +396,12 @@ extern "C" int buctd_bn_bwd(const float* dy, const float* y, const float* z, con
   const int nchunks = ceil_div(rows, BWD_ROWS);
   float* part = (float*)workspace;
   float* s = part + (long)nchunks * 2 * C;
-  hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(nchunks), dim3(256), 0, st, dy, y, z, mean, invstd, relu, rows, C,
-                     part);
+  if (C % 4 == 0 && C / 4 <= 256)
+    hipLaunchKernelGGL(bn_bwd_reduce_vec_kernel, dim3(nchunks), dim3(256), 0, st, dy, y, z, mean, invstd, relu, rows,
+                       C, part);
+  else
+    hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(nchunks), dim3(256), 0, st, dy, y, z, mean, invstd, relu, rows, C,
+                       part);
   BUCTD_CHECK_LAUNCH("buctd_bn_bwd(reduce)");
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(ceil_div(C, 4)), dim3(256), 0, st, (const float*)part, nchunks, C, s,
                      dgamma, dbeta, accumulate);

@@ -545,7 +545,7 @@ static void wgrad_plan(const buctd_conv_desc* d, int* bm, int* bn, int* nsplit, 
   const int ncols = d->R * d->S * d->Ci;
   const long tiles = (long)ceil_div(co, *bm) * ceil_div(ncols, *bn);
   const long Mpix = (long)d->N * d->Ho * d->Wo;
-  long want = (1536 + tiles - 1) / tiles;  // ~6 workgroups per CU in total
+  long want = (768 + tiles - 1) / tiles;   // ~3 workgroups per CU in total
   long maxsplit = (Mpix + 255) / 256;      // at least 256 pixels per split
   if (want > maxsplit) want = maxsplit;
   if (want < 1) want = 1;

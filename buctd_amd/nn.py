@@ -68,7 +68,27 @@ class ConvTranspose2d(tnn.ConvTranspose2d):
 
 class BatchNorm2d(tnn.BatchNorm2d):
     """nn.BatchNorm2d container. Stand-alone forward (no producing conv) is not needed on the path;
-    BN always runs fused behind a conv via conv_bn_act()."""
+    BN always runs fused behind a conv via conv_bn_act().  num_batches_tracked (only consumed when
+    momentum=None, which the path never uses) is counted on the host and written back when a
+    state_dict is taken, instead of launching one int64 add kernel per BN per step."""
+
+    _pending_batches = 0
+
+    def count_batch(self):
+        self._pending_batches += 1
+
+    def flush_batches(self):
+        if self._pending_batches and self.num_batches_tracked is not None:
+            self.num_batches_tracked += self._pending_batches
+        self._pending_batches = 0
+
+    def _save_to_state_dict(self, destination, prefix, keep_vars):
+        self.flush_batches()
+        super()._save_to_state_dict(destination, prefix, keep_vars)
+
+    def _load_from_state_dict(self, *args, **kwargs):
+        self._pending_batches = 0
+        super()._load_from_state_dict(*args, **kwargs)
 
     def forward(self, x):
         raise RuntimeError("buctd_amd.nn.BatchNorm2d runs fused with its convolution (conv_bn_act)")

@@ -469,8 +469,8 @@ class ConvBnAct(torch.autograd.Function):
             track = bn.track_running_stats and training
             mean, invstd = bn_finalize(part, info, rows, Cn, eps, momentum,
                                        bn.running_mean if track else None, bn.running_var if track else None)
-            if track and bn.num_batches_tracked is not None:
-                bn.num_batches_tracked += 1
+            if track:
+                bn.count_batch() if hasattr(bn, "count_batch") else bn.num_batches_tracked.add_(1)
             y = bn_apply(z, mean, invstd, gamma, beta, residual, relu)
             ctx.save_for_backward(x, z, mean, invstd, y if relu else None)
             ctx.has_res = residual is not None

@@ -1,0 +1,164 @@
+"""train() / validate() entry points (reference lib/core/function.py:102-175, 178-336) driven end to end on the GPU
+with an in-memory loader and a fake dataset, checked against the CPU oracle running the same loop semantics:
+per-batch loss values, final parameters after Adam steps, the decoded all_preds handed to dataset.evaluate and
+the flip-test path (device flip-merge + GPU re-rendered colored condition)."""
+import copy
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+class Writer:
+    def __init__(self):
+        self.scalars = []
+
+    def add_scalar(self, k, v, s):
+        self.scalars.append((k, float(v), s))
+
+    def add_scalars(self, k, d, s):
+        self.scalars.append((k, dict(d), s))
+
+
+class FakeDataset:
+    def __init__(self, n, image_size, flip_pairs, colors):
+        self.n, self.image_size, self.flip_pairs, self.kpt_colors = n, image_size, flip_pairs, colors
+        self.captured = None
+
+    def __len__(self):
+        return self.n
+
+    def evaluate(self, cfg, preds, output_dir, all_boxes, img_path, *args, **kwargs):
+        self.captured = (preds.copy(), all_boxes.copy(), list(img_path))
+        return {"AP": 0.5, "AP .5": 0.75}, 0.5
+
+
+def _cfg_for(train_cfg, flip):
+    from buctd_amd.config import cfg as base, hrnet_extra
+    c = base.clone()
+    c.defrost()
+    c.MODEL.NAME = "pose_hrnet_coam"
+    c.MODEL.NUM_JOINTS = 14
+    c.MODEL.IMAGE_SIZE = [64, 96]
+    c.MODEL.HEATMAP_SIZE = [16, 24]
+    c.MODEL.SIGMA = 2
+    c.MODEL.ATT_MODULES = [False, True, False, False]
+    c.MODEL.CONDITIONAL_TOPDOWN = True
+    c.MODEL.EXTRA = hrnet_extra(16, use_attention=True, modules=(1, 2, 2))
+    c.DATASET.COLORED = True
+    c.TRAIN.LR = 1e-3
+    c.PRINT_FREQ = 1
+    c.TEST.FLIP_TEST = flip
+    c.TEST.POST_PROCESS = True
+    c.TEST.SHIFT_HEATMAP = True
+    c.freeze()
+    return c
+
+
+def _batches(cfg, n_batches, batch):
+    from oracle import recipes, core as oc
+    out = []
+    for i in range(n_batches):
+        x, joints = recipes.make_inputs(cfg, batch, 500 + i, 3)
+        tgt, wt = recipes.make_targets(cfg, joints, 600 + i)
+        meta = {"center": torch.rand(batch, 2) * 100 + 50, "scale": torch.rand(batch, 2) + 0.5,
+                "score": torch.rand(batch), "annotation_id": torch.arange(batch) + i * batch,
+                "image": [f"img_{i}_{j}.jpg" for j in range(batch)],
+                "cond_joints": torch.cat([joints, torch.zeros(batch, 14, 1)], 2),
+                "cond_joints_vis": torch.ones(batch, 14, 3)}
+        out.append((x, tgt, wt, meta))
+    return out
+
+
+def test_train_entry_point_matches_oracle_loop(dev):
+    from oracle import recipes, core as oc
+    from buctd_amd import models, engine
+    from buctd_amd.core.function import train
+    from buctd_amd.core.loss import JointsMSELoss
+    cfg = _cfg_for(True, False)
+    _, omodel, _, _ = recipes.build("coam_w16_96x64_colored")
+    net = models.pose_hrnet_coam.get_pose_net(cfg, is_train=False)
+    net.load_state_dict(omodel.state_dict(), strict=True)
+    model = engine.DataParallel(net).cuda()
+    optimizer = engine.get_optimizer(cfg, model)
+    recipes.set_dropout(model, 0.0)
+    loader = _batches(cfg, 3, 2)
+    wd = {"writer": Writer(), "train_global_steps": 0}
+    train(cfg, loader, model, JointsMSELoss(True).cuda(), optimizer, 1, "/tmp", "/tmp", wd)
+    assert wd["train_global_steps"] == 3
+    losses = [v for k, v, _ in wd["writer"].scalars if k == "train_loss"]
+    # oracle: same loop with torch.optim.Adam
+    om = copy.deepcopy(omodel).train()
+    recipes.set_dropout(om, 0.0)
+    opt = torch.optim.Adam(om.parameters(), lr=1e-3)
+    ref_losses = []
+    for x, tgt, wt, _ in loader:
+        loss = oc.JointsMSELoss(True)(om(x), tgt, wt)
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        ref_losses.append(loss.item())
+    assert abs(losses[0] - ref_losses[0]) <= 1e-4 * abs(ref_losses[0]), (losses, ref_losses)
+    # later steps go through Adam's sign-like first update (m/sqrt(v) ~ +-1): tiny gradient noise moves weights by lr,
+    # so trajectories agree to a few percent, not to round-off
+    for a, b in zip(losses[1:], ref_losses[1:]):
+        assert abs(a - b) <= 5e-2 * abs(b), (losses, ref_losses)
+    sd = model.module.state_dict()
+    ref_sd = om.state_dict()
+    assert list(sd.keys()) == list(ref_sd.keys())
+    assert int(sd["bn1.num_batches_tracked"]) == 3
+    pnames = {k for k, _ in om.named_parameters()}
+    worst = max(((float((sd[k].cpu() - ref_sd[k]).abs().max()), k) for k in pnames), key=lambda t: t[0])
+    # each Adam step moves a weight by at most ~lr; 3 steps with possibly opposite signs -> <= 2*3*lr
+    assert worst[0] <= 6.5e-3, f"parameter {worst[1]} drifted {worst[0]} after 3 Adam steps (lr 1e-3)"
+    for k in sd:
+        if k.endswith("running_mean") or k.endswith("running_var"):
+            a, b = sd[k].cpu(), ref_sd[k]
+            assert float((a - b).abs().max()) <= 0.1 * max(1.0, float(b.abs().max())), f"buffer {k}"  # trajectories diverge by ~lr per Adam step
+    assert list(model.state_dict().keys())[0].startswith("module.")
+
+
+@pytest.mark.parametrize("flip", [False, True])
+def test_validate_entry_point_matches_oracle_loop(dev, flip):
+    from oracle import recipes, core as oc
+    from buctd_amd import models
+    from buctd_amd.core.function import validate
+    from buctd_amd.core.loss import JointsMSELoss
+    cfg = _cfg_for(False, flip)
+    _, omodel, _, _ = recipes.build("coam_w16_96x64_colored")
+    net = models.pose_hrnet_coam.get_pose_net(cfg, is_train=False)
+    net.load_state_dict(omodel.state_dict(), strict=True)
+    net = net.cuda()
+    loader = _batches(cfg, 2, 2)
+    ds = FakeDataset(4, [64, 96], oc.CROWDPOSE_FLIP_PAIRS, oc.CROWDPOSE_KPT_COLORS)
+    wd = {"writer": Writer(), "valid_global_steps": 0}
+    perf = validate(cfg, loader, ds, net, JointsMSELoss(True).cuda(), "/tmp", "/tmp", wd)
+    assert perf == 0.5 and wd["valid_global_steps"] == 1
+    preds, boxes, paths = ds.captured
+    assert paths == [f"img_{i}_{j}.jpg" for i in range(2) for j in range(2)]
+    # oracle loop (function.py:178-270 semantics)
+    omodel.eval()
+    idx = 0
+    for x, tgt, wt, meta in loader:
+        with torch.no_grad():
+            out = omodel(x).numpy()
+            if flip:
+                conds = []
+                for b in range(x.shape[0]):
+                    fj, _ = oc.fliplr_joints(meta["cond_joints"][b].numpy(), meta["cond_joints_vis"][b].numpy(), 64,
+                                              oc.CROWDPOSE_FLIP_PAIRS)
+                    conds.append(oc.get_condition_image_colored(fj, (96, 64, 3), oc.CROWDPOSE_KPT_COLORS).transpose(2, 0, 1))
+                xf = torch.cat([x[:, :3].flip(3), torch.from_numpy(np.stack(conds)).float()], 1)
+                out = oc.flip_test_merge(out, omodel(xf).numpy(), oc.CROWDPOSE_FLIP_PAIRS, True)
+        fp, mv = oc.get_final_preds(True, out, meta["center"].numpy(), meta["scale"].numpy())
+        n = x.shape[0]
+        # decoded arg-max positions must agree exactly except where two heat-map values tie within fp32 noise;
+        # final coordinates are in image pixels (scale ~ 200 * s / 16 per heat-map pixel)
+        assert np.abs(preds[idx:idx + n, :, :2] - fp).max() <= 1e-2, "final preds differ"
+        assert np.abs(preds[idx:idx + n, :, 2:3] - mv).max() <= 1e-3 * max(1.0, np.abs(mv).max())
+        assert np.allclose(boxes[idx:idx + n, 0:2], meta["center"].numpy())
+        assert np.allclose(boxes[idx:idx + n, 4], np.prod(meta["scale"].numpy() * 200, 1))
+        assert np.allclose(boxes[idx:idx + n, 6], meta["annotation_id"].numpy())
+        idx += n
