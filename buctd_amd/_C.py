@@ -54,7 +54,10 @@ SIGNATURES = {
     "buctd_conv2d_wgrad": (_I, [_PD, _P, _P, _P, _I, _P, _SZ, _P]),
     "buctd_matmul_workspace": (_SZ, [_PM]),
     "buctd_matmul": (_I, [_PM, _P, _P, _P, _P, _P, _SZ, _P]),
-    "buctd_bn_finalize": (_I, [_P, _I, _I, _L, _I, _F, _F, _P, _P, _P, _P, _P]),
+    "buctd_bn_finalize": (_I, [_P, _P, _I, _I, _L, _I, _F, _F, _P, _P, _P, _P, _P]),
+    "buctd_conv3x3_bf16x3_supported": (_I, [_I, _I, _I, _I, _I]),
+    "buctd_conv3x3_bf16x3_stats_groups": (_I, [_I, _I, _I, _I, _I, _PI, _PI]),
+    "buctd_conv3x3_bf16x3": (_I, [_I, _I, _I, _I, _I, _P, _P, _I, _P, _P, _P, _P, _I, _P, _P, _P, _P]),
     "buctd_bn_stats": (_I, [_P, _L, _I, _P, _PI, _PI, _P]),
     "buctd_bn_stats_groups": (_I, [_L, _I, _PI, _PI]),
     "buctd_bn_apply": (_I, [_P, _P, _P, _P, _P, _P, _I, _P, _L, _I, _P]),

@@ -64,7 +64,8 @@ __device__ __forceinline__ double block_sum_d(double v, double* sm) {
   __syncthreads();
   return sm[0] + sm[1] + sm[2] + sm[3];
 }
-__global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ part, int ngroups, int rpg,
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ part,
+                                                          const int* __restrict__ counts, int ngroups, int rpg,
                                                           long rows, int C, float eps, float momentum,
                                                           float* __restrict__ mean, float* __restrict__ invstd,
                                                           float* __restrict__ rmean, float* __restrict__ rvar) {
@@ -74,6 +75,7 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
   for (int g = threadIdx.x; g < ngroups; g += 256) {
     long n = rows - (long)g * rpg;
     n = n < 0 ? 0 : (n > rpg ? rpg : n);
+    if (counts) n = counts[g];
     if (n > 0) s += (double)n * (double)part[((long)g * C + c) * 2];
   }
   const double mu = block_sum_d(s, sm) / (double)rows;
@@ -81,6 +83,7 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
   for (int g = threadIdx.x; g < ngroups; g += 256) {
     long n = rows - (long)g * rpg;
     n = n < 0 ? 0 : (n > rpg ? rpg : n);
+    if (counts) n = counts[g];
     if (n > 0) {
       const double d = (double)part[((long)g * C + c) * 2] - mu;
       q += (double)part[((long)g * C + c) * 2 + 1] + (double)n * d * d;
@@ -349,14 +352,15 @@ extern "C" int buctd_bn_stats(const float* z, long rows, int C, float* partials,
   return BUCTD_OK;
 }
 
-extern "C" int buctd_bn_finalize(const float* partials, int ngroups, int rows_per_group, long rows, int C, float eps,
+extern "C" int buctd_bn_finalize(const float* partials, const int* group_counts, int ngroups, int rows_per_group,
+                                 long rows, int C, float eps,
                                  float momentum, float* mean, float* invstd, float* running_mean,
                                  float* running_var, void* stream) {
   BUCTD_CHECK_ARG(partials && mean && invstd && ngroups > 0 && rows_per_group > 0 && rows > 0 && C > 0,
                   "buctd_bn_finalize: bad argument");
   BUCTD_CHECK_ARG((running_mean == nullptr) == (running_var == nullptr),
                   "buctd_bn_finalize: running_mean/var go together");
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, partials, ngroups,
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, partials, group_counts, ngroups,
                      rows_per_group, rows, C, eps, momentum, mean, invstd, running_mean, running_var);
   BUCTD_CHECK_LAUNCH("buctd_bn_finalize");
   return BUCTD_OK;

@@ -13,6 +13,7 @@ autograd, so no AccumulateGrad add kernels run.
 """
 import ctypes as C
 import math
+import os
 
 import torch
 
@@ -131,10 +132,48 @@ def conv_desc(x_shape, w_shape, stride, pad):
     return ConvDesc(N, H, W, Ci, Co, R, S, stride, pad, Ho, Wo)
 
 
+_conv_math = {"mode": os.environ.get("BUCTD_CONV_MATH", "fp32")}
+
+
+def set_conv_math(mode):
+    """'fp32': every convolution on the exact fp32 MFMA path.  'bf16x3': 3x3/stride-1/pad-1 convolutions (forward and
+    data gradient) on the bf16 matrix cores with split-fp32 operands (conv3x3.hip); everything else unchanged."""
+    if mode not in ("fp32", "bf16x3"):
+        raise ValueError("conv math mode must be 'fp32' or 'bf16x3'")
+    _conv_math["mode"] = mode
+
+
+def get_conv_math():
+    return _conv_math["mode"]
+
+
+def _bf16x3_ok(d):
+    return (_conv_math["mode"] == "bf16x3" and d.R == 3 and d.S == 3 and d.stride == 1 and d.pad == 1 and
+            lib().buctd_conv3x3_bf16x3_supported(d.N, d.H, d.W, d.Ci, d.Co) == 1)
+
+
+def _conv3x3_bf16x3(x, w, flip, cin, cout, bias, scale, shift, residual, relu, stats):
+    N, H, W = x.shape[0], x.shape[1], x.shape[2]
+    y = torch.empty((N, H, W, cout), dtype=torch.float32, device=x.device)
+    part = counts = info = None
+    if stats:
+        ng, rpg = C.c_int(), C.c_int()
+        check(lib().buctd_conv3x3_bf16x3_stats_groups(N, H, W, cin, cout, C.byref(ng), C.byref(rpg)), "conv3x3 groups")
+        part = torch.empty((ng.value, cout, 2), dtype=torch.float32, device=x.device)
+        counts = torch.empty(ng.value, dtype=torch.int32, device=x.device)
+        info = (ng.value, rpg.value, counts)
+    check(lib().buctd_conv3x3_bf16x3(N, H, W, cin, cout, ptr(x), ptr(w), int(flip), ptr(bias), ptr(scale), ptr(shift),
+                                     ptr(residual), int(bool(relu)), ptr(y), ptr(part), ptr(counts), stream_ptr()),
+          "conv3x3_bf16x3")
+    return (y, part, info) if stats else y
+
+
 def conv_fwd(x, w, bias=None, stride=1, pad=0, scale=None, shift=None, residual=None, relu=False, stats=False):
     _f32(x, "conv input")
     weight_rsc(w)
     d = conv_desc(x.shape, _wshape(w), stride, pad)
+    if _bf16x3_ok(d):
+        return _conv3x3_bf16x3(x, w, 0, d.Ci, d.Co, bias, scale, shift, residual, relu, stats)
     y = torch.empty((d.N, d.Ho, d.Wo, d.Co), dtype=torch.float32, device=x.device)
     part = None
     info = None
@@ -155,6 +194,8 @@ def conv_dgrad(dy, w, x_shape, stride=1, pad=0, bias=None, stats=False):
     d = conv_desc(x_shape, _wshape(w), stride, pad)
     if tuple(dy.shape) != (d.N, d.Ho, d.Wo, d.Co):
         raise _C.BuctdHipError(f"conv_dgrad: dy shape {tuple(dy.shape)} != {(d.N, d.Ho, d.Wo, d.Co)}")
+    if _bf16x3_ok(d) and lib().buctd_conv3x3_bf16x3_supported(d.N, d.H, d.W, d.Co, d.Ci) == 1:
+        return _conv3x3_bf16x3(dy, w, 1, d.Co, d.Ci, bias, None, None, None, False, stats)
     dx = torch.empty(tuple(x_shape), dtype=torch.float32, device=dy.device)
     part = None
     info = None
@@ -199,9 +240,11 @@ def matmul(A, B, Cout, *, batch, M, N, K, a_layout, b_layout, lda, ldb, ldc, str
 
 
 def bn_finalize(part, info, rows, Cn, eps, momentum, running_mean, running_var):
+    """info = (ngroups, rows_per_group[, per-group valid-row counts tensor])."""
     mean = torch.empty(Cn, dtype=torch.float32, device=part.device)
     invstd = torch.empty(Cn, dtype=torch.float32, device=part.device)
-    check(lib().buctd_bn_finalize(ptr(part), info[0], info[1], rows, Cn, eps, momentum, ptr(mean), ptr(invstd),
+    counts = info[2] if len(info) > 2 else None
+    check(lib().buctd_bn_finalize(ptr(part), ptr(counts), info[0], info[1], rows, Cn, eps, momentum, ptr(mean), ptr(invstd),
                                   ptr(running_mean), ptr(running_var), stream_ptr()), "bn_finalize")
     return mean, invstd
 

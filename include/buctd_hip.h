@@ -58,6 +58,17 @@ size_t buctd_conv2d_wgrad_workspace(const buctd_conv_desc* d);
 int buctd_conv2d_wgrad(const buctd_conv_desc* d, const float* x, const float* dy, float* dw, int accumulate,
                        void* workspace, size_t workspace_bytes, void* stream);
 
+/* 3x3 / stride 1 / pad 1 convolution on the bf16 matrix cores with split-fp32 operands ("bf16x3": hi*hi + hi*lo +
+ * lo*hi, fp32 accumulate; ~2^-16 relative product error).  Same epilogue options as buctd_conv2d_fwd.
+ * flip = 0: forward, w = [Co][3][3][Ci].  flip = 1: data gradient of that convolution: x is dy [N][H][W][Ci],
+ * y is dx [N][H][W][Co], w is the forward weight [Ci][3][3][Co].  Replaces the BasicBlock convs of
+ * pose_hrnet.py:28-57 when the "bf16x3" math mode is selected. stats_counts: ngroups ints (valid rows per group). */
+int buctd_conv3x3_bf16x3_supported(int N, int H, int W, int Ci, int Co);
+int buctd_conv3x3_bf16x3_stats_groups(int N, int H, int W, int Ci, int Co, int* ngroups, int* rows_per_group);
+int buctd_conv3x3_bf16x3(int N, int H, int W, int Ci, int Co, const float* x, const float* w, int flip,
+                         const float* bias, const float* scale, const float* shift, const float* residual, int relu,
+                         float* y, float* stats_partials, int* stats_counts, void* stream);
+
 /* ---------------------------------------------------------------- matmul --- */
 typedef struct {
   int batch, M, N, K;
@@ -78,10 +89,11 @@ int buctd_matmul(const buctd_matmul_desc* d, const float* A, const float* B, con
 
 /* ------------------------------------------------------------- batchnorm --- */
 /* Combine Welford partials -> mean, invstd (biased var, eps) and update running stats
- * (momentum, unbiased var) exactly like nn.BatchNorm2d in train mode (pose_hrnet.py:37). */
-int buctd_bn_finalize(const float* partials, int ngroups, int rows_per_group, long rows, int C, float eps,
-                      float momentum, float* mean, float* invstd, float* running_mean, float* running_var,
-                      void* stream);
+ * (momentum, unbiased var) exactly like nn.BatchNorm2d in train mode (pose_hrnet.py:37).
+ * group_counts (NULL ok): valid rows of each group when they are not rows_per_group-regular. */
+int buctd_bn_finalize(const float* partials, const int* group_counts, int ngroups, int rows_per_group, long rows,
+                      int C, float eps, float momentum, float* mean, float* invstd, float* running_mean,
+                      float* running_var, void* stream);
 /* Welford partials of a plain [rows][C] tensor (when the producer was not a conv epilogue). */
 int buctd_bn_stats(const float* z, long rows, int C, float* partials, int* ngroups, int* rows_per_group,
                    void* stream);
