@@ -58,6 +58,9 @@ SIGNATURES = {
     "buctd_conv3x3_bf16x3_supported": (_I, [_I, _I, _I, _I, _I]),
     "buctd_conv3x3_bf16x3_stats_groups": (_I, [_I, _I, _I, _I, _I, _PI, _PI]),
     "buctd_conv3x3_bf16x3": (_I, [_I, _I, _I, _I, _I, _P, _P, _I, _P, _P, _P, _P, _I, _P, _P, _P, _P]),
+    "buctd_conv3x3_wgrad_bf16x3_supported": (_I, [_I, _I, _I, _I, _I]),
+    "buctd_conv3x3_wgrad_bf16x3_workspace": (_SZ, [_I, _I, _I, _I, _I]),
+    "buctd_conv3x3_wgrad_bf16x3": (_I, [_I, _I, _I, _I, _I, _P, _P, _P, _I, _P, _SZ, _P]),
     "buctd_bn_stats": (_I, [_P, _L, _I, _P, _PI, _PI, _P]),
     "buctd_bn_stats_groups": (_I, [_L, _I, _PI, _PI]),
     "buctd_bn_apply": (_I, [_P, _P, _P, _P, _P, _P, _I, _P, _L, _I, _P]),

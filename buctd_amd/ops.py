@@ -217,6 +217,13 @@ def conv_wgrad(x, dy, w_like, stride=1, pad=0, out=None, accumulate=0):
         out = _new_like_weight(w_like)
         accumulate = 0
     weight_rsc(out)
+    if (_conv_math["mode"] == "bf16x3" and d.R == 3 and d.S == 3 and d.stride == 1 and d.pad == 1 and
+            lib().buctd_conv3x3_wgrad_bf16x3_supported(d.N, d.H, d.W, d.Ci, d.Co) == 1):
+        need = lib().buctd_conv3x3_wgrad_bf16x3_workspace(d.N, d.H, d.W, d.Ci, d.Co)
+        ws = workspace(need, x.device)
+        check(lib().buctd_conv3x3_wgrad_bf16x3(d.N, d.H, d.W, d.Ci, d.Co, ptr(x), ptr(dy), ptr(out), int(accumulate),
+                                               ptr(ws), ws.numel(), stream_ptr()), "conv3x3_wgrad_bf16x3")
+        return out
     need = lib().buctd_conv2d_wgrad_workspace(C.byref(d))
     ws = workspace(need, x.device)
     check(lib().buctd_conv2d_wgrad(C.byref(d), ptr(x), ptr(dy), ptr(out), int(accumulate), ptr(ws), ws.numel(),

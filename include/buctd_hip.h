@@ -69,6 +69,13 @@ int buctd_conv3x3_bf16x3(int N, int H, int W, int Ci, int Co, const float* x, co
                          const float* bias, const float* scale, const float* shift, const float* residual, int relu,
                          float* y, float* stats_partials, int* stats_counts, void* stream);
 
+/* weight gradient of the same convolution on the bf16 matrix cores (transpose-read fragments from position-major
+ * LDS tiles, split over positions through `workspace`): dw (+)= sum_p dy[p] (x) x[p + tap].  dw: [Co][3][3][Ci]. */
+int buctd_conv3x3_wgrad_bf16x3_supported(int N, int H, int W, int Ci, int Co);
+size_t buctd_conv3x3_wgrad_bf16x3_workspace(int N, int H, int W, int Ci, int Co);
+int buctd_conv3x3_wgrad_bf16x3(int N, int H, int W, int Ci, int Co, const float* x, const float* dy, float* dw,
+                               int accumulate, void* workspace, size_t workspace_bytes, void* stream);
+
 /* ---------------------------------------------------------------- matmul --- */
 typedef struct {
   int batch, M, N, K;
