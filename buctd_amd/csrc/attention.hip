@@ -8,16 +8,6 @@
 #include "common.h"
 #include "../../include/buctd_hip.h"
 
-__device__ __forceinline__ float keep_scale(uint64_t seed, uint64_t idx, float p_drop, float inv_keep) {
-  // splitmix64 finalizer over a Weyl sequence keyed by the seed
-  uint64_t z = seed + (idx + 1) * 0x9E3779B97F4A7C15ull;
-  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-  z ^= z >> 31;
-  const float u = (float)(z >> 40) * (1.0f / 16777216.0f);
-  return u >= p_drop ? inv_keep : 0.f;
-}
-
 // ------------------------------------------------------ softmax, one block per row ----
 #define SM_NPT 32  // values cached per thread: rows up to 8192 columns stay in registers
 __global__ __launch_bounds__(256) void softmax_fwd_block_kernel(const float* __restrict__ s, int L, float scale,

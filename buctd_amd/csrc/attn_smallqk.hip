@@ -1,0 +1,413 @@
+// Fused (flash-style) attention for the CoAM position-attention core when the query/key contraction is narrow.
+//
+// Reference lib/models/self_attention.py:74-86 computes  softmax(fc_q(y_cond) fc_k(y)^T / sqrt(C)) -> dropout -> . V
+// and materialises the T x T matrix three times (191 MB per image at T = 6912).  Because fc_q acts on only
+// d_cond (+1 for its bias) input channels, the logits have rank R = d_cond + 1:
+//     S = [y_cond, 1] ([Wq | bq]^T K^T)          (verified there to 3e-9)
+// so the host (buctd_amd/models/self_attention.py) hands this kernel  q' = [y_cond, 1, 0-pad] (B,T,R4)  and
+// k' = K [Wq | bq] (B,T,R4), and the logits cost R4 FMAs per element on the VALU.  Nothing T x T ever reaches HBM:
+//   attn_stats : per query row, running max m and sum l of exp(s - m) over all keys (one pass, LDS-staged keys)
+//   attn_fwd   : O = P V with P = exp(s - m)/l (x dropout) regenerated on the fly as the MFMA A operand
+//   attn_bwd_q : dP = dO V^T on the MFMA, dS = P (g - D), D = dO.O ; accumulates dq' ; also writes D
+//   attn_bwd_kv: per key block: dV += Pd^T dO and dk' += dS^T q' (P regenerated in both fragment layouts)
+// All contractions over C or T run on v_mfma_f32_16x16x4_f32 (exact fp32).  Algorithmic HBM traffic per image is
+// O(T (R4 + C)) instead of O(T^2); the dropout mask is a counter hash of (seed, b*T + i, j).
+#include "gemm_core.h"
+#include "../../include/buctd_hip.h"
+
+__device__ __forceinline__ float keep32(uint32_t s0, uint32_t s1, uint32_t row, uint32_t col, float p_drop,
+                                        float inv_keep) {
+  uint32_t x = s0 ^ (row * 0x9E3779B1u) ^ (s1 + col * 0x85EBCA77u);
+  x ^= x >> 16; x *= 0x7FEB352Du; x ^= x >> 15; x *= 0x846CA68Bu; x ^= x >> 16;
+  return (float)(x >> 8) * (1.0f / 16777216.0f) >= p_drop ? inv_keep : 0.f;
+}
+
+struct AttnArgs {
+  const float* q;     // [B][T][R4]
+  const float* k;     // [B][T][R4]
+  const float* v;     // [B][T][C]
+  const float* o;     // [B][T][C]   (bwd)
+  const float* dout;  // [B][T][C]   (bwd)
+  float* m;           // [B][T] row max of the scaled logits
+  float* linv;        // [B][T] 1 / sum exp(s - m)
+  float* dvec;        // [B][T] D = dO . O
+  float* out;         // fwd: O ; bwd_q: dq' ; bwd_kv: dk'
+  float* out2;        // bwd_kv: dV
+  int T, C;
+  float scale, p_drop, inv_keep;
+  uint32_t s0, s1;
+};
+
+template <int R4>
+__device__ __forceinline__ float dotr(const float (&a)[R4], const float* b) {
+  float s = 0.f;
+#pragma unroll
+  for (int r = 0; r < R4; ++r) s += a[r] * b[r];
+  return s;
+}
+template <int R4>
+__device__ __forceinline__ void loadr(float (&a)[R4], const float* p) {
+#pragma unroll
+  for (int r = 0; r < R4; r += 4) {
+    const f32x4 t = *reinterpret_cast<const f32x4*>(p + r);
+    a[r] = t.x; a[r + 1] = t.y; a[r + 2] = t.z; a[r + 3] = t.w;
+  }
+}
+
+// ------------------------------------------------------------------------------------------- stats ----
+// one thread per query row, keys streamed through LDS in chunks of 512
+template <int R4>
+__global__ __launch_bounds__(256) void attn_stats_kernel(AttnArgs p) {
+  __shared__ __attribute__((aligned(16))) float ks[512 * R4];
+  const int b = blockIdx.y;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  float qv[R4];
+#pragma unroll
+  for (int r = 0; r < R4; ++r) qv[r] = 0.f;
+  if (i < p.T) loadr<R4>(qv, p.q + ((long)b * p.T + i) * R4);
+#pragma unroll
+  for (int r = 0; r < R4; ++r) qv[r] *= p.scale;
+  float mx = -INFINITY, sum = 0.f;
+  for (int j0 = 0; j0 < p.T; j0 += 512) {
+    const int nj = p.T - j0 < 512 ? p.T - j0 : 512;
+    __syncthreads();
+    for (int e = threadIdx.x; e < nj * R4 / 4; e += 256)
+      reinterpret_cast<f32x4*>(ks)[e] = reinterpret_cast<const f32x4*>(p.k + ((long)b * p.T + j0) * R4)[e];
+    __syncthreads();
+    for (int j = 0; j < nj; ++j) {
+      const float s = dotr<R4>(qv, ks + j * R4);
+      if (s > mx) {
+        sum = sum * __expf(mx - s) + 1.f;
+        mx = s;
+      } else {
+        sum += __expf(s - mx);
+      }
+    }
+  }
+  if (i < p.T) {
+    p.m[(long)b * p.T + i] = mx;
+    p.linv[(long)b * p.T + i] = 1.f / sum;
+  }
+}
+
+// --------------------------------------------------------------------------------------------- fwd ----
+// workgroup = 64 query rows (16 per wave); key blocks of 64
+template <int R4, int CF>
+__global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs p) {
+  // B-operand reads touch rows 4s+kq at columns nf*16 + i16: conflict-free when the row stride is 16 mod 64 floats
+  constexpr int C = CF * 16, LDV = C + (80 - C % 64) % 64;
+  __shared__ __attribute__((aligned(16))) float ks[64 * R4];
+  __shared__ __attribute__((aligned(16))) float vs[64 * LDV];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int i16 = lane & 15, kq = lane >> 4;
+  const int b = blockIdx.y;
+  const int i = blockIdx.x * 64 + wave * 16 + i16;          // A-layout row of this lane
+  const long rowbase = (long)b * p.T;
+  float qv[R4];
+  loadr<R4>(qv, p.q + (rowbase + i) * R4);
+#pragma unroll
+  for (int r = 0; r < R4; ++r) qv[r] *= p.scale;
+  const float mi = p.m[rowbase + i], li = p.linv[rowbase + i];
+  f32x4 acc[CF];
+#pragma unroll
+  for (int nf = 0; nf < CF; ++nf) acc[nf] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  for (int j0 = 0; j0 < p.T; j0 += 64) {
+    __syncthreads();
+    for (int e = t; e < 64 * R4 / 4; e += 256)
+      reinterpret_cast<f32x4*>(ks)[e] = reinterpret_cast<const f32x4*>(p.k + (rowbase + j0) * R4)[e];
+    for (int e = t; e < 64 * (C / 4); e += 256) {
+      const int r = e / (C / 4), c4 = e - r * (C / 4);
+      *reinterpret_cast<f32x4*>(vs + r * LDV + c4 * 4) = reinterpret_cast<const f32x4*>(p.v + (rowbase + j0 + r) * C)[c4];
+    }
+    __syncthreads();
+#pragma unroll 4
+    for (int s = 0; s < 16; ++s) {
+      const int j = 4 * s + kq;
+      float pv = __expf(dotr<R4>(qv, ks + j * R4) - mi) * li;
+      if (p.p_drop > 0.f) pv *= keep32(p.s0, p.s1, (uint32_t)(rowbase + i), (uint32_t)(j0 + j), p.p_drop, p.inv_keep);
+#pragma unroll
+      for (int nf = 0; nf < CF; ++nf)
+        acc[nf] = __builtin_amdgcn_mfma_f32_16x16x4f32(pv, vs[j * LDV + nf * 16 + i16], acc[nf], 0, 0, 0);
+    }
+  }
+  // C/D layout: row = kq*4 + reg, col = nf*16 + i16
+#pragma unroll
+  for (int nf = 0; nf < CF; ++nf)
+#pragma unroll
+    for (int rg = 0; rg < 4; ++rg)
+      p.out[(rowbase + blockIdx.x * 64 + wave * 16 + kq * 4 + rg) * C + nf * 16 + i16] = acc[nf][rg];
+}
+
+// ------------------------------------------------------------------------------------------- bwd_q ----
+template <int R4, int CF>
+__global__ __launch_bounds__(256) void attn_bwd_q_kernel(AttnArgs p) {
+  constexpr int C = CF * 16, CS = C / 4, LDV = C + 8;  // b128 row reads: stride 32 mod 64 bytes
+  __shared__ __attribute__((aligned(16))) float ks[64 * R4];
+  __shared__ __attribute__((aligned(16))) float vs[64 * LDV];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int i16 = lane & 15, kq = lane >> 4;
+  const int b = blockIdx.y;
+  const long rowbase = (long)b * p.T;
+  const int r0 = blockIdx.x * 64 + wave * 16;
+  // A operand: dO[row r0+i16][c = kq*CS + s]  (the reduction index c is permuted identically for A and B)
+  float ado[CS];
+  float dpart = 0.f;
+  {
+    const float* dp = p.dout + (rowbase + r0 + i16) * C + kq * CS;
+    const float* op = p.o + (rowbase + r0 + i16) * C + kq * CS;
+#pragma unroll
+    for (int s = 0; s < CS; s += 4) {
+      const f32x4 d = *reinterpret_cast<const f32x4*>(dp + s);
+      const f32x4 o = *reinterpret_cast<const f32x4*>(op + s);
+      ado[s] = d.x; ado[s + 1] = d.y; ado[s + 2] = d.z; ado[s + 3] = d.w;
+      dpart += d.x * o.x + d.y * o.y + d.z * o.z + d.w * o.w;
+    }
+  }
+  dpart += __shfl_xor(dpart, 16, 64);
+  dpart += __shfl_xor(dpart, 32, 64);            // D of row r0 + i16, in every lane of that column group
+  if (kq == 0) p.dvec[rowbase + r0 + i16] = dpart;
+  // C/D layout rows of this lane: r0 + kq*4 + rg
+  float qrow[4][R4], mrow[4], lrow[4], drow[4];
+#pragma unroll
+  for (int rg = 0; rg < 4; ++rg) {
+    const long row = rowbase + r0 + kq * 4 + rg;
+    loadr<R4>(qrow[rg], p.q + row * R4);
+#pragma unroll
+    for (int r = 0; r < R4; ++r) qrow[rg][r] *= p.scale;
+    mrow[rg] = p.m[row];
+    lrow[rg] = p.linv[row];
+    drow[rg] = __shfl(dpart, kq * 4 + rg, 64);   // lane (kq*4+rg) has i16 == that row
+  }
+  float dq[4][R4];
+#pragma unroll
+  for (int rg = 0; rg < 4; ++rg)
+#pragma unroll
+    for (int r = 0; r < R4; ++r) dq[rg][r] = 0.f;
+
+  for (int j0 = 0; j0 < p.T; j0 += 64) {
+    __syncthreads();
+    for (int e = t; e < 64 * R4 / 4; e += 256)
+      reinterpret_cast<f32x4*>(ks)[e] = reinterpret_cast<const f32x4*>(p.k + (rowbase + j0) * R4)[e];
+    for (int e = t; e < 64 * (C / 4); e += 256) {
+      const int r = e / (C / 4), c4 = e - r * (C / 4);
+      *reinterpret_cast<f32x4*>(vs + r * LDV + c4 * 4) = reinterpret_cast<const f32x4*>(p.v + (rowbase + j0 + r) * C)[c4];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int f = 0; f < 4; ++f) {
+      // dP[rows][keys 16f..16f+15] = dO V^T : B(k = c, n = key) = V[key][c]
+      f32x4 dp4 = (f32x4){0.f, 0.f, 0.f, 0.f};
+      const float* vrow = vs + (16 * f + i16) * LDV + kq * CS;
+#pragma unroll
+      for (int s = 0; s < CS; ++s) dp4 = __builtin_amdgcn_mfma_f32_16x16x4f32(ado[s], vrow[s], dp4, 0, 0, 0);
+      const int j = 16 * f + i16;                 // C/D column of this lane
+      float kv[R4];
+      loadr<R4>(kv, ks + j * R4);
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg) {
+        const float pv = __expf(dotr<R4>(qrow[rg], kv) - mrow[rg]) * lrow[rg];
+        float g = dp4[rg];
+        if (p.p_drop > 0.f)
+          g *= keep32(p.s0, p.s1, (uint32_t)(rowbase + r0 + kq * 4 + rg), (uint32_t)(j0 + j), p.p_drop, p.inv_keep);
+        const float ds = pv * (g - drow[rg]);
+#pragma unroll
+        for (int r = 0; r < R4; ++r) dq[rg][r] += ds * kv[r];
+      }
+    }
+  }
+  // reduce over the 16 column lanes, scale, store dq'
+#pragma unroll
+  for (int rg = 0; rg < 4; ++rg)
+#pragma unroll
+    for (int r = 0; r < R4; ++r) {
+      float v = dq[rg][r];
+      v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);
+      if (i16 == 0) p.out[(rowbase + r0 + kq * 4 + rg) * R4 + r] = v * p.scale;
+    }
+}
+
+// ------------------------------------------------------------------------------------------ bwd_kv ----
+// workgroup = 64 keys (16 per wave), loop over query blocks of 64
+template <int R4, int CF>
+__global__ __launch_bounds__(256) void attn_bwd_kv_kernel(AttnArgs p) {
+  constexpr int C = CF * 16, CS = C / 4, LDV = C + 8;  // b128 row reads: stride 32 mod 64 bytes
+  __shared__ __attribute__((aligned(16))) float qs[64 * R4];
+  __shared__ __attribute__((aligned(16))) float dos[64 * LDV];
+  __shared__ float ms[64], ls[64], dsm[64];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int i16 = lane & 15, kq = lane >> 4;
+  const int b = blockIdx.y;
+  const long rowbase = (long)b * p.T;
+  const int j0 = blockIdx.x * 64 + wave * 16;      // first key of this wave
+  // A-layout key of this lane (j0 + i16): k' for the P regeneration, V row for dP
+  float ka[R4];
+  loadr<R4>(ka, p.k + (rowbase + j0 + i16) * R4);
+  float av[CS];
+  {
+    const float* vp = p.v + (rowbase + j0 + i16) * C + kq * CS;
+#pragma unroll
+    for (int s = 0; s < CS; s += 4) {
+      const f32x4 d = *reinterpret_cast<const f32x4*>(vp + s);
+      av[s] = d.x; av[s + 1] = d.y; av[s + 2] = d.z; av[s + 3] = d.w;
+    }
+  }
+  // C/D-layout keys of this lane: j0 + kq*4 + rg
+  float krow[4][R4];
+#pragma unroll
+  for (int rg = 0; rg < 4; ++rg) loadr<R4>(krow[rg], p.k + (rowbase + j0 + kq * 4 + rg) * R4);
+  f32x4 dv[CF];
+#pragma unroll
+  for (int nf = 0; nf < CF; ++nf) dv[nf] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  float dk[4][R4];
+#pragma unroll
+  for (int rg = 0; rg < 4; ++rg)
+#pragma unroll
+    for (int r = 0; r < R4; ++r) dk[rg][r] = 0.f;
+
+  for (int i0 = 0; i0 < p.T; i0 += 64) {
+    __syncthreads();
+    for (int e = t; e < 64 * R4; e += 256) qs[e] = p.q[(rowbase + i0) * R4 + e] * p.scale;
+    for (int e = t; e < 64 * (C / 4); e += 256) {
+      const int r = e / (C / 4), c4 = e - r * (C / 4);
+      *reinterpret_cast<f32x4*>(dos + r * LDV + c4 * 4) =
+          reinterpret_cast<const f32x4*>(p.dout + (rowbase + i0 + r) * C)[c4];
+    }
+    if (t < 64) {
+      ms[t] = p.m[rowbase + i0 + t];
+      ls[t] = p.linv[rowbase + i0 + t];
+      dsm[t] = p.dvec[rowbase + i0 + t];
+    }
+    __syncthreads();
+    // (a) dV[key][c] += sum_i Pd[i][key] dO[i][c] : A(m = key, k = query) generated on the VALU
+#pragma unroll 4
+    for (int s = 0; s < 16; ++s) {
+      const int i = 4 * s + kq;
+      float pv = __expf(dotr<R4>(ka, qs + i * R4) - ms[i]) * ls[i];
+      if (p.p_drop > 0.f)
+        pv *= keep32(p.s0, p.s1, (uint32_t)(rowbase + i0 + i), (uint32_t)(j0 + i16), p.p_drop, p.inv_keep);
+#pragma unroll
+      for (int nf = 0; nf < CF; ++nf)
+        dv[nf] = __builtin_amdgcn_mfma_f32_16x16x4f32(pv, dos[i * LDV + nf * 16 + i16], dv[nf], 0, 0, 0);
+    }
+    // (b) dP^T[key][query] = V dO^T, then dS and dk' += dS^T q'
+#pragma unroll
+    for (int f = 0; f < 4; ++f) {
+      f32x4 dp4 = (f32x4){0.f, 0.f, 0.f, 0.f};
+      const float* drow = dos + (16 * f + i16) * LDV + kq * CS;
+#pragma unroll
+      for (int s = 0; s < CS; ++s) dp4 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s], drow[s], dp4, 0, 0, 0);
+      const int i = 16 * f + i16;                  // query column of this lane
+      float qv[R4];
+      loadr<R4>(qv, qs + i * R4);
+      const float mi = ms[i], li = ls[i], di = dsm[i];
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg) {
+        const float pv = __expf(dotr<R4>(krow[rg], qv) - mi) * li;
+        float g = dp4[rg];
+        if (p.p_drop > 0.f)
+          g *= keep32(p.s0, p.s1, (uint32_t)(rowbase + i0 + i), (uint32_t)(j0 + kq * 4 + rg), p.p_drop, p.inv_keep);
+        const float ds = pv * (g - di);
+#pragma unroll
+        for (int r = 0; r < R4; ++r) dk[rg][r] += ds * qv[r];   // qv already carries the 1/sqrt(C) scale
+      }
+    }
+  }
+#pragma unroll
+  for (int nf = 0; nf < CF; ++nf)
+#pragma unroll
+    for (int rg = 0; rg < 4; ++rg) p.out2[(rowbase + j0 + kq * 4 + rg) * C + nf * 16 + i16] = dv[nf][rg];
+#pragma unroll
+  for (int rg = 0; rg < 4; ++rg)
+#pragma unroll
+    for (int r = 0; r < R4; ++r) {
+      float v = dk[rg][r];
+      v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);
+      if (i16 == 0) p.out[(rowbase + j0 + kq * 4 + rg) * R4 + r] = v;
+    }
+}
+
+// -------------------------------------------------------------------------------------------- host ----
+static bool attn_shape_ok(int T, int R4, int C) {
+  return T > 0 && T % 64 == 0 && (R4 == 4 || R4 == 8 || R4 == 16 || R4 == 20) && (C == 48 || C == 96 || C == 192 ||
+                                                                                   C == 16 || C == 32 || C == 64 ||
+                                                                                   C == 128);
+}
+
+extern "C" int buctd_attn_smallqk_supported(int T, int R4, int C) { return attn_shape_ok(T, R4, C) ? 1 : 0; }
+
+template <int R4, int CF>
+static void attn_launch(int which, const AttnArgs& a, int B, hipStream_t st) {
+  const dim3 grid(a.T / 64, B);
+  if (which == 1) hipLaunchKernelGGL((attn_fwd_kernel<R4, CF>), grid, dim3(256), 0, st, a);
+  else if (which == 2) hipLaunchKernelGGL((attn_bwd_q_kernel<R4, CF>), grid, dim3(256), 0, st, a);
+  else hipLaunchKernelGGL((attn_bwd_kv_kernel<R4, CF>), grid, dim3(256), 0, st, a);
+}
+template <int R4>
+static void attn_dispatch_c(int which, const AttnArgs& a, int B, hipStream_t st) {
+  switch (a.C) {
+    case 16: attn_launch<R4, 1>(which, a, B, st); break;
+    case 32: attn_launch<R4, 2>(which, a, B, st); break;
+    case 48: attn_launch<R4, 3>(which, a, B, st); break;
+    case 64: attn_launch<R4, 4>(which, a, B, st); break;
+    case 96: attn_launch<R4, 6>(which, a, B, st); break;
+    case 128: attn_launch<R4, 8>(which, a, B, st); break;
+    default: attn_launch<R4, 12>(which, a, B, st); break;
+  }
+}
+static void attn_dispatch(int which, const AttnArgs& a, int R4, int B, hipStream_t st) {
+  if (which == 0) {
+    const dim3 grid(ceil_div(a.T, 256), B);
+    if (R4 == 4) hipLaunchKernelGGL((attn_stats_kernel<4>), grid, dim3(256), 0, st, a);
+    else if (R4 == 8) hipLaunchKernelGGL((attn_stats_kernel<8>), grid, dim3(256), 0, st, a);
+    else if (R4 == 16) hipLaunchKernelGGL((attn_stats_kernel<16>), grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((attn_stats_kernel<20>), grid, dim3(256), 0, st, a);
+    return;
+  }
+  if (R4 == 4) attn_dispatch_c<4>(which, a, B, st);
+  else if (R4 == 8) attn_dispatch_c<8>(which, a, B, st);
+  else if (R4 == 16) attn_dispatch_c<16>(which, a, B, st);
+  else attn_dispatch_c<20>(which, a, B, st);
+}
+
+static AttnArgs attn_args(int T, int C, float scale, float p_drop, uint64_t seed) {
+  AttnArgs a;
+  memset(&a, 0, sizeof(a));
+  a.T = T; a.C = C; a.scale = scale; a.p_drop = p_drop;
+  a.inv_keep = p_drop > 0.f ? 1.f / (1.f - p_drop) : 1.f;
+  a.s0 = (uint32_t)seed; a.s1 = (uint32_t)(seed >> 32);
+  return a;
+}
+
+extern "C" int buctd_attn_smallqk_fwd(int B, int T, int R4, int C, const float* q, const float* k, const float* v,
+                                      float scale, float p_drop, uint64_t seed, float* out, float* m, float* linv,
+                                      void* stream) {
+  BUCTD_CHECK_ARG(q && k && v && out && m && linv && B > 0, "buctd_attn_smallqk_fwd: null argument");
+  BUCTD_CHECK_ARG(attn_shape_ok(T, R4, C), "buctd_attn_smallqk_fwd: unsupported T=%d R4=%d C=%d", T, R4, C);
+  BUCTD_CHECK_ARG(p_drop >= 0.f && p_drop < 1.f && (long)B * T < 2147483647L, "buctd_attn_smallqk_fwd: bad p_drop / size");
+  AttnArgs a = attn_args(T, C, scale, p_drop, seed);
+  a.q = q; a.k = k; a.v = v; a.m = m; a.linv = linv; a.out = out;
+  attn_dispatch(0, a, R4, B, (hipStream_t)stream);
+  BUCTD_CHECK_LAUNCH("buctd_attn_smallqk_fwd(stats)");
+  attn_dispatch(1, a, R4, B, (hipStream_t)stream);
+  BUCTD_CHECK_LAUNCH("buctd_attn_smallqk_fwd");
+  return BUCTD_OK;
+}
+
+extern "C" int buctd_attn_smallqk_bwd(int B, int T, int R4, int C, const float* q, const float* k, const float* v,
+                                      const float* o, const float* dout, const float* m, const float* linv,
+                                      float scale, float p_drop, uint64_t seed, float* dq, float* dk, float* dv,
+                                      float* dvec_workspace, void* stream) {
+  BUCTD_CHECK_ARG(q && k && v && o && dout && m && linv && dq && dk && dv && dvec_workspace && B > 0,
+                  "buctd_attn_smallqk_bwd: null argument");
+  BUCTD_CHECK_ARG(attn_shape_ok(T, R4, C), "buctd_attn_smallqk_bwd: unsupported T=%d R4=%d C=%d", T, R4, C);
+  AttnArgs a = attn_args(T, C, scale, p_drop, seed);
+  a.q = q; a.k = k; a.v = v; a.o = o; a.dout = dout;
+  a.m = const_cast<float*>(m); a.linv = const_cast<float*>(linv); a.dvec = dvec_workspace;
+  a.out = dq;
+  attn_dispatch(2, a, R4, B, (hipStream_t)stream);
+  BUCTD_CHECK_LAUNCH("buctd_attn_smallqk_bwd(q)");
+  a.out = dk; a.out2 = dv;
+  attn_dispatch(3, a, R4, B, (hipStream_t)stream);
+  BUCTD_CHECK_LAUNCH("buctd_attn_smallqk_bwd(kv)");
+  return BUCTD_OK;
+}

@@ -64,3 +64,16 @@ __device__ __forceinline__ float block_max_256(float v, float* sm) {
   __syncthreads();
   return fmaxf(fmaxf(sm[0], sm[1]), fmaxf(sm[2], sm[3]));
 }
+
+// Counter-based dropout: keep/scale factor of element `idx` under `seed` (shared by the fused softmax, the
+// element-wise dropout and the fused attention kernels, so forward and backward regenerate the same mask).
+__device__ __forceinline__ float keep_scale(uint64_t seed, uint64_t idx, float p_drop, float inv_keep) {
+  // splitmix64 finalizer over a Weyl sequence keyed by the seed
+  uint64_t z = seed + (idx + 1) * 0x9E3779B97F4A7C15ull;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  z ^= z >> 31;
+  const float u = (float)(z >> 40) * (1.0f / 16777216.0f);
+  return u >= p_drop ? inv_keep : 0.f;
+}
+

@@ -720,6 +720,88 @@ class PositionAttention(torch.autograd.Function):
         return dq, (None if packed else dkk), dvv, None, None, None
 
 
+def attn_smallqk_ok(T, d_in, C, h=1):
+    """True when the fused narrow-contraction attention (attn_smallqk.hip) covers this shape."""
+    if h != 1 or d_in + 1 > 20:
+        return False
+    R4 = _smallqk_r4(d_in)
+    return bool(lib().buctd_attn_smallqk_supported(T, R4, C))
+
+
+def _smallqk_r4(d_in):
+    r = d_in + 1
+    return 4 if r <= 4 else 8 if r <= 8 else 16 if r <= 16 else 20
+
+
+class SmallQKAttention(torch.autograd.Function):
+    """fc_q -> softmax(q k^T / sqrt(C)) -> dropout -> . v (self_attention.py:74-86, h = 1) without the T x T matrix.
+    yq [B,T,d] are the raw condition tokens (fc_q's input), wq [C,d] / bq [C] fc_q's parameters, k / v [B,T,C].
+    fc_q is folded into the keys: logits = [yq, 1] ([wq | bq]^T k^T), so the kernels contract over R4 <= 20
+    channels on the VALU and keep the MFMA for the T- and C-contractions (attn_smallqk.hip)."""
+
+    @staticmethod
+    def forward(ctx, yq, wq, bq, k, v, p_drop, training):
+        B, T, d = yq.shape
+        Cn = k.shape[2]
+        R4 = _smallqk_r4(d)
+        dev = yq.device
+        qp = torch.zeros((B, T, R4), dtype=torch.float32, device=dev)
+        qp[:, :, :d] = yq
+        qp[:, :, d] = 1.0
+        w4t = torch.zeros((R4, Cn), dtype=torch.float32, device=dev)       # rows: wq^T, bq, 0-pad
+        w4t[:d] = wq.detach().t()
+        w4t[d] = bq.detach()
+        k = _contig(k)
+        v = _contig(v)
+        kp = torch.empty((B, T, R4), dtype=torch.float32, device=dev)
+        matmul(k, w4t, kp, batch=1, M=B * T, N=R4, K=Cn, a_layout=0, b_layout=0, lda=Cn, ldb=Cn, ldc=R4)
+        scale = 1.0 / math.sqrt(Cn)
+        p_eff = float(p_drop) if training else 0.0
+        seed = next_seed()
+        out = torch.empty((B, T, Cn), dtype=torch.float32, device=dev)
+        m = torch.empty((B, T), dtype=torch.float32, device=dev)
+        linv = torch.empty((B, T), dtype=torch.float32, device=dev)
+        check(lib().buctd_attn_smallqk_fwd(B, T, R4, Cn, ptr(qp), ptr(kp), ptr(v), scale, p_eff, seed, ptr(out), ptr(m),
+                                           ptr(linv), stream_ptr()), "attn_smallqk_fwd")
+        ctx.meta = (d, R4, scale, p_eff, seed)
+        ctx.save_for_backward(qp, kp, k, v, out, m, linv, w4t, wq, bq)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        d, R4, scale, p_eff, seed = ctx.meta
+        qp, kp, k, v, out, m, linv, w4t, wq, bq = ctx.saved_tensors
+        dout = _contig(dout)
+        B, T, Cn = v.shape
+        dev = v.device
+        dqp = torch.empty_like(qp)
+        dkp = torch.empty_like(kp)
+        dv = torch.empty_like(v)
+        dvec = torch.empty((B, T), dtype=torch.float32, device=dev)
+        check(lib().buctd_attn_smallqk_bwd(B, T, R4, Cn, ptr(qp), ptr(kp), ptr(v), ptr(out), ptr(dout), ptr(m), ptr(linv),
+                                           scale, p_eff, seed, ptr(dqp), ptr(dkp), ptr(dv), ptr(dvec), stream_ptr()),
+              "attn_smallqk_bwd")
+        # k' = k w4t^T  ->  dk = dk' w4t ; dw4t = dk'^T k
+        dk = torch.empty_like(k)
+        matmul(dkp, w4t, dk, batch=1, M=B * T, N=Cn, K=R4, a_layout=0, b_layout=1, lda=R4, ldb=Cn, ldc=Cn)
+        dw4t = torch.empty_like(w4t)
+        matmul(dkp, k, dw4t, batch=1, M=R4, N=Cn, K=B * T, a_layout=1, b_layout=1, lda=R4, ldb=Cn, ldc=Cn)
+        dyq = dqp[:, :, :d].contiguous() if ctx.needs_input_grad[0] else None
+        gw, acc = grad_target(wq)
+        if acc:
+            gw.add_(dw4t[:d].t())
+        else:
+            gw.copy_(dw4t[:d].t())
+        grad_done(wq)
+        gb, acc = grad_target(bq)
+        if acc:
+            gb.add_(dw4t[d])
+        else:
+            gb.copy_(dw4t[d])
+        grad_done(bq)
+        return dyq, None, None, dk, dv, None, None
+
+
 class ChannelAttention(torch.autograd.Function):
     """SimplifiedScaledDotProductAttention + fc_o on channel-major queries (self_attention.py:146-159)
     evaluated on NHWC token tensors: qn [B,T,C] (condition features), yn [B,T,C] (keys = values).

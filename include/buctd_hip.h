@@ -166,6 +166,20 @@ int buctd_softmax_dropout_fwd(const float* s, long rows, int L, float scale, flo
 /* ds = scale * p * (g - sum_j g_j p_j), g = dpd * keep/(1-p_drop) */
 int buctd_softmax_dropout_bwd(const float* dpd, const float* p, long rows, int L, float scale, float p_drop,
                               uint64_t seed, float* ds, void* stream);
+/* Fused position attention for narrow query/key contractions (self_attention.py:74-86 with fc_q folded into the
+ * keys: logits = scale * q' k'^T with q' = [y_cond, 1, 0-pad] and k' = fc_k(y) [Wq | bq | 0], both [B][T][R4]).
+ * out = dropout(softmax(logits)) v, v and out [B][T][C]; nothing of size T x T is written to memory.
+ * m / linv [B][T] receive the row max and reciprocal row sum (saved for the backward).  The dropout mask is a
+ * counter hash of (seed, b*T + i, j), rebuilt by the backward.  Shapes: T % 64 == 0, R4 in {4,8,16,20},
+ * C in {16,32,48,64,96,128,192} (buctd_attn_smallqk_supported). */
+int buctd_attn_smallqk_supported(int T, int R4, int C);
+int buctd_attn_smallqk_fwd(int B, int T, int R4, int C, const float* q, const float* k, const float* v, float scale,
+                           float p_drop, uint64_t seed, float* out, float* m, float* linv, void* stream);
+/* dq/dk: [B][T][R4] gradients of q'/k'; dv: [B][T][C]; dvec_workspace: B*T floats. */
+int buctd_attn_smallqk_bwd(int B, int T, int R4, int C, const float* q, const float* k, const float* v,
+                           const float* o, const float* dout, const float* m, const float* linv, float scale,
+                           float p_drop, uint64_t seed, float* dq, float* dk, float* dv, float* dvec_workspace,
+                           void* stream);
 /* elementwise inverted dropout (transpose_h.py:180-183), mask rebuilt from (seed, index) */
 int buctd_dropout(const float* x, float* y, long n, float p_drop, uint64_t seed, void* stream);
 /* LayerNorm over the last dim (transpose_h.py:178-179) */
