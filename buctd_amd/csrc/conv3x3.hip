@@ -14,12 +14,17 @@
 //   * a workgroup owns BM consecutive p's and all BN output channels; per 32-channel chunk it stages the
 //     BM + 2*SW + 2 input rows it needs ONCE (fp32 -> bf16 hi|lo, 160-byte rows: stride = 32 mod 64 bytes makes the
 //     four 16-lane groups of ds_read_b128 conflict free) and all 9 taps read shifted rows of that tile;
-//   * weights stream through a double-buffered 32-deep B stage (one (tap, chunk) per step);  the 16-channel tail of
-//     C = 48 pairs two taps in one K = 32 MFMA (lanes 0-31 feed tap t, lanes 32-63 tap t+1), so no MFMA lanes are
-//     wasted on padding;
+//   * weights are split and re-ordered ONCE per weight update by buctd_conv3x3_bf16x3_prep into the exact stage
+//     image the kernel consumes ([step][Co][32 hi | 32 lo] bf16; one (tap, 32-channel chunk) per step), so the
+//     double-buffered B stage is a plain 16-byte copy; the 16-channel tail of C = 48 pairs two taps in one K = 32
+//     MFMA (lanes 0-31 feed tap t, lanes 32-63 tap t+1), so no MFMA lanes are wasted on padding;
+//   * the 4 waves tile the workgroup 4x1 (BN = 48/64) or 2x2 (BN = 96/128): every wave issues its 2*(MF+NF)
+//     ds_read_b128 up front and then MF*NF*3 back-to-back MFMAs; the step loop is fully unrolled per chunk;
+//   * workgroups are renumbered so that each XCD (own L2) walks a contiguous run of position tiles;
 //   * epilogue as in conv.hip: bias, Welford BN partials (+ per-group valid-row counts, since pad positions are
 //     skipped), eval-BN scale/shift, residual, ReLU.
 #include "common.h"
+#include <stdlib.h>
 #include "../../include/buctd_hip.h"
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -30,7 +35,7 @@ typedef unsigned short u16x4 __attribute__((ext_vector_type(4)));
 
 struct C3Args {
   const float* x;
-  const float* w;
+  const unsigned char* wp;   // prepared weight image: [steps][Co][128 B = 32 bf16 hi | 32 bf16 lo]
   float* out;
   const float* bias;
   const float* scale;
@@ -40,7 +45,8 @@ struct C3Args {
   int* counts;
   int N, H, W, Ci, Co;
   int SW, IB, P;       // padded row width, padded image block, total padded positions
-  int relu, flip;
+  int dbg;
+  int relu, na;        // na: 32-row staging passes per chunk = ceil((BM + 2*SW + 2) / 32)
   unsigned ib_mul, ib_sh, sw_mul, sw_sh;   // n / d == mulhi(n, mul) >> sh for 0 <= n < 2^31 (Granlund-Montgomery)
 };
 
@@ -64,19 +70,36 @@ __device__ __forceinline__ void split_store(unsigned char* row, int c, f32x4 v) 
 
 #define MAX_SW 75          // W <= 73: the staged tile is at most BM + 152 rows
 
-template <int MF, int NF, bool FLIP>
+template <int V>
+struct IC { static constexpr int value = V; };
+
+template <int MF, int NF, int WM, int WN>
 __global__ __launch_bounds__(256, 2) void conv3x3_bf16x3_kernel(C3Args p) {
-  constexpr int BM = 4 * MF * 16, BN = NF * 16;
-  constexpr int PA = (BM + 2 * MAX_SW + 2 + 31) / 32;   // float4 loads per thread for one A chunk (8 per row)
-  constexpr int PB = (BN * 8 + 255) / 256;              // float4 loads per thread for one B step
+  constexpr int BM = WM * MF * 16, BN = WN * NF * 16;
+  constexpr int PA = (BM + 2 * MAX_SW + 2 + 31) / 32;   // float4 loads per thread for one A chunk (8 per row), max
+  constexpr int PB = (BN * 8 + 255) / 256;              // 16-byte pieces per thread for one B step
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const int R = BM + 2 * p.SW + 2;               // staged input rows
-  unsigned char* At = smem;                      // [R][ROWB]
-  unsigned char* Bt = smem + (size_t)R * ROWB;   // [2][BN][ROWB]
+  const int na = p.na;
+  unsigned char* At = smem;                              // [na*32][ROWB]
+  unsigned char* Bt = smem + (size_t)na * 32 * ROWB;     // [2][BN][ROWB]
 
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int i16 = lane & 15, g = lane >> 4;
-  const int p0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+  const int wave_m = wave % WM, wave_n = wave / WM;
+
+  // XCD-aware tile order: hardware workgroup id round-robins over the 8 XCDs; give every XCD a contiguous run of
+  // tiles so that the halo rows shared by neighbouring position tiles (and the N tiles of one position tile) hit
+  // the same L2.
+  int bx, by;
+  {
+    const unsigned gx = gridDim.x, gy = gridDim.y, total = gx * gy;
+    const unsigned lin = blockIdx.y * gx + blockIdx.x;
+    const unsigned xcd = lin & 7, idx = lin >> 3, per = total >> 3, rem = total & 7;
+    const unsigned L = xcd < rem ? xcd * (per + 1) + idx : rem * (per + 1) + (xcd - rem) * per + idx;
+    bx = (int)(L / gy);
+    by = (int)(L - (unsigned)bx * gy);
+  }
+  const int p0 = bx * BM, n0 = by * BN;
   const int halo = p.SW + 1;
   const int c4 = (t & 7) * 4;                    // this thread's 4-channel slot inside a 32-channel chunk
 
@@ -87,7 +110,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bf16x3_kernel(C3Args p) {
     const int row = (t >> 3) + 32 * q;
     const int pp = p0 - halo + row;
     int o = -1;
-    if (row < R && pp >= 0 && pp < p.P) {
+    if (q < na && pp >= 0 && pp < p.P) {
       const int n = fast_div(pp, p.ib_mul, p.ib_sh);
       const int rem = pp - n * p.IB;
       const int yy = fast_div(rem, p.sw_mul, p.sw_sh);   // 0 = pad row above the image
@@ -98,55 +121,45 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bf16x3_kernel(C3Args p) {
   }
 
   f32x4 areg[PA], breg[PB];
+  // unconditional loads from clamped (always valid) addresses; the zero-select for pad rows happens at store time so
+  // that nothing consumes the load result early (a branch around each load would serialise them behind vmcnt(0))
   auto load_a = [&](int c0, int cw) {
 #pragma unroll
-    for (int q = 0; q < PA; ++q) {
-      // unconditional load from a clamped (always valid) address + select: a branch around each load would
-      // serialise them behind vmcnt(0) waits
-      // (the zero-select for pad rows happens at store time so that nothing consumes the load result here)
-      const bool ok = goff[q] >= 0 && c4 < cw * 16;
-      areg[q] = *reinterpret_cast<const f32x4*>(p.x + (ok ? goff[q] + c0 + c4 : 0));
-    }
+    for (int q = 0; q < PA; ++q)
+      if (q < na) {
+        const bool ok = goff[q] >= 0 && c4 < cw * 16;
+        areg[q] = *reinterpret_cast<const f32x4*>(p.x + (ok ? goff[q] + c0 + c4 : 0));
+      }
   };
   auto store_a = [&](int cw) {
 #pragma unroll
-    for (int q = 0; q < PA; ++q) {
-      const int row = (t >> 3) + 32 * q;
-      const bool ok = goff[q] >= 0 && c4 < cw * 16;
-      if (row < R) split_store(At + (size_t)row * ROWB, c4, ok ? areg[q] : (f32x4){0.f, 0.f, 0.f, 0.f});
-    }
-  };
-  // B stage: step s of a chunk fills K = 32 reduction slots.  slot k4..k4+3 belongs to unit u = k4/16:
-  //   full chunk (cw = 2): (tap s, channels c0 + k4);   tail chunk (cw = 1): (tap 2s + u, channels c0 + k4 % 16)
-  auto load_b = [&](int c0, int cw, int s) {
-#pragma unroll
-    for (int q = 0; q < PB; ++q) {
-      const int idx = t + 256 * q;
-      const int nl = idx >> 3, n = n0 + nl;
-      const int u = c4 >> 4;
-      const int tap = cw == 2 ? s : 2 * s + u;
-      const int cc = cw == 2 ? c4 : (c4 & 15);
-      const bool ok = nl < BN && n < p.Co && tap < 9;
-      f32x4 v;
-      if (!FLIP) {
-        v = *reinterpret_cast<const f32x4*>(p.w + (ok ? ((long)n * 9 + tap) * p.Ci + c0 + cc : 0));
-      } else {
-        // data gradient: B(n = ci_out, k = (tap, co)) = w[co][8 - tap][ci_out]; here p.Ci is the channel
-        // count of the SOURCE tensor dy (= conv Co) and p.Co the output channels (= conv Ci)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] = p.w[ok ? ((long)(c0 + cc + j) * 9 + (8 - tap)) * p.Co + n : 0];
+    for (int q = 0; q < PA; ++q)
+      if (q < na) {
+        const int row = (t >> 3) + 32 * q;
+        const bool ok = goff[q] >= 0 && c4 < cw * 16;
+        split_store(At + (size_t)row * ROWB, c4, ok ? areg[q] : (f32x4){0.f, 0.f, 0.f, 0.f});
       }
-      breg[q] = v;   // zero-select at store time
-    }
   };
-  auto store_b = [&](int cw, int s, int buf) {
+  // B: one step image is [Co][128 B]; this thread copies 16-byte piece (t & 7) of rows (t >> 3) + 32 q
+  int bsrc[PB], bdst[PB];
 #pragma unroll
-    for (int q = 0; q < PB; ++q) {
-      const int nl = (t + 256 * q) >> 3;
-      const int tap = cw == 2 ? s : 2 * s + (c4 >> 4);
-      const bool ok = n0 + nl < p.Co && tap < 9;
-      if (nl < BN) split_store(Bt + ((size_t)buf * BN + nl) * ROWB, c4, ok ? breg[q] : (f32x4){0.f, 0.f, 0.f, 0.f});
-    }
+  for (int q = 0; q < PB; ++q) {
+    const int nl = (t >> 3) + 32 * q;
+    const bool ok = nl < BN;
+    bsrc[q] = ok ? (n0 + nl) * 128 + (t & 7) * 16 : 0;
+    bdst[q] = ok ? nl * ROWB + (t & 7) * 16 : -1;
+  }
+  const long step_bytes = (long)p.Co * 128;
+  auto load_b = [&](int gs) {
+    const unsigned char* src = p.wp + gs * step_bytes;
+#pragma unroll
+    for (int q = 0; q < PB; ++q) breg[q] = *reinterpret_cast<const f32x4*>(src + bsrc[q]);
+  };
+  auto store_b = [&](int buf) {
+    unsigned char* dst = Bt + (size_t)buf * BN * ROWB;
+#pragma unroll
+    for (int q = 0; q < PB; ++q)
+      if (bdst[q] >= 0) *reinterpret_cast<f32x4*>(dst + bdst[q]) = breg[q];
   };
 
   f32x4 acc[MF][NF];
@@ -155,136 +168,208 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bf16x3_kernel(C3Args p) {
 #pragma unroll
     for (int nf = 0; nf < NF; ++nf) acc[mf][nf] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  const int nchunks = (p.Ci + CK - 1) / CK;
-  load_a(0, p.Ci >= CK ? 2 : 1);
-  for (int ch = 0; ch < nchunks; ++ch) {
-    const int c0 = ch * CK;
-    const int cw = (p.Ci - c0 >= CK) ? 2 : 1;   // 16-channel groups in this chunk (Ci % 16 == 0)
-    const int nsteps = cw == 2 ? 9 : 5;
-    load_b(c0, cw, 0);
-    __syncthreads();                             // everybody finished reading the previous A tile / B stages
-    store_a(cw);
-    store_b(cw, 0, 0);
-    if (ch + 1 < nchunks) load_a(c0 + CK, (p.Ci - c0 - CK >= CK) ? 2 : 1);   // in flight during this chunk
-    __syncthreads();
-    for (int s = 0; s < nsteps; ++s) {
-      if (s + 1 < nsteps) load_b(c0, cw, s + 1);
-      // A row shift of the two 16-lane-pair halves of the wave
-      int tap0, tap1, cb0, cb1;
-      if (cw == 2) { tap0 = tap1 = s; cb0 = 0; cb1 = 32; }
-      else { tap0 = 2 * s; tap1 = 2 * s + 1 < 9 ? 2 * s + 1 : 2 * s; cb0 = cb1 = 0; }
-      const int sh0 = (tap0 / 3) * p.SW + tap0 % 3, sh1 = (tap1 / 3) * p.SW + tap1 % 3;
-      const int aoff = (g < 2 ? sh0 * ROWB + cb0 : sh1 * ROWB + cb1) + (g & 1) * 16;
-      const unsigned char* bb = Bt + (size_t)(s & 1) * BN * ROWB + g * 16;
-      bf16x8 bh[NF], bl[NF];
+  const int nfull = p.Ci / CK, tail = (p.Ci % CK) ? 1 : 0;
+  const int nchunks = nfull + tail, last_step = nfull * 9 + tail * 5 - 1;
+  const unsigned char* abase = At + (size_t)(wave_m * MF * 16 + i16) * ROWB + (g & 1) * 16;
+  const unsigned char* bbase = Bt + (size_t)(wave_n * NF * 16 + i16) * ROWB + g * 16;
+  const bool lowk = g < 2;     // lanes feeding reduction slots 0..15 of the K = 32 MFMA
+  int gs = 0, buf = 0;
+
+  // one chunk = NS fully unrolled steps; CW = 16-channel groups in the chunk (2: one tap per step, 1: two taps)
+  auto run_chunk = [&](auto cw_tag) {
+    constexpr int CW = decltype(cw_tag)::value;
+    constexpr int NS = CW == 2 ? 9 : 5;
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+      if (!(p.dbg & 1)) load_b(gs < last_step ? gs + 1 : last_step);
+      const int tap0 = CW == 2 ? s : 2 * s;
+      const int tap1 = CW == 2 ? s : (2 * s + 1 < 9 ? 2 * s + 1 : 2 * s);   // tap 9 of the tail: its weights are zero
+      const int o0 = ((tap0 / 3) * p.SW + tap0 % 3) * ROWB;
+      const int o1 = ((tap1 / 3) * p.SW + tap1 % 3) * ROWB + (CW == 2 ? 32 : 0);
+      const unsigned char* ap = abase + (lowk ? o0 : o1);
+      const unsigned char* bp = bbase + (size_t)buf * BN * ROWB;
+      bf16x8 ah[MF], al[MF], bh[NF], bl[NF];
 #pragma unroll
       for (int nf = 0; nf < NF; ++nf) {
-        const unsigned char* q = bb + (size_t)(nf * 16 + i16) * ROWB;
-        bh[nf] = *reinterpret_cast<const bf16x8*>(q);
-        bl[nf] = *reinterpret_cast<const bf16x8*>(q + 64);
+        bh[nf] = *reinterpret_cast<const bf16x8*>(bp + nf * 16 * ROWB);
+        bl[nf] = *reinterpret_cast<const bf16x8*>(bp + nf * 16 * ROWB + 64);
       }
 #pragma unroll
       for (int mf = 0; mf < MF; ++mf) {
-        const unsigned char* q = At + (size_t)(wave * MF * 16 + mf * 16 + i16) * ROWB + aoff;
-        const bf16x8 ah = *reinterpret_cast<const bf16x8*>(q);
-        const bf16x8 al = *reinterpret_cast<const bf16x8*>(q + 64);
-        // small terms first, then hi*hi; consecutive MFMAs hit different accumulators
-#pragma unroll
-        for (int nf = 0; nf < NF; ++nf) acc[mf][nf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh[nf], acc[mf][nf], 0, 0, 0);
-#pragma unroll
-        for (int nf = 0; nf < NF; ++nf) acc[mf][nf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl[nf], acc[mf][nf], 0, 0, 0);
-#pragma unroll
-        for (int nf = 0; nf < NF; ++nf) acc[mf][nf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh[nf], acc[mf][nf], 0, 0, 0);
+        ah[mf] = *reinterpret_cast<const bf16x8*>(ap + mf * 16 * ROWB);
+        al[mf] = *reinterpret_cast<const bf16x8*>(ap + mf * 16 * ROWB + 64);
       }
-      if (s + 1 < nsteps) store_b(cw, s + 1, (s + 1) & 1);
+      // small terms first, then hi*hi; consecutive MFMAs hit different accumulators
+      if (!(p.dbg & 2))
+#pragma unroll
+      for (int mf = 0; mf < MF; ++mf) {
+#pragma unroll
+        for (int nf = 0; nf < NF; ++nf)
+          acc[mf][nf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[mf], bh[nf], acc[mf][nf], 0, 0, 0);
+#pragma unroll
+        for (int nf = 0; nf < NF; ++nf)
+          acc[mf][nf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[mf], bl[nf], acc[mf][nf], 0, 0, 0);
+#pragma unroll
+        for (int nf = 0; nf < NF; ++nf)
+          acc[mf][nf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[mf], bh[nf], acc[mf][nf], 0, 0, 0);
+      }
+      if (!(p.dbg & 1)) store_b(buf ^ 1);
+      if (!(p.dbg & 16)) __syncthreads();
+      buf ^= 1;
+      ++gs;
+    }
+  };
+
+  if (!(p.dbg & 8)) load_a(0, nfull > 0 ? 2 : 1);
+  load_b(0);
+  if (!(p.dbg & 8)) store_a(nfull > 0 ? 2 : 1);
+  store_b(0);
+  if (nchunks > 1 && !(p.dbg & 8)) load_a(CK, nfull > 1 ? 2 : 1);   // in flight during the first chunk
+  __syncthreads();
+  for (int ch = 0; ch < nchunks; ++ch) {
+    const int cw = ch < nfull ? 2 : 1;
+    if (ch > 0 && !(p.dbg & 8)) {
+      store_a(cw);                                   // everybody left the previous tile at the last step's barrier
+      if (ch + 1 < nchunks) load_a((ch + 1) * CK, ch + 1 < nfull ? 2 : 1);
       __syncthreads();
     }
+    if (cw == 2) run_chunk(IC<2>{});
+    else run_chunk(IC<1>{});
   }
 
+  if ((p.dbg & 4) && acc[0][0][0] != 123.456f) return;
   // ---- epilogue ---------------------------------------------------------------------------------------
-  // accumulator (mf, nf, reg): row = wave*MF*16 + mf*16 + (lane>>4)*4 + reg, col = nf*16 + (lane&15)
-  long ooff[MF][4];
-  bool ok[MF][4];
-  int cnt = 0;
-#pragma unroll
-  for (int mf = 0; mf < MF; ++mf)
-#pragma unroll
-    for (int rg = 0; rg < 4; ++rg) {
-      const int pp = p0 + wave * MF * 16 + mf * 16 + g * 4 + rg;
-      bool v = pp < p.P;
-      long o = 0;
-      if (v) {
-        const int n = fast_div(pp, p.ib_mul, p.ib_sh);
-        const int rem = pp - n * p.IB;
-        const int yy = fast_div(rem, p.sw_mul, p.sw_sh), xx = rem - yy * p.SW;
-        v = n < p.N && yy >= 1 && xx >= 1 && xx <= p.W;
-        o = ((long)(n * p.H + yy - 1) * p.W + xx - 1) * p.Co;
-      }
-      ok[mf][rg] = v;
-      ooff[mf][rg] = o;
-      cnt += v ? 1 : 0;
+  // accumulator (mf, nf, reg): row = wave_m*MR + mf*16 + (lane>>4)*4 + reg, col = wave_n*NF*16 + nf*16 + (lane&15).
+  // The tile goes through LDS (the A tile is dead after the last step's barrier) so that every output row leaves as
+  // 16-byte pieces of one contiguous run instead of 64-byte column slivers of four rows.
+  constexpr int MR = MF * 16;              // rows of this wave's tile
+  constexpr int LD = NF * 16 + 4;          // staging row stride in floats: 4*LD = 16 mod 64 keeps the writes conflict-free
+  constexpr int EP = MF >= 2 ? 2 : 1;      // 16-row fragments staged per pass
+  float* stg = reinterpret_cast<float*>(smem) + wave * (EP * 16 * LD);
+  int* rowoff = reinterpret_cast<int*>(smem) + 4 * EP * 16 * LD + wave * 64;
+  int myoff = -1;                          // lane r: element offset of output row r of this wave (-1: pad position)
+  if (lane < MR) {
+    const int pp = p0 + wave_m * MR + lane;
+    if (pp < p.P) {
+      const int n = fast_div(pp, p.ib_mul, p.ib_sh);
+      const int rem = pp - n * p.IB;
+      const int yy = fast_div(rem, p.sw_mul, p.sw_sh), xx = rem - yy * p.SW;
+      if (n < p.N && yy >= 1 && xx >= 1 && xx <= p.W) myoff = ((n * p.H + yy - 1) * p.W + xx - 1) * p.Co;
     }
-  // valid rows of this wave's row group (identical for the 16 lanes of a column group)
-  cnt += __shfl_xor(cnt, 16, 64);
-  cnt += __shfl_xor(cnt, 32, 64);
-  const int grp = blockIdx.x * 4 + wave;
-  if (p.stats && p.counts && blockIdx.y == 0 && lane == 0) p.counts[grp] = cnt;
+  }
+  const unsigned long long vmask = __ballot(myoff >= 0);
+  const int cnt = __popcll(vmask);
+  rowoff[lane] = myoff;
+  const int grp = bx * WM + wave_m;
+  if (p.stats && p.counts && by == 0 && wave_n == 0 && lane == 0) p.counts[grp] = cnt;
+  const int ncol0 = n0 + wave_n * NF * 16;
+  float bv[NF];
 #pragma unroll
-  for (int nf = 0; nf < NF; ++nf) {
-    const int n = n0 + nf * 16 + i16;
-    const bool nok = n < p.Co;
-    const float bv = (p.bias && nok) ? p.bias[n] : 0.f;
-    if (p.stats) {
+  for (int nf = 0; nf < NF; ++nf) bv[nf] = p.bias ? p.bias[ncol0 + nf * 16 + i16] : 0.f;
+  if (p.stats && !(p.dbg & 32)) {
+    const float inv_cnt = cnt > 0 ? 1.f / (float)cnt : 0.f;
+#pragma unroll
+    for (int nf = 0; nf < NF; ++nf) {
       float s1 = 0.f;
 #pragma unroll
       for (int mf = 0; mf < MF; ++mf)
 #pragma unroll
         for (int rg = 0; rg < 4; ++rg)
-          if (ok[mf][rg]) s1 += acc[mf][nf][rg] + bv;
+          s1 += ((vmask >> (mf * 16 + g * 4 + rg)) & 1) ? acc[mf][nf][rg] + bv[nf] : 0.f;
       s1 += __shfl_xor(s1, 16, 64);
       s1 += __shfl_xor(s1, 32, 64);
-      const float mean = cnt > 0 ? s1 / (float)cnt : 0.f;
+      const float mean = s1 * inv_cnt;
       float s2 = 0.f;
 #pragma unroll
       for (int mf = 0; mf < MF; ++mf)
 #pragma unroll
-        for (int rg = 0; rg < 4; ++rg)
-          if (ok[mf][rg]) {
-            const float d = acc[mf][nf][rg] + bv - mean;
-            s2 += d * d;
-          }
+        for (int rg = 0; rg < 4; ++rg) {
+          const float d = acc[mf][nf][rg] + bv[nf] - mean;
+          s2 += ((vmask >> (mf * 16 + g * 4 + rg)) & 1) ? d * d : 0.f;
+        }
       s2 += __shfl_xor(s2, 16, 64);
       s2 += __shfl_xor(s2, 32, 64);
-      if (nok && g == 0) {
-        p.stats[((long)grp * p.Co + n) * 2 + 0] = mean;
-        p.stats[((long)grp * p.Co + n) * 2 + 1] = s2;
+      if (g == 0) {
+        const int n = ncol0 + nf * 16 + i16;
+        *reinterpret_cast<float2*>(p.stats + ((long)grp * p.Co + n) * 2) = make_float2(mean, s2);
       }
     }
-    if (nok) {
-      const float sc = p.scale ? p.scale[n] : 1.f;
-      const float sh = p.shift ? p.shift[n] : 0.f;
+  }
 #pragma unroll
-      for (int mf = 0; mf < MF; ++mf)
+  for (int ps = 0; ps < MF / EP; ++ps) {
+    if (ps) __syncthreads();
+#pragma unroll
+    for (int e = 0; e < EP; ++e)
+#pragma unroll
+      for (int nf = 0; nf < NF; ++nf)
 #pragma unroll
         for (int rg = 0; rg < 4; ++rg)
-          if (ok[mf][rg]) {
-            float v = (acc[mf][nf][rg] + bv) * sc + sh;
-            const long o = ooff[mf][rg] + n;
-            if (p.res) v += p.res[o];
-            if (p.relu) v = fmaxf(v, 0.f);
-            p.out[o] = v;
-          }
+          stg[(e * 16 + g * 4 + rg) * LD + nf * 16 + i16] = acc[ps * EP + e][nf][rg] + bv[nf];
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < EP * NF; ++k) {
+      const int item = lane + 64 * k;
+      const int row = item / (NF * 4), c4 = item - row * (NF * 4);
+      f32x4 v = *reinterpret_cast<const f32x4*>(stg + row * LD + c4 * 4);
+      const int off = rowoff[ps * EP * 16 + row];
+      const int n = ncol0 + c4 * 4;
+      if (off >= 0 && (!(p.dbg & 64) || v[0] == 123.456f)) {
+        if (p.scale) {
+          const f32x4 sc = *reinterpret_cast<const f32x4*>(p.scale + n);
+          const f32x4 sh = *reinterpret_cast<const f32x4*>(p.shift + n);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) v[j] = v[j] * sc[j] + sh[j];
+        }
+        if (p.res) {
+          const f32x4 r = *reinterpret_cast<const f32x4*>(p.res + off + n);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) v[j] += r[j];
+        }
+        if (p.relu) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
+        }
+        *reinterpret_cast<f32x4*>(p.out + off + n) = v;
+      }
     }
   }
 }
 
-// ---------------------------------------------------------------------------------------------- host ----
-struct C3Plan { int MF, NF, BM, BN; size_t lds; };
+// ------------------------------------------------------------------------------------- weight preparation ----
+// out[step][n][k]: step = (chunk, s); full chunk: (tap s, channel c0 + k); 16-channel tail: slots 0-15 = tap 2s,
+// 16-31 = tap 2s + 1 (tap 9 = zero).  flip = 0: B(n, tap, c) = w[n][tap][c] (w = [Nc][9][Kc]);
+// flip = 1 (data gradient): B(n, tap, c) = w[c][8 - tap][n] (w = [Kc][9][Nc]).
+__global__ __launch_bounds__(256) void conv3x3_prep_kernel(const float* __restrict__ w, unsigned char* __restrict__ out,
+                                                           int Kc, int Nc, int flip, long pieces) {
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= pieces) return;
+  const int k4 = (int)(idx & 7);
+  const long rown = idx >> 3;
+  const int n = (int)(rown % Nc), step = (int)(rown / Nc);
+  const int nfull = Kc / CK;
+  int c0, s, cw;
+  if (step < nfull * 9) { c0 = (step / 9) * CK; s = step % 9; cw = 2; }
+  else { c0 = nfull * CK; s = step - nfull * 9; cw = 1; }
+  const int c4 = k4 * 4;
+  const int tap = cw == 2 ? s : 2 * s + (c4 >> 4);
+  const int cc = c0 + (cw == 2 ? c4 : (c4 & 15));
+  f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
+  if (tap < 9) {
+    if (!flip) v = *reinterpret_cast<const f32x4*>(w + ((long)n * 9 + tap) * Kc + cc);
+    else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[j] = w[((long)(cc + j) * 9 + (8 - tap)) * Nc + n];
+    }
+  }
+  split_store(out + rown * 128, c4, v);
+}
 
-// magic for unsigned division of n < 2^31 by d (1 <= d < 2^31): q = mulhi(n, mul) >> sh, mul = ceil(2^(32+sh)/d)
-// with sh = ceil(log2 d); mul < 2^33, so d >= 2 keeps it in 32 bits after the usual "sh - 1" adjustment below.
+// ---------------------------------------------------------------------------------------------- host ----
+struct C3Plan { int MF, NF, WM, WN, BM, BN, na; size_t lds; };
+
+// magic for unsigned division of n < 2^31 by d (2 <= d < 2^31): q = mulhi(n, mul) >> sh
 static void magic_u32(unsigned d, unsigned* mul, unsigned* sh) {
-  if (d == 1) { *mul = 0xFFFFFFFFu; *sh = 0; return; }   // mulhi(n, 2^32-1) == n - 1 for n >= 1, 0 for 0: avoid, d>1 always here
+  if (d == 1) { *mul = 0xFFFFFFFFu; *sh = 0; return; }   // never taken: IB and SW are >= 3
   unsigned l = 0;
   while ((1ull << l) < d) ++l;                  // l = ceil(log2 d)
   // n < 2^31: m = ceil(2^(31+l) / d) fits in 32 bits and q = (n*m) >> (31+l) is exact
@@ -293,19 +378,31 @@ static void magic_u32(unsigned d, unsigned* mul, unsigned* sh) {
   *sh = l - 1;                                  // mulhi already shifts by 32: total shift 31 + l
 }
 
+static int c3_steps(int Kc) { return (Kc / CK) * 9 + ((Kc % CK) ? 5 : 0); }
+
 static bool c3_plan(int N, int H, int W, int Ci, int Co, C3Plan* pl) {
-  if (Ci % 16 != 0 || Co % 16 != 0 || W + 2 > MAX_SW) return false;
+  if (N <= 0 || H <= 0 || W <= 0 || Ci <= 0 || Co <= 0 || Ci % 16 != 0 || Co % 16 != 0 || W + 2 > MAX_SW) return false;
   const long P = (long)N * (H + 1) * (W + 2) + (W + 2);
-  int nf = Co % 96 == 0 ? 6 : (Co % 64 == 0 ? 4 : (Co % 48 == 0 ? 3 : (Co % 32 == 0 ? 2 : 0)));
-  if (Co == 16) nf = 1;
-  if (nf == 0) return false;
-  // keep >= ~2 workgroups per CU when the image planes are small
-  int mf = 4;
-  if ((P / 256) * (Co / (nf * 16)) < 512) mf = 2;
-  if (nf == 6) mf = 2;                       // 256x96 tiles would spill (24 accumulators + staging registers)
-  if (mf == 2 && nf == 6 && (P / 128) * (Co / 96) < 512 && Co % 48 == 0) nf = 3;
-  pl->MF = mf; pl->NF = nf; pl->BM = 64 * mf; pl->BN = 16 * nf;
-  pl->lds = (size_t)(pl->BM + 2 * (W + 2) + 2) * ROWB + (size_t)2 * pl->BN * ROWB;
+  int nf, wn;
+  if (Co % 96 == 0) { nf = 3; wn = 2; }
+  else if (Co % 48 == 0) { nf = 3; wn = 1; }
+  else if (Co % 128 == 0) { nf = 4; wn = 2; }
+  else if (Co % 64 == 0) { nf = 4; wn = 1; }
+  else if (Co % 32 == 0) { nf = 2; wn = 1; }
+  else { nf = 1; wn = 1; }
+  const int wm = 4 / wn, bn = wn * nf * 16;
+  // largest position tile that still gives every CU work (256 CUs, 2 resident workgroups each)
+  int mf = 1;
+  const int cand[2] = {4, 2};
+  for (int i = (nf == 4 ? 1 : 0); i < 2; ++i) {   // 64-row x 64-column wave tiles would spill
+    const long blocks = ((P + wm * cand[i] * 16 - 1) / (wm * cand[i] * 16)) * (Co / bn);
+    if (blocks >= (cand[i] == 4 ? 320 : 200)) { mf = cand[i]; break; }
+  }
+  pl->MF = mf; pl->NF = nf; pl->WM = wm; pl->WN = wn; pl->BM = wm * mf * 16; pl->BN = bn;
+  pl->na = (pl->BM + 2 * (W + 2) + 2 + 31) / 32;
+  const size_t stage = (size_t)4 * (mf >= 2 ? 2 : 1) * 16 * (nf * 16 + 4) * 4 + 4 * 64 * 4;   // epilogue staging + row offsets
+  while ((size_t)pl->na * 32 * ROWB < stage) ++pl->na;
+  pl->lds = (size_t)pl->na * 32 * ROWB + (size_t)2 * pl->BN * ROWB;
   return pl->lds <= 160 * 1024;
 }
 
@@ -320,15 +417,33 @@ extern "C" int buctd_conv3x3_bf16x3_stats_groups(int N, int H, int W, int Ci, in
   BUCTD_CHECK_ARG(ngroups && rows_per_group && c3_plan(N, H, W, Ci, Co, &pl),
                   "buctd_conv3x3_bf16x3_stats_groups: unsupported shape");
   const long P = (long)N * (H + 1) * (W + 2) + (W + 2);
-  *ngroups = ceil_div(P, pl.BM) * 4;
+  *ngroups = ceil_div(P, pl.BM) * pl.WM;
   *rows_per_group = pl.MF * 16;
   return BUCTD_OK;
 }
 
-template <int MF, int NF, bool FLIP>
+extern "C" size_t buctd_conv3x3_bf16x3_prep_bytes(int Ci, int Co, int flip) {
+  if (Ci <= 0 || Co <= 0 || Ci % 16 != 0 || Co % 16 != 0) return 0;
+  const int Kc = flip ? Co : Ci, Nc = flip ? Ci : Co;
+  return (size_t)c3_steps(Kc) * Nc * 128;
+}
+
+extern "C" int buctd_conv3x3_bf16x3_prep(int Ci, int Co, const float* w, int flip, void* wprep, void* stream) {
+  BUCTD_CHECK_ARG(w && wprep, "buctd_conv3x3_bf16x3_prep: null pointer");
+  BUCTD_CHECK_ARG(Ci > 0 && Co > 0 && Ci % 16 == 0 && Co % 16 == 0, "buctd_conv3x3_bf16x3_prep: Ci=%d Co=%d must be multiples of 16",
+                  Ci, Co);
+  const int Kc = flip ? Co : Ci, Nc = flip ? Ci : Co;
+  const long pieces = (long)c3_steps(Kc) * Nc * 8;
+  hipLaunchKernelGGL(conv3x3_prep_kernel, dim3(ceil_div(pieces, 256)), dim3(256), 0, (hipStream_t)stream, w,
+                     (unsigned char*)wprep, Kc, Nc, flip ? 1 : 0, pieces);
+  BUCTD_CHECK_LAUNCH("buctd_conv3x3_bf16x3_prep");
+  return BUCTD_OK;
+}
+
+template <int MF, int NF, int WM, int WN>
 static int c3_launch(const C3Args& a, const C3Plan& pl, hipStream_t st) {
   static bool attr_set = false;
-  auto fn = conv3x3_bf16x3_kernel<MF, NF, FLIP>;
+  auto fn = conv3x3_bf16x3_kernel<MF, NF, WM, WN>;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        160 * 1024);
@@ -338,45 +453,49 @@ static int c3_launch(const C3Args& a, const C3Plan& pl, hipStream_t st) {
     }
     attr_set = true;
   }
-  dim3 grid(ceil_div(a.P, pl.BM), ceil_div(a.Co, pl.BN));
+  dim3 grid(ceil_div(a.P, pl.BM), a.Co / pl.BN);
   hipLaunchKernelGGL(fn, grid, dim3(256), pl.lds, st, a);
   BUCTD_CHECK_LAUNCH("buctd_conv3x3_bf16x3");
   return BUCTD_OK;
 }
 
-template <bool FLIP>
 static int c3_dispatch(const C3Args& a, const C3Plan& pl, hipStream_t st) {
-#define C3_CASE(mf, nf) if (pl.MF == mf && pl.NF == nf) return c3_launch<mf, nf, FLIP>(a, pl, st);
-  C3_CASE(4, 1) C3_CASE(4, 2) C3_CASE(4, 3) C3_CASE(4, 4) C3_CASE(4, 6)
-  C3_CASE(2, 1) C3_CASE(2, 2) C3_CASE(2, 3) C3_CASE(2, 4) C3_CASE(2, 6)
+#define C3_CASE(mf, nf, wm, wn) \
+  if (pl.MF == mf && pl.NF == nf && pl.WN == wn) return c3_launch<mf, nf, wm, wn>(a, pl, st);
+#define C3_MF(nf, wm, wn) C3_CASE(4, nf, wm, wn) C3_CASE(2, nf, wm, wn) C3_CASE(1, nf, wm, wn)
+  C3_MF(1, 4, 1) C3_MF(2, 4, 1) C3_MF(3, 4, 1) C3_MF(3, 2, 2)
+  C3_CASE(2, 4, 4, 1) C3_CASE(1, 4, 4, 1) C3_CASE(2, 4, 2, 2) C3_CASE(1, 4, 2, 2)
+#undef C3_MF
 #undef C3_CASE
-  buctd_set_error("conv3x3_bf16x3: no kernel for MF=%d NF=%d", pl.MF, pl.NF);
+  buctd_set_error("conv3x3_bf16x3: no kernel for MF=%d NF=%d WN=%d", pl.MF, pl.NF, pl.WN);
   return BUCTD_EINVAL;
 }
 
-// x: [N][H][W][Ci] -> y: [N][H][W][Co]; w: [Cw_out][3][3][Cw_in] of the FORWARD convolution.
-// flip == 0: forward (Cw_out = Co, Cw_in = Ci).  flip == 1: data gradient - x is dy ([N][H][W][Ci = Cw_out]),
-// y is dx ([N][H][W][Co = Cw_in]).
-extern "C" int buctd_conv3x3_bf16x3(int N, int H, int W, int Ci, int Co, const float* x, const float* w, int flip,
+// x: [N][H][W][Ci] -> y: [N][H][W][Co], wprep from buctd_conv3x3_bf16x3_prep.  Forward: prep(Ci, Co, w, 0).
+// Data gradient of a forward conv (CiF -> CoF): x = dy ([N][H][W][CoF]), y = dx ([N][H][W][CiF]), i.e. this call's
+// Ci = CoF, Co = CiF, and wprep = prep(CiF, CoF, w, 1).
+extern "C" int buctd_conv3x3_bf16x3(int N, int H, int W, int Ci, int Co, const float* x, const void* wprep,
                                     const float* bias, const float* scale, const float* shift, const float* residual,
                                     int relu, float* y, float* stats_partials, int* stats_counts, void* stream) {
   C3Plan pl;
-  BUCTD_CHECK_ARG(x && w && y, "buctd_conv3x3_bf16x3: null tensor pointer");
+  BUCTD_CHECK_ARG(x && wprep && y, "buctd_conv3x3_bf16x3: null tensor pointer");
   BUCTD_CHECK_ARG(c3_plan(N, H, W, Ci, Co, &pl), "buctd_conv3x3_bf16x3: unsupported shape N%d H%d W%d Ci%d Co%d", N, H,
                   W, Ci, Co);
   BUCTD_CHECK_ARG((scale == nullptr) == (shift == nullptr), "buctd_conv3x3_bf16x3: scale and shift go together");
   BUCTD_CHECK_ARG((stats_partials == nullptr) == (stats_counts == nullptr),
                   "buctd_conv3x3_bf16x3: stats partials and counts go together");
   C3Args a;
-  a.x = x; a.w = w; a.out = y; a.bias = bias; a.scale = scale; a.shift = shift; a.res = residual;
-  a.stats = stats_partials; a.counts = stats_counts;
+  a.x = x; a.wp = (const unsigned char*)wprep; a.out = y; a.bias = bias; a.scale = scale; a.shift = shift;
+  a.res = residual; a.stats = stats_partials; a.counts = stats_counts;
   a.N = N; a.H = H; a.W = W; a.Ci = Ci; a.Co = Co;
   a.SW = W + 2; a.IB = (H + 1) * (W + 2);
   const long P = (long)N * a.IB + a.SW;
-  BUCTD_CHECK_ARG(P < 2147483647L, "buctd_conv3x3_bf16x3: tensor too large");
+  BUCTD_CHECK_ARG(P < 2147483647L && (long)N * H * W * (Ci > Co ? Ci : Co) < 2147483647L,
+                  "buctd_conv3x3_bf16x3: tensor too large");
   a.P = (int)P;
-  a.relu = relu; a.flip = flip;
+  a.relu = relu; a.na = pl.na;
+  { static int dbg = -1; if (dbg < 0) { const char* e = getenv("BUCTD_C3_DEBUG"); dbg = e ? atoi(e) : 0; } a.dbg = dbg; }
   magic_u32((unsigned)a.IB, &a.ib_mul, &a.ib_sh);
   magic_u32((unsigned)a.SW, &a.sw_mul, &a.sw_sh);
-  return flip ? c3_dispatch<true>(a, pl, (hipStream_t)stream) : c3_dispatch<false>(a, pl, (hipStream_t)stream);
+  return c3_dispatch(a, pl, (hipStream_t)stream);
 }

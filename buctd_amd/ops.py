@@ -152,8 +152,36 @@ def _bf16x3_ok(d):
             lib().buctd_conv3x3_bf16x3_supported(d.N, d.H, d.W, d.Ci, d.Co) == 1)
 
 
+_weights_epoch = {"n": 0}
+
+
+def weights_updated():
+    """Called by whoever rewrites parameters through raw pointers (FusedAdam): invalidates prepared filter images."""
+    _weights_epoch["n"] += 1
+
+
+def _conv3x3_prepared(w, flip):
+    """bf16 hi|lo stage image of a 3x3 filter (conv3x3.hip), cached on the weight tensor until it changes."""
+    Co, Ci = _wshape(w)[0], _wshape(w)[1]
+    key = (w.data_ptr(), w._version, _weights_epoch["n"])
+    cache = getattr(w, "_buctd_prep", None)
+    if cache is None or cache[0] != key:
+        cache = [key, None, None]
+        try:
+            w._buctd_prep = cache
+        except (AttributeError, RuntimeError):
+            pass
+    if cache[1 + flip] is None:
+        nbytes = lib().buctd_conv3x3_bf16x3_prep_bytes(Ci, Co, flip)
+        img = torch.empty(nbytes, dtype=torch.uint8, device=w.device)
+        check(lib().buctd_conv3x3_bf16x3_prep(Ci, Co, ptr(w), flip, ptr(img), stream_ptr()), "conv3x3_bf16x3_prep")
+        cache[1 + flip] = img
+    return cache[1 + flip]
+
+
 def _conv3x3_bf16x3(x, w, flip, cin, cout, bias, scale, shift, residual, relu, stats):
     N, H, W = x.shape[0], x.shape[1], x.shape[2]
+    wp = _conv3x3_prepared(w, flip)
     y = torch.empty((N, H, W, cout), dtype=torch.float32, device=x.device)
     part = counts = info = None
     if stats:
@@ -162,7 +190,7 @@ def _conv3x3_bf16x3(x, w, flip, cin, cout, bias, scale, shift, residual, relu, s
         part = torch.empty((ng.value, cout, 2), dtype=torch.float32, device=x.device)
         counts = torch.empty(ng.value, dtype=torch.int32, device=x.device)
         info = (ng.value, rpg.value, counts)
-    check(lib().buctd_conv3x3_bf16x3(N, H, W, cin, cout, ptr(x), ptr(w), int(flip), ptr(bias), ptr(scale), ptr(shift),
+    check(lib().buctd_conv3x3_bf16x3(N, H, W, cin, cout, ptr(x), ptr(wp), ptr(bias), ptr(scale), ptr(shift),
                                      ptr(residual), int(bool(relu)), ptr(y), ptr(part), ptr(counts), stream_ptr()),
           "conv3x3_bf16x3")
     return (y, part, info) if stats else y

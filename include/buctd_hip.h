@@ -60,14 +60,21 @@ int buctd_conv2d_wgrad(const buctd_conv_desc* d, const float* x, const float* dy
 
 /* 3x3 / stride 1 / pad 1 convolution on the bf16 matrix cores with split-fp32 operands ("bf16x3": hi*hi + hi*lo +
  * lo*hi, fp32 accumulate; ~2^-16 relative product error).  Same epilogue options as buctd_conv2d_fwd.
- * flip = 0: forward, w = [Co][3][3][Ci].  flip = 1: data gradient of that convolution: x is dy [N][H][W][Ci],
- * y is dx [N][H][W][Co], w is the forward weight [Ci][3][3][Co].  Replaces the BasicBlock convs of
- * pose_hrnet.py:28-57 when the "bf16x3" math mode is selected. stats_counts: ngroups ints (valid rows per group). */
+ * Replaces the BasicBlock convs of pose_hrnet.py:28-57 when the "bf16x3" math mode is selected.
+ *
+ * The filter is consumed as a prepared image (bf16 hi|lo halves in the kernel's stage order), produced once per
+ * weight update by buctd_conv3x3_bf16x3_prep from the forward filter w = [Co][3][3][Ci]:
+ *   flip = 0: image for the forward convolution (Ci -> Co);
+ *   flip = 1: image for its data gradient (the call below then takes x = dy [N][H][W][Co] with "Ci" = Co and
+ *             produces y = dx [N][H][W][Ci] with "Co" = Ci).
+ * stats_counts: ngroups ints (valid rows per group; pad positions of the flattened tile are skipped). */
 int buctd_conv3x3_bf16x3_supported(int N, int H, int W, int Ci, int Co);
 int buctd_conv3x3_bf16x3_stats_groups(int N, int H, int W, int Ci, int Co, int* ngroups, int* rows_per_group);
-int buctd_conv3x3_bf16x3(int N, int H, int W, int Ci, int Co, const float* x, const float* w, int flip,
-                         const float* bias, const float* scale, const float* shift, const float* residual, int relu,
-                         float* y, float* stats_partials, int* stats_counts, void* stream);
+size_t buctd_conv3x3_bf16x3_prep_bytes(int Ci, int Co, int flip);
+int buctd_conv3x3_bf16x3_prep(int Ci, int Co, const float* w, int flip, void* wprep, void* stream);
+int buctd_conv3x3_bf16x3(int N, int H, int W, int Ci, int Co, const float* x, const void* wprep, const float* bias,
+                         const float* scale, const float* shift, const float* residual, int relu, float* y,
+                         float* stats_partials, int* stats_counts, void* stream);
 
 /* weight gradient of the same convolution on the bf16 matrix cores (transpose-read fragments from position-major
  * LDS tiles, split over positions through `workspace`): dw (+)= sum_p dy[p] (x) x[p + tap].  dw: [Co][3][3][Ci]. */
