@@ -67,7 +67,7 @@ SIGNATURES = {
     "buctd_bn_stats_groups": (_I, [_L, _I, _PI, _PI]),
     "buctd_bn_apply": (_I, [_P, _P, _P, _P, _P, _P, _I, _P, _L, _I, _P]),
     "buctd_bn_bwd_workspace": (_SZ, [_L, _I]),
-    "buctd_bn_bwd": (_I, [_P, _P, _P, _P, _P, _P, _I, _L, _I, _P, _P, _P, _P, _I, _P, _SZ, _P]),
+    "buctd_bn_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _L, _I, _P, _P, _P, _P, _I, _P, _SZ, _P]),
     "buctd_bn_fold": (_I, [_P, _P, _P, _P, _F, _I, _P, _P, _P]),
     "buctd_add": (_I, [_P, _P, _P, _L, _I, _P]),
     "buctd_scale": (_I, [_P, _P, _F, _P, _L, _P]),

@@ -69,28 +69,40 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
                                                           long rows, int C, float eps, float momentum,
                                                           float* __restrict__ mean, float* __restrict__ invstd,
                                                           float* __restrict__ rmean, float* __restrict__ rvar) {
+  // One workgroup per channel, ONE pass: S1 = sum n_g mean_g and S2 = sum (M2_g + n_g mean_g^2) in fp64.  The products
+  // of fp32 inputs are exact in fp64, so var = (S2 - S1^2/N)/N keeps ~16 - 2 log10(|mean|/std) digits - far beyond the
+  // fp32 result for any activation statistics (|mean|/std < 1e4) - while the partials are gathered once, four
+  // independent 8-byte loads in flight per thread.
   __shared__ double sm[4];
   const int c = blockIdx.x;
-  double s = 0.0;
-  for (int g = threadIdx.x; g < ngroups; g += 256) {
-    long n = rows - (long)g * rpg;
-    n = n < 0 ? 0 : (n > rpg ? rpg : n);
-    if (counts) n = counts[g];
-    if (n > 0) s += (double)n * (double)part[((long)g * C + c) * 2];
-  }
-  const double mu = block_sum_d(s, sm) / (double)rows;
-  double q = 0.0;
-  for (int g = threadIdx.x; g < ngroups; g += 256) {
-    long n = rows - (long)g * rpg;
-    n = n < 0 ? 0 : (n > rpg ? rpg : n);
-    if (counts) n = counts[g];
-    if (n > 0) {
-      const double d = (double)part[((long)g * C + c) * 2] - mu;
-      q += (double)part[((long)g * C + c) * 2 + 1] + (double)n * d * d;
+  double s1 = 0.0, s2 = 0.0;
+  const float2* pp = reinterpret_cast<const float2*>(part) + c;
+  for (int g0 = threadIdx.x; g0 < ngroups; g0 += 1024) {
+    float2 v[4];
+    int n[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int g = g0 + 256 * u;
+      const bool ok = g < ngroups;
+      const int gc = ok ? g : 0;
+      v[u] = pp[(long)gc * C];
+      long cnt = rows - (long)gc * rpg;
+      cnt = cnt < 0 ? 0 : (cnt > rpg ? rpg : cnt);
+      n[u] = ok ? (counts ? counts[gc] : (int)cnt) : 0;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const double m = (double)v[u].x, nn = (double)n[u];
+      s1 += nn * m;
+      if (n[u] > 0) s2 += (double)v[u].y + nn * m * m;
     }
   }
-  const double m2 = block_sum_d(q, sm);
+  s1 = block_sum_d(s1, sm);
+  s2 = block_sum_d(s2, sm);
   if (threadIdx.x == 0) {
+    const double mu = s1 / (double)rows;
+    double m2 = s2 - s1 * mu;
+    if (m2 < 0.0) m2 = 0.0;
     const double var = m2 / (double)rows;
     mean[c] = (float)mu;
     invstd[c] = (float)(1.0 / sqrt(var + (double)eps));
@@ -159,7 +171,9 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_vec_kernel(const float* __r
                                                                 const float* __restrict__ y,
                                                                 const float* __restrict__ z,
                                                                 const float* __restrict__ mean,
-                                                                const float* __restrict__ invstd, int relu, long rows,
+                                                                const float* __restrict__ invstd,
+                                                                const float* __restrict__ gamma,
+                                                                const float* __restrict__ beta, int relu, long rows,
                                                                 int C, float* __restrict__ part) {
   __shared__ f32x4 sm[2][256];
   const int c4n = C >> 2;
@@ -172,12 +186,19 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_vec_kernel(const float* __r
   if (tr < rl) {
     const f32x4 mu = reinterpret_cast<const f32x4*>(mean)[tc];
     const f32x4 is = reinterpret_cast<const f32x4*>(invstd)[tc];
+    f32x4 sc = is, be = is;
+    if (relu && !y) {   // mask recomputed exactly as bn_apply formed its output (no residual in the forward)
+      sc = is * reinterpret_cast<const f32x4*>(gamma)[tc];
+      be = reinterpret_cast<const f32x4*>(beta)[tc];
+    }
     for (long r = r0 + tr; r < r1; r += rl) {
       const long o = r * c4n + tc;
       f32x4 g = reinterpret_cast<const f32x4*>(dy)[o];
       const f32x4 zz = reinterpret_cast<const f32x4*>(z)[o];
       if (relu) {
-        const f32x4 yy = reinterpret_cast<const f32x4*>(y)[o];
+        f32x4 yy;
+        if (y) yy = reinterpret_cast<const f32x4*>(y)[o];
+        else yy = (zz - mu) * sc + be;
 #pragma unroll
         for (int j = 0; j < 4; ++j)
           if (!(yy[j] > 0.f)) g[j] = 0.f;
@@ -202,7 +223,9 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_vec_kernel(const float* __r
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restrict__ dy, const float* __restrict__ y,
                                                             const float* __restrict__ z,
                                                             const float* __restrict__ mean,
-                                                            const float* __restrict__ invstd, int relu, long rows,
+                                                            const float* __restrict__ invstd,
+                                                            const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta, int relu, long rows,
                                                             int C, float* __restrict__ part) {
   __shared__ float sm[2][256];
   const int cw = C < 256 ? C : 256;        // channels handled per sweep
@@ -216,11 +239,16 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
     float s1 = 0.f, s2 = 0.f;
     if (c < C && tr < rl) {
       const float mu = mean[c], is = invstd[c];
+      const float sc = (relu && !y) ? is * gamma[c] : 0.f, be = (relu && !y) ? beta[c] : 0.f;
       for (long r = r0 + tr; r < r1; r += rl) {
         float g = dy[r * C + c];
-        if (relu && !(y[r * C + c] > 0.f)) g = 0.f;
+        const float zz = z[r * C + c];
+        if (relu) {
+          const float yy = y ? y[r * C + c] : (zz - mu) * sc + be;
+          if (!(yy > 0.f)) g = 0.f;
+        }
         s1 += g;
-        s2 += g * (z[r * C + c] - mu) * is;
+        s2 += g * (zz - mu) * is;
       }
     }
     sm[0][threadIdx.x] = s1;
@@ -238,24 +266,34 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
   }
 }
 
-// pass 2: one wave per channel sums the chunk partials (fp64), writes s[2][C] and dgamma/dbeta
+// pass 2: one workgroup per channel sums the chunk partials (fp64, four loads in flight), writes s[2][C] and
+// dgamma/dbeta
 __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __restrict__ part, int nchunks, int C,
                                                               float* __restrict__ s, float* __restrict__ dgamma,
                                                               float* __restrict__ dbeta, int accumulate) {
-  const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
-  const int lane = threadIdx.x & 63;
-  if (c >= C) return;
+  __shared__ double sm[4];
+  const int c = blockIdx.x;
   double s1 = 0.0, s2 = 0.0;
-  for (int k = lane; k < nchunks; k += 64) {
-    s1 += (double)part[((long)k * 2 + 0) * C + c];
-    s2 += (double)part[((long)k * 2 + 1) * C + c];
-  }
+  for (int k0 = threadIdx.x; k0 < nchunks; k0 += 1024) {
+    float a[4], b[4];
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
-    s1 += shfl_xor_d(s1, o);
-    s2 += shfl_xor_d(s2, o);
+    for (int u = 0; u < 4; ++u) {
+      const int k = k0 + 256 * u;
+      const bool ok = k < nchunks;
+      const long kc = ok ? k : 0;
+      a[u] = part[(kc * 2 + 0) * C + c];
+      b[u] = part[(kc * 2 + 1) * C + c];
+      if (!ok) { a[u] = 0.f; b[u] = 0.f; }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      s1 += (double)a[u];
+      s2 += (double)b[u];
+    }
   }
-  if (lane == 0) {
+  s1 = block_sum_d(s1, sm);
+  s2 = block_sum_d(s2, sm);
+  if (threadIdx.x == 0) {
     s[c] = (float)s1;
     s[C + c] = (float)s2;
     if (dbeta) dbeta[c] = accumulate ? dbeta[c] + (float)s1 : (float)s1;
@@ -270,6 +308,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
                                                            const float* __restrict__ mean,
                                                            const float* __restrict__ invstd,
                                                            const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta,
                                                            const float* __restrict__ s, int relu, long total, int C,
                                                            float inv_rows, float* __restrict__ dz,
                                                            float* __restrict__ dres) {
@@ -284,7 +323,15 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
       f32x4 g = reinterpret_cast<const f32x4*>(dy)[i];
       const f32x4 zz = reinterpret_cast<const f32x4*>(z)[i];
       if (relu) {
-        const f32x4 yy = reinterpret_cast<const f32x4*>(y)[i];
+        f32x4 yy;
+        if (y) yy = reinterpret_cast<const f32x4*>(y)[i];
+        else {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const float sc = invstd[c + j] * gamma[c + j];
+            yy[j] = (zz[j] - mean[c + j]) * sc + beta[c + j];
+          }
+        }
 #pragma unroll
         for (int j = 0; j < 4; ++j)
           if (!(yy[j] > 0.f)) g[j] = 0.f;
@@ -307,7 +354,10 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
       c += dc;
       if (c >= C) c -= C;
       float g = dy[i];
-      if (relu && !(y[i] > 0.f)) g = 0.f;
+      if (relu) {
+        const float yy = y ? y[i] : (z[i] - mean[c]) * (invstd[c] * gamma[c]) + beta[c];
+        if (!(yy > 0.f)) g = 0.f;
+      }
       const float is = invstd[c];
       const float zh = (z[i] - mean[c]) * is;
       dz[i] = gamma[c] * is * (g - s[c] * inv_rows - zh * s[C + c] * inv_rows);
@@ -387,10 +437,11 @@ extern "C" size_t buctd_bn_bwd_workspace(long rows, int C) {
 }
 
 extern "C" int buctd_bn_bwd(const float* dy, const float* y, const float* z, const float* mean, const float* invstd,
-                            const float* gamma, int relu, long rows, int C, float* dz, float* dres, float* dgamma,
-                            float* dbeta, int accumulate, void* workspace, size_t workspace_bytes, void* stream) {
+                            const float* gamma, const float* beta, int relu, long rows, int C, float* dz, float* dres,
+                            float* dgamma, float* dbeta, int accumulate, void* workspace, size_t workspace_bytes,
+                            void* stream) {
   BUCTD_CHECK_ARG(dy && z && mean && invstd && gamma && dz && rows > 0 && C > 0, "buctd_bn_bwd: bad argument");
-  BUCTD_CHECK_ARG(!relu || y, "buctd_bn_bwd: relu backward needs the forward output");
+  BUCTD_CHECK_ARG(!relu || y || beta, "buctd_bn_bwd: relu backward needs the forward output, or beta to rebuild its sign");
   const size_t need = buctd_bn_bwd_workspace(rows, C);
   if (!workspace || workspace_bytes < need) {
     buctd_set_error("buctd_bn_bwd: workspace %zu bytes < required %zu", workspace_bytes, need);
@@ -401,23 +452,23 @@ extern "C" int buctd_bn_bwd(const float* dy, const float* y, const float* z, con
   float* part = (float*)workspace;
   float* s = part + (long)nchunks * 2 * C;
   if (C % 4 == 0 && C / 4 <= 256)
-    hipLaunchKernelGGL(bn_bwd_reduce_vec_kernel, dim3(nchunks), dim3(256), 0, st, dy, y, z, mean, invstd, relu, rows,
-                       C, part);
+    hipLaunchKernelGGL(bn_bwd_reduce_vec_kernel, dim3(nchunks), dim3(256), 0, st, dy, y, z, mean, invstd, gamma, beta, relu,
+                       rows, C, part);
   else
-    hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(nchunks), dim3(256), 0, st, dy, y, z, mean, invstd, relu, rows, C,
-                       part);
+    hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(nchunks), dim3(256), 0, st, dy, y, z, mean, invstd, gamma, beta, relu, rows,
+                       C, part);
   BUCTD_CHECK_LAUNCH("buctd_bn_bwd(reduce)");
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(ceil_div(C, 4)), dim3(256), 0, st, (const float*)part, nchunks, C, s,
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(256), 0, st, (const float*)part, nchunks, C, s,
                      dgamma, dbeta, accumulate);
   BUCTD_CHECK_LAUNCH("buctd_bn_bwd(finalize)");
   const long total = rows * C;
   const float inv_rows = 1.0f / (float)rows;
   if (C % 4 == 0)
     hipLaunchKernelGGL(bn_bwd_apply_kernel<true>, dim3(stream_grid(total / 4)), dim3(256), 0, st, dy, y, z, mean,
-                       invstd, gamma, (const float*)s, relu, total, C, inv_rows, dz, dres);
+                       invstd, gamma, beta, (const float*)s, relu, total, C, inv_rows, dz, dres);
   else
     hipLaunchKernelGGL(bn_bwd_apply_kernel<false>, dim3(stream_grid(total)), dim3(256), 0, st, dy, y, z, mean, invstd,
-                       gamma, (const float*)s, relu, total, C, inv_rows, dz, dres);
+                       gamma, beta, (const float*)s, relu, total, C, inv_rows, dz, dres);
   BUCTD_CHECK_LAUNCH("buctd_bn_bwd(apply)");
   return BUCTD_OK;
 }

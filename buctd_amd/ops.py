@@ -302,15 +302,18 @@ def bn_apply(z, mean, invstd, gamma, beta, residual=None, relu=False):
     return y
 
 
-def bn_bwd(dy, y, z, mean, invstd, gamma, relu, want_dres, dgamma, dbeta, accumulate):
+def bn_bwd(dy, y, z, mean, invstd, gamma, relu, want_dres, dgamma, dbeta, accumulate, beta=None):
+    """y=None with relu: the ReLU mask is rebuilt from z, gamma and beta (forward without residual only)."""
     Cn = z.shape[-1]
     rows = z.numel() // Cn
     dz = torch.empty_like(z)
     dres = torch.empty_like(z) if want_dres else None
     need = lib().buctd_bn_bwd_workspace(rows, Cn)
     ws = workspace(need, z.device)
+    if relu and y is None and beta is None:
+        raise _C.BuctdHipError("bn_bwd: ReLU backward needs the forward output or beta")
     check(lib().buctd_bn_bwd(ptr(dy), ptr(y) if relu else None, ptr(z), ptr(mean), ptr(invstd), ptr(gamma),
-                             int(bool(relu)), rows, Cn, ptr(dz), ptr(dres), ptr(dgamma), ptr(dbeta), int(accumulate),
+                             ptr(beta) if (relu and y is None) else None, int(bool(relu)), rows, Cn, ptr(dz), ptr(dres), ptr(dgamma), ptr(dbeta), int(accumulate),
                              ptr(ws), ws.numel(), stream_ptr()), "bn_bwd")
     return dz, dres
 
@@ -550,8 +553,9 @@ class ConvBnAct(torch.autograd.Function):
             if track:
                 bn.count_batch() if hasattr(bn, "count_batch") else bn.num_batches_tracked.add_(1)
             y = bn_apply(z, mean, invstd, gamma, beta, residual, relu)
-            ctx.save_for_backward(x, z, mean, invstd, y if relu else None)
             ctx.has_res = residual is not None
+            # without a residual the ReLU mask is rebuilt from z in the backward kernels: y is not kept (nor re-read)
+            ctx.save_for_backward(x, z, mean, invstd, y if (relu and ctx.has_res) else None)
             return y
         scale, shift = bn_fold(gamma, beta, bn.running_mean, bn.running_var, eps)
         if transposed_shape is None:
@@ -575,7 +579,8 @@ class ConvBnAct(torch.autograd.Function):
         dgamma, acc_g = grad_target(bn.weight)
         dbeta, acc_b = grad_target(bn.bias)
         assert acc_g == acc_b
-        dz, dres = bn_bwd(dy, y, z, mean, invstd, bn.weight, relu, ctx.has_res and relu, dgamma, dbeta, acc_g)
+        dz, dres = bn_bwd(dy, y, z, mean, invstd, bn.weight, relu, ctx.has_res and relu, dgamma, dbeta, acc_g,
+                          beta=bn.bias)
         if ctx.has_res and not relu:
             dres = dy
         dx = None

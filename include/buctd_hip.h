@@ -115,13 +115,15 @@ int buctd_bn_stats_groups(long rows, int C, int* ngroups, int* rows_per_group);
 /* y = act((z-mean)*invstd*gamma+beta (+residual)) */
 int buctd_bn_apply(const float* z, const float* mean, const float* invstd, const float* gamma, const float* beta,
                    const float* residual, int relu, float* y, long rows, int C, void* stream);
-/* Backward of bn_apply in train mode. y is the forward output (ReLU mask), may be NULL when relu==0.
+/* Backward of bn_apply in train mode. y is the forward output (ReLU mask), may be NULL when relu==0.  With relu != 0
+ * and y == NULL the mask is rebuilt bit-exactly from z as (z-mean)*(invstd*gamma)+beta > 0 - valid only when the
+ * forward had no residual - which saves one full read of the activation tensor per pass (beta is read only then).
  * Writes dz; dres (NULL ok) receives the masked upstream gradient (gradient of the residual input);
  * dgamma/dbeta are overwritten (accumulate=0) or added to. workspace: buctd_bn_bwd_workspace bytes. */
 size_t buctd_bn_bwd_workspace(long rows, int C);
 int buctd_bn_bwd(const float* dy, const float* y, const float* z, const float* mean, const float* invstd,
-                 const float* gamma, int relu, long rows, int C, float* dz, float* dres, float* dgamma,
-                 float* dbeta, int accumulate, void* workspace, size_t workspace_bytes, void* stream);
+                 const float* gamma, const float* beta, int relu, long rows, int C, float* dz, float* dres,
+                 float* dgamma, float* dbeta, int accumulate, void* workspace, size_t workspace_bytes, void* stream);
 /* eval-mode helpers: scale = gamma/sqrt(var+eps), shift = beta - mean*scale */
 int buctd_bn_fold(const float* gamma, const float* beta, const float* running_mean, const float* running_var,
                   float eps, int C, float* scale, float* shift, void* stream);
