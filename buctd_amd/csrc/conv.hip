@@ -36,6 +36,8 @@ struct ConvArgs {
   int M, K;           // M = N*RH*RW, K = R*S*SC
   int wRSCi, wCi;     // weight strides: R*S*Ci and Ci
   int relu;
+  int par;            // dgrad of a stride-2 conv split by output-pixel parity (blockIdx.z = 2*py + px): every class
+                      // only visits the taps that reach it (1, 2, 2 or 4 of the 9) instead of testing all nine
 };
 
 template <class T, bool DGRAD, bool VEC>
@@ -59,18 +61,29 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvArgs p) {
   const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
   const int arow = t >> 2, chunk = t & 3;
 
+  // parity class (stride-2 data gradient only): rows of this launch slice are the pixels (2a+py, 2b+px)
+  const bool par = DGRAD && p.par;
+  const int py = par ? (int)(blockIdx.z >> 1) : 0, px = par ? (int)(blockIdx.z & 1) : 0;
+  const int RHc = par ? (p.RH - py + 1) / 2 : p.RH, RWc = par ? (p.RW - px + 1) / 2 : p.RW;
+  const int Mc = par ? p.N * RHc * RWc : p.M;
+  if (m0 >= Mc) return;
+  const int tr0 = par ? ((py + p.pad) & 1) : 0, ts0 = par ? ((px + p.pad) & 1) : 0;   // first reaching tap
+  const int tns = par ? (p.S - ts0 + 1) / 2 : p.S;
+  const int Kc = par ? ((p.R - tr0 + 1) / 2) * tns * p.SC : p.K;
+
   // per-pass row decode for the A gather
   int r_img[PA], r_a[PA], r_b[PA];
   bool r_ok[PA];
 #pragma unroll
   for (int q = 0; q < PA; ++q) {
     const int m = m0 + arow + 64 * q;
-    r_ok[q] = m < p.M;
+    r_ok[q] = m < Mc;
     const int mm = r_ok[q] ? m : 0;
-    const int img = mm / (p.RH * p.RW);
-    const int rem = mm - img * (p.RH * p.RW);
-    r_a[q] = rem / p.RW;
-    r_b[q] = rem - r_a[q] * p.RW;
+    const int img = mm / (RHc * RWc);
+    const int rem = mm - img * (RHc * RWc);
+    r_a[q] = rem / RWc;
+    r_b[q] = rem - r_a[q] * RWc;
+    if (par) { r_a[q] = 2 * r_a[q] + py; r_b[q] = 2 * r_b[q] + px; }
     r_img[q] = img * p.SH * p.SW * p.SC;
   }
 
@@ -97,7 +110,8 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvArgs p) {
     // ---- A: gathered source rows --------------------------------------
     if (VEC) {
       const int tap = k0 / p.SC, c0 = k0 - tap * p.SC;
-      const int r = tap / p.S, s = tap - r * p.S;
+      int r = tap / tns, s = tap - r * tns;
+      if (par) { r = tr0 + 2 * r; s = ts0 + 2 * s; }
 #pragma unroll
       for (int q = 0; q < PA; ++q) {
         bool ok;
@@ -152,8 +166,10 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvArgs p) {
         const int krow = idx / NB4, n4 = idx - krow * NB4;
         const int k = k0 + krow, n = n0 + n4 * 4;
         f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
-        if (krow < GK && k < p.K && n < p.OC) {
-          const int tap = k / p.SC, co = k - tap * p.SC;
+        if (krow < GK && k < Kc && n < p.OC) {
+          int tap = k / p.SC;
+          const int co = k - tap * p.SC;
+          if (par) { const int tr = tap / tns; tap = (tr0 + 2 * tr) * p.S + ts0 + 2 * (tap - tr * tns); }
           const float* wp = p.w + (long)co * p.wRSCi + tap * p.wCi + n;
           if (VEC) {
             v = *reinterpret_cast<const f32x4*>(wp);
@@ -192,9 +208,11 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvArgs p) {
   f32x4 acc[T::MF][T::NF];
   zero_acc<T>(acc);
 
-  const int nk = (p.K + GK - 1) / GK;
-  load_stage(0);
-  store_stage(0);
+  const int nk = (Kc + GK - 1) / GK;
+  if (nk > 0) {
+    load_stage(0);
+    store_stage(0);
+  }
   __syncthreads();
   for (int kt = 0; kt < nk; ++kt) {
     const int cur = kt & 1;
@@ -255,9 +273,15 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvArgs p) {
 #pragma unroll
         for (int rg = 0; rg < 4; ++rg) {
           const int m = m0 + acc_row<T>(wm, mf, lane, rg);
-          if (m < p.M) {
+          if (m < Mc) {
             float v = (acc[mf][nf][rg] + bv) * sc + sh;
-            const long o = (long)m * p.OC + n;
+            long orow = m;
+            if (par) {
+              const int img = m / (RHc * RWc), rem = m - img * (RHc * RWc);
+              const int a = rem / RWc, b = rem - a * RWc;
+              orow = ((long)img * p.RH + 2 * a + py) * p.RW + 2 * b + px;
+            }
+            const long o = orow * p.OC + n;
             if (p.res) v += p.res[o];
             if (p.relu) v = fmaxf(v, 0.f);
             p.out[o] = v;
@@ -445,6 +469,10 @@ static int check_desc(const buctd_conv_desc* d, const char* who) {
 template <class T, bool DGRAD, bool VEC>
 static void launch_conv(const ConvArgs& a, hipStream_t st) {
   dim3 grid(ceil_div(a.M, T::BM), ceil_div(a.OC, T::BN));
+  if (DGRAD && a.par) {   // four parity classes; the (even, even) one is the largest
+    const long mc = (long)a.N * ((a.RH + 1) / 2) * ((a.RW + 1) / 2);
+    grid = dim3(ceil_div(mc, T::BM), ceil_div(a.OC, T::BN), 4);
+  }
   hipLaunchKernelGGL((conv_gemm_kernel<T, DGRAD, VEC>), grid, dim3(256), 0, st, a);
 }
 
@@ -512,7 +540,7 @@ extern "C" int buctd_conv2d_fwd(const buctd_conv_desc* d, const float* x, const 
   a.R = d->R; a.S = d->S; a.stride = d->stride; a.pad = d->pad;
   a.M = d->N * d->Ho * d->Wo; a.K = d->R * d->S * d->Ci;
   a.wRSCi = d->R * d->S * d->Ci; a.wCi = d->Ci;
-  a.relu = relu;
+  a.relu = relu; a.par = 0;
   dispatch_conv<false>(a, fwd_vec_ok(d), (hipStream_t)stream);
   BUCTD_CHECK_LAUNCH("buctd_conv2d_fwd");
   return BUCTD_OK;
@@ -532,6 +560,7 @@ extern "C" int buctd_conv2d_dgrad(const buctd_conv_desc* d, const float* dy, con
   a.M = d->N * d->H * d->W; a.K = d->R * d->S * d->Co;
   a.wRSCi = d->R * d->S * d->Ci; a.wCi = d->Ci;
   a.relu = 0;
+  a.par = (d->stride == 2 && d->R == 3 && d->S == 3 && d->pad == 1 && !stats_partials && dgrad_vec_ok(d)) ? 1 : 0;
   dispatch_conv<true>(a, dgrad_vec_ok(d), (hipStream_t)stream);
   BUCTD_CHECK_LAUNCH("buctd_conv2d_dgrad");
   return BUCTD_OK;

@@ -48,6 +48,10 @@ CONV_CASES = [
     (8, 96, 72, 48, 48, 3, 1, 1, False),   # BM=128 tile path
     (4, 48, 36, 96, 96, 3, 1, 1, False),
     (2, 8, 6, 256, 256, 4, 2, 1, False),   # deconv geometry
+    (2, 24, 18, 48, 96, 3, 2, 1, False),   # stride-2 data gradient: parity-class decomposition, even sizes
+    (2, 16, 12, 48, 48, 3, 2, 1, True),
+    (2, 13, 8, 192, 384, 3, 2, 1, False),  # odd height, even width
+    (1, 6, 5, 64, 64, 3, 2, 1, False),
 ]
 
 
