@@ -213,8 +213,11 @@ class DataParallel(torch.nn.Module):
             ev.record(torch.cuda.current_stream())
             with torch.cuda.stream(self._comm_stream):
                 self._comm_stream.wait_event(ev)
+                ops.wait_side_stream(self._comm_stream)   # weight gradients are produced on ops' side stream
                 self._handles.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, async_op=True))
         else:
+            if view.is_cuda:
+                ops.wait_side_stream()
             self._handles.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, async_op=True))
 
     def _grad_ready(self, p):

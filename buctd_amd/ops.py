@@ -259,6 +259,52 @@ def conv_wgrad(x, dy, w_like, stride=1, pad=0, out=None, accumulate=0):
     return out
 
 
+# Weight gradients are off the critical path of the backward pass (nothing downstream of dgrad needs them), so they
+# run on a second HIP stream and fill the CUs that the latency-bound BN / dgrad chain leaves idle.  The join is queued
+# as an autograd end-of-backward callback, so param.grad is complete on the caller's stream when backward() returns.
+_side = {"on": os.environ.get("BUCTD_WGRAD_STREAM", "1") == "1", "streams": {}, "joined": True}
+
+
+def _side_stream(device):
+    st = _side["streams"].get(device.index)
+    if st is None:
+        st = torch.cuda.Stream(device=device)
+        _side["streams"][device.index] = st
+    return st
+
+
+def wait_side_stream(stream=None):
+    """Make `stream` (default: the current one) wait for every weight-gradient kernel enqueued so far."""
+    for idx, st in _side["streams"].items():
+        target = stream if stream is not None else torch.cuda.current_stream(torch.device("cuda", idx))
+        target.wait_stream(st)
+
+
+def _join_side():
+    _side["joined"] = True
+    wait_side_stream()
+
+
+def conv_wgrad_async(x, dy, w_like, stride, pad, out, accumulate):
+    """conv_wgrad on the side stream (backward passes only: the join rides on the autograd engine's final callback)."""
+    if not (_side["on"] and x.is_cuda):
+        return conv_wgrad(x, dy, w_like, stride, pad, out=out, accumulate=accumulate)
+    main = torch.cuda.current_stream(x.device)
+    side = _side_stream(x.device)
+    side.wait_stream(main)
+    with torch.cuda.stream(side):
+        conv_wgrad(x, dy, w_like, stride, pad, out=out, accumulate=accumulate)
+    x.record_stream(side)
+    dy.record_stream(side)
+    if _side["joined"]:
+        _side["joined"] = False
+        try:
+            torch.autograd.Variable._execution_engine.queue_callback(_join_side)
+        except RuntimeError:      # not inside a backward pass: join right away
+            _join_side()
+    return out
+
+
 def matmul(A, B, Cout, *, batch, M, N, K, a_layout, b_layout, lda, ldb, ldc, stride_a=0, stride_b=0, stride_c=0,
            Kc=None, gsa=0, gsbk=0, Nc=None, gsbn=0, gsc=0, alpha=1.0, bias=None, bias_axis=0,
            a_off=0, b_off=0, c_off=0):
@@ -588,14 +634,14 @@ class ConvBnAct(torch.autograd.Function):
             if ctx.needs_input_grad[0]:
                 dx = conv_dgrad(dz, conv_w, x_shape, stride, pad)
             dw, acc_w = grad_target(conv_w)
-            conv_wgrad(x, dz, conv_w, stride, pad, out=dw, accumulate=acc_w)
+            conv_wgrad_async(x, dz, conv_w, stride, pad, dw, acc_w)
         else:
             # forward was a transposed conv: its data gradient is a plain conv, its weight gradient
             # swaps the roles of input and output gradient
             if ctx.needs_input_grad[0]:
                 dx = conv_fwd(dz, conv_w, None, stride, pad)
             dw, acc_w = grad_target(conv_w)
-            conv_wgrad(dz, x, conv_w, stride, pad, out=dw, accumulate=acc_w)
+            conv_wgrad_async(dz, x, conv_w, stride, pad, dw, acc_w)
         if conv_b is not None:
             db, acc = grad_target(conv_b)
             colsum(dz, dz.shape[-1], db, acc)
@@ -623,7 +669,7 @@ class Conv(torch.autograd.Function):
         dx = conv_dgrad(dy, w, x_shape, stride, pad) if ctx.needs_input_grad[0] else None
         if w.requires_grad:
             dw, acc = grad_target(w)
-            conv_wgrad(x, dy, w, stride, pad, out=dw, accumulate=acc)
+            conv_wgrad_async(x, dy, w, stride, pad, dw, acc)
         if b is not None and b.requires_grad:
             db, acc = grad_target(b)
             colsum(dy, dy.shape[-1], db, acc)
