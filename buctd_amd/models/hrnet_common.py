@@ -138,9 +138,10 @@ class HighResolutionModule(nn.Module):
     def forward(self, x):
         if self.num_branches == 1:
             return [self.branches[0](x[0])]
-        xs = [self.branches[i](x[i]) for i in range(self.num_branches)]
-        outs = []
-        for i, row in enumerate(self.fuse_layers):
+        xs = ops.fork_join([lambda i=i: self.branches[i](x[i]) for i in range(self.num_branches)],
+                           [x[i] for i in range(self.num_branches)])
+
+        def fuse_row(i, row):
             terms, shifts = [], []
             for j in range(self.num_branches):
                 if j == i:
@@ -152,8 +153,10 @@ class HighResolutionModule(nn.Module):
                 else:
                     terms.append(row[j](xs[j]))
                     shifts.append(0)
-            outs.append(ops.FuseSum.apply(tuple(shifts), True, *terms))
-        return outs
+            return ops.FuseSum.apply(tuple(shifts), True, *terms)
+
+        rows = list(enumerate(self.fuse_layers))
+        return ops.fork_join([lambda i=i, row=row: fuse_row(i, row) for i, row in rows], [xs for _ in rows], tag=1)
 
 
 def make_transition_layer(pre, cur):

@@ -20,7 +20,12 @@ Parameter = tnn.Parameter
 
 def _as_channels_last_(p):
     if p.dim() == 4 and not p.is_contiguous(memory_format=torch.channels_last):
-        p.data = p.data.contiguous(memory_format=torch.channels_last)
+        old = p.data
+        p.data = old.contiguous(memory_format=torch.channels_last)
+        if old.is_cuda:
+            # the first forward may run on a branch stream (ops.fork_join): keep the old storage away from the
+            # allocator until that stream's copy has read it
+            old.record_stream(torch.cuda.current_stream(old.device))
 
 
 def prepare_module(module):

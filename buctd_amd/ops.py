@@ -274,10 +274,78 @@ def _side_stream(device):
 
 
 def wait_side_stream(stream=None):
-    """Make `stream` (default: the current one) wait for every weight-gradient kernel enqueued so far."""
+    """Make `stream` (default: the current one) wait for everything enqueued so far on the streams this module owns
+    (weight-gradient stream and branch streams)."""
     for idx, st in _side["streams"].items():
         target = stream if stream is not None else torch.cuda.current_stream(torch.device("cuda", idx))
         target.wait_stream(st)
+    for (idx, _), st in _branch["streams"].items():
+        target = stream if stream is not None else torch.cuda.current_stream(torch.device("cuda", idx))
+        if target != st:
+            target.wait_stream(st)
+
+
+# Independent sub-graphs (the parallel resolution branches of an HRNet module, the rows of its fuse stage) are
+# enqueued on separate HIP streams: the low-resolution branches are launch/latency bound and hide under the
+# bandwidth-bound high-resolution one.  Autograd replays every backward node on the stream of its forward op, so the
+# backward pass inherits the same concurrency.
+_branch = {"on": os.environ.get("BUCTD_BRANCH_STREAMS", "1") == "1", "streams": {}}
+
+
+def _branch_stream(device, i):
+    key = (device.index, i)
+    st = _branch["streams"].get(key)
+    if st is None:
+        st = torch.cuda.Stream(device=device)
+        _branch["streams"][key] = st
+    return st
+
+
+def _record(t, stream):
+    if torch.is_tensor(t):
+        if t.is_cuda:
+            t.record_stream(stream)
+    elif isinstance(t, (list, tuple)):
+        for u in t:
+            _record(u, stream)
+
+
+def fork_join(fns, inputs, tag=0):
+    """Run fns[i]() concurrently: fns[0] on the current stream, the others on branch streams that first wait for the
+    work enqueued so far; returns their results once the current stream has been made to wait for all of them.
+    inputs[i]: the tensors fns[i] reads (so that the allocator knows they are in use on that stream)."""
+    dev = None
+    for t in inputs:
+        for u in (t if isinstance(t, (list, tuple)) else [t]):
+            if torch.is_tensor(u) and u.is_cuda:
+                dev = u.device
+    dbg = int(os.environ.get("BUCTD_FORK_DEBUG", "0"))
+    if not _branch["on"] or dev is None or len(fns) < 2 or (dbg & (1 << tag)):
+        return [f() for f in fns]
+    main = torch.cuda.current_stream(dev)
+    start = torch.cuda.Event()
+    start.record(main)
+    outs = [None] * len(fns)
+    done = []
+    outs[0] = fns[0]()      # same op creation order as the serial path: autograd then accumulates in the same order
+    for i in range(1, len(fns)):
+        st = _branch_stream(dev, i)
+        if st == main:          # nested fork on a branch stream: run inline
+            outs[i] = fns[i]()
+            continue
+        st.wait_event(start)
+        _record(inputs[i], st)
+        with torch.cuda.stream(st):
+            outs[i] = fns[i]()
+            ev = torch.cuda.Event()
+            ev.record(st)
+        _record(outs[i], main)
+        done.append(ev)
+    for ev in done:
+        main.wait_event(ev)
+    if dbg & 4:
+        torch.cuda.synchronize()
+    return outs
 
 
 def _join_side():
