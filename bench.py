@@ -25,6 +25,7 @@ sys.path.insert(0, ROOT)
 # MI355X_MICROARCH.md: fp32 MFMA (v_mfma_f32_16x16x4_f32) peak = fp32 vector peak; HBM3E spec peak
 PEAK_FP32_MFMA_TFLOPS = 157.3
 PEAK_HBM_GBPS = 8000.0
+PMC_TRAFFIC_BYTES_N32 = 106.4e6
 
 
 def coam_w48_cfg(batch):
@@ -283,17 +284,26 @@ def main():
             bytes_ = 4.0 * (2 * n * 48 * 96 * 72) + 4.0 * 9 * 48 * 48
             tf = flops / (ms * 1e-3) / 1e12
             kname = ("conv_gemm_kernel<128x48> (fp32 MFMA)" if args.conv_math == "fp32"
-                     else "conv3x3_bf16x3_kernel<256x48> (bf16 MFMA, split fp32 operands)")
+                     else "conv3x3_bf16x3_kernel<4,3,4,1> = 256 positions x 48 channels / workgroup (bf16 MFMA, split fp32 operands)")
             gbps = bytes_ / (ms * 1e-3) / 1e9
             if args.conv_math == "bf16x3":
                 # with the bf16 matrix cores the 3x3 conv is no longer compute-bound at the fp32 rate: price it
                 # against HBM (north_star: >= 60 % HBM roofline on the HRNet stage-4 conv)
                 out["roofline"] = {"kernel": kname + " fwd 3x3 48->48 @96x72 (HRNet stage-3/4 branch 0)",
                                    "bound": "hbm", "achieved": round(gbps, 1), "peak": PEAK_HBM_GBPS, "unit": "GB/s",
-                                   "frac": round(gbps / PEAK_HBM_GBPS, 4), "traffic": None,
+                                   "frac": round(gbps / PEAK_HBM_GBPS, 4),
+                                   # HBM-side bytes per launch from separate rocprofv3 --pmc passes over this kernel at
+                                   # this shape (2 x FETCH_SIZE + WRITE_SIZE, profiles/r01_pmc_conv3x3_bf16x3_fetch_write.txt);
+                                   # counters cannot be read from inside the timed run, so the figure is only quoted
+                                   # for the batch it was collected at
+                                   "traffic": PMC_TRAFFIC_BYTES_N32 if n == 32 else None,
+                                   "traffic_unit": "bytes/launch (PMC, standalone launches)",
+                                   "algorithmic_bytes": bytes_,
                                    "launches_timed": len(timer.pairs), "avg_launch_us": round(ms * 1e3, 2),
                                    "tflops_equivalent": round(tf, 2),
-                                   "note": "algorithmic bytes 85.0 MB / launch (in + out + weights, fp32); 3 bf16 MFMAs "
+                                   "note": "algorithmic bytes 85.0 MB / launch (in + out + weights, fp32); the timed "
+                                           "launches run inside the train step, i.e. concurrently with the kernels of "
+                                           "the other HRNet branches and of the weight-gradient stream; 3 bf16 MFMAs "
                                            "per product keep the MFMA time (~14 us) below the HBM time (~11-17 us)"}
                 ms = None
         if ms is not None:

@@ -359,6 +359,42 @@ __global__ __launch_bounds__(256) void conv3x3_prep_kernel(const float* __restri
   split_store(out + rown * 128, c4, v);
 }
 
+// the same for many filters in one launch (all prepared images of a model after an optimizer step): items live in
+// device memory, thread -> item by binary search over the running piece count
+__global__ __launch_bounds__(256) void conv3x3_prep_batched_kernel(const buctd_c3_prep_item* __restrict__ items, int n,
+                                                                   long total) {
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= total) return;
+  int lo = 0, hi = n - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (items[mid].piece_begin <= idx) lo = mid;
+    else hi = mid - 1;
+  }
+  const buctd_c3_prep_item it = items[lo];
+  const long local = idx - it.piece_begin;
+  const int Kc = it.flip ? it.Co : it.Ci, Nc = it.flip ? it.Ci : it.Co;
+  const int k4 = (int)(local & 7);
+  const long rown = local >> 3;
+  const int nn = (int)(rown % Nc), step = (int)(rown / Nc);
+  const int nfull = Kc / CK;
+  int c0, s, cw;
+  if (step < nfull * 9) { c0 = (step / 9) * CK; s = step % 9; cw = 2; }
+  else { c0 = nfull * CK; s = step - nfull * 9; cw = 1; }
+  const int c4 = k4 * 4;
+  const int tap = cw == 2 ? s : 2 * s + (c4 >> 4);
+  const int cc = c0 + (cw == 2 ? c4 : (c4 & 15));
+  f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
+  if (tap < 9) {
+    if (!it.flip) v = *reinterpret_cast<const f32x4*>(it.w + ((long)nn * 9 + tap) * Kc + cc);
+    else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[j] = it.w[((long)(cc + j) * 9 + (8 - tap)) * Nc + nn];
+    }
+  }
+  split_store(reinterpret_cast<unsigned char*>(it.wprep) + rown * 128, c4, v);
+}
+
 // ---------------------------------------------------------------------------------------------- host ----
 struct C3Plan { int MF, NF, WM, WN, BM, BN, na; size_t lds; };
 
@@ -432,6 +468,15 @@ extern "C" int buctd_conv3x3_bf16x3_prep(int Ci, int Co, const float* w, int fli
   hipLaunchKernelGGL(conv3x3_prep_kernel, dim3(ceil_div(pieces, 256)), dim3(256), 0, (hipStream_t)stream, w,
                      (unsigned char*)wprep, Kc, Nc, flip ? 1 : 0, pieces);
   BUCTD_CHECK_LAUNCH("buctd_conv3x3_bf16x3_prep");
+  return BUCTD_OK;
+}
+
+extern "C" int buctd_conv3x3_bf16x3_prep_batched(const buctd_c3_prep_item* items_device, int n, long total_pieces,
+                                                 void* stream) {
+  BUCTD_CHECK_ARG(items_device && n > 0 && total_pieces > 0, "buctd_conv3x3_bf16x3_prep_batched: bad argument");
+  hipLaunchKernelGGL(conv3x3_prep_batched_kernel, dim3(ceil_div(total_pieces, 256)), dim3(256), 0, (hipStream_t)stream,
+                     items_device, n, total_pieces);
+  BUCTD_CHECK_LAUNCH("buctd_conv3x3_bf16x3_prep_batched");
   return BUCTD_OK;
 }
 

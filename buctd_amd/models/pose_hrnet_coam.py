@@ -64,13 +64,19 @@ class DAModule(nn.Module):
         self.channel_attention_module = ChannelAttentionModule(d_model=d_model, d_cond=d_cond,
                                                                kernel_size=kernel_size, H=H, W=W, n_heads=n_heads)
 
-    def forward(self, input, cond):
-        b, h, w, c = input.shape
-        c_out = self.channel_attention_module(input, cond).view(b, h, w, c)
+    def parts(self):
+        """the independent attention cores of this module, as callables (input, cond) -> [B, T, C]"""
         if self.channel_only:
             raise NotImplementedError("MODEL.ATT_CHANNEL_ONLY (input * c_out) is not used by any BUCTD recipe")
-        p_out = self.position_attention_module(input, cond).view(b, h, w, c)
-        return ops.AddN.apply(input, p_out, c_out)
+        return [self.channel_attention_module, self.position_attention_module]
+
+    def combine(self, input, outs):
+        b, h, w, c = input.shape
+        c_out, p_out = outs
+        return ops.AddN.apply(input, p_out.view(b, h, w, c), c_out.view(b, h, w, c))
+
+    def forward(self, input, cond):
+        return self.combine(input, [part(input, cond) for part in self.parts()])
 
 
 class CoAMBlock(nn.Module):
@@ -93,12 +99,13 @@ class CoAMBlock(nn.Module):
     def forward(self, y_list, x_nchw):
         """x_nchw: the full NCHW network input; the condition is its channel slice [3, 3 + d_cond)
         (mono: 'we only want one channel of the heatmap', pose_hrnet_coam.py:751-752)."""
-        out = []
-        for i, y in enumerate(y_list):
+        conds = []
+        for i in range(len(y_list)):
             hh, ww = self.spat_dims[i][1], self.spat_dims[i][0]
-            cond = ops.resize_bilinear_from_nchw(x_nchw, 3, self.d_cond, hh, ww)
-            out.append(self.att_layers[i](y, cond))
-        return out
+            conds.append(ops.resize_bilinear_from_nchw(x_nchw, 3, self.d_cond, hh, ww))
+        # (running the 2 x n attention cores on separate HIP streams was measured and is a loss: the fused position
+        #  attention streams its K/V tiles out of L2 and co-running kernels evict them - 88.4 vs 83.5 ms/step)
+        return [self.att_layers[i](y, conds[i]) for i, y in enumerate(y_list)]
 
 
 class SelfDAModule(nn.Module):

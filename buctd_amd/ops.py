@@ -153,6 +153,10 @@ def _bf16x3_ok(d):
 
 
 _weights_epoch = {"n": 0}
+# one batched refresh launch instead of ~430 small ones per train step: fewer launches (CPU side) but the small ones
+# overlap with other streams' work and measured 1.5 ms/step faster while the step is GPU-bound; off by default
+_PREP_BATCH = os.environ.get("BUCTD_PREP_BATCH", "0") == "1"
+_prep_registry = {"weights": [], "table": None, "table_key": None, "event": None, "stream": None, "waited": set()}
 
 
 def weights_updated():
@@ -160,22 +164,79 @@ def weights_updated():
     _weights_epoch["n"] += 1
 
 
+class _PrepItem(C.Structure):
+    _fields_ = [("w", C.c_void_p), ("wprep", C.c_void_p), ("Ci", C.c_int), ("Co", C.c_int), ("flip", C.c_int),
+                ("reserved", C.c_int), ("piece_begin", C.c_long)]
+
+
+def _prep_all(device):
+    """Refresh every registered prepared image whose filter was rewritten in place (same storage, new epoch) with ONE
+    launch instead of one per filter and direction (~430 per CoAM-W48 train step)."""
+    import weakref
+    epoch = _weights_epoch["n"]
+    items, live, total = [], [], 0
+    for ref in _prep_registry["weights"]:
+        w = ref()
+        if w is None or not w.is_cuda or w.device != device:
+            continue
+        cache = getattr(w, "_buctd_prep", None)
+        if cache is None or cache[0][0] != w.data_ptr():
+            continue
+        live.append(ref)
+        if cache[0] == (w.data_ptr(), w._version, epoch):
+            continue
+        Co, Ci = _wshape(w)[0], _wshape(w)[1]
+        for flip in (0, 1):
+            img = cache[1 + flip]
+            if img is None:
+                continue
+            items.append((w.data_ptr(), img.data_ptr(), Ci, Co, flip, 0, total))
+            total += img.numel() // 16
+        cache[0] = (w.data_ptr(), w._version, epoch)
+    _prep_registry["weights"] = live
+    if not items:
+        return
+    key = tuple(items)
+    if _prep_registry["table_key"] != key:
+        arr = (_PrepItem * len(items))(*[_PrepItem(*it) for it in items])
+        host = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8)
+        _prep_registry["table"] = host.to(device)
+        _prep_registry["table_key"] = key
+    check(lib().buctd_conv3x3_bf16x3_prep_batched(ptr(_prep_registry["table"]), len(items), total, stream_ptr()),
+          "conv3x3_bf16x3_prep_batched")
+    ev = torch.cuda.Event()
+    ev.record()
+    _prep_registry["event"], _prep_registry["stream"] = ev, torch.cuda.current_stream(device).cuda_stream
+    _prep_registry["waited"] = set()
+
+
 def _conv3x3_prepared(w, flip):
     """bf16 hi|lo stage image of a 3x3 filter (conv3x3.hip), cached on the weight tensor until it changes."""
+    import weakref
     Co, Ci = _wshape(w)[0], _wshape(w)[1]
-    key = (w.data_ptr(), w._version, _weights_epoch["n"])
+    epoch = _weights_epoch["n"]
+    key = (w.data_ptr(), w._version, epoch)
     cache = getattr(w, "_buctd_prep", None)
+    if cache is not None and cache[0] != key and cache[0][:2] == key[:2] and _PREP_BATCH:
+        _prep_all(w.device)       # rewritten in place by the optimizer kernel: batch-refresh all registered images
     if cache is None or cache[0] != key:
         cache = [key, None, None]
         try:
             w._buctd_prep = cache
-        except (AttributeError, RuntimeError):
+            _prep_registry["weights"].append(weakref.ref(w))
+        except (AttributeError, RuntimeError, TypeError):
             pass
     if cache[1 + flip] is None:
         nbytes = lib().buctd_conv3x3_bf16x3_prep_bytes(Ci, Co, flip)
         img = torch.empty(nbytes, dtype=torch.uint8, device=w.device)
         check(lib().buctd_conv3x3_bf16x3_prep(Ci, Co, ptr(w), flip, ptr(img), stream_ptr()), "conv3x3_bf16x3_prep")
         cache[1 + flip] = img
+    ev = _prep_registry["event"]
+    if ev is not None:
+        cur = torch.cuda.current_stream(w.device).cuda_stream
+        if cur != _prep_registry["stream"] and cur not in _prep_registry["waited"]:
+            torch.cuda.current_stream(w.device).wait_event(ev)   # batched refresh ran on another stream
+            _prep_registry["waited"].add(cur)
     return cache[1 + flip]
 
 

@@ -72,6 +72,16 @@ int buctd_conv3x3_bf16x3_supported(int N, int H, int W, int Ci, int Co);
 int buctd_conv3x3_bf16x3_stats_groups(int N, int H, int W, int Ci, int Co, int* ngroups, int* rows_per_group);
 size_t buctd_conv3x3_bf16x3_prep_bytes(int Ci, int Co, int flip);
 int buctd_conv3x3_bf16x3_prep(int Ci, int Co, const float* w, int flip, void* wprep, void* stream);
+/* The same for n filters in ONE launch (every prepared image of a model after an optimizer step).  `items_device` is
+ * an array in device memory; piece_begin is the running sum of buctd_conv3x3_bf16x3_prep_bytes(..)/16 over the
+ * preceding items and total_pieces the sum over all of them. */
+typedef struct {
+  const float* w;       /* forward filter [Co][3][3][Ci] */
+  void* wprep;          /* destination image */
+  int Ci, Co, flip, reserved;
+  long piece_begin;
+} buctd_c3_prep_item;
+int buctd_conv3x3_bf16x3_prep_batched(const buctd_c3_prep_item* items_device, int n, long total_pieces, void* stream);
 int buctd_conv3x3_bf16x3(int N, int H, int W, int Ci, int Co, const float* x, const void* wprep, const float* bias,
                          const float* scale, const float* shift, const float* residual, int relu, float* y,
                          float* stats_partials, int* stats_counts, void* stream);
