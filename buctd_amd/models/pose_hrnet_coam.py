@@ -103,9 +103,20 @@ class CoAMBlock(nn.Module):
         for i in range(len(y_list)):
             hh, ww = self.spat_dims[i][1], self.spat_dims[i][0]
             conds.append(ops.resize_bilinear_from_nchw(x_nchw, 3, self.d_cond, hh, ww))
-        # (running the 2 x n attention cores on separate HIP streams was measured and is a loss: the fused position
-        #  attention streams its K/V tiles out of L2 and co-running kernels evict them - 88.4 vs 83.5 ms/step)
-        return [self.att_layers[i](y, conds[i]) for i, y in enumerate(y_list)]
+        # the channel cores (token-contraction GEMMs + the 191 MB fc_o stream) and the position cores (fused attention,
+        # VALU/MFMA bound) overlap on two HIP streams: +1.2 %.  (One stream per core - six - was measured and is a
+        # loss: the fused position attention streams its K/V tiles out of L2 and co-running kernels evict them.)
+        n = len(y_list)
+
+        def chan():
+            return [self.att_layers[i].parts()[0](y_list[i], conds[i]) for i in range(n)]
+
+        def pos():
+            return [self.att_layers[i].parts()[1](y_list[i], conds[i]) for i in range(n)]
+
+        ins = list(y_list) + conds
+        c_outs, p_outs = ops.fork_join([chan, pos], [ins, ins], tag=3)
+        return [self.att_layers[i].combine(y_list[i], [c_outs[i], p_outs[i]]) for i in range(n)]
 
 
 class SelfDAModule(nn.Module):
