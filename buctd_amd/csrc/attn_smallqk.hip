@@ -227,7 +227,11 @@ __global__ __launch_bounds__(256) void attn_bwd_q_kernel(AttnArgs p) {
 }
 
 // ------------------------------------------------------------------------------------------ bwd_kv ----
-// workgroup = 64 keys (16 per wave), loop over query blocks of 64
+// workgroup = 64 keys (16 per wave), loop over query blocks of 64.  Per 16 x 16 (query, key) block:
+//   dP[i][j] = dO V^T on the MFMA with the QUERIES as rows: in the C/D layout lane (j = lane&15, kq) then holds queries
+//   i = 4 kq + reg, which is exactly the A-operand layout of Pd^T for  dV += Pd^T dO  when the reduction index of that
+//   MFMA is enumerated as i = 4 kq + s (legal: A and B use the same permutation).  So P, the dropout hash and dS are
+//   computed ONCE per element and feed both the dk' accumulation (lane-local) and the dV MFMA.
 template <int R4, int CF>
 __global__ __launch_bounds__(256) void attn_bwd_kv_kernel(AttnArgs p) {
   constexpr int C = CF * 16, CS = C / 4, LDV = C + 8;  // b128 row reads: stride 32 mod 64 bytes
@@ -238,10 +242,10 @@ __global__ __launch_bounds__(256) void attn_bwd_kv_kernel(AttnArgs p) {
   const int i16 = lane & 15, kq = lane >> 4;
   const int b = blockIdx.y;
   const long rowbase = (long)b * p.T;
-  const int j0 = blockIdx.x * 64 + wave * 16;      // first key of this wave
-  // A-layout key of this lane (j0 + i16): k' for the P regeneration, V row for dP
+  const int j0 = blockIdx.x * 64 + wave * 16;      // first key of this wave; this lane's key is j0 + i16
   float ka[R4];
   loadr<R4>(ka, p.k + (rowbase + j0 + i16) * R4);
+  // B operand of dP: V[key j0 + i16][c = kq*CS + s]
   float av[CS];
   {
     const float* vp = p.v + (rowbase + j0 + i16) * C + kq * CS;
@@ -251,18 +255,12 @@ __global__ __launch_bounds__(256) void attn_bwd_kv_kernel(AttnArgs p) {
       av[s] = d.x; av[s + 1] = d.y; av[s + 2] = d.z; av[s + 3] = d.w;
     }
   }
-  // C/D-layout keys of this lane: j0 + kq*4 + rg
-  float krow[4][R4];
-#pragma unroll
-  for (int rg = 0; rg < 4; ++rg) loadr<R4>(krow[rg], p.k + (rowbase + j0 + kq * 4 + rg) * R4);
   f32x4 dv[CF];
 #pragma unroll
   for (int nf = 0; nf < CF; ++nf) dv[nf] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  float dk[4][R4];
+  float dk[R4];
 #pragma unroll
-  for (int rg = 0; rg < 4; ++rg)
-#pragma unroll
-    for (int r = 0; r < R4; ++r) dk[rg][r] = 0.f;
+  for (int r = 0; r < R4; ++r) dk[r] = 0.f;
 
   for (int i0 = 0; i0 < p.T; i0 += 64) {
     __syncthreads();
@@ -278,52 +276,52 @@ __global__ __launch_bounds__(256) void attn_bwd_kv_kernel(AttnArgs p) {
       dsm[t] = p.dvec[rowbase + i0 + t];
     }
     __syncthreads();
-    // (a) dV[key][c] += sum_i Pd[i][key] dO[i][c] : A(m = key, k = query) generated on the VALU
-#pragma unroll 4
-    for (int s = 0; s < 16; ++s) {
-      const int i = 4 * s + kq;
-      float pv = __expf(dotr<R4>(ka, qs + i * R4) - ms[i]) * ls[i];
-      if (p.p_drop > 0.f)
-        pv *= keep32(p.s0, p.s1, (uint32_t)(rowbase + i0 + i), (uint32_t)(j0 + i16), p.p_drop, p.inv_keep);
-#pragma unroll
-      for (int nf = 0; nf < CF; ++nf)
-        dv[nf] = __builtin_amdgcn_mfma_f32_16x16x4f32(pv, dos[i * LDV + nf * 16 + i16], dv[nf], 0, 0, 0);
-    }
-    // (b) dP^T[key][query] = V dO^T, then dS and dk' += dS^T q'
 #pragma unroll
     for (int f = 0; f < 4; ++f) {
+      // dP[query 16f + m][key n]: A(m, k = c) = dO[16f + i16][kq*CS + s], B(k = c, n) = V[key i16][kq*CS + s]
       f32x4 dp4 = (f32x4){0.f, 0.f, 0.f, 0.f};
       const float* drow = dos + (16 * f + i16) * LDV + kq * CS;
 #pragma unroll
-      for (int s = 0; s < CS; ++s) dp4 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s], drow[s], dp4, 0, 0, 0);
-      const int i = 16 * f + i16;                  // query column of this lane
-      float qv[R4];
-      loadr<R4>(qv, qs + i * R4);
-      const float mi = ms[i], li = ls[i], di = dsm[i];
+      for (int s = 0; s < CS; ++s) dp4 = __builtin_amdgcn_mfma_f32_16x16x4f32(drow[s], av[s], dp4, 0, 0, 0);
+      // C/D layout: lane (key i16, kq), reg rg <-> query 16f + 4kq + rg
+      float pd[4];
 #pragma unroll
       for (int rg = 0; rg < 4; ++rg) {
-        const float pv = __expf(dotr<R4>(krow[rg], qv) - mi) * li;
-        float g = dp4[rg];
+        const int i = 16 * f + 4 * kq + rg;
+        float qv[R4];
+        loadr<R4>(qv, qs + i * R4);                 // already carries the 1/sqrt(C) scale
+        const float pv = __expf(dotr<R4>(ka, qv) - ms[i]) * ls[i];
+        float keep = 1.f;
         if (p.p_drop > 0.f)
-          g *= keep32(p.s0, p.s1, (uint32_t)(rowbase + i0 + i), (uint32_t)(j0 + kq * 4 + rg), p.p_drop, p.inv_keep);
-        const float ds = pv * (g - di);
+          keep = keep32(p.s0, p.s1, (uint32_t)(rowbase + i0 + i), (uint32_t)(j0 + i16), p.p_drop, p.inv_keep);
+        const float ds = pv * (dp4[rg] * keep - dsm[i]);
 #pragma unroll
-        for (int r = 0; r < R4; ++r) dk[rg][r] += ds * qv[r];   // qv already carries the 1/sqrt(C) scale
+        for (int r = 0; r < R4; ++r) dk[r] += ds * qv[r];
+        pd[rg] = pv * keep;
       }
+      // dV[key m][c n] += sum_i Pd[i][key] dO[i][c]: A(m = key i16, k = i = 4kq + s) = pd[s],
+      //                                              B(k = i, n = c) = dO[16f + 4kq + s][nf*16 + i16]
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int nf = 0; nf < CF; ++nf)
+          dv[nf] = __builtin_amdgcn_mfma_f32_16x16x4f32(pd[s], dos[(16 * f + 4 * kq + s) * LDV + nf * 16 + i16], dv[nf],
+                                                        0, 0, 0);
     }
   }
+  // dV: C/D layout rows = keys j0 + kq*4 + rg, cols = nf*16 + i16
 #pragma unroll
   for (int nf = 0; nf < CF; ++nf)
 #pragma unroll
     for (int rg = 0; rg < 4; ++rg) p.out2[(rowbase + j0 + kq * 4 + rg) * C + nf * 16 + i16] = dv[nf][rg];
+  // dk': this lane holds the partial of key j0 + i16 over its queries (4 of every 16): sum the 4 kq lanes
 #pragma unroll
-  for (int rg = 0; rg < 4; ++rg)
-#pragma unroll
-    for (int r = 0; r < R4; ++r) {
-      float v = dk[rg][r];
-      v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);
-      if (i16 == 0) p.out[(rowbase + j0 + kq * 4 + rg) * R4 + r] = v;
-    }
+  for (int r = 0; r < R4; ++r) {
+    float v = dk[r];
+    v += __shfl_xor(v, 16, 64);
+    v += __shfl_xor(v, 32, 64);
+    if (kq == 0) p.out[(rowbase + j0 + i16) * R4 + r] = v;
+  }
 }
 
 // -------------------------------------------------------------------------------------------- host ----
