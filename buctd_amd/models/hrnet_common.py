@@ -35,6 +35,11 @@ class BasicBlock(nn.Module):
         self.stride = stride
 
     def forward(self, x):
+        if (self.training and self.downsample is None and self.stride == 1 and x.is_cuda and torch.is_grad_enabled()
+                and self.conv1.bias is None and self.conv2.bias is None):
+            nn._as_channels_last_(self.conv1.weight)
+            nn._as_channels_last_(self.conv2.weight)
+            return ops.BasicBlockFn.apply(x, self.conv1.weight, self.bn1, self.conv2.weight, self.bn2)
         residual = x if self.downsample is None else self.downsample(x)
         out = nn.conv_bn_act(x, self.conv1, self.bn1, relu=True)
         return nn.conv_bn_act(out, self.conv2, self.bn2, relu=True, residual=residual)

@@ -276,15 +276,18 @@ def conv_fwd(x, w, bias=None, stride=1, pad=0, scale=None, shift=None, residual=
     return (y, part, info) if stats else y
 
 
-def conv_dgrad(dy, w, x_shape, stride=1, pad=0, bias=None, stats=False):
-    """dx of a convolution == forward of a transposed convolution."""
+def conv_dgrad(dy, w, x_shape, stride=1, pad=0, bias=None, stats=False, residual=None):
+    """dx of a convolution == forward of a transposed convolution.  residual (not with stats): added to dx - the
+    gradient arriving through a skip connection - in the kernel epilogue where the kernel supports it."""
     _f32(dy, "conv dgrad input")
     weight_rsc(w)
     d = conv_desc(x_shape, _wshape(w), stride, pad)
     if tuple(dy.shape) != (d.N, d.Ho, d.Wo, d.Co):
         raise _C.BuctdHipError(f"conv_dgrad: dy shape {tuple(dy.shape)} != {(d.N, d.Ho, d.Wo, d.Co)}")
     if _bf16x3_ok(d) and lib().buctd_conv3x3_bf16x3_supported(d.N, d.H, d.W, d.Co, d.Ci) == 1:
-        return _conv3x3_bf16x3(dy, w, 1, d.Co, d.Ci, bias, None, None, None, False, stats)
+        return _conv3x3_bf16x3(dy, w, 1, d.Co, d.Ci, bias, None, None, residual, False, stats)
+    if residual is not None and stats:
+        raise _C.BuctdHipError("conv_dgrad: residual and stats do not combine")
     dx = torch.empty(tuple(x_shape), dtype=torch.float32, device=dy.device)
     part = None
     info = None
@@ -295,6 +298,8 @@ def conv_dgrad(dy, w, x_shape, stride=1, pad=0, bias=None, stats=False):
         info = (ng.value, rpg.value)
     check(lib().buctd_conv2d_dgrad(C.byref(d), ptr(dy), ptr(w), ptr(bias), ptr(dx), ptr(part), stream_ptr()),
           "conv2d_dgrad")
+    if residual is not None:
+        add(dx, residual, out=dx)
     return (dx, part, info) if stats else dx
 
 
@@ -776,6 +781,59 @@ class ConvBnAct(torch.autograd.Function):
             colsum(dz, dz.shape[-1], db, acc)
         grad_done(bn.weight, bn.bias, conv_w, conv_b)
         return dx, None, None, None, dres, None, None, None, None, None
+
+
+class BasicBlockFn(torch.autograd.Function):
+    """One autograd node for the whole residual BasicBlock (reference lib/models/pose_hrnet.py:28-57, train mode, stride
+    1, no downsample):  y = relu(bn2(conv2(relu(bn1(conv1(x))))) + x).
+    Same kernels as two ConvBnAct nodes; what the single node buys: the gradient of the skip connection is added in the
+    epilogue of conv1's data-gradient kernel instead of by an autograd accumulation kernel (one launch and three
+    tensor passes per block), and the host walks one node instead of two plus an accumulation."""
+
+    @staticmethod
+    def forward(ctx, x, w1, bn1, w2, bn2):
+        saved = []
+        y = x
+        for w, bn, res in ((w1, bn1, None), (w2, bn2, x)):
+            momentum = 0.1 if bn.momentum is None else bn.momentum
+            z, part, info = conv_fwd(y, w, None, 1, 1, stats=True)
+            Cn = z.shape[-1]
+            track = bn.track_running_stats
+            mean, invstd = bn_finalize(part, info, z.numel() // Cn, Cn, bn.eps, momentum,
+                                       bn.running_mean if track else None, bn.running_var if track else None)
+            if track:
+                bn.count_batch() if hasattr(bn, "count_batch") else bn.num_batches_tracked.add_(1)
+            yin = y
+            y = bn_apply(z, mean, invstd, bn.weight, bn.bias, res, True)
+            saved += [yin, z, mean, invstd]
+        ctx.meta = (w1, bn1, w2, bn2)
+        ctx.save_for_backward(*saved, y)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        w1, bn1, w2, bn2 = ctx.meta
+        x, z1, mean1, invstd1, y1, z2, mean2, invstd2, y2 = ctx.saved_tensors
+        dy = _contig(dy)
+        # conv2 / bn2 (+ skip): dres = masked upstream gradient
+        dg, acc_g = grad_target(bn2.weight)
+        db, acc_b = grad_target(bn2.bias)
+        assert acc_g == acc_b
+        dz2, dres = bn_bwd(dy, y2, z2, mean2, invstd2, bn2.weight, True, True, dg, db, acc_g)
+        dy1 = conv_dgrad(dz2, w2, tuple(y1.shape), 1, 1)
+        dw, acc_w = grad_target(w2)
+        conv_wgrad_async(y1, dz2, w2, 1, 1, dw, acc_w)
+        grad_done(bn2.weight, bn2.bias, w2)
+        # conv1 / bn1: ReLU mask rebuilt from z1; the skip gradient joins in the dgrad epilogue
+        dg, acc_g = grad_target(bn1.weight)
+        db, acc_b = grad_target(bn1.bias)
+        assert acc_g == acc_b
+        dz1, _ = bn_bwd(dy1, None, z1, mean1, invstd1, bn1.weight, True, False, dg, db, acc_g, beta=bn1.bias)
+        dx = conv_dgrad(dz1, w1, tuple(x.shape), 1, 1, residual=dres) if ctx.needs_input_grad[0] else None
+        dw, acc_w = grad_target(w1)
+        conv_wgrad_async(x, dz1, w1, 1, 1, dw, acc_w)
+        grad_done(bn1.weight, bn1.bias, w1)
+        return dx, None, None, None, None
 
 
 class Conv(torch.autograd.Function):
