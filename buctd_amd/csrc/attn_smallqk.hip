@@ -15,11 +15,22 @@
 #include "gemm_core.h"
 #include "../../include/buctd_hip.h"
 
-__device__ __forceinline__ float keep32(uint32_t s0, uint32_t s1, uint32_t row, uint32_t col, float p_drop,
-                                        float inv_keep) {
-  uint32_t x = s0 ^ (row * 0x9E3779B1u) ^ (s1 + col * 0x85EBCA77u);
+// Dropout mask: keep(i, j) = fin(rowkey(i) + colkey(j)) >= p * 2^32.  The two keys are full lowbias32 hashes of
+// (seed, index), computed once per row / column of a tile; the per-element finisher is one rotate-xor, ONE integer
+// multiply (quarter rate on CDNA) and one shift-xor - the previous per-element lowbias32 cost four multiplies and was
+// 21 % of the attention time.
+__device__ __forceinline__ uint32_t mix32(uint32_t x) {
   x ^= x >> 16; x *= 0x7FEB352Du; x ^= x >> 15; x *= 0x846CA68Bu; x ^= x >> 16;
-  return (float)(x >> 8) * (1.0f / 16777216.0f) >= p_drop ? inv_keep : 0.f;
+  return x;
+}
+__device__ __forceinline__ uint32_t rowkey(uint32_t s0, uint32_t row) { return mix32(s0 ^ (row * 0x9E3779B1u)); }
+__device__ __forceinline__ uint32_t colkey(uint32_t s1, uint32_t col) { return mix32(s1 + col * 0x85EBCA77u); }
+__device__ __forceinline__ float keepf(uint32_t rk, uint32_t ck, uint32_t thr, float inv_keep) {
+  uint32_t x = rk + ck;
+  x ^= __builtin_amdgcn_alignbit(x, x, 21);     // rotate left by 11
+  x *= 0x9E3779B1u;
+  x ^= x >> 15;
+  return x >= thr ? inv_keep : 0.f;
 }
 
 struct AttnArgs {
@@ -34,8 +45,8 @@ struct AttnArgs {
   float* out;         // fwd: O ; bwd_q: dq' ; bwd_kv: dk'
   float* out2;        // bwd_kv: dV
   int T, C;
-  float scale, p_drop, inv_keep;
-  uint32_t s0, s1;
+  float scale, scale2, p_drop, inv_keep;   // scale2 = scale * log2(e): logits are formed in the exp2 domain
+  uint32_t s0, s1, thr;
 };
 
 template <int R4>
@@ -66,7 +77,7 @@ __global__ __launch_bounds__(256) void attn_stats_kernel(AttnArgs p) {
   for (int r = 0; r < R4; ++r) qv[r] = 0.f;
   if (i < p.T) loadr<R4>(qv, p.q + ((long)b * p.T + i) * R4);
 #pragma unroll
-  for (int r = 0; r < R4; ++r) qv[r] *= p.scale;
+  for (int r = 0; r < R4; ++r) qv[r] *= p.scale2;
   float mx = -INFINITY, sum = 0.f;
   for (int j0 = 0; j0 < p.T; j0 += 512) {
     const int nj = p.T - j0 < 512 ? p.T - j0 : 512;
@@ -77,10 +88,10 @@ __global__ __launch_bounds__(256) void attn_stats_kernel(AttnArgs p) {
     for (int j = 0; j < nj; ++j) {
       const float s = dotr<R4>(qv, ks + j * R4);
       if (s > mx) {
-        sum = sum * __expf(mx - s) + 1.f;
+        sum = sum * __builtin_amdgcn_exp2f(mx - s) + 1.f;
         mx = s;
       } else {
-        sum += __expf(s - mx);
+        sum += __builtin_amdgcn_exp2f(s - mx);
       }
     }
   }
@@ -92,21 +103,23 @@ __global__ __launch_bounds__(256) void attn_stats_kernel(AttnArgs p) {
 
 // --------------------------------------------------------------------------------------------- fwd ----
 // workgroup = 64 query rows (16 per wave); key blocks of 64
-template <int R4, int CF>
+template <int R4, int CF, bool DROP>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs p) {
   // B-operand reads touch rows 4s+kq at columns nf*16 + i16: conflict-free when the row stride is 16 mod 64 floats
   constexpr int C = CF * 16, LDV = C + (80 - C % 64) % 64;
   __shared__ __attribute__((aligned(16))) float ks[64 * R4];
   __shared__ __attribute__((aligned(16))) float vs[64 * LDV];
+  __shared__ uint32_t cks[64];
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int i16 = lane & 15, kq = lane >> 4;
   const int b = blockIdx.y;
   const int i = blockIdx.x * 64 + wave * 16 + i16;          // A-layout row of this lane
   const long rowbase = (long)b * p.T;
+  const uint32_t rk = rowkey(p.s0, (uint32_t)(rowbase + i));
   float qv[R4];
   loadr<R4>(qv, p.q + (rowbase + i) * R4);
 #pragma unroll
-  for (int r = 0; r < R4; ++r) qv[r] *= p.scale;
+  for (int r = 0; r < R4; ++r) qv[r] *= p.scale2;
   const float mi = p.m[rowbase + i], li = p.linv[rowbase + i];
   f32x4 acc[CF];
 #pragma unroll
@@ -119,15 +132,25 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs p) {
       const int r = e / (C / 4), c4 = e - r * (C / 4);
       *reinterpret_cast<f32x4*>(vs + r * LDV + c4 * 4) = reinterpret_cast<const f32x4*>(p.v + (rowbase + j0 + r) * C)[c4];
     }
+    if (DROP && t < 64) cks[t] = colkey(p.s1, (uint32_t)(j0 + t));
     __syncthreads();
-#pragma unroll 4
-    for (int s = 0; s < 16; ++s) {
-      const int j = 4 * s + kq;
-      float pv = __expf(dotr<R4>(qv, ks + j * R4) - mi) * li;
-      if (p.p_drop > 0.f) pv *= keep32(p.s0, p.s1, (uint32_t)(rowbase + i), (uint32_t)(j0 + j), p.p_drop, p.inv_keep);
+    // four k-steps at a time: probabilities on the VALU, all twelve V fragments in flight, then the MFMAs back to back
 #pragma unroll
-      for (int nf = 0; nf < CF; ++nf)
-        acc[nf] = __builtin_amdgcn_mfma_f32_16x16x4f32(pv, vs[j * LDV + nf * 16 + i16], acc[nf], 0, 0, 0);
+    for (int s0 = 0; s0 < 16; s0 += 4) {
+      float pv[4], bv[4][CF];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int j = 4 * (s0 + u) + kq;
+#pragma unroll
+        for (int nf = 0; nf < CF; ++nf) bv[u][nf] = vs[j * LDV + nf * 16 + i16];
+        pv[u] = __builtin_amdgcn_exp2f(dotr<R4>(qv, ks + j * R4) - mi) * li;
+        if (DROP) pv[u] *= keepf(rk, cks[j], p.thr, p.inv_keep);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int nf = 0; nf < CF; ++nf)
+          acc[nf] = __builtin_amdgcn_mfma_f32_16x16x4f32(pv[u], bv[u][nf], acc[nf], 0, 0, 0);
     }
   }
   // C/D layout: row = kq*4 + reg, col = nf*16 + i16
@@ -139,11 +162,12 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs p) {
 }
 
 // ------------------------------------------------------------------------------------------- bwd_q ----
-template <int R4, int CF>
+template <int R4, int CF, bool DROP>
 __global__ __launch_bounds__(256) void attn_bwd_q_kernel(AttnArgs p) {
   constexpr int C = CF * 16, CS = C / 4, LDV = C + 8;  // b128 row reads: stride 32 mod 64 bytes
   __shared__ __attribute__((aligned(16))) float ks[64 * R4];
   __shared__ __attribute__((aligned(16))) float vs[64 * LDV];
+  __shared__ uint32_t cks[64];
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int i16 = lane & 15, kq = lane >> 4;
   const int b = blockIdx.y;
@@ -168,12 +192,14 @@ __global__ __launch_bounds__(256) void attn_bwd_q_kernel(AttnArgs p) {
   if (kq == 0) p.dvec[rowbase + r0 + i16] = dpart;
   // C/D layout rows of this lane: r0 + kq*4 + rg
   float qrow[4][R4], mrow[4], lrow[4], drow[4];
+  uint32_t rkrow[4];
 #pragma unroll
   for (int rg = 0; rg < 4; ++rg) {
     const long row = rowbase + r0 + kq * 4 + rg;
+    rkrow[rg] = rowkey(p.s0, (uint32_t)row);
     loadr<R4>(qrow[rg], p.q + row * R4);
 #pragma unroll
-    for (int r = 0; r < R4; ++r) qrow[rg][r] *= p.scale;
+    for (int r = 0; r < R4; ++r) qrow[rg][r] *= p.scale2;
     mrow[rg] = p.m[row];
     lrow[rg] = p.linv[row];
     drow[rg] = __shfl(dpart, kq * 4 + rg, 64);   // lane (kq*4+rg) has i16 == that row
@@ -192,6 +218,7 @@ __global__ __launch_bounds__(256) void attn_bwd_q_kernel(AttnArgs p) {
       const int r = e / (C / 4), c4 = e - r * (C / 4);
       *reinterpret_cast<f32x4*>(vs + r * LDV + c4 * 4) = reinterpret_cast<const f32x4*>(p.v + (rowbase + j0 + r) * C)[c4];
     }
+    if (DROP && t < 64) cks[t] = colkey(p.s1, (uint32_t)(j0 + t));
     __syncthreads();
 #pragma unroll
     for (int f = 0; f < 4; ++f) {
@@ -205,10 +232,9 @@ __global__ __launch_bounds__(256) void attn_bwd_q_kernel(AttnArgs p) {
       loadr<R4>(kv, ks + j * R4);
 #pragma unroll
       for (int rg = 0; rg < 4; ++rg) {
-        const float pv = __expf(dotr<R4>(qrow[rg], kv) - mrow[rg]) * lrow[rg];
+        const float pv = __builtin_amdgcn_exp2f(dotr<R4>(qrow[rg], kv) - mrow[rg]) * lrow[rg];
         float g = dp4[rg];
-        if (p.p_drop > 0.f)
-          g *= keep32(p.s0, p.s1, (uint32_t)(rowbase + r0 + kq * 4 + rg), (uint32_t)(j0 + j), p.p_drop, p.inv_keep);
+        if (DROP) g *= keepf(rkrow[rg], cks[j], p.thr, p.inv_keep);
         const float ds = pv * (g - drow[rg]);
 #pragma unroll
         for (int r = 0; r < R4; ++r) dq[rg][r] += ds * kv[r];
@@ -232,17 +258,19 @@ __global__ __launch_bounds__(256) void attn_bwd_q_kernel(AttnArgs p) {
 //   i = 4 kq + reg, which is exactly the A-operand layout of Pd^T for  dV += Pd^T dO  when the reduction index of that
 //   MFMA is enumerated as i = 4 kq + s (legal: A and B use the same permutation).  So P, the dropout hash and dS are
 //   computed ONCE per element and feed both the dk' accumulation (lane-local) and the dV MFMA.
-template <int R4, int CF>
+template <int R4, int CF, bool DROP>
 __global__ __launch_bounds__(256) void attn_bwd_kv_kernel(AttnArgs p) {
   constexpr int C = CF * 16, CS = C / 4, LDV = C + 8;  // b128 row reads: stride 32 mod 64 bytes
   __shared__ __attribute__((aligned(16))) float qs[64 * R4];
   __shared__ __attribute__((aligned(16))) float dos[64 * LDV];
   __shared__ float ms[64], ls[64], dsm[64];
+  __shared__ uint32_t rks[64];
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int i16 = lane & 15, kq = lane >> 4;
   const int b = blockIdx.y;
   const long rowbase = (long)b * p.T;
   const int j0 = blockIdx.x * 64 + wave * 16;      // first key of this wave; this lane's key is j0 + i16
+  const uint32_t ck = colkey(p.s1, (uint32_t)(j0 + i16));
   float ka[R4];
   loadr<R4>(ka, p.k + (rowbase + j0 + i16) * R4);
   // B operand of dP: V[key j0 + i16][c = kq*CS + s]
@@ -264,7 +292,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kv_kernel(AttnArgs p) {
 
   for (int i0 = 0; i0 < p.T; i0 += 64) {
     __syncthreads();
-    for (int e = t; e < 64 * R4; e += 256) qs[e] = p.q[(rowbase + i0) * R4 + e] * p.scale;
+    for (int e = t; e < 64 * R4; e += 256) qs[e] = p.q[(rowbase + i0) * R4 + e] * p.scale2;
     for (int e = t; e < 64 * (C / 4); e += 256) {
       const int r = e / (C / 4), c4 = e - r * (C / 4);
       *reinterpret_cast<f32x4*>(dos + r * LDV + c4 * 4) =
@@ -274,6 +302,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kv_kernel(AttnArgs p) {
       ms[t] = p.m[rowbase + i0 + t];
       ls[t] = p.linv[rowbase + i0 + t];
       dsm[t] = p.dvec[rowbase + i0 + t];
+      if (DROP) rks[t] = rowkey(p.s0, (uint32_t)(rowbase + i0 + t));
     }
     __syncthreads();
 #pragma unroll
@@ -289,11 +318,10 @@ __global__ __launch_bounds__(256) void attn_bwd_kv_kernel(AttnArgs p) {
       for (int rg = 0; rg < 4; ++rg) {
         const int i = 16 * f + 4 * kq + rg;
         float qv[R4];
-        loadr<R4>(qv, qs + i * R4);                 // already carries the 1/sqrt(C) scale
-        const float pv = __expf(dotr<R4>(ka, qv) - ms[i]) * ls[i];
+        loadr<R4>(qv, qs + i * R4);                 // carries scale * log2(e); undone at the final store
+        const float pv = __builtin_amdgcn_exp2f(dotr<R4>(ka, qv) - ms[i]) * ls[i];
         float keep = 1.f;
-        if (p.p_drop > 0.f)
-          keep = keep32(p.s0, p.s1, (uint32_t)(rowbase + i0 + i), (uint32_t)(j0 + i16), p.p_drop, p.inv_keep);
+        if (DROP) keep = keepf(rks[i], ck, p.thr, p.inv_keep);
         const float ds = pv * (dp4[rg] * keep - dsm[i]);
 #pragma unroll
         for (int r = 0; r < R4; ++r) dk[r] += ds * qv[r];
@@ -320,7 +348,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kv_kernel(AttnArgs p) {
     float v = dk[r];
     v += __shfl_xor(v, 16, 64);
     v += __shfl_xor(v, 32, 64);
-    if (kq == 0) p.out[(rowbase + j0 + i16) * R4 + r] = v;
+    if (kq == 0) p.out[(rowbase + j0 + i16) * R4 + r] = v * (p.scale / p.scale2);
   }
 }
 
@@ -336,9 +364,17 @@ extern "C" int buctd_attn_smallqk_supported(int T, int R4, int C) { return attn_
 template <int R4, int CF>
 static void attn_launch(int which, const AttnArgs& a, int B, hipStream_t st) {
   const dim3 grid(a.T / 64, B);
-  if (which == 1) hipLaunchKernelGGL((attn_fwd_kernel<R4, CF>), grid, dim3(256), 0, st, a);
-  else if (which == 2) hipLaunchKernelGGL((attn_bwd_q_kernel<R4, CF>), grid, dim3(256), 0, st, a);
-  else hipLaunchKernelGGL((attn_bwd_kv_kernel<R4, CF>), grid, dim3(256), 0, st, a);
+  const bool drop = a.p_drop > 0.f;
+  if (which == 1) {
+    if (drop) hipLaunchKernelGGL((attn_fwd_kernel<R4, CF, true>), grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((attn_fwd_kernel<R4, CF, false>), grid, dim3(256), 0, st, a);
+  } else if (which == 2) {
+    if (drop) hipLaunchKernelGGL((attn_bwd_q_kernel<R4, CF, true>), grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((attn_bwd_q_kernel<R4, CF, false>), grid, dim3(256), 0, st, a);
+  } else {
+    if (drop) hipLaunchKernelGGL((attn_bwd_kv_kernel<R4, CF, true>), grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((attn_bwd_kv_kernel<R4, CF, false>), grid, dim3(256), 0, st, a);
+  }
 }
 template <int R4>
 static void attn_dispatch_c(int which, const AttnArgs& a, int B, hipStream_t st) {
@@ -370,9 +406,11 @@ static void attn_dispatch(int which, const AttnArgs& a, int R4, int B, hipStream
 static AttnArgs attn_args(int T, int C, float scale, float p_drop, uint64_t seed) {
   AttnArgs a;
   memset(&a, 0, sizeof(a));
-  a.T = T; a.C = C; a.scale = scale; a.p_drop = p_drop;
+  a.T = T; a.C = C; a.scale = scale; a.scale2 = scale * 1.44269504088896340736f; a.p_drop = p_drop;
   a.inv_keep = p_drop > 0.f ? 1.f / (1.f - p_drop) : 1.f;
   a.s0 = (uint32_t)seed; a.s1 = (uint32_t)(seed >> 32);
+  const double th = (double)p_drop * 4294967296.0;
+  a.thr = th >= 4294967295.0 ? 0xFFFFFFFFu : (uint32_t)th;
   return a;
 }
 
