@@ -45,6 +45,7 @@ struct AttnArgs {
   float* out;         // fwd: O ; bwd_q: dq' ; bwd_kv: dk'
   float* out2;        // bwd_kv: dV
   int T, C;
+  int b3;               // 1: bf16x3 kernels
   float scale, scale2, p_drop, inv_keep;   // scale2 = scale * log2(e): logits are formed in the exp2 domain
   uint32_t s0, s1, thr;
 };
@@ -159,6 +160,336 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs p) {
 #pragma unroll
     for (int rg = 0; rg < 4; ++rg)
       p.out[(rowbase + blockIdx.x * 64 + wave * 16 + kq * 4 + rg) * C + nf * 16 + i16] = acc[nf][rg];
+}
+
+// ------------------------------------------------------------------------- bf16x3 variants (math mode) ----
+// Same algorithm with the T- and C-contractions on v_mfma_f32_16x16x32_bf16 and split-fp32 operands
+// (x = hi + lo, a*b ~= al*bh + ah*bl + ah*bh, fp32 accumulate, ~2^-16 relative product error): the fp32 MFMA
+// (32 cycles for 2 kFLOP) paces the kernels above at 40-50 % pipe occupancy; three bf16 MFMAs (17 cycles, 16 kFLOP
+// each) do the same product in a fifth of the time, which leaves the kernels VALU-bound (exp2, hash, split).
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned short u16x4 __attribute__((ext_vector_type(4)));
+
+// channels c..c+3 of one LDS row -> bf16 hi at byte 2c, lo at LO + 2c
+template <int LO>
+__device__ __forceinline__ void split_store4(unsigned char* row, int c, f32x4 v) {
+  u16x4 hi, lo;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const __bf16 h = (__bf16)v[j];
+    const __bf16 l = (__bf16)(v[j] - (float)h);
+    hi[j] = __builtin_bit_cast(unsigned short, h);
+    lo[j] = __builtin_bit_cast(unsigned short, l);
+  }
+  *reinterpret_cast<u16x4*>(row + 2 * c) = hi;
+  *reinterpret_cast<u16x4*>(row + LO + 2 * c) = lo;
+}
+// gfx950 transpose read: the 16 lanes of a group address 4 rows x 16 bf16; lane c receives the 4 rows of column c.
+// Two of them (rows +0..3 at p, rows +0..3 at q) give the 8 reduction slots of one MFMA operand.
+__device__ __forceinline__ bf16x8 tr_pair(const unsigned char* p, const unsigned char* q) {
+  typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
+  const bf16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)p);
+  const bf16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)q);
+  return __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+__device__ __forceinline__ void split8(const float (&x)[8], bf16x8& h, bf16x8& l) {
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const __bf16 hh = (__bf16)x[e];
+    h[e] = hh;
+    l[e] = (__bf16)(x[e] - (float)hh);
+  }
+}
+#define MFMA_B3(acc, ah, al, bh, bl)                                          \
+  do {                                                                        \
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh, acc, 0, 0, 0);      \
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl, acc, 0, 0, 0);      \
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh, acc, 0, 0, 0);      \
+  } while (0)
+
+// forward: workgroup = 64 query rows (16 per wave); per 32-key step lane (row i16, g) generates the probabilities of
+// keys 8g..8g+7 - exactly the A operand of the K = 32 MFMA - and the V fragments (lane = channel, 8 keys) come out of
+// the key-major bf16 tile through the transpose read.
+template <int R4, int CF, bool DROP>
+__global__ __launch_bounds__(256) void attn_fwd_b3_kernel(AttnArgs p) {
+  constexpr int C = CF * 16, LO = C * 2, RS = C * 4 + 32;   // V rows: C bf16 hi | C bf16 lo | 32 B pad (= 32 mod 64)
+  __shared__ __attribute__((aligned(16))) float ks[64 * R4];
+  __shared__ __attribute__((aligned(16))) unsigned char vt[64 * RS];
+  __shared__ uint32_t cks[64];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int i16 = lane & 15, g = lane >> 4;
+  const int b = blockIdx.y;
+  const int i = blockIdx.x * 64 + wave * 16 + i16;
+  const long rowbase = (long)b * p.T;
+  const uint32_t rk = rowkey(p.s0, (uint32_t)(rowbase + i));
+  float qv[R4];
+  loadr<R4>(qv, p.q + (rowbase + i) * R4);
+#pragma unroll
+  for (int r = 0; r < R4; ++r) qv[r] *= p.scale2;
+  const float mi = p.m[rowbase + i], li = p.linv[rowbase + i];
+  f32x4 acc[CF];
+#pragma unroll
+  for (int nf = 0; nf < CF; ++nf) acc[nf] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const int tr_off = (g * 8 + (i16 >> 2)) * RS + (i16 & 3) * 8;
+  for (int j0 = 0; j0 < p.T; j0 += 64) {
+    __syncthreads();
+    for (int e = t; e < 64 * R4 / 4; e += 256)
+      reinterpret_cast<f32x4*>(ks)[e] = reinterpret_cast<const f32x4*>(p.k + (rowbase + j0) * R4)[e];
+    for (int e = t; e < 64 * (C / 4); e += 256) {
+      const int r = e / (C / 4), c4 = e - r * (C / 4);
+      split_store4<LO>(vt + r * RS, c4 * 4, reinterpret_cast<const f32x4*>(p.v + (rowbase + j0 + r) * C)[c4]);
+    }
+    if (DROP && t < 64) cks[t] = colkey(p.s1, (uint32_t)(j0 + t));
+    __syncthreads();
+#pragma unroll
+    for (int kstep = 0; kstep < 2; ++kstep) {
+      float pv[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int j = 32 * kstep + 8 * g + e;
+        pv[e] = __builtin_amdgcn_exp2f(dotr<R4>(qv, ks + j * R4) - mi) * li;
+        if (DROP) pv[e] *= keepf(rk, cks[j], p.thr, p.inv_keep);
+      }
+      bf16x8 ph, pl;
+      split8(pv, ph, pl);
+      const unsigned char* vb = vt + 32 * kstep * RS + tr_off;
+#pragma unroll
+      for (int nf = 0; nf < CF; ++nf) {
+        const bf16x8 bh = tr_pair(vb + nf * 32, vb + nf * 32 + 4 * RS);
+        const bf16x8 bl = tr_pair(vb + nf * 32 + LO, vb + nf * 32 + LO + 4 * RS);
+        MFMA_B3(acc[nf], ph, pl, bh, bl);
+      }
+    }
+  }
+#pragma unroll
+  for (int nf = 0; nf < CF; ++nf)
+#pragma unroll
+    for (int rg = 0; rg < 4; ++rg)
+      p.out[(rowbase + blockIdx.x * 64 + wave * 16 + g * 4 + rg) * C + nf * 16 + i16] = acc[nf][rg];
+}
+
+// 8 consecutive channels [c0, c0+8) of one fp32 row as bf16 hi / lo MFMA operands (zeros past channel C)
+__device__ __forceinline__ void load_split8(const float* row, int c0, int C, bf16x8& h, bf16x8& l) {
+  float x[8];
+  if (c0 < C) {
+    const f32x4 a = *reinterpret_cast<const f32x4*>(row + c0);
+    const f32x4 b = *reinterpret_cast<const f32x4*>(row + c0 + 4);
+    x[0] = a.x; x[1] = a.y; x[2] = a.z; x[3] = a.w; x[4] = b.x; x[5] = b.y; x[6] = b.z; x[7] = b.w;
+  } else {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) x[e] = 0.f;
+  }
+  split8(x, h, l);
+}
+
+// dq' pass: dP = dO V^T with the channel contraction on the bf16 MFMA (dO fragments live in registers for the whole
+// kernel, V rows come out of the bf16 tile with plain 16-byte reads); everything else as attn_bwd_q_kernel.
+template <int R4, int CF, bool DROP>
+__global__ __launch_bounds__(256) void attn_bwd_q_b3_kernel(AttnArgs p) {
+  constexpr int C = CF * 16, CS = C / 4, LO = C * 2, RS = C * 4 + 32, NK = (C + 31) / 32;
+  __shared__ __attribute__((aligned(16))) float ks[64 * R4];
+  __shared__ __attribute__((aligned(16))) unsigned char vt[64 * RS];
+  __shared__ uint32_t cks[64];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int i16 = lane & 15, kq = lane >> 4;
+  const int b = blockIdx.y;
+  const long rowbase = (long)b * p.T;
+  const int r0 = blockIdx.x * 64 + wave * 16;
+  // D = dO . O of row r0 + i16 (each lane sums a quarter of the channels)
+  float dpart = 0.f;
+  {
+    const float* dp = p.dout + (rowbase + r0 + i16) * C + kq * CS;
+    const float* op = p.o + (rowbase + r0 + i16) * C + kq * CS;
+#pragma unroll
+    for (int s = 0; s < CS; s += 4) {
+      const f32x4 d = *reinterpret_cast<const f32x4*>(dp + s);
+      const f32x4 o = *reinterpret_cast<const f32x4*>(op + s);
+      dpart += d.x * o.x + d.y * o.y + d.z * o.z + d.w * o.w;
+    }
+  }
+  dpart += __shfl_xor(dpart, 16, 64);
+  dpart += __shfl_xor(dpart, 32, 64);
+  if (kq == 0) p.dvec[rowbase + r0 + i16] = dpart;
+  // A operand: dO[row r0 + i16][32 kk + 8 kq .. +7]
+  bf16x8 ah[NK], al[NK];
+#pragma unroll
+  for (int kk = 0; kk < NK; ++kk) load_split8(p.dout + (rowbase + r0 + i16) * C, 32 * kk + 8 * kq, C, ah[kk], al[kk]);
+  float qrow[4][R4], mrow[4], lrow[4], drow[4];
+  uint32_t rkrow[4];
+#pragma unroll
+  for (int rg = 0; rg < 4; ++rg) {
+    const long row = rowbase + r0 + kq * 4 + rg;
+    rkrow[rg] = rowkey(p.s0, (uint32_t)row);
+    loadr<R4>(qrow[rg], p.q + row * R4);
+#pragma unroll
+    for (int r = 0; r < R4; ++r) qrow[rg][r] *= p.scale2;
+    mrow[rg] = p.m[row];
+    lrow[rg] = p.linv[row];
+    drow[rg] = __shfl(dpart, kq * 4 + rg, 64);
+  }
+  float dq[4][R4];
+#pragma unroll
+  for (int rg = 0; rg < 4; ++rg)
+#pragma unroll
+    for (int r = 0; r < R4; ++r) dq[rg][r] = 0.f;
+  // byte offset of this lane's 8 channels inside a tile row (clamped for the zero-padded tail of the last step)
+  int boff[NK];
+#pragma unroll
+  for (int kk = 0; kk < NK; ++kk) {
+    const int c0 = 32 * kk + 8 * kq;
+    boff[kk] = (c0 < C ? c0 : 0) * 2;
+  }
+
+  for (int j0 = 0; j0 < p.T; j0 += 64) {
+    __syncthreads();
+    for (int e = t; e < 64 * R4 / 4; e += 256)
+      reinterpret_cast<f32x4*>(ks)[e] = reinterpret_cast<const f32x4*>(p.k + (rowbase + j0) * R4)[e];
+    for (int e = t; e < 64 * (C / 4); e += 256) {
+      const int r = e / (C / 4), c4 = e - r * (C / 4);
+      split_store4<LO>(vt + r * RS, c4 * 4, reinterpret_cast<const f32x4*>(p.v + (rowbase + j0 + r) * C)[c4]);
+    }
+    if (DROP && t < 64) cks[t] = colkey(p.s1, (uint32_t)(j0 + t));
+    __syncthreads();
+#pragma unroll
+    for (int f = 0; f < 4; ++f) {
+      f32x4 dp4 = (f32x4){0.f, 0.f, 0.f, 0.f};
+      const unsigned char* vrow = vt + (16 * f + i16) * RS;    // B(k = channel, n = key 16f + i16)
+#pragma unroll
+      for (int kk = 0; kk < NK; ++kk) {
+        const bf16x8 bh = *reinterpret_cast<const bf16x8*>(vrow + boff[kk]);
+        const bf16x8 bl = *reinterpret_cast<const bf16x8*>(vrow + boff[kk] + LO);
+        MFMA_B3(dp4, ah[kk], al[kk], bh, bl);
+      }
+      const int j = 16 * f + i16;
+      float kv[R4];
+      loadr<R4>(kv, ks + j * R4);
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg) {
+        const float pv = __builtin_amdgcn_exp2f(dotr<R4>(qrow[rg], kv) - mrow[rg]) * lrow[rg];
+        float gg = dp4[rg];
+        if (DROP) gg *= keepf(rkrow[rg], cks[j], p.thr, p.inv_keep);
+        const float ds = pv * (gg - drow[rg]);
+#pragma unroll
+        for (int r = 0; r < R4; ++r) dq[rg][r] += ds * kv[r];
+      }
+    }
+  }
+#pragma unroll
+  for (int rg = 0; rg < 4; ++rg)
+#pragma unroll
+    for (int r = 0; r < R4; ++r) {
+      float v = dq[rg][r];
+      v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);
+      if (i16 == 0) p.out[(rowbase + r0 + kq * 4 + rg) * R4 + r] = v * p.scale;
+    }
+}
+
+// dk' / dV pass.  dP (queries as rows) per 16 x 16 block as in attn_bwd_kv_kernel; two such blocks give, per lane,
+// eight dropped probabilities of its key - the A operand of ONE K = 32 MFMA of dV += Pd^T dO when the reduction slot
+// e of lane group g is enumerated as query 16 (e >> 2) + 4 g + (e & 3); the dO fragments in that enumeration come
+// out of the query-major bf16 tile through two transpose reads.
+template <int R4, int CF, bool DROP>
+__global__ __launch_bounds__(256) void attn_bwd_kv_b3_kernel(AttnArgs p) {
+  constexpr int C = CF * 16, LO = C * 2, RS = C * 4 + 32, NK = (C + 31) / 32;
+  __shared__ __attribute__((aligned(16))) float qs[64 * R4];
+  __shared__ __attribute__((aligned(16))) unsigned char dt[64 * RS];     // dO tile: [query][hi C | lo C]
+  __shared__ float ms[64], ls[64], dsm[64];
+  __shared__ uint32_t rks[64];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int i16 = lane & 15, kq = lane >> 4;
+  const int b = blockIdx.y;
+  const long rowbase = (long)b * p.T;
+  const int j0 = blockIdx.x * 64 + wave * 16;
+  const uint32_t ck = colkey(p.s1, (uint32_t)(j0 + i16));
+  float ka[R4];
+  loadr<R4>(ka, p.k + (rowbase + j0 + i16) * R4);
+  // B operand of dP: V[key j0 + i16][32 kk + 8 kq .. +7]
+  bf16x8 vh[NK], vl[NK];
+  int boff[NK];
+#pragma unroll
+  for (int kk = 0; kk < NK; ++kk) {
+    const int c0 = 32 * kk + 8 * kq;
+    load_split8(p.v + (rowbase + j0 + i16) * C, c0, C, vh[kk], vl[kk]);
+    boff[kk] = (c0 < C ? c0 : 0) * 2;
+  }
+  f32x4 dv[CF];
+#pragma unroll
+  for (int nf = 0; nf < CF; ++nf) dv[nf] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  float dk[R4];
+#pragma unroll
+  for (int r = 0; r < R4; ++r) dk[r] = 0.f;
+  const int tr_off = (4 * kq + (i16 >> 2)) * RS + (i16 & 3) * 8;   // rows 4 kq .. 4 kq + 3 of a 16-query block
+
+  for (int i0 = 0; i0 < p.T; i0 += 64) {
+    __syncthreads();
+    for (int e = t; e < 64 * R4; e += 256) qs[e] = p.q[(rowbase + i0) * R4 + e] * p.scale2;
+    for (int e = t; e < 64 * (C / 4); e += 256) {
+      const int r = e / (C / 4), c4 = e - r * (C / 4);
+      split_store4<LO>(dt + r * RS, c4 * 4, reinterpret_cast<const f32x4*>(p.dout + (rowbase + i0 + r) * C)[c4]);
+    }
+    if (t < 64) {
+      ms[t] = p.m[rowbase + i0 + t];
+      ls[t] = p.linv[rowbase + i0 + t];
+      dsm[t] = p.dvec[rowbase + i0 + t];
+      if (DROP) rks[t] = rowkey(p.s0, (uint32_t)(rowbase + i0 + t));
+    }
+    __syncthreads();
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {          // 32 queries per step: blocks f = 2h, 2h + 1
+      float pd[8];
+#pragma unroll
+      for (int fb = 0; fb < 2; ++fb) {
+        const int f = 2 * h + fb;
+        // dP[query 16f + m][key n]: A = dO rows of the tile, B = this lane's V fragments
+        f32x4 dp4 = (f32x4){0.f, 0.f, 0.f, 0.f};
+        const unsigned char* drow = dt + (16 * f + i16) * RS;
+#pragma unroll
+        for (int kk = 0; kk < NK; ++kk) {
+          bf16x8 ah = *reinterpret_cast<const bf16x8*>(drow + boff[kk]);
+          bf16x8 al = *reinterpret_cast<const bf16x8*>(drow + boff[kk] + LO);
+          if (32 * kk + 8 * kq >= C) {       // zero-padded tail of the channel contraction
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { ah[e] = (__bf16)0.f; al[e] = (__bf16)0.f; }
+          }
+          MFMA_B3(dp4, ah, al, vh[kk], vl[kk]);
+        }
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) {
+          const int i = 16 * f + 4 * kq + rg;
+          float qv[R4];
+          loadr<R4>(qv, qs + i * R4);
+          const float pv = __builtin_amdgcn_exp2f(dotr<R4>(ka, qv) - ms[i]) * ls[i];
+          float keep = 1.f;
+          if (DROP) keep = keepf(rks[i], ck, p.thr, p.inv_keep);
+          const float ds = pv * (dp4[rg] * keep - dsm[i]);
+#pragma unroll
+          for (int r = 0; r < R4; ++r) dk[r] += ds * qv[r];
+          pd[4 * fb + rg] = pv * keep;
+        }
+      }
+      bf16x8 ph, pl;
+      split8(pd, ph, pl);
+      const unsigned char* db = dt + 32 * h * RS + tr_off;
+#pragma unroll
+      for (int nf = 0; nf < CF; ++nf) {
+        const bf16x8 bh = tr_pair(db + nf * 32, db + nf * 32 + 16 * RS);
+        const bf16x8 bl = tr_pair(db + nf * 32 + LO, db + nf * 32 + LO + 16 * RS);
+        MFMA_B3(dv[nf], ph, pl, bh, bl);
+      }
+    }
+  }
+#pragma unroll
+  for (int nf = 0; nf < CF; ++nf)
+#pragma unroll
+    for (int rg = 0; rg < 4; ++rg) p.out2[(rowbase + j0 + kq * 4 + rg) * C + nf * 16 + i16] = dv[nf][rg];
+#pragma unroll
+  for (int r = 0; r < R4; ++r) {
+    float v = dk[r];
+    v += __shfl_xor(v, 16, 64);
+    v += __shfl_xor(v, 32, 64);
+    if (kq == 0) p.out[(rowbase + j0 + i16) * R4 + r] = v * (p.scale / p.scale2);
+  }
 }
 
 // ------------------------------------------------------------------------------------------- bwd_q ----
@@ -365,9 +696,18 @@ template <int R4, int CF>
 static void attn_launch(int which, const AttnArgs& a, int B, hipStream_t st) {
   const dim3 grid(a.T / 64, B);
   const bool drop = a.p_drop > 0.f;
-  if (which == 1) {
+  if (which == 1 && a.b3 && R4 <= 8) {
+    if (drop) hipLaunchKernelGGL((attn_fwd_b3_kernel<R4 <= 8 ? R4 : 4, CF, true>), grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((attn_fwd_b3_kernel<R4 <= 8 ? R4 : 4, CF, false>), grid, dim3(256), 0, st, a);
+  } else if (which == 1) {
     if (drop) hipLaunchKernelGGL((attn_fwd_kernel<R4, CF, true>), grid, dim3(256), 0, st, a);
     else hipLaunchKernelGGL((attn_fwd_kernel<R4, CF, false>), grid, dim3(256), 0, st, a);
+  } else if (which == 2 && a.b3 && R4 <= 8) {
+    if (drop) hipLaunchKernelGGL((attn_bwd_q_b3_kernel<R4 <= 8 ? R4 : 4, CF, true>), grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((attn_bwd_q_b3_kernel<R4 <= 8 ? R4 : 4, CF, false>), grid, dim3(256), 0, st, a);
+  } else if (which == 3 && a.b3 && R4 <= 8) {
+    if (drop) hipLaunchKernelGGL((attn_bwd_kv_b3_kernel<R4 <= 8 ? R4 : 4, CF, true>), grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((attn_bwd_kv_b3_kernel<R4 <= 8 ? R4 : 4, CF, false>), grid, dim3(256), 0, st, a);
   } else if (which == 2) {
     if (drop) hipLaunchKernelGGL((attn_bwd_q_kernel<R4, CF, true>), grid, dim3(256), 0, st, a);
     else hipLaunchKernelGGL((attn_bwd_q_kernel<R4, CF, false>), grid, dim3(256), 0, st, a);
@@ -415,13 +755,13 @@ static AttnArgs attn_args(int T, int C, float scale, float p_drop, uint64_t seed
 }
 
 extern "C" int buctd_attn_smallqk_fwd(int B, int T, int R4, int C, const float* q, const float* k, const float* v,
-                                      float scale, float p_drop, uint64_t seed, float* out, float* m, float* linv,
-                                      void* stream) {
+                                      float scale, float p_drop, uint64_t seed, int bf16x3, float* out, float* m,
+                                      float* linv, void* stream) {
   BUCTD_CHECK_ARG(q && k && v && out && m && linv && B > 0, "buctd_attn_smallqk_fwd: null argument");
   BUCTD_CHECK_ARG(attn_shape_ok(T, R4, C), "buctd_attn_smallqk_fwd: unsupported T=%d R4=%d C=%d", T, R4, C);
   BUCTD_CHECK_ARG(p_drop >= 0.f && p_drop < 1.f && (long)B * T < 2147483647L, "buctd_attn_smallqk_fwd: bad p_drop / size");
   AttnArgs a = attn_args(T, C, scale, p_drop, seed);
-  a.q = q; a.k = k; a.v = v; a.m = m; a.linv = linv; a.out = out;
+  a.q = q; a.k = k; a.v = v; a.m = m; a.linv = linv; a.out = out; a.b3 = bf16x3 ? 1 : 0;
   attn_dispatch(0, a, R4, B, (hipStream_t)stream);
   BUCTD_CHECK_LAUNCH("buctd_attn_smallqk_fwd(stats)");
   attn_dispatch(1, a, R4, B, (hipStream_t)stream);
@@ -431,14 +771,14 @@ extern "C" int buctd_attn_smallqk_fwd(int B, int T, int R4, int C, const float* 
 
 extern "C" int buctd_attn_smallqk_bwd(int B, int T, int R4, int C, const float* q, const float* k, const float* v,
                                       const float* o, const float* dout, const float* m, const float* linv,
-                                      float scale, float p_drop, uint64_t seed, float* dq, float* dk, float* dv,
-                                      float* dvec_workspace, void* stream) {
+                                      float scale, float p_drop, uint64_t seed, int bf16x3, float* dq, float* dk,
+                                      float* dv, float* dvec_workspace, void* stream) {
   BUCTD_CHECK_ARG(q && k && v && o && dout && m && linv && dq && dk && dv && dvec_workspace && B > 0,
                   "buctd_attn_smallqk_bwd: null argument");
   BUCTD_CHECK_ARG(attn_shape_ok(T, R4, C), "buctd_attn_smallqk_bwd: unsupported T=%d R4=%d C=%d", T, R4, C);
   AttnArgs a = attn_args(T, C, scale, p_drop, seed);
   a.q = q; a.k = k; a.v = v; a.o = o; a.dout = dout;
-  a.m = const_cast<float*>(m); a.linv = const_cast<float*>(linv); a.dvec = dvec_workspace;
+  a.m = const_cast<float*>(m); a.linv = const_cast<float*>(linv); a.dvec = dvec_workspace; a.b3 = bf16x3 ? 1 : 0;
   a.out = dq;
   attn_dispatch(2, a, R4, B, (hipStream_t)stream);
   BUCTD_CHECK_LAUNCH("buctd_attn_smallqk_bwd(q)");

@@ -1027,15 +1027,16 @@ class SmallQKAttention(torch.autograd.Function):
         out = torch.empty((B, T, Cn), dtype=torch.float32, device=dev)
         m = torch.empty((B, T), dtype=torch.float32, device=dev)
         linv = torch.empty((B, T), dtype=torch.float32, device=dev)
-        check(lib().buctd_attn_smallqk_fwd(B, T, R4, Cn, ptr(qp), ptr(kp), ptr(v), scale, p_eff, seed, ptr(out), ptr(m),
+        b3 = 1 if _conv_math["mode"] == "bf16x3" else 0
+        check(lib().buctd_attn_smallqk_fwd(B, T, R4, Cn, ptr(qp), ptr(kp), ptr(v), scale, p_eff, seed, b3, ptr(out), ptr(m),
                                            ptr(linv), stream_ptr()), "attn_smallqk_fwd")
-        ctx.meta = (d, R4, scale, p_eff, seed)
+        ctx.meta = (d, R4, scale, p_eff, seed, b3)
         ctx.save_for_backward(qp, kp, k, v, out, m, linv, w4t, wq, bq)
         return out
 
     @staticmethod
     def backward(ctx, dout):
-        d, R4, scale, p_eff, seed = ctx.meta
+        d, R4, scale, p_eff, seed, b3 = ctx.meta
         qp, kp, k, v, out, m, linv, w4t, wq, bq = ctx.saved_tensors
         dout = _contig(dout)
         B, T, Cn = v.shape
@@ -1045,7 +1046,7 @@ class SmallQKAttention(torch.autograd.Function):
         dv = torch.empty_like(v)
         dvec = torch.empty((B, T), dtype=torch.float32, device=dev)
         check(lib().buctd_attn_smallqk_bwd(B, T, R4, Cn, ptr(qp), ptr(kp), ptr(v), ptr(out), ptr(dout), ptr(m), ptr(linv),
-                                           scale, p_eff, seed, ptr(dqp), ptr(dkp), ptr(dv), ptr(dvec), stream_ptr()),
+                                           scale, p_eff, seed, b3, ptr(dqp), ptr(dkp), ptr(dv), ptr(dvec), stream_ptr()),
               "attn_smallqk_bwd")
         # k' = k w4t^T  ->  dk = dk' w4t ; dw4t = dk'^T k
         dk = torch.empty_like(k)

@@ -190,15 +190,17 @@ int buctd_softmax_dropout_bwd(const float* dpd, const float* p, long rows, int L
  * out = dropout(softmax(logits)) v, v and out [B][T][C]; nothing of size T x T is written to memory.
  * m / linv [B][T] receive the row max and reciprocal row sum (saved for the backward).  The dropout mask is a
  * counter hash of (seed, b*T + i, j), rebuilt by the backward.  Shapes: T % 64 == 0, R4 in {4,8,16,20},
- * C in {16,32,48,64,96,128,192} (buctd_attn_smallqk_supported). */
+ * C in {16,32,48,64,96,128,192} (buctd_attn_smallqk_supported).  bf16x3 != 0 selects the variants whose T- and
+ * C-contractions run on the bf16 matrix cores with split-fp32 operands (same accuracy class as
+ * buctd_conv3x3_bf16x3; R4 <= 8 only, wider contractions silently use the fp32 kernels). */
 int buctd_attn_smallqk_supported(int T, int R4, int C);
 int buctd_attn_smallqk_fwd(int B, int T, int R4, int C, const float* q, const float* k, const float* v, float scale,
-                           float p_drop, uint64_t seed, float* out, float* m, float* linv, void* stream);
+                           float p_drop, uint64_t seed, int bf16x3, float* out, float* m, float* linv, void* stream);
 /* dq/dk: [B][T][R4] gradients of q'/k'; dv: [B][T][C]; dvec_workspace: B*T floats. */
 int buctd_attn_smallqk_bwd(int B, int T, int R4, int C, const float* q, const float* k, const float* v,
                            const float* o, const float* dout, const float* m, const float* linv, float scale,
-                           float p_drop, uint64_t seed, float* dq, float* dk, float* dv, float* dvec_workspace,
-                           void* stream);
+                           float p_drop, uint64_t seed, int bf16x3, float* dq, float* dk, float* dv,
+                           float* dvec_workspace, void* stream);
 /* elementwise inverted dropout (transpose_h.py:180-183), mask rebuilt from (seed, index) */
 int buctd_dropout(const float* x, float* y, long n, float p_drop, uint64_t seed, void* stream);
 /* LayerNorm over the last dim (transpose_h.py:178-179) */

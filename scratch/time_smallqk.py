@@ -9,6 +9,7 @@ k = torch.randn(B, T, C, generator=g).to(dev).requires_grad_(True)
 v = torch.randn(B, T, C, generator=g).to(dev).requires_grad_(True)
 wq = torch.nn.Parameter((torch.randn(C, d, generator=g) * 0.1).to(dev)); bq = torch.nn.Parameter(torch.zeros(C).to(dev))
 dout = torch.randn(B, T, C, generator=g).to(dev)
+ops.set_conv_math(os.environ.get("MATH", "bf16x3"))
 for training in (True, False):
     for it in range(3):
         e = [torch.cuda.Event(enable_timing=True) for _ in range(3)]

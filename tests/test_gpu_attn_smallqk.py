@@ -64,6 +64,36 @@ def test_smallqk_vs_fp64(dev, B, T, d, C):
         assert err <= 2e-5, f"smallqk {name} (B{B} T{T} d{d} C{C}): rel err {err:.2e}"
 
 
+@pytest.mark.parametrize("B,T,d,C", [(2, 128, 3, 48), (2, 384, 1, 16), (1, 1728, 3, 96), (2, 192, 7, 32), (2, 64, 5, 64),
+                                     (1, 64, 3, 192), (1, 128, 2, 128)])
+def test_smallqk_bf16x3_vs_fp64(dev, B, T, d, C):
+    """bf16x3 math mode: T- and C-contractions on the bf16 matrix cores with split operands; bar 5e-5 relative."""
+    from buctd_amd import ops
+    old = ops.get_conv_math()
+    ops.set_conv_math("bf16x3")
+    try:
+        args = _inputs(B, T, d, C, B * 1000 + T + d)
+        ref_o, ref_g = _reference(*args)
+        o, grads = _run(dev, *args, 0.1, False)
+        for name, a, b in zip(["out", "dyq", "dwq", "dbq", "dk", "dv"], [o] + grads, [ref_o] + ref_g):
+            err = _e(a, b)
+            assert err <= 5e-5, f"smallqk[bf16x3] {name} (B{B} T{T} d{d} C{C}): rel err {err:.2e}"
+        # dropout: forward and backward must still agree on the mask (v = I exposes it)
+        if C == 64 and T == 64:
+            yq, wq, bq, k, v, dout = args
+            eye = torch.eye(T, dtype=torch.float64).expand(B, T, T).contiguous()
+            ops.manual_seed(77)
+            pd, _ = _run(dev, yq, wq, bq, k, eye, dout, 0.3, True)
+            mask = (pd.cpu() != 0).double()
+            ops.manual_seed(77)
+            o, grads = _run(dev, yq, wq, bq, k, v, dout, 0.3, True)
+            ref_o, ref_g = _reference(yq, wq, bq, k, v, dout, mask, 0.3)
+            for name, a, b in zip(["out", "dyq", "dwq", "dbq", "dk", "dv"], [o] + grads, [ref_o] + ref_g):
+                assert _e(a, b) <= 5e-5, f"smallqk[bf16x3]+dropout {name}: rel err {_e(a, b):.2e}"
+    finally:
+        ops.set_conv_math(old)
+
+
 def test_smallqk_unsupported_shapes_fall_back():
     from buctd_amd import ops
     assert not ops.attn_smallqk_ok(432, 3, 48)       # T not a multiple of 64
