@@ -210,7 +210,9 @@ __device__ __forceinline__ void split8(const float (&x)[8], bf16x8& h, bf16x8& l
 
 // forward: workgroup = 64 query rows (16 per wave); per 32-key step lane (row i16, g) generates the probabilities of
 // keys 8g..8g+7 - exactly the A operand of the K = 32 MFMA - and the V fragments (lane = channel, 8 keys) come out of
-// the key-major bf16 tile through the transpose read.
+// the key-major bf16 tile through the transpose read.  The soft-max statistics are computed on the fly (running row
+// maximum, accumulators rescaled when it moves - rare after the first tiles), so the separate statistics pass of the
+// fp32 path is gone; m and 1/l are written at the end for the backward kernels.
 template <int R4, int CF, bool DROP>
 __global__ __launch_bounds__(256) void attn_fwd_b3_kernel(AttnArgs p) {
   constexpr int C = CF * 16, LO = C * 2, RS = C * 4 + 32;   // V rows: C bf16 hi | C bf16 lo | 32 B pad (= 32 mod 64)
@@ -227,7 +229,7 @@ __global__ __launch_bounds__(256) void attn_fwd_b3_kernel(AttnArgs p) {
   loadr<R4>(qv, p.q + (rowbase + i) * R4);
 #pragma unroll
   for (int r = 0; r < R4; ++r) qv[r] *= p.scale2;
-  const float mi = p.m[rowbase + i], li = p.linv[rowbase + i];
+  float mrun = -INFINITY, lrun = 0.f;     // row i16: running maximum (same in its 4 lanes), this lane's share of the sum
   f32x4 acc[CF];
 #pragma unroll
   for (int nf = 0; nf < CF; ++nf) acc[nf] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -244,12 +246,32 @@ __global__ __launch_bounds__(256) void attn_fwd_b3_kernel(AttnArgs p) {
     __syncthreads();
 #pragma unroll
     for (int kstep = 0; kstep < 2; ++kstep) {
-      float pv[8];
+      float sv[8], pv[8];
+      float mx = -INFINITY;
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
-        const int j = 32 * kstep + 8 * g + e;
-        pv[e] = __builtin_amdgcn_exp2f(dotr<R4>(qv, ks + j * R4) - mi) * li;
-        if (DROP) pv[e] *= keepf(rk, cks[j], p.thr, p.inv_keep);
+        sv[e] = dotr<R4>(qv, ks + (32 * kstep + 8 * g + e) * R4);
+        mx = fmaxf(mx, sv[e]);
+      }
+      mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      const float mnew = fmaxf(mrun, mx);
+      if (__any(mnew > mrun)) {
+        const float fac = __builtin_amdgcn_exp2f(mrun - mnew);   // 1 where the maximum stayed, 0 on the first tile
+        lrun *= fac;
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) {
+          const float fr = __shfl(fac, g * 4 + rg, 64);          // accumulator rows are g*4 + rg
+#pragma unroll
+          for (int nf = 0; nf < CF; ++nf) acc[nf][rg] *= fr;
+        }
+        mrun = mnew;
+      }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        pv[e] = __builtin_amdgcn_exp2f(sv[e] - mrun);
+        lrun += pv[e];
+        if (DROP) pv[e] *= keepf(rk, cks[32 * kstep + 8 * g + e], p.thr, p.inv_keep);
       }
       bf16x8 ph, pl;
       split8(pv, ph, pl);
@@ -262,11 +284,20 @@ __global__ __launch_bounds__(256) void attn_fwd_b3_kernel(AttnArgs p) {
       }
     }
   }
+  lrun += __shfl_xor(lrun, 16, 64);
+  lrun += __shfl_xor(lrun, 32, 64);
+  const float linv = 1.f / lrun;
+  if (g == 0) {
+    p.m[rowbase + i] = mrun;
+    p.linv[rowbase + i] = linv;
+  }
 #pragma unroll
-  for (int nf = 0; nf < CF; ++nf)
+  for (int rg = 0; rg < 4; ++rg) {
+    const float fl = __shfl(linv, g * 4 + rg, 64);
 #pragma unroll
-    for (int rg = 0; rg < 4; ++rg)
-      p.out[(rowbase + blockIdx.x * 64 + wave * 16 + g * 4 + rg) * C + nf * 16 + i16] = acc[nf][rg];
+    for (int nf = 0; nf < CF; ++nf)
+      p.out[(rowbase + blockIdx.x * 64 + wave * 16 + g * 4 + rg) * C + nf * 16 + i16] = acc[nf][rg] * fl;
+  }
 }
 
 // 8 consecutive channels [c0, c0+8) of one fp32 row as bf16 hi / lo MFMA operands (zeros past channel C)
@@ -762,8 +793,10 @@ extern "C" int buctd_attn_smallqk_fwd(int B, int T, int R4, int C, const float* 
   BUCTD_CHECK_ARG(p_drop >= 0.f && p_drop < 1.f && (long)B * T < 2147483647L, "buctd_attn_smallqk_fwd: bad p_drop / size");
   AttnArgs a = attn_args(T, C, scale, p_drop, seed);
   a.q = q; a.k = k; a.v = v; a.m = m; a.linv = linv; a.out = out; a.b3 = bf16x3 ? 1 : 0;
-  attn_dispatch(0, a, R4, B, (hipStream_t)stream);
-  BUCTD_CHECK_LAUNCH("buctd_attn_smallqk_fwd(stats)");
+  if (!(a.b3 && R4 <= 8)) {            // the bf16x3 forward kernel computes the soft-max statistics on the fly
+    attn_dispatch(0, a, R4, B, (hipStream_t)stream);
+    BUCTD_CHECK_LAUNCH("buctd_attn_smallqk_fwd(stats)");
+  }
   attn_dispatch(1, a, R4, B, (hipStream_t)stream);
   BUCTD_CHECK_LAUNCH("buctd_attn_smallqk_fwd");
   return BUCTD_OK;
