@@ -52,9 +52,9 @@ struct AttnArgs {
 
 template <int R4>
 __device__ __forceinline__ float dotr(const float (&a)[R4], const float* b) {
-  float s = 0.f;
+  float s = a[0] * b[0];     // explicit FMAs: the file is compiled with -ffp-contract=off
 #pragma unroll
-  for (int r = 0; r < R4; ++r) s += a[r] * b[r];
+  for (int r = 1; r < R4; ++r) s = __builtin_fmaf(a[r], b[r], s);
   return s;
 }
 template <int R4>
@@ -234,16 +234,31 @@ __global__ __launch_bounds__(256) void attn_fwd_b3_kernel(AttnArgs p) {
 #pragma unroll
   for (int nf = 0; nf < CF; ++nf) acc[nf] = (f32x4){0.f, 0.f, 0.f, 0.f};
   const int tr_off = (g * 8 + (i16 >> 2)) * RS + (i16 & 3) * 8;
-  for (int j0 = 0; j0 < p.T; j0 += 64) {
-    __syncthreads();
-    for (int e = t; e < 64 * R4 / 4; e += 256)
-      reinterpret_cast<f32x4*>(ks)[e] = reinterpret_cast<const f32x4*>(p.k + (rowbase + j0) * R4)[e];
-    for (int e = t; e < 64 * (C / 4); e += 256) {
-      const int r = e / (C / 4), c4 = e - r * (C / 4);
-      split_store4<LO>(vt + r * RS, c4 * 4, reinterpret_cast<const f32x4*>(p.v + (rowbase + j0 + r) * C)[c4]);
+  // next tile's k' and V rows travel through registers while the current tile is being multiplied
+  f32x4 kreg = (f32x4){0.f, 0.f, 0.f, 0.f}, vreg[CF];
+  auto load_tile = [&](int j0) {
+    if (t < 64 * R4 / 4) kreg = reinterpret_cast<const f32x4*>(p.k + (rowbase + j0) * R4)[t];
+#pragma unroll
+    for (int q = 0; q < CF; ++q) {
+      const int e = t + 256 * q, r = e / (C / 4), c4 = e - r * (C / 4);
+      vreg[q] = reinterpret_cast<const f32x4*>(p.v + (rowbase + j0 + r) * C)[c4];
+    }
+  };
+  auto store_tile = [&](int j0) {
+    if (t < 64 * R4 / 4) reinterpret_cast<f32x4*>(ks)[t] = kreg;
+#pragma unroll
+    for (int q = 0; q < CF; ++q) {
+      const int e = t + 256 * q, r = e / (C / 4), c4 = e - r * (C / 4);
+      split_store4<LO>(vt + r * RS, c4 * 4, vreg[q]);
     }
     if (DROP && t < 64) cks[t] = colkey(p.s1, (uint32_t)(j0 + t));
+  };
+  load_tile(0);
+  for (int j0 = 0; j0 < p.T; j0 += 64) {
     __syncthreads();
+    store_tile(j0);
+    __syncthreads();
+    if (j0 + 64 < p.T) load_tile(j0 + 64);
 #pragma unroll
     for (int kstep = 0; kstep < 2; ++kstep) {
       float sv[8], pv[8];
@@ -372,16 +387,30 @@ __global__ __launch_bounds__(256) void attn_bwd_q_b3_kernel(AttnArgs p) {
     boff[kk] = (c0 < C ? c0 : 0) * 2;
   }
 
-  for (int j0 = 0; j0 < p.T; j0 += 64) {
-    __syncthreads();
-    for (int e = t; e < 64 * R4 / 4; e += 256)
-      reinterpret_cast<f32x4*>(ks)[e] = reinterpret_cast<const f32x4*>(p.k + (rowbase + j0) * R4)[e];
-    for (int e = t; e < 64 * (C / 4); e += 256) {
-      const int r = e / (C / 4), c4 = e - r * (C / 4);
-      split_store4<LO>(vt + r * RS, c4 * 4, reinterpret_cast<const f32x4*>(p.v + (rowbase + j0 + r) * C)[c4]);
+  f32x4 kreg = (f32x4){0.f, 0.f, 0.f, 0.f}, vreg[CF];
+  auto load_tile = [&](int j0) {
+    if (t < 64 * R4 / 4) kreg = reinterpret_cast<const f32x4*>(p.k + (rowbase + j0) * R4)[t];
+#pragma unroll
+    for (int q = 0; q < CF; ++q) {
+      const int e = t + 256 * q, r = e / (C / 4), c4 = e - r * (C / 4);
+      vreg[q] = reinterpret_cast<const f32x4*>(p.v + (rowbase + j0 + r) * C)[c4];
+    }
+  };
+  auto store_tile = [&](int j0) {
+    if (t < 64 * R4 / 4) reinterpret_cast<f32x4*>(ks)[t] = kreg;
+#pragma unroll
+    for (int q = 0; q < CF; ++q) {
+      const int e = t + 256 * q, r = e / (C / 4), c4 = e - r * (C / 4);
+      split_store4<LO>(vt + r * RS, c4 * 4, vreg[q]);
     }
     if (DROP && t < 64) cks[t] = colkey(p.s1, (uint32_t)(j0 + t));
+  };
+  load_tile(0);
+  for (int j0 = 0; j0 < p.T; j0 += 64) {
     __syncthreads();
+    store_tile(j0);
+    __syncthreads();
+    if (j0 + 64 < p.T) load_tile(j0 + 64);
 #pragma unroll
     for (int f = 0; f < 4; ++f) {
       f32x4 dp4 = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -452,20 +481,41 @@ __global__ __launch_bounds__(256) void attn_bwd_kv_b3_kernel(AttnArgs p) {
   for (int r = 0; r < R4; ++r) dk[r] = 0.f;
   const int tr_off = (4 * kq + (i16 >> 2)) * RS + (i16 & 3) * 8;   // rows 4 kq .. 4 kq + 3 of a 16-query block
 
-  for (int i0 = 0; i0 < p.T; i0 += 64) {
-    __syncthreads();
-    for (int e = t; e < 64 * R4; e += 256) qs[e] = p.q[(rowbase + i0) * R4 + e] * p.scale2;
-    for (int e = t; e < 64 * (C / 4); e += 256) {
-      const int r = e / (C / 4), c4 = e - r * (C / 4);
-      split_store4<LO>(dt + r * RS, c4 * 4, reinterpret_cast<const f32x4*>(p.dout + (rowbase + i0 + r) * C)[c4]);
+  f32x4 qreg = (f32x4){0.f, 0.f, 0.f, 0.f}, dreg[CF];
+  float mreg = 0.f, lreg = 0.f, sreg = 0.f;
+  auto load_tile = [&](int i0) {
+    if (t < 64 * R4 / 4) qreg = reinterpret_cast<const f32x4*>(p.q + (rowbase + i0) * R4)[t];
+#pragma unroll
+    for (int q = 0; q < CF; ++q) {
+      const int e = t + 256 * q, r = e / (C / 4), c4 = e - r * (C / 4);
+      dreg[q] = reinterpret_cast<const f32x4*>(p.dout + (rowbase + i0 + r) * C)[c4];
     }
     if (t < 64) {
-      ms[t] = p.m[rowbase + i0 + t];
-      ls[t] = p.linv[rowbase + i0 + t];
-      dsm[t] = p.dvec[rowbase + i0 + t];
+      mreg = p.m[rowbase + i0 + t];
+      lreg = p.linv[rowbase + i0 + t];
+      sreg = p.dvec[rowbase + i0 + t];
+    }
+  };
+  auto store_tile = [&](int i0) {
+    if (t < 64 * R4 / 4) reinterpret_cast<f32x4*>(qs)[t] = qreg * p.scale2;
+#pragma unroll
+    for (int q = 0; q < CF; ++q) {
+      const int e = t + 256 * q, r = e / (C / 4), c4 = e - r * (C / 4);
+      split_store4<LO>(dt + r * RS, c4 * 4, dreg[q]);
+    }
+    if (t < 64) {
+      ms[t] = mreg;
+      ls[t] = lreg;
+      dsm[t] = sreg;
       if (DROP) rks[t] = rowkey(p.s0, (uint32_t)(rowbase + i0 + t));
     }
+  };
+  load_tile(0);
+  for (int i0 = 0; i0 < p.T; i0 += 64) {
     __syncthreads();
+    store_tile(i0);
+    __syncthreads();
+    if (i0 + 64 < p.T) load_tile(i0 + 64);
 #pragma unroll
     for (int h = 0; h < 2; ++h) {          // 32 queries per step: blocks f = 2h, 2h + 1
       float pd[8];
