@@ -271,9 +271,11 @@ def init_distributed():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if torch.cuda.is_available():
+        if os.environ.get("BUCTD_SINGLE_DEVICE") == "1":   # test hook: every rank on GPU 0 (needs a non-RCCL backend)
+            local = 0
         torch.cuda.set_device(local)
         device = torch.device("cuda", local)
-        backend = "nccl"  # RCCL on ROCm
+        backend = os.environ.get("BUCTD_DIST_BACKEND", "nccl")  # "nccl" is RCCL on ROCm
     else:
         device = torch.device("cpu")
         backend = "gloo"

@@ -1,0 +1,52 @@
+"""Worker for tests/test_gpu_ddp.py: N ranks (all on GPU 0, gloo) or one plain process train the same small model on
+the same batch for two steps and dump a checksum of the parameters.  usage: ddp_worker.py OUT.npz"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+
+from buctd_amd import engine, models, ops  # noqa: E402
+from buctd_amd.core.loss import JointsMSELoss  # noqa: E402
+from oracle import recipes  # noqa: E402
+
+
+def main():
+    rank, world, dev = engine.init_distributed()
+    ops.set_conv_math(os.environ.get("BUCTD_CONV_MATH", "fp32"))
+    cfg, omodel, x, joints = recipes.build("coam_w16_96x64_colored")
+    net = getattr(models, cfg.MODEL.NAME).get_pose_net(cfg, is_train=True)
+    net.load_state_dict(omodel.state_dict(), strict=True)
+    net = net.to(dev).train()
+    recipes.set_dropout(net, 0.0)
+    model = engine.DataParallel(net, bucket_bytes=1 << 16)   # many small buckets: exercises the overlap machinery
+    opt = engine.get_optimizer(cfg, model)
+    tgt, wt = recipes.make_targets(cfg, joints, 77)
+    crit = JointsMSELoss(True)
+    xd, td, wd = x.to(dev), tgt.to(dev), wt.to(dev)
+    losses = []
+    for _ in range(2):
+        loss = crit(model(xd), td, wd)
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        losses.append(loss.item())
+    torch.cuda.synchronize()
+    flat = model.flat.flat.detach().cpu().numpy()
+    if rank == 0:
+        np.savez(sys.argv[1], flat=flat, losses=np.array(losses), world=world)
+    if world > 1:
+        import torch.distributed as dist
+        # every rank must hold the same parameters
+        ref = model.flat.flat.clone()
+        dist.broadcast(ref, src=0)
+        assert torch.equal(ref, model.flat.flat), "ranks diverged"
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
