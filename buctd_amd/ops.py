@@ -385,8 +385,7 @@ def fork_join(fns, inputs, tag=0):
         for u in (t if isinstance(t, (list, tuple)) else [t]):
             if torch.is_tensor(u) and u.is_cuda:
                 dev = u.device
-    dbg = int(os.environ.get("BUCTD_FORK_DEBUG", "0"))
-    if not _branch["on"] or dev is None or len(fns) < 2 or (dbg & (1 << tag)):
+    if not _branch["on"] or dev is None or len(fns) < 2:
         return [f() for f in fns]
     main = torch.cuda.current_stream(dev)
     start = torch.cuda.Event()
@@ -409,8 +408,6 @@ def fork_join(fns, inputs, tag=0):
         done.append(ev)
     for ev in done:
         main.wait_event(ev)
-    if dbg & 4:
-        torch.cuda.synchronize()
     return outs
 
 
