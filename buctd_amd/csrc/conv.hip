@@ -438,13 +438,40 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs p) {
   }
 }
 
+// Slab reduction: a workgroup covers 32 output columns (float4 each when VEC) with 8 split-lanes per column, so even a
+// small gradient with hundreds of slabs keeps every slab read independent and spreads over many workgroups (one
+// thread per element with a serial loop over the slabs is latency-bound: 384 dependent loads).
+template <bool VEC>
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ part, float* __restrict__ out,
                                                             long n, int nsplit, int accumulate, float alpha) {
-  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
-    float s = 0.f;
-    for (int z = 0; z < nsplit; ++z) s += part[(long)z * n + i];
-    s *= alpha;
-    out[i] = accumulate ? out[i] + s : s;
+  __shared__ f32x4 sm[8][32];
+  const long cols = VEC ? (n >> 2) : n;
+  const int col = threadIdx.x & 31, zl = threadIdx.x >> 5;
+  for (long base = (long)blockIdx.x * 32; base < cols; base += (long)gridDim.x * 32) {
+    const long i = base + col;
+    f32x4 s = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (i < cols) {
+      if (VEC) {
+        for (int z = zl; z < nsplit; z += 8) s += reinterpret_cast<const f32x4*>(part + (long)z * n)[i];
+      } else {
+        for (int z = zl; z < nsplit; z += 8) s.x += part[(long)z * n + i];
+      }
+    }
+    sm[zl][col] = s;
+    __syncthreads();
+    if (zl == 0 && i < cols) {
+#pragma unroll
+      for (int k = 1; k < 8; ++k) s += sm[k][col];
+      if (VEC) {
+        s *= alpha;
+        if (accumulate) s += reinterpret_cast<const f32x4*>(out)[i];
+        reinterpret_cast<f32x4*>(out)[i] = s;
+      } else {
+        const float v = s.x * alpha;
+        out[i] = accumulate ? out[i] + v : v;
+      }
+    }
+    __syncthreads();
   }
 }
 
@@ -624,10 +651,17 @@ extern "C" int buctd_conv2d_wgrad(const buctd_conv_desc* d, const float* x, cons
   else launch_wgrad<TileCfg<2, 2, 4, 2>, true>(a, ns, st);                // 128x64
   BUCTD_CHECK_LAUNCH("buctd_conv2d_wgrad");
   const long n = (long)d->Co * a.Ncols;
-  int blocks = ceil_div(n, 256);
-  if (blocks > 2048) blocks = 2048;
-  hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, (const float*)workspace, dw, n, ns,
-                     accumulate, 1.0f);
+  if (n % 4 == 0) {
+    int blocks = ceil_div(n / 4, 32);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(splitk_reduce_kernel<true>, dim3(blocks), dim3(256), 0, st, (const float*)workspace, dw, n, ns,
+                       accumulate, 1.0f);
+  } else {
+    int blocks = ceil_div(n, 32);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(splitk_reduce_kernel<false>, dim3(blocks), dim3(256), 0, st, (const float*)workspace, dw, n, ns,
+                       accumulate, 1.0f);
+  }
   BUCTD_CHECK_LAUNCH("buctd_conv2d_wgrad(reduce)");
   return BUCTD_OK;
 }

@@ -205,18 +205,34 @@ __global__ __launch_bounds__(256) void matmul_kernel(MMArgs p) {
   }
 }
 
-// reduce split-K slabs [batch][nsplit][M][N] into the strided C
+// reduce split-K slabs [batch][nsplit][M][N] into the strided C: 32 outputs x 8 split-lanes per workgroup (every slab
+// read independent; a serial loop per output would chain hundreds of dependent loads for the tall-skinny products)
 __global__ __launch_bounds__(256) void matmul_splitk_reduce(const float* __restrict__ part, MMArgs p, int nbatch) {
+  __shared__ float sm[8][32];
   const long per = (long)p.M * p.N;
   const long total = per * nbatch;
-  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-    const int b = (int)(i / per);
-    const long r = i - (long)b * per;
-    const int m = (int)(r / p.N), n = (int)(r - (long)m * p.N);
+  const int col = threadIdx.x & 31, zl = threadIdx.x >> 5;
+  for (long base = (long)blockIdx.x * 32; base < total; base += (long)gridDim.x * 32) {
+    const long i = base + col;
     float s = 0.f;
-    for (int z = 0; z < p.nsplit; ++z) s += part[((long)(b * p.nsplit + z) * p.M + m) * p.N + n];
-    const int g = n / p.Nc, c = n - g * p.Nc;
-    p.C[(long)b * p.sCb + (long)m * p.ldc + (long)g * p.gsCn + c] = s * p.alpha + (p.bias ? p.bias[p.bias_axis == 1 ? m : n] : 0.f);
+    int b = 0, m = 0, n = 0;
+    if (i < total) {
+      b = (int)(i / per);
+      const long r = i - (long)b * per;
+      m = (int)(r / p.N);
+      n = (int)(r - (long)m * p.N);
+      for (int z = zl; z < p.nsplit; z += 8) s += part[((long)(b * p.nsplit + z) * p.M + m) * p.N + n];
+    }
+    sm[zl][col] = s;
+    __syncthreads();
+    if (zl == 0 && i < total) {
+#pragma unroll
+      for (int k = 1; k < 8; ++k) s += sm[k][col];
+      const int g = n / p.Nc, c = n - g * p.Nc;
+      p.C[(long)b * p.sCb + (long)m * p.ldc + (long)g * p.gsCn + c] =
+          s * p.alpha + (p.bias ? p.bias[p.bias_axis == 1 ? m : n] : 0.f);
+    }
+    __syncthreads();
   }
 }
 
@@ -307,8 +323,8 @@ extern "C" int buctd_matmul(const buctd_matmul_desc* d, const float* A, const fl
   BUCTD_CHECK_LAUNCH("buctd_matmul");
   if (a.nsplit > 1) {
     const long total = (long)d->batch * d->M * d->N;
-    int blocks = ceil_div(total, 256);
-    if (blocks > 2048) blocks = 2048;
+    int blocks = ceil_div(total, 32);
+    if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(matmul_splitk_reduce, dim3(blocks), dim3(256), 0, st, (const float*)workspace, a, d->batch);
     BUCTD_CHECK_LAUNCH("buctd_matmul(reduce)");
   }
