@@ -241,7 +241,8 @@ static bool wg3_plan(int N, int H, int W, int Ci, int Co, WG3Plan* pl) {
   const int ch = cf * 16;
   const long P = (long)N * (H + 1) * (W + 2) + (W + 2);
   const long pairs = (long)(Co / ch) * (Ci / ch);
-  long want = (320 + pairs - 1) / pairs;          // ~1.25 workgroups per CU: partial-slab traffic grows with the split
+  long want = (384 + pairs - 1) / pairs;          // ~1.5 workgroups per CU (measured flat optimum 320..512 inside the
+                                                  // train step): partial-slab traffic grows with the split
   const long stages = (P + WG_KB - 1) / WG_KB;
   if (want > stages) want = stages;
   if (want < 1) want = 1;

@@ -328,21 +328,25 @@ def conv_wgrad(x, dy, w_like, stride=1, pad=0, out=None, accumulate=0):
 # Weight gradients are off the critical path of the backward pass (nothing downstream of dgrad needs them), so they
 # run on a second HIP stream and fill the CUs that the latency-bound BN / dgrad chain leaves idle.  The join is queued
 # as an autograd end-of-backward callback, so param.grad is complete on the caller's stream when backward() returns.
-_side = {"on": os.environ.get("BUCTD_WGRAD_STREAM", "1") == "1", "streams": {}, "joined": True}
+_side = {"on": os.environ.get("BUCTD_WGRAD_STREAM", "1") == "1", "streams": {}, "joined": True, "rr": 0,
+         "n": max(1, int(os.environ.get("BUCTD_WGRAD_STREAMS", "1")))}   # more than one measured slower (L2 contention)
 
 
 def _side_stream(device):
-    st = _side["streams"].get(device.index)
+    """Weight-gradient streams, used round-robin (consecutive layers' gradients are independent of each other)."""
+    _side["rr"] = (_side["rr"] + 1) % _side["n"]
+    key = (device.index, _side["rr"])
+    st = _side["streams"].get(key)
     if st is None:
         st = torch.cuda.Stream(device=device)
-        _side["streams"][device.index] = st
+        _side["streams"][key] = st
     return st
 
 
 def wait_side_stream(stream=None):
     """Make `stream` (default: the current one) wait for everything enqueued so far on the streams this module owns
     (weight-gradient stream and branch streams)."""
-    for idx, st in _side["streams"].items():
+    for (idx, _), st in _side["streams"].items():
         target = stream if stream is not None else torch.cuda.current_stream(torch.device("cuda", idx))
         target.wait_stream(st)
     for (idx, _), st in _branch["streams"].items():
