@@ -10,7 +10,10 @@
 // tiles through the gfx950 transpose read ds_read_b64_tr_b16 (4 rows x 16 channels -> lane c gets 4 positions of
 // channel c; verified on hardware, scratch/tr_probe).  One workgroup owns a (co-chunk, ci-chunk) pair - CH = 48 or
 // 32 channels each - for a range of positions and all 9 taps: 9*CH/16 n-fragments dealt round-robin to the 4 waves,
-// CH/16 m-fragments each.  Position ranges are split over the grid; per-split slabs are summed by splitk_reduce.
+// CH/16 m-fragments each.  Position ranges are split over the grid; per-split slabs are summed by wg3_reduce.
+// The X tile is a 256-row ring indexed by (position - first staged position) & 255: consecutive stages of a workgroup
+// overlap in all but WG_KB rows, so after the first stage only the WG_KB new rows are fetched and split (the halo of
+// 2*SW+2 rows used to be re-staged every stage: 2.6x the traffic and VALU work at W = 72).
 #include "common.h"
 #include "../../include/buctd_hip.h"
 
@@ -21,6 +24,7 @@ typedef short s16x4 __attribute__((ext_vector_type(4)));
 
 #define WG_KB 96          // positions per LDS stage (3 MFMA k-steps of 32)
 #define WG_MAX_SW 75
+#define WG_RING 256        // X ring rows (power of two >= WG_KB + 2*WG_MAX_SW + 2)
 
 struct WG3Args {
   const float* x;
@@ -61,6 +65,14 @@ __device__ __forceinline__ bf16x8 tr_frag(const unsigned char* p, int row_bytes)
   return __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
 }
 
+__device__ __forceinline__ bf16x8 tr_frag2(const unsigned char* p, const unsigned char* q) {
+  // as tr_frag with the two 4-row groups addressed separately (the ring may wrap between them)
+  typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
+  const bf16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)p);
+  const bf16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)q);
+  return __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+
 template <int CF>   // channel fragments (of 16) per chunk: 3 -> 48 channels, 2 -> 32
 __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_bf16x3_kernel(WG3Args p) {
   constexpr int CH = CF * 16;
@@ -69,14 +81,14 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_bf16x3_kernel(WG3Args p)
   constexpr int C4 = CH / 4;                 // float4 per row
   constexpr int XR = WG_KB + 2 * WG_MAX_SW + 2;
   constexpr int PD = (WG_KB * C4 + 255) / 256;
-  constexpr int PX = (XR * C4 + 255) / 256;
+  constexpr int PX = (WG_KB * C4 + 255) / 256;   // X rows travel WG_KB at a time (the first stage takes several rounds)
   constexpr int NFR = 9 * CF;                // n-fragments (tap, ci16)
   constexpr int NW = (NFR + 3) / 4;          // n-fragments per wave
 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int R = WG_KB + 2 * p.SW + 2;
   unsigned char* Dt = smem;                          // dY tile [WG_KB][RS]
-  unsigned char* Xt = smem + (size_t)WG_KB * RS;     // X  tile [R][RS]
+  unsigned char* Xt = smem + (size_t)WG_KB * RS;     // X  ring [WG_RING][RS]
 
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int t16 = lane & 15, g = lane >> 4;
@@ -98,9 +110,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_bf16x3_kernel(WG3Args p)
 
   f32x4 dreg[PD], xreg[PX];
   unsigned dmask = 0, xmask = 0;             // bit q: the row loaded in pass q is a real pixel (else zero row)
-  auto load_stage = [&](int k0) {
+  auto load_d = [&](int k0) {
     dmask = 0;
-    xmask = 0;
 #pragma unroll
     for (int q = 0; q < PD; ++q) {
       const int idx = t + 256 * q;
@@ -110,16 +121,21 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_bf16x3_kernel(WG3Args p)
       dmask |= (o >= 0 ? 1u : 0u) << q;
       dreg[q] = *reinterpret_cast<const f32x4*>(p.dy + (o >= 0 ? o + co0 + c4 : 0));
     }
-#pragma unroll
-    for (int q = 0; q < PX; ++q) {
-      const int idx = t + 256 * q;
-      const int row = idx / C4, c4 = (idx - row * C4) * 4;
-      const int o = row < R ? pos_offset(k0 - halo + row, p.Ci) : -1;
-      xmask |= (o >= 0 ? 1u : 0u) << q;
-      xreg[q] = *reinterpret_cast<const f32x4*>(p.x + (o >= 0 ? o + ci0 + c4 : 0));
-    }
   };
-  auto store_stage = [&]() {
+  // X rows rel0 .. rel0 + nrows - 1, counted from position k_begin - halo (ring slot = rel & 255)
+  auto load_x = [&](int rel0, int nrows) {
+    xmask = 0;
+#pragma unroll
+    for (int q = 0; q < PX; ++q)
+      if (256 * q < nrows * C4) {
+        const int idx = t + 256 * q;
+        const int row = idx / C4, c4 = (idx - row * C4) * 4;
+        const int o = row < nrows ? pos_offset(k_begin - halo + rel0 + row, p.Ci) : -1;
+        xmask |= (o >= 0 ? 1u : 0u) << q;
+        xreg[q] = *reinterpret_cast<const f32x4*>(p.x + (o >= 0 ? o + ci0 + c4 : 0));
+      }
+  };
+  auto store_d = [&]() {
 #pragma unroll
     for (int q = 0; q < PD; ++q) {
       const int idx = t + 256 * q;
@@ -127,12 +143,17 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_bf16x3_kernel(WG3Args p)
       if (row < WG_KB)
         wg_split_store<LO>(Dt + (size_t)row * RS, c4, ((dmask >> q) & 1u) ? dreg[q] : (f32x4){0.f, 0.f, 0.f, 0.f});
     }
+  };
+  auto store_x = [&](int rel0, int nrows) {
 #pragma unroll
-    for (int q = 0; q < PX; ++q) {
-      const int idx = t + 256 * q;
-      const int row = idx / C4, c4 = (idx - row * C4) * 4;
-      if (row < R) wg_split_store<LO>(Xt + (size_t)row * RS, c4, ((xmask >> q) & 1u) ? xreg[q] : (f32x4){0.f, 0.f, 0.f, 0.f});
-    }
+    for (int q = 0; q < PX; ++q)
+      if (256 * q < nrows * C4) {
+        const int idx = t + 256 * q;
+        const int row = idx / C4, c4 = (idx - row * C4) * 4;
+        if (row < nrows)
+          wg_split_store<LO>(Xt + (size_t)((rel0 + row) & (WG_RING - 1)) * RS, c4,
+                             ((xmask >> q) & 1u) ? xreg[q] : (f32x4){0.f, 0.f, 0.f, 0.f});
+      }
   };
 
   f32x4 acc[CF][NW];
@@ -142,14 +163,35 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_bf16x3_kernel(WG3Args p)
     for (int j = 0; j < NW; ++j) acc[mf][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   // transpose-read lane addressing: lane t16 of group g points at row g*8 + (t16>>2), channels 4*(t16&3)..+3
-  const int lane_off = (g * 8 + (t16 >> 2)) * RS + (t16 & 3) * 8;
+  const int lane_row = g * 8 + (t16 >> 2), lane_col = (t16 & 3) * 8;
+  const int lane_off = lane_row * RS + lane_col;
 
-  if (k_begin < k_end) load_stage(k_begin);
-  for (int k0 = k_begin; k0 < k_end; k0 += WG_KB) {
+  // first stage: the halo rows go in synchronously, WG_KB at a time through the same registers as the steady state
+  int rel0 = 0, nrows = R < WG_KB ? R : WG_KB;
+  if (k_begin < k_end) {
+    dmask = 0;
+    while (rel0 + WG_KB < R) {
+      load_x(rel0, WG_KB);
+      store_x(rel0, WG_KB);
+      rel0 += WG_KB;
+    }
+    nrows = R - rel0;
+    load_d(k_begin);
+    load_x(rel0, nrows);
+  }
+  int si = 0;
+  for (int k0 = k_begin; k0 < k_end; k0 += WG_KB, ++si) {
     __syncthreads();                       // previous stage fully consumed
-    store_stage();
-    if (k0 + WG_KB < k_end) load_stage(k0 + WG_KB);   // in flight during the MFMAs below
+    store_d();
+    store_x(rel0, nrows);
+    if (k0 + WG_KB < k_end) {              // in flight during the MFMAs below
+      rel0 = R + si * WG_KB;
+      nrows = WG_KB;
+      load_d(k0 + WG_KB);
+      load_x(rel0, nrows);
+    }
     __syncthreads();
+    const int xbase = si * WG_KB + lane_row;   // ring row (before wrapping) of this lane's first position, tap shift 0
 #pragma unroll
     for (int ks = 0; ks < WG_KB / 32; ++ks) {
       bf16x8 ah[CF], al[CF];
@@ -164,10 +206,12 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_bf16x3_kernel(WG3Args p)
         const int nf = wave + 4 * j;         // (tap, ci16) fragment of this wave
         if (nf < NFR) {
           const int tap = nf / CF, cf = nf - tap * CF;
-          const int shift = (tap / 3) * p.SW + tap % 3;      // row of Xt holding position k + shift(tap) - halo... (+halo)
-          const unsigned char* q = Xt + (size_t)(ks * 32 + shift) * RS + lane_off + cf * 32;
-          const bf16x8 bh = tr_frag(q, RS);
-          const bf16x8 bl = tr_frag(q + LO, RS);
+          const int shift = (tap / 3) * p.SW + tap % 3;      // X row of position k + shift(tap) (the ring starts at -halo)
+          const int r0 = (xbase + ks * 32 + shift) & (WG_RING - 1), r1 = (r0 + 4) & (WG_RING - 1);
+          const unsigned char* q0 = Xt + (size_t)r0 * RS + lane_col + cf * 32;
+          const unsigned char* q1 = Xt + (size_t)r1 * RS + lane_col + cf * 32;
+          const bf16x8 bh = tr_frag2(q0, q1);
+          const bf16x8 bl = tr_frag2(q0 + LO, q1 + LO);
 #pragma unroll
           for (int mf = 0; mf < CF; ++mf) acc[mf][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[mf], bh, acc[mf][j], 0, 0, 0);
 #pragma unroll
@@ -251,7 +295,7 @@ static bool wg3_plan(int N, int H, int W, int Ci, int Co, WG3Plan* pl) {
   pl->pps = (int)(per * WG_KB);
   pl->nsplit = (int)((P + pl->pps - 1) / pl->pps);
   const int rs = ch * 4 + 32;
-  pl->lds = (size_t)WG_KB * rs + (size_t)(WG_KB + 2 * (W + 2) + 2) * rs;
+  pl->lds = (size_t)WG_KB * rs + (size_t)WG_RING * rs;
   return pl->lds <= 160 * 1024;
 }
 
