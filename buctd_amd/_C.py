@@ -132,8 +132,20 @@ def check(rc, what=""):
         raise BuctdHipError(f"{what} failed ({rc}): {msg.decode() if msg else ''}")
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+_raw_device = getattr(torch._C, "_cuda_getDevice", None)
+
+
+def current_stream_handle():
+    """Raw hipStream_t of torch's current stream as an int.  torch.cuda.current_stream() builds a Stream object through
+    several Python layers (~8 us); with ~4000 kernel launches per train step that alone was a third of the host time."""
+    if _raw_stream is not None and _raw_device is not None:
+        return _raw_stream(_raw_device())
+    return torch.cuda.current_stream().cuda_stream
+
+
 def stream_ptr():
-    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    return C.c_void_p(current_stream_handle())
 
 
 def ptr(t):

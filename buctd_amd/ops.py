@@ -29,7 +29,7 @@ _workspaces = {}
 def workspace(nbytes, device):
     """Grow-only scratch buffer per (device, stream); ops on one stream run in order, so
     sharing it between consecutive ops is safe."""
-    key = (device.index, torch.cuda.current_stream(device).cuda_stream)
+    key = (device.index, _C.current_stream_handle())
     buf = _workspaces.get(key)
     if buf is None or buf.numel() < nbytes:
         buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)

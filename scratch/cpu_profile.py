@@ -1,0 +1,26 @@
+"""Host-side cost of one train step: cProfile over 3 steps at batch 2 (GPU work negligible)."""
+import cProfile, pstats, os, sys, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench
+from buctd_amd import engine, models, ops
+from buctd_amd.core.loss import JointsMSELoss
+ops.set_conv_math("bf16x3")
+dev = torch.device("cuda:0")
+cfg = bench.coam_w48_cfg(2)
+net = models.pose_hrnet_coam.get_pose_net(cfg, is_train=True).to(dev).train()
+model = engine.DataParallel(net)
+opt = engine.get_optimizer(cfg, model)
+x, tgt, wt = bench.synthetic_batch(cfg, 2, dev, 1)
+crit = JointsMSELoss(True)
+def step():
+    loss = crit(model(x), tgt, wt); opt.zero_grad(); loss.backward(); opt.step()
+for _ in range(3): step()
+torch.cuda.synchronize()
+import time
+t0 = time.time()
+for _ in range(5): step()
+torch.cuda.synchronize(); print("ms/step", (time.time() - t0) / 5 * 1e3)
+pr = cProfile.Profile(); pr.enable()
+for _ in range(3): step()
+torch.cuda.synchronize(); pr.disable()
+st = pstats.Stats(pr); st.sort_stats("tottime").print_stats(32)
