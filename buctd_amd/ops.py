@@ -420,9 +420,28 @@ def _join_side():
     wait_side_stream()
 
 
+def _queue_join():
+    """Queue the end-of-backward join once per backward pass.  Keyed on the autograd graph-task id, so a backward that
+    died with an exception (its callback never ran) cannot leave the next one without a join."""
+    task = torch._C._current_graph_task_id() if hasattr(torch._C, "_current_graph_task_id") else None
+    if task is not None and task >= 0:
+        if _side.get("task") == task:
+            return
+        _side["task"] = task
+    elif not _side["joined"]:
+        return
+    _side["joined"] = False
+    try:
+        torch.autograd.Variable._execution_engine.queue_callback(_join_side)
+    except RuntimeError:      # not inside a backward pass: join right away
+        _join_side()
+
+
 def conv_wgrad_async(x, dy, w_like, stride, pad, out, accumulate):
     """conv_wgrad on the side stream (backward passes only: the join rides on the autograd engine's final callback)."""
     if not (_side["on"] and x.is_cuda):
+        if x.is_cuda and _branch["on"]:
+            _queue_join()     # parameter gradients may be written on branch streams: still join them at the end
         return conv_wgrad(x, dy, w_like, stride, pad, out=out, accumulate=accumulate)
     main = torch.cuda.current_stream(x.device)
     side = _side_stream(x.device)
@@ -431,12 +450,7 @@ def conv_wgrad_async(x, dy, w_like, stride, pad, out, accumulate):
         conv_wgrad(x, dy, w_like, stride, pad, out=out, accumulate=accumulate)
     x.record_stream(side)
     dy.record_stream(side)
-    if _side["joined"]:
-        _side["joined"] = False
-        try:
-            torch.autograd.Variable._execution_engine.queue_callback(_join_side)
-        except RuntimeError:      # not inside a backward pass: join right away
-            _join_side()
+    _queue_join()
     return out
 
 
