@@ -57,6 +57,8 @@ SIGNATURES = {
     "buctd_bn_finalize": (_I, [_P, _P, _I, _I, _L, _I, _F, _F, _P, _P, _P, _P, _P]),
     "buctd_conv3x3_bf16x3_supported": (_I, [_I, _I, _I, _I, _I]),
     "buctd_conv3x3_bf16x3_stats_groups": (_I, [_I, _I, _I, _I, _I, _PI, _PI]),
+    "buctd_conv3x3_bf16x3_timing_begin": (_I, [_I, _I, _I, _I, _I]),
+    "buctd_conv3x3_bf16x3_timing_end": (_I, [_P, _PI]),
     "buctd_conv3x3_bf16x3_prep_bytes": (_SZ, [_I, _I, _I]),
     "buctd_conv3x3_bf16x3_prep": (_I, [_I, _I, _P, _I, _P, _P]),
     "buctd_conv3x3_bf16x3_prep_batched": (_I, [_P, _I, _L, _P]),

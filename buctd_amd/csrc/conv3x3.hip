@@ -24,6 +24,8 @@
 //   * epilogue as in conv.hip: bias, Welford BN partials (+ per-group valid-row counts, since pad positions are
 //     skipped), eval-BN scale/shift, residual, ReLU.
 #include "common.h"
+#include <hip/hip_ext.h>
+#include <vector>
 #include "../../include/buctd_hip.h"
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -480,6 +482,16 @@ extern "C" int buctd_conv3x3_bf16x3_prep_batched(const buctd_c3_prep_item* items
   return BUCTD_OK;
 }
 
+// Optional live timing of the launches of one shape (bench.py's roofline figure): HIP events attached to the dispatch
+// itself (hipExtLaunchKernelGGL start/stop events) time the kernel exactly as a kernel trace does - events recorded
+// around the launch on the stream would also count marker handling and whatever the stream waits for.
+struct C3Timing {
+  bool on = false;
+  int N = 0, H = 0, W = 0, Ci = 0, Co = 0;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
+};
+static C3Timing g_c3_timing;
+
 template <int MF, int NF, int WM, int WN>
 static int c3_launch(const C3Args& a, const C3Plan& pl, hipStream_t st) {
   static bool attr_set = false;
@@ -494,8 +506,48 @@ static int c3_launch(const C3Args& a, const C3Plan& pl, hipStream_t st) {
     attr_set = true;
   }
   dim3 grid(ceil_div(a.P, pl.BM), a.Co / pl.BN);
+  C3Timing& tm = g_c3_timing;
+  if (tm.on && a.N == tm.N && a.H == tm.H && a.W == tm.W && a.Ci == tm.Ci && a.Co == tm.Co) {
+    hipEvent_t e0, e1;
+    if (hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess) {
+      hipExtLaunchKernelGGL(fn, grid, dim3(256), (uint32_t)pl.lds, st, e0, e1, 0, a);
+      tm.events.emplace_back(e0, e1);
+      BUCTD_CHECK_LAUNCH("buctd_conv3x3_bf16x3");
+      return BUCTD_OK;
+    }
+  }
   hipLaunchKernelGGL(fn, grid, dim3(256), pl.lds, st, a);
   BUCTD_CHECK_LAUNCH("buctd_conv3x3_bf16x3");
+  return BUCTD_OK;
+}
+
+extern "C" int buctd_conv3x3_bf16x3_timing_begin(int N, int H, int W, int Ci, int Co) {
+  C3Timing& tm = g_c3_timing;
+  for (auto& ev : tm.events) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
+  tm.events.clear();
+  tm.N = N; tm.H = H; tm.W = W; tm.Ci = Ci; tm.Co = Co;
+  tm.on = true;
+  return BUCTD_OK;
+}
+
+extern "C" int buctd_conv3x3_bf16x3_timing_end(double* total_us, int* launches) {
+  BUCTD_CHECK_ARG(total_us && launches, "buctd_conv3x3_bf16x3_timing_end: null pointer");
+  C3Timing& tm = g_c3_timing;
+  tm.on = false;
+  double tot = 0.0;
+  int n = 0;
+  for (auto& ev : tm.events) {
+    float ms = 0.f;
+    if (hipEventSynchronize(ev.second) == hipSuccess && hipEventElapsedTime(&ms, ev.first, ev.second) == hipSuccess) {
+      tot += (double)ms * 1e3;
+      ++n;
+    }
+    (void)hipEventDestroy(ev.first);
+    (void)hipEventDestroy(ev.second);
+  }
+  tm.events.clear();
+  *total_us = tot;
+  *launches = n;
   return BUCTD_OK;
 }
 

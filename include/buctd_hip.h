@@ -82,6 +82,10 @@ typedef struct {
   long piece_begin;
 } buctd_c3_prep_item;
 int buctd_conv3x3_bf16x3_prep_batched(const buctd_c3_prep_item* items_device, int n, long total_pieces, void* stream);
+/* Measurement aid (bench.py roofline): between timing_begin and timing_end every launch of the given shape carries
+ * HIP events attached to the dispatch itself; timing_end synchronises on them and returns the summed kernel time. */
+int buctd_conv3x3_bf16x3_timing_begin(int N, int H, int W, int Ci, int Co);
+int buctd_conv3x3_bf16x3_timing_end(double* total_us, int* launches);
 int buctd_conv3x3_bf16x3(int N, int H, int W, int Ci, int Co, const float* x, const void* wprep, const float* bias,
                          const float* scale, const float* shift, const float* residual, int relu, float* y,
                          float* stats_partials, int* stats_counts, void* stream);
