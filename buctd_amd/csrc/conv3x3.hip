@@ -423,13 +423,16 @@ static bool c3_plan(int N, int H, int W, int Ci, int Co, C3Plan* pl) {
   else if (Co % 64 == 0) { nf = 4; wn = 1; }
   else if (Co % 32 == 0) { nf = 2; wn = 1; }
   else { nf = 1; wn = 1; }
-  const int wm = 4 / wn, bn = wn * nf * 16;
+  // wide column tiles (2x2 waves, BN = 96) only pay while they still fill the machine: the low-resolution branches
+  // (192 ch @24x18, 384 ch @12x9) run faster as 4x1 waves with BN = 48 and twice as many workgroups (measured)
+  if (Co % 96 == 0 && ((P + 127) / 128) * (Co / 96) < 320) { nf = 3; wn = 1; }
+  int wm = 4 / wn, bn = wn * nf * 16;
   // largest position tile that still gives every CU work (256 CUs, 2 resident workgroups each)
   int mf = 1;
   const int cand[2] = {4, 2};
   for (int i = (nf == 4 ? 1 : 0); i < 2; ++i) {   // 64-row x 64-column wave tiles would spill
     const long blocks = ((P + wm * cand[i] * 16 - 1) / (wm * cand[i] * 16)) * (Co / bn);
-    if (blocks >= (cand[i] == 4 ? 320 : 200)) { mf = cand[i]; break; }
+    if (blocks >= 320) { mf = cand[i]; break; }
   }
   pl->MF = mf; pl->NF = nf; pl->WM = wm; pl->WN = wn; pl->BM = wm * mf * 16; pl->BN = bn;
   pl->na = (pl->BM + 2 * (W + 2) + 2 + 31) / 32;
