@@ -1,13 +1,15 @@
 """train() / validate() - drop-in for reference lib/core/function.py:102-175 and 178-336 (same signatures,
-same side effects on model / optimizer / writer_dict / returned perf indicator).
+same side effects on model / optimizer / writer_dict, same log lines, same returned perf indicator).
 
 What changed underneath (not in behaviour):
   * heat-maps never cross PCIe: accuracy and decoding read K*(2+1) floats per person produced by the arg-max
-    kernel, the flip test is merged on the GPU (flip_back + 1-px shift + average in one kernel), the flipped
-    colored condition is re-rendered on the GPU;
+    kernel (the quarter-pixel refinement of get_final_preds included), the flip test is merged on the GPU
+    (flip_back + 1-px shift + average in one kernel), the flipped colored condition is re-rendered on the GPU;
   * the per-iteration host syncs of the reference (loss.item() at 141, the full-heat-map D2H + numpy arg-max at
     143-145) are deferred: loss scalars and decoded key points are copied asynchronously and folded into the
-    meters one iteration later, so the GPU queue never drains inside the loop.
+    meters one iteration later, so the GPU queue never drains inside the loop;
+  * under a one-process-per-GPU launch validate() shards the batches of val_loader over the ranks and
+    all-gathers all_preds / all_boxes / image paths before rank 0 calls val_dataset.evaluate.
 """
 import logging
 import os
@@ -15,50 +17,30 @@ import time
 
 import numpy as np
 import torch
+import torch.distributed as dist
 
 from .. import ops
 from ..utils.transforms import flip_hm, flip_merge_device
-from .evaluate import calc_dists, dist_acc
+from .evaluate import pck_from_coords
 from .inference import get_final_preds
 
 logger = logging.getLogger(__name__)
 
 
 class AverageMeter(object):
-    """Computes and stores the average and current value"""
+    """Running mean with the reference's public fields (val, avg, sum, count)."""
 
     def __init__(self):
         self.reset()
 
     def reset(self):
-        self.val = 0
-        self.avg = 0
-        self.sum = 0
-        self.count = 0
+        self.val = self.avg = self.sum = self.count = 0
 
     def update(self, val, n=1):
         self.val = val
-        self.sum += val * n
-        self.count += n
-        self.avg = self.sum / self.count if self.count != 0 else 0
-
-
-def _accuracy_from_preds(pred, target, h, w, thr=0.5):
-    """evaluate.accuracy() on already decoded arg-max coordinates (numpy [N,K,2])."""
-    norm = np.ones((pred.shape[0], 2)) * np.array([h, w]) / 10
-    dists = calc_dists(pred, target, norm)
-    k = pred.shape[1]
-    acc = np.zeros(k + 1)
-    avg_acc, cnt = 0, 0
-    for i in range(k):
-        acc[i + 1] = dist_acc(dists[i], thr)
-        if acc[i + 1] >= 0:
-            avg_acc += acc[i + 1]
-            cnt += 1
-    avg_acc = avg_acc / cnt if cnt != 0 else 0
-    if cnt != 0:
-        acc[0] = avg_acc
-    return acc, avg_acc, cnt, pred
+        self.sum = self.sum + val * n
+        self.count = self.count + n
+        self.avg = self.sum / self.count if self.count else 0
 
 
 class _DeferredStats:
@@ -82,37 +64,46 @@ class _DeferredStats:
     def resolve(self, losses, acc):
         self.event.synchronize()
         losses.update(float(self.loss), self.n)
-        _, avg_acc, cnt, pred = _accuracy_from_preds(self.p_out.numpy(), self.p_tgt.numpy(), self.h, self.w)
+        _, avg_acc, cnt, pred = pck_from_coords(self.p_out.numpy(), self.p_tgt.numpy(), self.h, self.w)
         acc.update(avg_acc, cnt)
         return pred
 
 
+def _forward_with_loss(model, criterion, input, target, target_weight):
+    """A model may return one heat-map tensor or a list of them (reference function.py:127-133): the loss is summed
+    over the list, the last entry is the prediction."""
+    outputs = model(input)
+    heads = outputs if isinstance(outputs, list) else [outputs]
+    loss = None
+    for head in heads:
+        term = criterion(head, target, target_weight)
+        loss = term if loss is None else loss + term
+    return heads[-1], loss
+
+
+def _train_line(epoch, i, total, batch_time, data_time, losses, acc, batch):
+    speed = batch / max(batch_time.val, 1e-9)
+    return (f'Epoch: [{epoch}][{i}/{total}]\t'
+            f'Time {batch_time.val:.3f}s ({batch_time.avg:.3f}s)\t'
+            f'Speed {speed:.1f} samples/s\t'
+            f'Data {data_time.val:.3f}s ({data_time.avg:.3f}s)\t'
+            f'Loss {losses.val:.5f} ({losses.avg:.5f})\t'
+            f'Accuracy {acc.val:.3f} ({acc.avg:.3f})')
+
+
 def train(config, train_loader, model, criterion, optimizer, epoch, output_dir, tb_log_dir, writer_dict,
           print_prefix=''):
-    batch_time = AverageMeter()
-    data_time = AverageMeter()
-    losses = AverageMeter()
-    acc = AverageMeter()
+    batch_time, data_time, losses, acc = AverageMeter(), AverageMeter(), AverageMeter(), AverageMeter()
     model.train()
-
-    end = time.time()
+    conditional = bool(config.MODEL.CONDITIONAL_TOPDOWN)
+    tick = time.time()
     pending = None
     for i, (input, target, target_weight, meta) in enumerate(train_loader):
-        data_time.update(time.time() - end)
-        if not config.MODEL.CONDITIONAL_TOPDOWN:
-            input = input[:, :3]
-        input = input.cuda(non_blocking=True)
-        outputs = model(input)
+        data_time.update(time.time() - tick)
+        input = (input if conditional else input[:, :3]).cuda(non_blocking=True)
         target = target.cuda(non_blocking=True)
         target_weight = target_weight.cuda(non_blocking=True)
-        if isinstance(outputs, list):
-            loss = criterion(outputs[0], target, target_weight)
-            for output in outputs[1:]:
-                loss = loss + criterion(output, target, target_weight)
-            output = outputs[-1]
-        else:
-            output = outputs
-            loss = criterion(output, target, target_weight)
+        output, loss = _forward_with_loss(model, criterion, input, target, target_weight)
 
         optimizer.zero_grad()
         loss.backward()
@@ -123,34 +114,25 @@ def train(config, train_loader, model, criterion, optimizer, epoch, output_dir, 
             pending.resolve(losses, acc)
         pending = _DeferredStats(loss, output, target, input.size(0))
 
-        batch_time.update(time.time() - end)
-        end = time.time()
+        now = time.time()
+        batch_time.update(now - tick)
+        tick = now
 
-        if i % config.PRINT_FREQ == 0:
-            pred = pending.resolve(losses, acc)
-            pending = None
-            msg = 'Epoch: [{0}][{1}/{2}]\t' \
-                  'Time {batch_time.val:.3f}s ({batch_time.avg:.3f}s)\t' \
-                  'Speed {speed:.1f} samples/s\t' \
-                  'Data {data_time.val:.3f}s ({data_time.avg:.3f}s)\t' \
-                  'Loss {loss.val:.5f} ({loss.avg:.5f})\t' \
-                  'Accuracy {acc.val:.3f} ({acc.avg:.3f})'.format(
-                      epoch, i, len(train_loader), batch_time=batch_time,
-                      speed=input.size(0) / max(batch_time.val, 1e-9), data_time=data_time, loss=losses, acc=acc)
-            logger.info(msg)
-            if writer_dict:
-                writer = writer_dict['writer']
-                global_steps = writer_dict['train_global_steps']
-                writer.add_scalar('train_loss', losses.val, global_steps)
-                writer.add_scalar('train_acc', acc.val, global_steps)
-                writer_dict['train_global_steps'] = global_steps + 1
-            if epoch % 50 == 0 and config.DEBUG.DEBUG:
-                _save_debug_images(config, input, meta, target, pred * 4, output,
-                                   '{}_epoch_{}_iter_{}_{}'.format(os.path.join(output_dir, 'train'), epoch, i,
-                                                                   print_prefix))
+        if i % config.PRINT_FREQ != 0:
+            continue
+        pred = pending.resolve(losses, acc)
+        pending = None
+        logger.info(_train_line(epoch, i, len(train_loader), batch_time, data_time, losses, acc, input.size(0)))
+        if writer_dict:
+            step = writer_dict['train_global_steps']
+            writer_dict['writer'].add_scalar('train_loss', losses.val, step)
+            writer_dict['writer'].add_scalar('train_acc', acc.val, step)
+            writer_dict['train_global_steps'] = step + 1
+        if config.DEBUG.DEBUG and epoch % 50 == 0:
+            tag = '{}_epoch_{}_iter_{}_{}'.format(os.path.join(output_dir, 'train'), epoch, i, print_prefix)
+            _save_debug_images(config, input, meta, target, pred * 4, output, tag)
     if pending is not None:
         pending.resolve(losses, acc)
-    return
 
 
 def _save_debug_images(config, input, meta, target, pred, output, prefix, output_dir=None):
@@ -159,108 +141,161 @@ def _save_debug_images(config, input, meta, target, pred, output, prefix, output
     logger.debug('debug image dump skipped (%s)', prefix)
 
 
+# ------------------------------------------------------------------------------------------ validate ----
+def _dist_world():
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(), dist.get_world_size()
+    return 0, 1
+
+
+def gather_validation_shards(all_preds, all_boxes, image_path, filled):
+    """Merge the per-rank result tables of a sharded validate(): every rank filled the rows of the batches it
+    processed (`filled` [num_samples] bool, disjoint across ranks) and the matching entries of image_path
+    (a list with None elsewhere).  After the call every rank holds the complete tables.  The tables are tiny
+    (K*3 + 7 floats per person), so one all-reduce of the masked tables is the whole exchange."""
+    rank, world = _dist_world()
+    if world == 1:
+        return all_preds, all_boxes, image_path
+    backend = dist.get_backend()
+    dev = torch.device('cuda', torch.cuda.current_device()) if backend == 'nccl' else torch.device('cpu')
+    mask = np.asarray(filled, dtype=bool)
+    packed = np.concatenate([np.where(mask[:, None], all_preds.reshape(len(mask), -1), 0).astype(np.float64),
+                             np.where(mask[:, None], all_boxes, 0).astype(np.float64),
+                             mask[:, None].astype(np.float64)], axis=1)
+    t = torch.from_numpy(packed).to(dev)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    merged = t.cpu().numpy()
+    owners = merged[:, -1]
+    if not np.all(owners == 1):
+        raise RuntimeError('validate(): %d samples were processed by no rank or by several' % int((owners != 1).sum()))
+    kcols = all_preds.shape[1] * all_preds.shape[2]
+    preds = merged[:, :kcols].reshape(all_preds.shape).astype(all_preds.dtype)
+    boxes = merged[:, kcols:kcols + all_boxes.shape[1]].astype(all_boxes.dtype)
+    paths = [None] * world
+    dist.all_gather_object(paths, [(i, p) for i, p in enumerate(image_path) if p is not None])
+    full = list(image_path)
+    for part in paths:
+        for i, p in part:
+            full[i] = p
+    return preds, boxes, full
+
+
+def _flip_test_forward(config, model, val_dataset, input, meta):
+    """Second forward on the mirrored input (reference function.py:213-236); returns the flipped output."""
+    if config.MODEL.CONDITIONAL_TOPDOWN:
+        cond = flip_hm(input[:, 3:], val_dataset, meta['cond_joints'], meta['cond_joints_vis'])
+        mirrored = torch.cat((input[:, :3].flip(3), cond.to(input.device)), dim=1)
+    else:
+        mirrored = input.flip(3)
+    out = model(mirrored)
+    return out[-1] if isinstance(out, list) else out
+
+
 def validate(config, val_loader, val_dataset, model, criterion, output_dir, tb_log_dir, writer_dict=None, epoch=-1,
              print_prefix=''):
-    batch_time = AverageMeter()
-    losses = AverageMeter()
-    acc = AverageMeter()
+    batch_time, losses, acc = AverageMeter(), AverageMeter(), AverageMeter()
     model.eval()
-
+    rank, world = _dist_world()
     num_samples = len(val_dataset)
-    all_preds = np.zeros((num_samples, config.MODEL.NUM_JOINTS, 3), dtype=np.float32)
+    num_joints = config.MODEL.NUM_JOINTS
+    all_preds = np.zeros((num_samples, num_joints, 3), dtype=np.float32)
     all_boxes = np.zeros((num_samples, 6 + 1))
-    image_path = []
-    filenames = []
-    imgnums = []
-    idx = 0
+    filled = np.zeros(num_samples, dtype=bool)
+    image_path = [None] * num_samples if world > 1 else []
+    filenames, imgnums = [], []
+    cursor = 0
+    last = len(val_loader) - 1
+    conditional = bool(config.MODEL.CONDITIONAL_TOPDOWN)
 
     with torch.no_grad():
-        end = time.time()
+        tick = time.time()
         for i, (input, target, target_weight, meta) in enumerate(val_loader):
-            if not config.MODEL.CONDITIONAL_TOPDOWN:
-                input = input[:, :3]
-            input = input.cuda(non_blocking=True)
-            outputs = model(input)
-            output = outputs[-1] if isinstance(outputs, list) else outputs
-
+            count = input.size(0)
+            rows = slice(cursor, cursor + count)
+            cursor += count
+            if world > 1 and i % world != rank:
+                continue                      # another rank's batch
+            input = (input if conditional else input[:, :3]).cuda(non_blocking=True)
+            out = model(input)
+            output = out[-1] if isinstance(out, list) else out
             if config.TEST.FLIP_TEST:
-                if config.MODEL.CONDITIONAL_TOPDOWN:
-                    cond_f = flip_hm(input[:, 3:], val_dataset, meta['cond_joints'], meta['cond_joints_vis'])
-                    input_flipped = torch.cat((input[:, :3].flip(3), cond_f.to(input.device)), dim=1)
-                else:
-                    input_flipped = input.flip(3)
-                outputs_flipped = model(input_flipped)
-                output_flipped = outputs_flipped[-1] if isinstance(outputs_flipped, list) else outputs_flipped
-                output = flip_merge_device(output, output_flipped, val_dataset.flip_pairs,
-                                           bool(config.TEST.SHIFT_HEATMAP))
-
+                output = flip_merge_device(output, _flip_test_forward(config, model, val_dataset, input, meta),
+                                           val_dataset.flip_pairs, bool(config.TEST.SHIFT_HEATMAP))
             target = target.cuda(non_blocking=True)
             target_weight = target_weight.cuda(non_blocking=True)
             loss = criterion(output, target, target_weight)
-            num_images = input.size(0)
-            stats = _DeferredStats(loss, output, target, num_images)
+            stats = _DeferredStats(loss, output, target, count)
 
-            c = meta['center'].numpy()
-            s = meta['scale'].numpy()
-            score = meta['score'].numpy()
-            annotation_id = meta['annotation_id'].numpy()
-            preds, maxvals = get_final_preds(config, output, c, s)
+            center = meta['center'].numpy()
+            scale = meta['scale'].numpy()
+            preds, maxvals = get_final_preds(config, output, center, scale)
             pred = stats.resolve(losses, acc)
 
-            batch_time.update(time.time() - end)
-            end = time.time()
+            now = time.time()
+            batch_time.update(now - tick)
+            tick = now
 
-            all_preds[idx:idx + num_images, :, 0:2] = preds[:, :, 0:2]
-            all_preds[idx:idx + num_images, :, 2:3] = maxvals
-            all_boxes[idx:idx + num_images, 0:2] = c[:, 0:2]
-            all_boxes[idx:idx + num_images, 2:4] = s[:, 0:2]
-            all_boxes[idx:idx + num_images, 4] = np.prod(s * 200, 1)
-            all_boxes[idx:idx + num_images, 5] = score
-            all_boxes[idx:idx + num_images, 6] = annotation_id
-            image_path.extend(meta['image'])
-            idx += num_images
-
-            if (i % config.PRINT_FREQ == 0) or (i == (len(val_loader) - 1)):
-                msg = 'Test: [{0}/{1}]\t' \
-                      'Time {batch_time.val:.3f} ({batch_time.avg:.3f})\t' \
-                      'Loss {loss.val:.6f} ({loss.avg:.6f})\t' \
-                      'Accuracy {acc.val:.3f} ({acc.avg:.3f})'.format(
-                          i, len(val_loader) - 1, batch_time=batch_time, loss=losses, acc=acc)
-                logger.info(msg)
-                if config.DEBUG.DEBUG:
-                    _save_debug_images(config, input, meta, target, pred * 4, output,
-                                       '{}_epoch_{:09d}_iter_{}_{}'.format(os.path.join(output_dir, 'val'), epoch, i,
-                                                                           print_prefix), output_dir=output_dir)
-
-        name_values, perf_indicator = val_dataset.evaluate(config, all_preds, output_dir, all_boxes, image_path, epoch,
-                                                           filenames, imgnums)
-        model_name = config.MODEL.NAME
-        if isinstance(name_values, list):
-            for name_value in name_values:
-                _print_name_value(name_value, model_name)
-        else:
-            _print_name_value(name_values, model_name)
-
-        if writer_dict:
-            writer = writer_dict['writer']
-            global_steps = writer_dict['valid_global_steps']
-            writer.add_scalar('valid_loss', losses.avg, global_steps)
-            writer.add_scalar('valid_acc', acc.avg, global_steps)
-            if isinstance(name_values, list):
-                for name_value in name_values:
-                    writer.add_scalars('valid', dict(name_value), global_steps)
+            all_preds[rows, :, 0:2] = preds[:, :, 0:2]
+            all_preds[rows, :, 2:3] = maxvals
+            all_boxes[rows, 0:2] = center[:, 0:2]
+            all_boxes[rows, 2:4] = scale[:, 0:2]
+            all_boxes[rows, 4] = np.prod(scale * 200, 1)
+            all_boxes[rows, 5] = meta['score'].numpy()
+            all_boxes[rows, 6] = meta['annotation_id'].numpy()
+            filled[rows] = True
+            if world > 1:
+                image_path[rows] = list(meta['image'])
             else:
-                writer.add_scalars('valid', dict(name_values), global_steps)
-            writer_dict['valid_global_steps'] = global_steps + 1
+                image_path.extend(meta['image'])
+
+            if i % config.PRINT_FREQ == 0 or i == last:
+                logger.info(f'Test: [{i}/{last}]\t'
+                            f'Time {batch_time.val:.3f} ({batch_time.avg:.3f})\t'
+                            f'Loss {losses.val:.6f} ({losses.avg:.6f})\t'
+                            f'Accuracy {acc.val:.3f} ({acc.avg:.3f})')
+                if config.DEBUG.DEBUG:
+                    tag = '{}_epoch_{:09d}_iter_{}_{}'.format(os.path.join(output_dir, 'val'), epoch, i, print_prefix)
+                    _save_debug_images(config, input, meta, target, pred * 4, output, tag, output_dir=output_dir)
+
+        if world > 1:
+            all_preds, all_boxes, image_path = gather_validation_shards(all_preds, all_boxes, image_path, filled)
+            stat = torch.tensor([losses.sum, losses.count, acc.sum, acc.count], dtype=torch.float64)
+            if dist.get_backend() == 'nccl':
+                stat = stat.cuda()
+            dist.all_reduce(stat)
+            stat = stat.cpu().tolist()
+            losses.avg = stat[0] / stat[1] if stat[1] else 0
+            acc.avg = stat[2] / stat[3] if stat[3] else 0
+
+        if rank == 0:
+            name_values, perf_indicator = val_dataset.evaluate(config, all_preds, output_dir, all_boxes, image_path,
+                                                               epoch, filenames, imgnums)
+            tables = name_values if isinstance(name_values, list) else [name_values]
+            for table in tables:
+                _print_name_value(table, config.MODEL.NAME)
+            if writer_dict:
+                step = writer_dict['valid_global_steps']
+                writer = writer_dict['writer']
+                writer.add_scalar('valid_loss', losses.avg, step)
+                writer.add_scalar('valid_acc', acc.avg, step)
+                for table in tables:
+                    writer.add_scalars('valid', dict(table), step)
+                writer_dict['valid_global_steps'] = step + 1
+        else:
+            perf_indicator = None
+        if world > 1:
+            box = [perf_indicator]
+            dist.broadcast_object_list(box, src=0)
+            perf_indicator = box[0]
     return perf_indicator
 
 
 def _print_name_value(name_value, full_arch_name):
-    names = name_value.keys()
-    values = name_value.values()
-    num_values = len(name_value)
-    logger.info('| Arch ' + ' '.join(['| {}'.format(name) for name in names]) + ' |')
-    logger.info('|---' * (num_values + 1) + '|')
-    if len(full_arch_name) > 15:
-        full_arch_name = full_arch_name[:8] + '...'
-    logger.info('| ' + full_arch_name + ' ' + ' '.join(['| {:.3f}'.format(value) for value in values]) + ' |')
+    """The markdown table of the reference (function.py:340-357): header, separator, one row of 3-decimal values;
+    architecture names longer than 15 characters are abbreviated to 8 + '...'."""
+    arch = full_arch_name if len(full_arch_name) <= 15 else full_arch_name[:8] + '...'
+    header = ' '.join('| {}'.format(k) for k in name_value.keys())
+    row = ' '.join('| {:.3f}'.format(v) for v in name_value.values())
+    logger.info('| Arch ' + header + ' |')
+    logger.info('|---' * (len(name_value) + 1) + '|')
+    logger.info('| ' + arch + ' ' + row + ' |')

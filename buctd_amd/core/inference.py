@@ -2,15 +2,25 @@
 
 get_max_preds keeps the reference's numpy-in / numpy-out contract for callers that already hold host
 arrays; device tensors are decoded by the arg-max kernel (first-index tie break, preds zeroed where
-maxval <= 0) so that validate() moves K*3 floats per person over PCIe instead of the whole heat-map.
+maxval <= 0, quarter-pixel refinement included) so that validate() moves K*(2+1+2) floats per person over
+PCIe instead of the whole heat-map.
 """
-import math
-
 import numpy as np
 import torch
 
 from .. import ops
 from ..utils.transforms import transform_preds
+
+
+def _decode_host(heatmaps):
+    """numpy [N,K,H,W] -> (coords [N,K,2] float32 zeroed where the peak is <= 0, peak values [N,K,1])."""
+    n, k, _, w = heatmaps.shape
+    flat = heatmaps.reshape(n, k, -1)
+    where = flat.argmax(axis=2)                        # first index on ties, like np.argmax in the reference
+    peak = np.take_along_axis(flat, where[..., None], axis=2)
+    coords = np.stack([where % w, where // w], axis=2).astype(np.float32)
+    coords *= (peak > 0.0).astype(np.float32)
+    return coords, peak
 
 
 def get_max_preds(batch_heatmaps):
@@ -20,33 +30,35 @@ def get_max_preds(batch_heatmaps):
         return preds.cpu().numpy(), maxvals.cpu().numpy()
     assert isinstance(batch_heatmaps, np.ndarray), 'batch_heatmaps should be numpy.ndarray or a device tensor'
     assert batch_heatmaps.ndim == 4, 'batch_images should be 4-ndim'
-    n, k, _, w = batch_heatmaps.shape
-    flat = batch_heatmaps.reshape((n, k, -1))
-    idx = np.argmax(flat, 2).reshape((n, k, 1))
-    maxvals = np.amax(flat, 2).reshape((n, k, 1))
-    preds = np.tile(idx, (1, 1, 2)).astype(np.float32)
-    preds[:, :, 0] = preds[:, :, 0] % w
-    preds[:, :, 1] = np.floor(preds[:, :, 1] / w)
-    preds *= np.tile(np.greater(maxvals, 0.0), (1, 1, 2)).astype(np.float32)
-    return preds, maxvals
+    return _decode_host(batch_heatmaps)
+
+
+def _quarter_offsets_host(heatmaps, coords):
+    """POST_PROCESS (reference 68-77): +-0.25 px towards the higher neighbour for peaks strictly inside the map."""
+    n, k, hh, hw = heatmaps.shape
+    px = np.floor(coords[..., 0] + 0.5).astype(np.int64)
+    py = np.floor(coords[..., 1] + 0.5).astype(np.int64)
+    inside = (px > 1) & (px < hw - 1) & (py > 1) & (py < hh - 1)
+    cx, cy = np.clip(px, 1, hw - 2), np.clip(py, 1, hh - 2)
+    bi, ji = np.meshgrid(np.arange(n), np.arange(k), indexing='ij')
+    dx = heatmaps[bi, ji, cy, cx + 1] - heatmaps[bi, ji, cy, cx - 1]
+    dy = heatmaps[bi, ji, cy + 1, cx] - heatmaps[bi, ji, cy - 1, cx]
+    return np.stack([np.sign(dx), np.sign(dy)], axis=2) * 0.25 * inside[..., None]
 
 
 def get_final_preds(config, batch_heatmaps, center, scale, use_dark=False):
     if use_dark:
         raise NotImplementedError("the DARK decoder is dead code in the reference (use_dark=False default)")
-    coords, maxvals = get_max_preds(batch_heatmaps)
     hh, hw = batch_heatmaps.shape[2], batch_heatmaps.shape[3]
-    if config.TEST.POST_PROCESS:
-        hm = batch_heatmaps.detach().cpu().numpy() if isinstance(batch_heatmaps, torch.Tensor) else batch_heatmaps
-        for n in range(coords.shape[0]):
-            for p in range(coords.shape[1]):
-                px = int(math.floor(coords[n][p][0] + 0.5))
-                py = int(math.floor(coords[n][p][1] + 0.5))
-                if 1 < px < hw - 1 and 1 < py < hh - 1:
-                    h = hm[n][p]
-                    diff = np.array([h[py][px + 1] - h[py][px - 1], h[py + 1][px] - h[py - 1][px]])
-                    coords[n][p] += np.sign(diff) * .25
-    preds = coords.copy()
-    for i in range(coords.shape[0]):
-        preds[i] = transform_preds(coords[i], center[i], scale[i], [hw, hh])
-    return preds, maxvals
+    refine = bool(config.TEST.POST_PROCESS)
+    if isinstance(batch_heatmaps, torch.Tensor):
+        res = ops.argmax_decode(batch_heatmaps.contiguous(), refine=refine)
+        coords, maxvals = res[0].cpu().numpy(), res[1].cpu().numpy()
+        if refine:
+            coords = coords + res[3].cpu().numpy()
+    else:
+        coords, maxvals = get_max_preds(batch_heatmaps)
+        if refine:
+            coords = coords + _quarter_offsets_host(batch_heatmaps, coords).astype(coords.dtype)
+    preds = np.stack([transform_preds(coords[b], center[b], scale[b], [hw, hh]) for b in range(coords.shape[0])])
+    return preds.astype(coords.dtype), maxvals

@@ -54,7 +54,7 @@ extern "C" int buctd_joints_mse(const float* pred, const float* gt, const float*
 // ------------------------------------------------------------ argmax decode ----
 __global__ __launch_bounds__(256) void argmax_kernel(const float* __restrict__ hm, int HW, int W,
                                                      float* __restrict__ preds, float* __restrict__ maxvals,
-                                                     int32_t* __restrict__ idx) {
+                                                     int32_t* __restrict__ idx, float* __restrict__ quarter) {
   __shared__ float sv[4];
   __shared__ int si[4];
   const long row = blockIdx.x;
@@ -93,13 +93,39 @@ __global__ __launch_bounds__(256) void argmax_kernel(const float* __restrict__ h
     preds[row * 2 + 1] = floorf((float)bi / (float)W) * m;
     maxvals[row] = best;
     if (idx) idx[row] = bi;
+    if (quarter) {
+      // reference core/inference.py:68-77 (POST_PROCESS): a quarter pixel towards the higher neighbour, only for
+      // peaks with 1 < px < W-1 and 1 < py < H-1 (a masked peak decodes to (0,0) and never qualifies)
+      const int H = HW / W;
+      const int px = best > 0.f ? bi % W : 0, py = best > 0.f ? bi / W : 0;
+      float qx = 0.f, qy = 0.f;
+      if (px > 1 && px < W - 1 && py > 1 && py < H - 1) {
+        const float* h = hm + row * HW;
+        const float dx = h[py * W + px + 1] - h[py * W + px - 1];
+        const float dy = h[(py + 1) * W + px] - h[(py - 1) * W + px];
+        qx = dx > 0.f ? 0.25f : (dx < 0.f ? -0.25f : 0.f);
+        qy = dy > 0.f ? 0.25f : (dy < 0.f ? -0.25f : 0.f);
+      }
+      quarter[row * 2 + 0] = qx;
+      quarter[row * 2 + 1] = qy;
+    }
   }
 }
 extern "C" int buctd_argmax_decode(const float* hm, int rows, int H, int W, float* preds, float* maxvals,
                                    int32_t* idx, void* stream) {
   BUCTD_CHECK_ARG(hm && preds && maxvals && rows > 0 && H > 0 && W > 0, "buctd_argmax_decode: bad argument");
-  hipLaunchKernelGGL(argmax_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, hm, H * W, W, preds, maxvals, idx);
+  hipLaunchKernelGGL(argmax_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, hm, H * W, W, preds, maxvals, idx,
+                     (float*)nullptr);
   BUCTD_CHECK_LAUNCH("buctd_argmax_decode");
+  return BUCTD_OK;
+}
+extern "C" int buctd_argmax_decode_refined(const float* hm, int rows, int H, int W, float* preds, float* maxvals,
+                                           int32_t* idx, float* quarter, void* stream) {
+  BUCTD_CHECK_ARG(hm && preds && maxvals && quarter && rows > 0 && H > 0 && W > 0,
+                  "buctd_argmax_decode_refined: bad argument");
+  hipLaunchKernelGGL(argmax_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, hm, H * W, W, preds, maxvals, idx,
+                     quarter);
+  BUCTD_CHECK_LAUNCH("buctd_argmax_decode_refined");
   return BUCTD_OK;
 }
 

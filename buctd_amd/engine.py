@@ -116,15 +116,58 @@ class FusedAdam(torch.optim.Optimizer):
             p.grad = None
 
     def state_dict(self):
-        return {"step": self.step_count, "exp_avg": self.exp_avg, "exp_avg_sq": self.exp_avg_sq,
-                "param_groups": [{k: v for k, v in g.items() if k != "params"} for g in self.param_groups]}
+        """torch.optim.Adam's checkpoint format (what the reference stores under checkpoint['optimizer'],
+        tools/train.py:243-266): per-parameter 'step' / 'exp_avg' / 'exp_avg_sq' keyed by parameter index."""
+        state = {}
+        if self.step_count > 0:
+            for i, p in enumerate(self.flat.params):
+                o, e = self.flat.span(p)
+                state[i] = {"step": torch.tensor(float(self.step_count)),
+                            "exp_avg": torch.as_strided(self.exp_avg, p.shape, p.stride(), o).clone(),
+                            "exp_avg_sq": torch.as_strided(self.exp_avg_sq, p.shape, p.stride(), o).clone()}
+        groups = []
+        for g in self.param_groups:
+            d = {k: v for k, v in g.items() if k != "params"}
+            for k, v in (("weight_decay", 0), ("amsgrad", False), ("maximize", False)):
+                d.setdefault(k, v)
+            d["params"] = list(range(len(self.flat.params)))
+            groups.append(d)
+        return {"state": state, "param_groups": groups}
 
     def load_state_dict(self, sd):
-        self.step_count = int(sd["step"])
-        self.exp_avg.copy_(sd["exp_avg"])
-        self.exp_avg_sq.copy_(sd["exp_avg_sq"])
-        for g, s in zip(self.param_groups, sd["param_groups"]):
-            g.update(s)
+        """Accepts a torch.optim.Adam state_dict (reference checkpoints) or this class's round-1 flat format."""
+        if "state" not in sd:                      # round-1 private format: flat arenas
+            self.step_count = int(sd["step"])
+            self.exp_avg.copy_(sd["exp_avg"])
+            self.exp_avg_sq.copy_(sd["exp_avg_sq"])
+        else:
+            state = sd["state"]
+            steps = set()
+            self.exp_avg.zero_()
+            self.exp_avg_sq.zero_()
+            for i, p in enumerate(self.flat.params):
+                st = state.get(i, state.get(str(i)))
+                if st is None:
+                    continue
+                o, _ = self.flat.span(p)
+                for name, arena in (("exp_avg", self.exp_avg), ("exp_avg_sq", self.exp_avg_sq)):
+                    src = st[name]
+                    if tuple(src.shape) != tuple(p.shape):
+                        raise ValueError(f"optimizer state of parameter {i}: shape {tuple(src.shape)} != {tuple(p.shape)}")
+                    torch.as_strided(arena, p.shape, p.stride(), o).copy_(src)
+                steps.add(int(float(st["step"])))
+            if len(steps) > 1:
+                raise ValueError("FusedAdam keeps one step counter: per-parameter steps differ in this state_dict")
+            self.step_count = steps.pop() if steps else 0
+        for g, src in zip(self.param_groups, sd["param_groups"]):
+            for k, v in src.items():
+                if k == "params":
+                    continue
+                if k in ("weight_decay",) and v not in (0, 0.0):
+                    raise ValueError("FusedAdam implements Adam without weight decay (the BUCTD recipe)")
+                if k in ("amsgrad", "maximize") and v:
+                    raise ValueError(f"FusedAdam does not implement {k}")
+                g[k] = v
 
 
 class GradBuckets:
@@ -136,18 +179,28 @@ class GradBuckets:
         target = bucket_bytes // 4
         self.buckets = []  # (start, end, set(param ids))
         cur_ids, cur_end, cur_start = set(), None, None
+        def close():
+            nonlocal cur_ids, cur_end
+            if cur_ids:
+                self.buckets.append((cur_start, cur_end, cur_ids))
+            cur_ids, cur_end = set(), None
+
         for p in reversed(flat.params):
-            s, e = flat.span(p)
+            s, _ = flat.span(p)
             e = flat.offsets[id(p)] + (p.numel() + _ALIGN - 1) // _ALIGN * _ALIGN
+            if e - s >= target:
+                # a tensor as large as a bucket (CoAM fc_o: 191 MB of the 462 MB) travels alone, so that its
+                # all-reduce starts the moment its gradient GEMM is enqueued instead of waiting for neighbours
+                close()
+                self.buckets.append((s, e, {id(p)}))
+                continue
             if cur_end is None:
                 cur_end = e
             cur_start = s
             cur_ids.add(id(p))
             if cur_end - cur_start >= target:
-                self.buckets.append((cur_start, cur_end, cur_ids))
-                cur_ids, cur_end = set(), None
-        if cur_ids:
-            self.buckets.append((cur_start, cur_end, cur_ids))
+                close()
+        close()
         self.of_param = {}
         for i, (_, _, ids) in enumerate(self.buckets):
             for pid in ids:
@@ -169,7 +222,9 @@ class DataParallel(torch.nn.Module):
         self.bucket_bytes = bucket_bytes
         self.overlap = overlap
         self._handles = []
-        self._pending = None
+        self._pending = False
+        self._dirty = False
+        self._entry_stream = None
         self._comm_stream = None
 
     # -- construction-time helpers ---------------------------------------------------------
@@ -203,17 +258,30 @@ class DataParallel(torch.nn.Module):
     # -- gradient exchange -----------------------------------------------------------------
     def _start_step(self):
         self._handles = []
-        self._pending = [len(ids) for (_, _, ids) in self.buckets.buckets]
+        nb = len(self.buckets.buckets)
+        self._ready = [set() for _ in range(nb)]       # parameter ids whose gradient is final, per bucket
+        self._streams = [dict() for _ in range(nb)]    # streams that produced gradient work of the bucket
+        self._launched = [False] * nb
+        self._pending = True
+        if self.flat.flat.is_cuda:
+            # the stream the backward pass is entered on: autograd replays nodes of the main path here
+            self._entry_stream = torch.cuda.current_stream(self.flat.flat.device)
 
     def _launch(self, i):
         s, e, _ = self.buckets.buckets[i]
         view = self.flat.grad[s:e]
+        self._launched[i] = True
         if self._comm_stream is not None:
-            ev = torch.cuda.Event()
-            ev.record(torch.cuda.current_stream())
-            with torch.cuda.stream(self._comm_stream):
+            # one event per stream that wrote into this bucket, recorded now: stream order makes it cover the
+            # bucket's kernels on that stream (and nothing of streams that did not contribute)
+            streams = dict(self._streams[i])
+            for st in (torch.cuda.current_stream(view.device), self._entry_stream):
+                streams[st.cuda_stream] = st
+            for st in streams.values():
+                ev = torch.cuda.Event()
+                ev.record(st)
                 self._comm_stream.wait_event(ev)
-                ops.wait_side_stream(self._comm_stream)   # weight gradients are produced on ops' side stream
+            with torch.cuda.stream(self._comm_stream):
                 self._handles.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, async_op=True))
         else:
             if view.is_cuda:
@@ -221,14 +289,25 @@ class DataParallel(torch.nn.Module):
             self._handles.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, async_op=True))
 
     def _grad_ready(self, p):
-        """Called by the backward ops right after the kernels writing p.grad were enqueued."""
-        if self._pending is None:
+        """Called by the backward ops right after the kernels writing p.grad were enqueued (on the current stream
+        and, for weight gradients, on ops' side stream)."""
+        if not self._pending:
             return
         i = self.buckets.of_param.get(id(p))
         if i is None or not self.flat.grad_is_arena(p):
             return
-        self._pending[i] -= 1
-        if self._pending[i] == 0:
+        if self._launched[i] or id(p) in self._ready[i]:
+            # a second gradient write to an already counted parameter (shared weight, or a second backward before
+            # step()): the early all-reduce would miss it -> redo everything synchronously in sync_gradients
+            self._dirty = True
+            return
+        if p.is_cuda:
+            cur = torch.cuda.current_stream(p.device)
+            self._streams[i][cur.cuda_stream] = cur
+            for st in ops.side_streams(p.device):
+                self._streams[i][st.cuda_stream] = st
+        self._ready[i].add(id(p))
+        if len(self._ready[i]) == len(self.buckets.buckets[i][2]):
             self._launch(i)
 
     def sync_gradients(self):
@@ -236,17 +315,21 @@ class DataParallel(torch.nn.Module):
         gradient of the global-batch mean loss (what nn.DataParallel computes)."""
         if self.world == 1:
             return 1.0
-        if self._pending is None:
+        if not self._pending:
             self._start_step()
-        for i, left in enumerate(self._pending):
-            if left != 0:  # not launched during backward (overlap off, or a parameter without gradient)
-                self._pending[i] = 0
+        if self._dirty:
+            raise RuntimeError("engine.DataParallel: a parameter received a second gradient after its bucket was "
+                               "counted (shared weights / gradient accumulation need overlap=False)")
+        if self.flat.flat.is_cuda:
+            ops.wait_side_stream()          # buckets launched here see every gradient kernel enqueued so far
+        for i in range(len(self.buckets.buckets)):
+            if not self._launched[i]:       # not closed during backward (overlap off, or a parameter without gradient)
                 self._launch(i)
         for h in self._handles:
             h.wait()
         if self._comm_stream is not None:
             torch.cuda.current_stream().wait_stream(self._comm_stream)
-        self._handles, self._pending = [], None
+        self._handles, self._pending = [], False
         return 1.0 / self.world
 
     # -- nn.Module plumbing so that checkpoints carry the reference's 'module.' prefix ------
@@ -283,4 +366,6 @@ def init_distributed():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    # every replica draws its own dropout masks (like the replicas of nn.DataParallel), derived from the user's seed
+    ops.manual_seed(ops.mix_seed(torch.initial_seed(), rank))
     return rank, world, device

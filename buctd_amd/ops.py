@@ -37,7 +37,15 @@ def workspace(nbytes, device):
     return buf
 
 
-_seed_state = {"seed": 0x5EEDBC7D, "counter": 0}
+_seed_state = {"seed": None, "counter": 0}
+
+
+def mix_seed(seed, rank=0):
+    """splitmix64 of (seed, rank): distinct, well-spread dropout streams per replica."""
+    z = (int(seed) + 0x9E3779B97F4A7C15 * (int(rank) + 1)) & 0xFFFFFFFFFFFFFFFF
+    z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & 0xFFFFFFFFFFFFFFFF
+    z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & 0xFFFFFFFFFFFFFFFF
+    return z ^ (z >> 31)
 
 
 def manual_seed(seed):
@@ -46,6 +54,13 @@ def manual_seed(seed):
 
 
 def next_seed():
+    if _seed_state["seed"] is None:
+        # first use without an explicit ops.manual_seed: follow torch.manual_seed (and the rank, if a process group
+        # is up), so that runs honour the user's seed and replicas draw different masks
+        rank = 0
+        if torch.distributed.is_available() and torch.distributed.is_initialized():
+            rank = torch.distributed.get_rank()
+        manual_seed(mix_seed(torch.initial_seed(), rank))
     _seed_state["counter"] += 1
     return (_seed_state["seed"] * 0x9E3779B97F4A7C15 + _seed_state["counter"] * 0xD1B54A32D192ED03) & 0xFFFFFFFFFFFFFFFF
 
@@ -343,6 +358,11 @@ def _side_stream(device):
     return st
 
 
+def side_streams(device):
+    """The weight-gradient streams created so far on `device`."""
+    return [st for (idx, _), st in _side["streams"].items() if idx == device.index]
+
+
 def wait_side_stream(stream=None):
     """Make `stream` (default: the current one) wait for everything enqueued so far on the streams this module owns
     (weight-gradient stream and branch streams)."""
@@ -629,11 +649,17 @@ def joints_mse(pred, gt, w, want_grad, gscale=1.0):
     return loss, grad
 
 
-def argmax_decode(hm):
+def argmax_decode(hm, refine=False):
+    """refine: also return the quarter-pixel offsets of get_final_preds' POST_PROCESS step ([N,K,2])."""
     N, K, H, W = hm.shape
     preds = torch.empty((N, K, 2), dtype=torch.float32, device=hm.device)
     maxvals = torch.empty((N, K, 1), dtype=torch.float32, device=hm.device)
     idx = torch.empty((N, K), dtype=torch.int32, device=hm.device)
+    if refine:
+        quarter = torch.empty((N, K, 2), dtype=torch.float32, device=hm.device)
+        check(lib().buctd_argmax_decode_refined(ptr(hm), N * K, H, W, ptr(preds), ptr(maxvals), ptr(idx), ptr(quarter),
+                                                stream_ptr()), "argmax_decode_refined")
+        return preds, maxvals, idx, quarter
     check(lib().buctd_argmax_decode(ptr(hm), N * K, H, W, ptr(preds), ptr(maxvals), ptr(idx), stream_ptr()),
           "argmax_decode")
     return preds, maxvals, idx

@@ -1,100 +1,111 @@
-"""Flip-test helpers and the decode affine - drop-in for reference lib/utils/transforms.py:16-118.
-numpy entry points keep the reference signatures; *_device variants run on the GPU."""
+"""Flip-test helpers and the crop <-> image affine - drop-in for reference lib/utils/transforms.py:16-118.
+numpy entry points keep the reference names and signatures; *_device variants run on the GPU."""
 import numpy as np
 import torch
 
 from .. import ops
 
 
+def _swap_table(count, matched_parts):
+    """Channel permutation that exchanges every left/right pair."""
+    table = np.arange(count)
+    for left, right in matched_parts:
+        table[left], table[right] = right, left
+    return table
+
+
 def flip_back(output_flipped, matched_parts):
-    assert output_flipped.ndim == 4, 'output_flipped should be [batch_size, num_joints, height, width]'
-    out = output_flipped[:, :, :, ::-1].copy()
-    for a, b in matched_parts:
-        tmp = out[:, a, :, :].copy()
-        out[:, a, :, :] = out[:, b, :, :]
-        out[:, b, :, :] = tmp
-    return out
+    """Undo a horizontal flip on heat-maps [N, K, H, W]: mirror the width axis, exchange left/right joints."""
+    if output_flipped.ndim != 4:
+        raise AssertionError('output_flipped should be [batch_size, num_joints, height, width]')
+    table = _swap_table(output_flipped.shape[1], matched_parts)
+    return np.ascontiguousarray(output_flipped[:, table, :, ::-1])
 
 
 def flip_perm(num_joints, matched_parts, device):
-    perm = list(range(num_joints))
-    for a, b in matched_parts:
-        perm[a], perm[b] = b, a
-    return torch.tensor(perm, dtype=torch.int32, device=device)
+    return torch.as_tensor(_swap_table(num_joints, matched_parts), dtype=torch.int32, device=device)
 
 
 def flip_merge_device(output, output_flipped, matched_parts, shift):
-    """(output + shift(flip_back(output_flipped))) * 0.5 in one kernel (core/function.py:226-236)."""
+    """(output + shift(flip_back(output_flipped))) * 0.5 in one kernel (reference core/function.py:226-236)."""
     perm = flip_perm(output.shape[1], matched_parts, output.device)
     return ops.flipback_avg(output.contiguous(), output_flipped.contiguous(), perm, shift)
 
 
 def fliplr_joints(joints, joints_vis, width, matched_parts):
+    """Mirror key points [K, 3] about the vertical axis of a `width`-pixel image (in place, like the reference)
+    and exchange left/right rows; invisible joints come back zeroed."""
     joints[:, 0] = width - joints[:, 0] - 1
-    for a, b in matched_parts:
-        joints[a, :], joints[b, :] = joints[b, :], joints[a, :].copy()
-        joints_vis[a, :], joints_vis[b, :] = joints_vis[b, :], joints_vis[a, :].copy()
+    table = _swap_table(joints.shape[0], matched_parts)
+    joints[:] = joints[table]
+    joints_vis[:] = joints_vis[table]
     return joints * joints_vis, joints_vis
 
 
 def flip_hm(heatmap, dataset, cond_joints, cond_joints_vis):
-    """Condition flip for the flip test (reference 33-58): colored conditions are re-rendered from the
-    flipped key points (on the GPU), stacked ones are reversed with left/right channels swapped."""
-    matched = dataset.flip_pairs
-    if heatmap.shape[1] == 3:
-        cj = cond_joints.cpu().numpy().copy()
-        cv = cond_joints_vis.cpu().numpy().copy()
-        flipped = np.stack([fliplr_joints(cj[i], cv[i], dataset.image_size[0], matched)[0] for i in range(len(cj))])
-        jt = torch.from_numpy(np.ascontiguousarray(flipped)).float().to(heatmap.device)
+    """Condition flip for the flip test (reference 33-58): a 3-channel condition is re-rendered (colored) from the
+    mirrored key points - on the GPU here; a stacked one is mirrored with left/right channels exchanged."""
+    channels = heatmap.shape[1]
+    if channels == 3:
+        width, height = int(dataset.image_size[0]), int(dataset.image_size[1])
+        kp = cond_joints.detach().cpu().numpy().copy()
+        vis = cond_joints_vis.detach().cpu().numpy().copy()
+        mirrored = [fliplr_joints(kp[b], vis[b], width, dataset.flip_pairs)[0] for b in range(kp.shape[0])]
+        pts = torch.from_numpy(np.ascontiguousarray(np.stack(mirrored))).float().to(heatmap.device)
         colors = torch.tensor(dataset.kpt_colors, dtype=torch.float32, device=heatmap.device)
-        return ops.cond_render(jt, colors, int(dataset.image_size[1]), int(dataset.image_size[0]))
-    if heatmap.shape[1] > 3:
-        perm = list(range(heatmap.shape[1]))
-        for a, b in matched:
-            perm[a], perm[b] = b, a
-        return heatmap.flip(3)[:, perm].contiguous()
-    return heatmap.flip(3)
+        return ops.cond_render(pts, colors, height, width)
+    mirrored = heatmap.flip(3)
+    if channels > 3:
+        table = torch.as_tensor(_swap_table(channels, dataset.flip_pairs), device=heatmap.device)
+        mirrored = mirrored.index_select(1, table)
+    return mirrored.contiguous()
 
 
-def get_affine_transform(center, scale, rot, output_size, shift=np.array([0, 0], dtype=np.float32), inv=0):
-    """3-point affine exactly as cv2.getAffineTransform solves it (float64 linear system)."""
-    if not isinstance(scale, np.ndarray) and not isinstance(scale, list):
-        scale = np.array([scale, scale])
-    scale_tmp = scale * 200.0
-    src_w, dst_w, dst_h = scale_tmp[0], output_size[0], output_size[1]
-    rot_rad = np.pi * rot / 180
-    src_dir = get_dir([0, src_w * -0.5], rot_rad)
-    dst_dir = np.array([0, dst_w * -0.5], np.float32)
-    src = np.zeros((3, 2), dtype=np.float32)
-    dst = np.zeros((3, 2), dtype=np.float32)
-    src[0, :] = center + scale_tmp * shift
-    src[1, :] = center + src_dir + scale_tmp * shift
-    dst[0, :] = [dst_w * 0.5, dst_h * 0.5]
-    dst[1, :] = np.array([dst_w * 0.5, dst_h * 0.5]) + dst_dir
-    src[2:, :] = get_3rd_point(src[0, :], src[1, :])
-    dst[2:, :] = get_3rd_point(dst[0, :], dst[1, :])
-    a, b = (dst, src) if inv else (src, dst)
-    lhs = np.concatenate([a.astype(np.float64), np.ones((3, 1))], axis=1)
-    return np.linalg.solve(lhs, b.astype(np.float64)).T
-
-
-def affine_transform(pt, t):
-    return np.dot(t, np.array([pt[0], pt[1], 1.]).T)[:2]
+# ---------------------------------------------------------------------------------------------- affine ----
+def get_dir(src_point, rot_rad):
+    """src_point rotated by rot_rad (counter-clockwise in image coordinates with y down)."""
+    s, c = np.sin(rot_rad), np.cos(rot_rad)
+    x, y = src_point[0], src_point[1]
+    return [x * c - y * s, x * s + y * c]
 
 
 def get_3rd_point(a, b):
-    direct = a - b
-    return b + np.array([-direct[1], direct[0]], dtype=np.float32)
+    """Third corner of the right-angled isosceles triangle on the segment a-b (float32 like the reference)."""
+    dx, dy = a[0] - b[0], a[1] - b[1]
+    return b + np.array([-dy, dx], dtype=np.float32)
 
 
-def get_dir(src_point, rot_rad):
-    sn, cs = np.sin(rot_rad), np.cos(rot_rad)
-    return [src_point[0] * cs - src_point[1] * sn, src_point[0] * sn + src_point[1] * cs]
+def _triangle(origin, arm):
+    """The three float32 control points the reference feeds to cv2.getAffineTransform."""
+    pts = np.zeros((3, 2), dtype=np.float32)
+    pts[0] = origin
+    pts[1] = origin + arm
+    pts[2] = get_3rd_point(pts[0], pts[1])
+    return pts
+
+
+def get_affine_transform(center, scale, rot, output_size, shift=np.array([0, 0], dtype=np.float32), inv=0):
+    """2x3 matrix mapping the person box (center, scale*200 px, rotated by rot degrees) onto an output_size crop
+    (inv=1: the reverse).  cv2.getAffineTransform solves the 3-point system in float64; so does this."""
+    if not isinstance(scale, (np.ndarray, list)):
+        scale = np.array([scale, scale])
+    box = np.asarray(scale) * 200.0
+    out_w, out_h = output_size[0], output_size[1]
+    offset = box * shift
+    box_pts = _triangle(center + offset, np.asarray(get_dir([0, box[0] * -0.5], np.pi * rot / 180)))
+    crop_pts = _triangle(np.array([out_w * 0.5, out_h * 0.5]), np.array([0, out_w * -0.5], np.float32))
+    frm, to = (crop_pts, box_pts) if inv else (box_pts, crop_pts)
+    system = np.hstack([frm.astype(np.float64), np.ones((3, 1))])
+    return np.linalg.solve(system, to.astype(np.float64)).T
+
+
+def affine_transform(pt, t):
+    return t[:, :2] @ np.array([pt[0], pt[1]], dtype=np.float64) + t[:, 2]
 
 
 def transform_preds(coords, center, scale, output_size):
-    target_coords = np.zeros(coords.shape)
-    trans = get_affine_transform(center, scale, 0, output_size, inv=1)
-    for p in range(coords.shape[0]):
-        target_coords[p, 0:2] = affine_transform(coords[p, 0:2], trans)
-    return target_coords
+    """Heat-map coordinates [K, >=2] -> image coordinates through the inverse crop affine (rot = 0)."""
+    t = get_affine_transform(center, scale, 0, output_size, inv=1)
+    mapped = np.zeros(coords.shape)
+    mapped[:, 0:2] = coords[:, 0:2].astype(np.float64) @ t[:, :2].T + t[:, 2]
+    return mapped

@@ -11,22 +11,30 @@ from ..engine import get_optimizer  # noqa: F401  (same name / signature as the 
 
 
 def save_checkpoint(states, is_best, output_dir, filename='checkpoint.pth'):
-    torch.save(states, os.path.join(output_dir, filename))
-    if is_best and 'state_dict' in states:
-        torch.save(states['best_state_dict'], os.path.join(output_dir, 'model_best.pth'))
+    """Writes the checkpoint dict; a best-so-far run additionally leaves its bare best_state_dict as
+    model_best.pth (what tools/test.py loads).  Same files as the reference helper."""
+    target = os.path.join(output_dir, filename)
+    torch.save(states, target)
+    best = states.get('best_state_dict') if (is_best and 'state_dict' in states) else None
+    if best is not None:
+        torch.save(best, os.path.join(output_dir, 'model_best.pth'))
+    return target
 
 
 def create_logger(cfg, cfg_name, phase='train'):
-    root = cfg.OUTPUT_DIR or 'output'
-    name = os.path.basename(cfg_name).split('.')[0]
-    final_output_dir = os.path.join(root, cfg.DATASET.DATASET, cfg.MODEL.NAME, name)
-    os.makedirs(final_output_dir, exist_ok=True)
-    time_str = time.strftime('%Y-%m-%d-%H-%M')
-    log_file = os.path.join(final_output_dir, '{}_{}_{}.log'.format(name, time_str, phase))
-    logging.basicConfig(filename=log_file, format='%(asctime)-15s %(message)s')
-    log = logging.getLogger()
-    log.setLevel(logging.INFO)
-    logging.getLogger('').addHandler(logging.StreamHandler())
-    tb_dir = os.path.join(cfg.LOG_DIR or 'log', cfg.DATASET.DATASET, cfg.MODEL.NAME, name + '_' + time_str)
-    os.makedirs(tb_dir, exist_ok=True)
-    return log, str(final_output_dir), str(tb_dir)
+    """<OUTPUT_DIR>/<dataset>/<model>/<cfg name>/ for logs and checkpoints, <LOG_DIR>/.../<cfg name>_<time>/ for
+    tensorboard; returns (logger, output dir, tensorboard dir)."""
+    stamp = time.strftime('%Y-%m-%d-%H-%M')
+    stem = os.path.splitext(os.path.basename(cfg_name))[0]
+    leaf = os.path.join(cfg.DATASET.DATASET, cfg.MODEL.NAME)
+    out_dir = os.path.join(cfg.OUTPUT_DIR or 'output', leaf, stem)
+    tb_dir = os.path.join(cfg.LOG_DIR or 'log', leaf, stem + '_' + stamp)
+    for d in (out_dir, tb_dir):
+        os.makedirs(d, exist_ok=True)
+    root = logging.getLogger()
+    root.setLevel(logging.INFO)
+    file_handler = logging.FileHandler(os.path.join(out_dir, f'{stem}_{stamp}_{phase}.log'))
+    file_handler.setFormatter(logging.Formatter('%(asctime)-15s %(message)s'))
+    root.addHandler(file_handler)
+    root.addHandler(logging.StreamHandler())
+    return root, str(out_dir), str(tb_dir)

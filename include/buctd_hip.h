@@ -224,6 +224,10 @@ int buctd_joints_mse(const float* pred, const float* gt, const float* w, int N, 
  * preds[row] = (x, y) zeroed where maxval <= 0. */
 int buctd_argmax_decode(const float* hm, int rows, int H, int W, float* preds, float* maxvals, int32_t* idx,
                         void* stream);
+/* the same plus the POST_PROCESS refinement of get_final_preds (core/inference.py:68-77): quarter[row] = the
+ * (+-0.25 | 0, +-0.25 | 0) offset towards the higher neighbour for interior peaks, (0, 0) otherwise. */
+int buctd_argmax_decode_refined(const float* hm, int rows, int H, int W, float* preds, float* maxvals, int32_t* idx,
+                                float* quarter, void* stream);
 /* generate_target (dataset/JointsDataset.py:397-453): joints [B][K][3] (crop px), vis [B][K] ->
  * target [B][K][Hh][Wh], weight [B][K]. */
 int buctd_gaussian_target(const float* joints, const float* vis, int B, int K, int Hh, int Wh, float stride_x,

@@ -5,6 +5,7 @@ import re
 import subprocess
 import sys
 
+import numpy as np
 import pytest
 import torch
 
@@ -138,3 +139,93 @@ def test_data_parallel_gloo_world2():
         assert same, "parameters were not broadcast from rank 0"
         assert nb >= 2, "expected several gradient buckets"
         assert scale == 0.5 and vals == {1.5}, (vals, scale)   # (1 + 2) / 2: mean over the two replicas
+
+
+def test_host_mirror_numpy_paths_match_reference_golden():
+    """The product's host-side (numpy) entry points of core.inference / core.evaluate / utils.transforms against the
+    outputs the REFERENCE produced for the same inputs (tests/golden/core.npz)."""
+    from buctd_amd.core import evaluate, inference
+    from buctd_amd.utils import transforms
+    from oracle import core as oc
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "core.npz"))
+    preds, maxvals = inference.get_max_preds(g["hm"])
+    assert np.array_equal(preds, g["preds"]) and np.array_equal(maxvals, g["maxvals"])
+
+    class Cfg:
+        class TEST:
+            POST_PROCESS = True
+    fp, mv = inference.get_final_preds(Cfg, g["hm"].copy(), g["center"], g["scale"])
+    assert np.abs(fp - g["final_preds"]).max() <= 1e-4 and np.array_equal(mv, g["maxvals"])
+    acc, avg, cnt, _ = evaluate.accuracy(g["hm"], g["gt"])
+    assert np.allclose(acc, g["acc"]) and abs(avg - float(g["avg_acc"])) <= 1e-12 and cnt == int(g["cnt"])
+    assert np.array_equal(transforms.flip_back(g["hm"].copy(), oc.CROWDPOSE_FLIP_PAIRS), g["flip_back"])
+    # fliplr_joints and the affine against the oracle's restatement (pinned on the reference by make_golden.py)
+    rng = np.random.RandomState(3)
+    j, v = rng.rand(14, 3) * 200, (rng.rand(14, 1) > 0.3).astype(np.float64).repeat(3, 1)
+    a, av = transforms.fliplr_joints(j.copy(), v.copy(), 288, oc.CROWDPOSE_FLIP_PAIRS)
+    b, bv = oc.fliplr_joints(j.copy(), v.copy(), 288, oc.CROWDPOSE_FLIP_PAIRS)
+    assert np.array_equal(a, b) and np.array_equal(av, bv)
+    for rot, inv in ((0, 0), (0, 1), (30, 0), (-40, 1)):
+        c, s = np.array([123.4, 77.7], np.float32), np.array([1.3, 1.7], np.float32)
+        t = transforms.get_affine_transform(c, s, rot, [72, 96], inv=inv)
+        assert np.abs(t - oc.get_affine_transform(c, s, rot, [72, 96], inv=inv)).max() <= 1e-9
+
+
+def test_validate_shard_merge_gloo_world2(tmp_path):
+    """gather_validation_shards (core/function.py): two ranks fill disjoint batches, both end with the full tables."""
+    import subprocess
+    import sys
+    script = tmp_path / "w.py"
+    script.write_text(
+        "import os, sys, numpy as np, torch.distributed as dist\n"
+        f"sys.path.insert(0, {ROOT!r})\n"
+        "from buctd_amd.core.function import gather_validation_shards\n"
+        "dist.init_process_group('gloo')\n"
+        "r = dist.get_rank()\n"
+        "n, k = 10, 3\n"
+        "full_p = np.arange(n * k * 3, dtype=np.float32).reshape(n, k, 3) + 0.25\n"
+        "full_b = np.arange(n * 7, dtype=np.float64).reshape(n, 7) * 1.5\n"
+        "mine = np.array([(i // 2) % 2 == r for i in range(n)])\n"
+        "p = np.where(mine[:, None, None], full_p, 0).astype(np.float32)\n"
+        "b = np.where(mine[:, None], full_b, 0)\n"
+        "paths = [f'img{i}.jpg' if mine[i] else None for i in range(n)]\n"
+        "P, B, S = gather_validation_shards(p, b, paths, mine)\n"
+        "assert np.array_equal(P, full_p) and np.array_equal(B, full_b) and S == [f'img{i}.jpg' for i in range(n)]\n"
+        "print('OK', r)\n")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                          "--master-addr", "127.0.0.1", "--master-port", "29517", str(script)],
+                         capture_output=True, text=True, timeout=300, env=env)
+    assert out.returncode == 0 and out.stdout.count("OK") == 2, out.stdout + out.stderr
+
+
+def test_fused_adam_checkpoint_is_torch_adam_format():
+    """engine.FusedAdam reads and writes torch.optim.Adam state_dicts (what the reference keeps in
+    checkpoint['optimizer'], tools/train.py:243-266), so optimizer state moves between the two in both directions."""
+    import copy
+    from buctd_amd import engine
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Conv2d(3, 8, 3), torch.nn.BatchNorm2d(8), torch.nn.Conv2d(8, 4, 1))
+    twin = copy.deepcopy(net)
+    ref = torch.optim.Adam(net.parameters(), lr=1e-3)
+    for _ in range(2):
+        ref.zero_grad()
+        net(torch.randn(2, 3, 8, 8)).square().mean().backward()
+        ref.step()
+    sd = ref.state_dict()
+    fused = engine.FusedAdam(engine.FlatParams(twin), lr=5e-4)
+    fused.load_state_dict(copy.deepcopy(sd))
+    assert fused.step_count == 2 and fused.param_groups[0]["lr"] == 1e-3
+    for i, p in enumerate(fused.flat.params):
+        o, e = fused.flat.span(p)
+        assert torch.equal(torch.as_strided(fused.exp_avg, p.shape, p.stride(), o), sd["state"][i]["exp_avg"])
+        assert torch.equal(torch.as_strided(fused.exp_avg_sq, p.shape, p.stride(), o), sd["state"][i]["exp_avg_sq"])
+    back = torch.optim.Adam(copy.deepcopy(net).parameters(), lr=1.0)
+    back.load_state_dict(fused.state_dict())            # the reverse direction: torch accepts what FusedAdam writes
+    st = back.state_dict()["state"]
+    assert all(torch.equal(st[i]["exp_avg"], sd["state"][i]["exp_avg"]) and float(st[i]["step"]) == 2.0 for i in st)
+    assert back.param_groups[0]["lr"] == 1e-3
+    bad = copy.deepcopy(sd)
+    bad["param_groups"][0]["weight_decay"] = 0.1
+    with pytest.raises(ValueError):
+        fused.load_state_dict(bad)
