@@ -22,10 +22,15 @@ import torch.distributed as dist
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-# MI355X_MICROARCH.md: fp32 MFMA (v_mfma_f32_16x16x4_f32) peak = fp32 vector peak; HBM3E spec peak
+# MI355X_MICROARCH.md: fp32 MFMA (v_mfma_f32_16x16x4_f32) peak = fp32 vector peak; dense bf16 MFMA peak; HBM3E spec
 PEAK_FP32_MFMA_TFLOPS = 157.3
+PEAK_BF16_MFMA_TFLOPS = 2500.0
 PEAK_HBM_GBPS = 8000.0
-PMC_TRAFFIC_BYTES_N32 = 106.4e6
+MFMAS_PER_PRODUCT = {"bf16x6": 6, "bf16x3": 3}
+# HBM-side bytes per launch of the roofline kernels at N = 32 from separate rocprofv3 --pmc passes (2 x FETCH_SIZE +
+# WRITE_SIZE, gfx950 correction; profiles/r02_pmc_*.txt).  Counters cannot be read inside the timed run, so the figure is
+# quoted only for the math mode and batch it was collected at.
+PMC_TRAFFIC_BYTES_N32 = {}
 
 
 def coam_w48_cfg(batch):
@@ -75,49 +80,118 @@ def synthetic_batch(cfg, batch, device, seed):
 
 
 class KernelTimer:
-    """HIP events around every launch of the dominant kernel class (stage-3/4 branch-0 3x3 conv forward,
-    48 -> 48 channels at 96x72) on the stream it is launched on, during the timed steps."""
+    """HIP events (torch.cuda.Event = hipEvent) recorded on the launching stream right before and after every launch
+    of the roofline shape - the 3x3 48 -> 48 convolution at 96x72 (HRNet stage-2/3/4 branch 0) - during the timed
+    steps: forward, data-gradient and weight-gradient launches are kept apart."""
 
-    def __init__(self):
-        self.pairs = []
+    def __init__(self, batch):
+        self.batch = batch
+        self.pairs = {"fwd": [], "dgrad": [], "wgrad": []}
         self.enabled = False
 
     def match(self, d):
-        return d.R == 3 and d.stride == 1 and d.Ci == 48 and d.Co == 48 and d.H == 96 and d.W == 72
+        return (d.R == 3 and d.stride == 1 and d.pad == 1 and d.Ci == 48 and d.Co == 48 and d.H == 96 and d.W == 72
+                and d.N == self.batch)
 
-    def start(self):
-        e = torch.cuda.Event(enable_timing=True)
-        e.record()
-        return e
-
-    def stop(self, e0):
-        e1 = torch.cuda.Event(enable_timing=True)
+    def timed(self, kind, fn):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        out = fn()
         e1.record()
-        self.pairs.append((e0, e1))
+        self.pairs[kind].append((e0, e1))
+        return out
 
-    def mean_ms(self):
-        if not self.pairs:
-            return None
-        return sum(a.elapsed_time(b) for a, b in self.pairs) / len(self.pairs)
+    def mean_us(self, kind):
+        ps = self.pairs[kind]
+        return (1e3 * sum(a.elapsed_time(b) for a, b in ps) / len(ps), len(ps)) if ps else (None, 0)
+
+    def reset(self):
+        for k in self.pairs:
+            self.pairs[k] = []
 
 
 def install_timer(timer):
     from buctd_amd import ops
-    raw = ops.conv_fwd
+    raw_fwd, raw_dgrad, raw_wgrad = ops.conv_fwd, ops.conv_dgrad, ops.conv_wgrad
 
-    def timed_conv_fwd(x, w, bias=None, stride=1, pad=0, **kw):
+    def conv_fwd(x, w, bias=None, stride=1, pad=0, **kw):
         if timer.enabled:
             d = ops.conv_desc(x.shape, ops._wshape(w), stride, pad)
             if timer.match(d):
                 if ops._bf16x3_ok(d):
-                    ops._conv3x3_prepared(w, 0)   # the (per weight version) filter re-layout is not part of the kernel
-                e0 = timer.start()
-                out = raw(x, w, bias, stride, pad, **kw)
-                timer.stop(e0)
-                return out
-        return raw(x, w, bias, stride, pad, **kw)
+                    ops._conv3x3_prepared(w, 0)   # the per-weight-version filter re-layout is its own kernel
+                return timer.timed("fwd", lambda: raw_fwd(x, w, bias, stride, pad, **kw))
+        return raw_fwd(x, w, bias, stride, pad, **kw)
 
-    ops.conv_fwd = timed_conv_fwd
+    def conv_dgrad(dy, w, x_shape, stride=1, pad=0, **kw):
+        if timer.enabled:
+            d = ops.conv_desc(x_shape, ops._wshape(w), stride, pad)
+            if timer.match(d):
+                if ops._bf16x3_ok(d):
+                    ops._conv3x3_prepared(w, 1)
+                return timer.timed("dgrad", lambda: raw_dgrad(dy, w, x_shape, stride, pad, **kw))
+        return raw_dgrad(dy, w, x_shape, stride, pad, **kw)
+
+    def conv_wgrad(x, dy, w_like, stride=1, pad=0, **kw):
+        if timer.enabled:
+            d = ops.conv_desc(x.shape, ops._wshape(w_like), stride, pad)
+            if timer.match(d):
+                return timer.timed("wgrad", lambda: raw_wgrad(x, dy, w_like, stride, pad, **kw))
+        return raw_wgrad(x, dy, w_like, stride, pad, **kw)
+
+    ops.conv_fwd, ops.conv_dgrad, ops.conv_wgrad = conv_fwd, conv_dgrad, conv_wgrad
+
+
+def roofline_entry(math, batch, kind, in_step, solo, traffic):
+    """One roofline object.  Algorithmic work of one launch (SURVEY 8d x batch): 2*N*96*72*48*48*9 FLOP and
+    fp32 bytes in + out + weights.  in_step / solo = (average launch us, launches)."""
+    n = batch
+    flops = 2.0 * n * 96 * 72 * 48 * 48 * 9
+    if kind == "wgrad":
+        bytes_ = 4.0 * (2 * n * 48 * 96 * 72) + 4.0 * 9 * 48 * 48       # read x and dy once, write dW
+    else:
+        bytes_ = 4.0 * (2 * n * 48 * 96 * 72) + 4.0 * 9 * 48 * 48       # read x, write y, read W
+    t_head = in_step[0] if in_step[0] else solo[0]
+    if not t_head:
+        return None
+    names = {"fwd": "forward + data-gradient launches", "wgrad": "weight-gradient launches (kernel + slab reduction)"}
+    if math == "fp32":
+        peak, unit_note = PEAK_FP32_MFMA_TFLOPS, "exact fp32 MFMA (v_mfma_f32_16x16x4_f32) = the fp32 vector peak"
+        kernel = "conv_gemm_kernel / conv_wgrad_kernel (fp32 MFMA)"
+    else:
+        k = MFMAS_PER_PRODUCT[math]
+        peak = PEAK_BF16_MFMA_TFLOPS / k
+        unit_note = (f"dense bf16 MFMA peak 2500 TFLOP/s / {k} MFMAs per fp32 product (split operands) = "
+                     f"{peak:.1f} TFLOP/s-equivalent")
+        kernel = ("conv3x3_split_kernel<NP=%d,4,3,4,1>" if kind == "fwd" else "conv3x3_wgrad_split_kernel<NP=%d,3>") % \
+            (3 if math == "bf16x6" else 2)
+    hbm_us = bytes_ / (PEAK_HBM_GBPS * 1e3)
+    mfma_us = flops / (peak * 1e6)
+    bound = "mfma" if mfma_us >= hbm_us else "hbm"
+
+    def frac(us):
+        return round((mfma_us if bound == "mfma" else hbm_us) / us, 4) if us else None
+
+    tf = flops / t_head / 1e6
+    gbps = bytes_ / t_head / 1e3
+    return {"kernel": f"{kernel}: 3x3 48->48 @96x72 N={n} (HRNet branch 0), {names[kind]}",
+            "bound": bound,
+            "achieved": round(tf, 2) if bound == "mfma" else round(gbps, 1),
+            "peak": round(peak, 1) if bound == "mfma" else PEAK_HBM_GBPS,
+            "unit": "TFLOP/s" if bound == "mfma" else "GB/s",
+            "frac": frac(t_head),
+            "traffic": traffic, "traffic_unit": "HBM bytes/launch (PMC, standalone launches)" if traffic else None,
+            "algorithmic_flops": flops, "algorithmic_bytes": bytes_,
+            "avg_launch_us": round(t_head, 2), "launches_timed": in_step[1] if in_step[0] else solo[1],
+            "avg_launch_us_solo": round(solo[0], 2) if solo[0] else None, "launches_timed_solo": solo[1],
+            "frac_solo": frac(solo[0]),
+            "hbm_gbps": round(gbps, 1), "hbm_frac": round(gbps / PEAK_HBM_GBPS, 4),
+            "roof_times_us": {"mfma": round(mfma_us, 2), "hbm": round(hbm_us, 2)},
+            "timing": "HIP events on the launching stream around each launch. avg_launch_us: every launch of this "
+                      "shape inside the timed steps (the step keeps 4 streams busy, so a launch shares the GPU with "
+                      "its co-runners); avg_launch_us_solo: 30 launches of the same kernel alone on the GPU right "
+                      "after the timed steps",
+            "note": f"binding roof = {bound}: {unit_note}; HBM roof 8 TB/s on {bytes_ / 1e6:.1f} MB/launch"}
 
 
 def _host_cores(cap=32):
@@ -196,9 +270,11 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=32, help="images per GPU (scripts: 32, W48 YAML: 24)")
-    ap.add_argument("--conv-math", default=os.environ.get("BUCTD_CONV_MATH", "bf16x3"), choices=["fp32", "bf16x3"],
-                    help="fp32: every conv on the exact fp32 MFMA path; bf16x3: 3x3/s1 convs (fwd + dgrad) on bf16 MFMA "
-                         "with split-fp32 operands (heat-maps stay within the 1e-3 parity bar, tests/test_gpu_bf16x3.py)")
+    ap.add_argument("--conv-math", default=os.environ.get("BUCTD_CONV_MATH", "bf16x6"),
+                    choices=["fp32", "bf16x6", "bf16x3"],
+                    help="how the 3x3/s1 convs (fwd, dgrad, wgrad) are computed: bf16x6 (default) = fp32-class, exact "
+                         "3-way bf16 split, 6 MFMAs per product; fp32 = v_mfma_f32_16x16x4_f32; bf16x3 = optional "
+                         "reduced precision (~2^-16 per product) - not a headline mode")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timer", action="store_true")
     args = ap.parse_args()
@@ -223,7 +299,7 @@ def main():
         model.flatten()
     criterion = JointsMSELoss(cfg.LOSS.USE_TARGET_WEIGHT)
     x, target, weight = synthetic_batch(cfg, args.batch, device, seed=100 + rank)
-    timer = KernelTimer()
+    timer = KernelTimer(args.batch)
     if not args.no_kernel_timer:
         install_timer(timer)
     losses, acc = AverageMeter(), AverageMeter()
@@ -248,41 +324,31 @@ def main():
     for _ in range(args.warmup):
         step()
     fence()
-    lib_timing = (args.conv_math == "bf16x3" and not args.no_kernel_timer)
-    if lib_timing:
-        # dispatch-attached HIP events inside the library (exact kernel time, as a kernel trace reports it) for every
-        # launch of the roofline shape: forward AND data-gradient launches of the 48->48 conv at 96x72 (same kernel,
-        # same bytes)
-        from buctd_amd._C import lib as _lib, check as _check
-        _check(_lib().buctd_conv3x3_bf16x3_timing_begin(args.batch, 96, 72, 48, 48), "timing_begin")
-    else:
-        timer.enabled = True
+    timer.enabled = not args.no_kernel_timer
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     fence()
     dt = time.perf_counter() - t0
     timer.enabled = False
-    lib_us, lib_n = None, 0
-    if lib_timing:
-        import ctypes
-        tot, cnt = ctypes.c_double(), ctypes.c_int()
-        _check(_lib().buctd_conv3x3_bf16x3_timing_end(ctypes.byref(tot), ctypes.byref(cnt)), "timing_end")
-        in_step_us, in_step_n = (tot.value / cnt.value, cnt.value) if cnt.value else (None, 0)
-        # the same kernel alone on the GPU (the step keeps 4-5 kernels in flight, so an in-step duration includes the
-        # share of the machine its co-runners take): 30 forward launches with the BN-statistics epilogue on a
-        # stage-4-branch-0 sized activation and one of the model's own 48->48 filters
+    in_step = {k: timer.mean_us(k) for k in ("fwd", "dgrad", "wgrad")}
+    solo = {k: (None, 0) for k in in_step}
+    if not args.no_kernel_timer and rank == 0:
+        # the same kernels alone on the GPU: 30 launches each on a stage-4-branch-0 sized activation with one of the
+        # model's own 48 -> 48 filters (forward with the BN-statistics epilogue, as in the step)
+        timer.reset()
         wsel = next(p for p in net.parameters() if tuple(p.shape) == (48, 48, 3, 3))
         xs = torch.randn(args.batch, 96, 72, 48, device=device)
-        for _ in range(5):
+        dys = torch.randn(args.batch, 96, 72, 48, device=device)
+        gw = torch.empty_like(wsel)
+        for it in range(35):
+            timer.enabled = it >= 5
             ops.conv_fwd(xs, wsel, None, 1, 1, stats=True)
-        torch.cuda.synchronize()
-        _check(_lib().buctd_conv3x3_bf16x3_timing_begin(args.batch, 96, 72, 48, 48), "timing_begin")
-        for _ in range(30):
-            ops.conv_fwd(xs, wsel, None, 1, 1, stats=True)
-        _check(_lib().buctd_conv3x3_bf16x3_timing_end(ctypes.byref(tot), ctypes.byref(cnt)), "timing_end")
-        if cnt.value:
-            lib_us, lib_n = tot.value / cnt.value, cnt.value
+            ops.conv_dgrad(dys, wsel, tuple(xs.shape), 1, 1)
+            ops.conv_wgrad(xs, dys, wsel, 1, 1, out=gw, accumulate=0)
+            torch.cuda.synchronize()
+        timer.enabled = False
+        solo = {k: timer.mean_us(k) for k in ("fwd", "dgrad", "wgrad")}
     state["pending"].resolve(losses, acc)
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=device)
@@ -296,7 +362,10 @@ def main():
             "metric": "images/sec (train) BUCTD-CoAM-W48 384x288", "value": round(value, 3), "unit": "images/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1000 * dt / args.steps, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32" if args.conv_math == "fp32" else "f32 (3x3 convs: bf16x3 split-operand MFMA, fp32 accumulate)",
+            "dtype": {"fp32": "f32", "bf16x6": "f32 (3x3 convs: operands split exactly into 3 bf16 pieces, 6 bf16 MFMAs "
+                                "per product, fp32 accumulate - fp32-class)",
+                      "bf16x3": "f32 with REDUCED-PRECISION 3x3 convs (2 bf16 pieces, ~2^-16 per product) - not a "
+                                "headline mode"}[args.conv_math],
             "data": "synthetic",
             "config": {"workload": "BUCTD-CoAM-W48 (pose_hrnet_coam, ATT_MODULES [F,T,F,F], colored condition) "
                                    "384x288 CrowdPose-14kpt full train step: fwd + JointsMSE + bwd + grad all-reduce + "
@@ -305,54 +374,18 @@ def main():
                        "params": sum(p.numel() for p in net.parameters()), "parallelism": f"dp{world}",
                        "conv_math": args.conv_math, "loss": round(losses.avg, 6)},
         }
-        ms = timer.mean_ms()
-        ntimed = len(timer.pairs)
-        if lib_us is not None:
-            ms, ntimed = lib_us * 1e-3, lib_n
-        if ms is not None:
-            # one stage-3/4 branch-0 conv call = 286.65 MFLOP/img; algorithmic bytes (fp32) =
-            # 4*(N*48*96*72 in + N*48*96*72 out) + 4*9*48*48 weights + stats partials (ignored)
-            n = args.batch
-            flops = 2.0 * n * 96 * 72 * 48 * 48 * 9
-            bytes_ = 4.0 * (2 * n * 48 * 96 * 72) + 4.0 * 9 * 48 * 48
-            tf = flops / (ms * 1e-3) / 1e12
-            kname = ("conv_gemm_kernel<128x48> (fp32 MFMA)" if args.conv_math == "fp32"
-                     else "conv3x3_bf16x3_kernel<4,3,4,1> = 256 positions x 48 channels / workgroup (bf16 MFMA, split fp32 operands), fwd + dgrad launches,")
-            gbps = bytes_ / (ms * 1e-3) / 1e9
-            if args.conv_math == "bf16x3":
-                # with the bf16 matrix cores the 3x3 conv is no longer compute-bound at the fp32 rate: price it
-                # against HBM (north_star: >= 60 % HBM roofline on the HRNet stage-4 conv)
-                out["roofline"] = {"kernel": kname + " fwd 3x3 48->48 @96x72 (HRNet stage-3/4 branch 0)",
-                                   "bound": "hbm", "achieved": round(gbps, 1), "peak": PEAK_HBM_GBPS, "unit": "GB/s",
-                                   "frac": round(gbps / PEAK_HBM_GBPS, 4),
-                                   # HBM-side bytes per launch from separate rocprofv3 --pmc passes over this kernel at
-                                   # this shape (2 x FETCH_SIZE + WRITE_SIZE, profiles/r01_pmc_conv3x3_bf16x3_fetch_write.txt);
-                                   # counters cannot be read from inside the timed run, so the figure is only quoted
-                                   # for the batch it was collected at
-                                   "traffic": PMC_TRAFFIC_BYTES_N32 if n == 32 else None,
-                                   "traffic_unit": "bytes/launch (PMC, standalone launches)",
-                                   "algorithmic_bytes": bytes_,
-                                   "launches_timed": ntimed, "avg_launch_us": round(ms * 1e3, 2),
-                                   "timing": "HIP events attached to each dispatch (hipExtLaunchKernelGGL); avg_launch_us = "
-                                             "30 solo forward launches right after the timed steps; "
-                                             "avg_launch_us_in_step = every forward and data-gradient launch of this "
-                                             "shape inside the timed steps, where 4-5 kernels run concurrently and "
-                                             "a kernel's wall duration includes its co-runners' share of the GPU",
-                                   "avg_launch_us_in_step": round(in_step_us, 2) if in_step_us else None,
-                                   "launches_timed_in_step": in_step_n,
-                                   "tflops_equivalent": round(tf, 2),
-                                   "note": "algorithmic bytes 85.0 MB / launch (in + out + weights, fp32); 3 bf16 MFMAs "
-                                           "per product keep the MFMA time (~14 us) below the HBM time (~11-17 us)"}
-                ms = None
-        if ms is not None:
-            out["roofline"] = {"kernel": kname + " fwd 3x3 48->48 @96x72 (HRNet stage-3/4 branch 0)",
-                               "bound": "mfma", "achieved": round(tf, 3), "peak": PEAK_FP32_MFMA_TFLOPS,
-                               "unit": "TFLOP/s", "frac": round(tf / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
-                               "launches_timed": len(timer.pairs), "avg_launch_us": round(ms * 1e3, 2),
-                               "hbm_gbps": round(bytes_ / (ms * 1e-3) / 1e9, 1),
-                               "hbm_frac": round(bytes_ / (ms * 1e-3) / 1e9 / PEAK_HBM_GBPS, 4),
-                               "note": "fp32 MFMA (exact fp32) binds: AI 108 FLOP/B > fp32 ridge 20 FLOP/B; "
-                                       "hbm_* is the same launch priced against the 8 TB/s HBM roof"}
+        def merge(a, b):     # forward and data-gradient launches run the same kernel on the same bytes
+            n = a[1] + b[1]
+            return ((a[0] * a[1] + b[0] * b[1]) / n, n) if n else (None, 0)
+
+        traffic = PMC_TRAFFIC_BYTES_N32.get(args.conv_math, {}) if args.batch == 32 else {}
+        main = roofline_entry(args.conv_math, args.batch, "fwd", merge(in_step["fwd"], in_step["dgrad"]),
+                              merge(solo["fwd"], solo["dgrad"]), traffic.get("fwd"))
+        wg = roofline_entry(args.conv_math, args.batch, "wgrad", in_step["wgrad"], solo["wgrad"], traffic.get("wgrad"))
+        if main is not None:
+            out["roofline"] = main
+        if wg is not None:
+            out["roofline_wgrad"] = wg
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)

@@ -57,8 +57,6 @@ SIGNATURES = {
     "buctd_bn_finalize": (_I, [_P, _P, _I, _I, _L, _I, _F, _F, _P, _P, _P, _P, _P]),
     "buctd_conv3x3_bf16x3_supported": (_I, [_I, _I, _I, _I, _I]),
     "buctd_conv3x3_bf16x3_stats_groups": (_I, [_I, _I, _I, _I, _I, _PI, _PI]),
-    "buctd_conv3x3_bf16x3_timing_begin": (_I, [_I, _I, _I, _I, _I]),
-    "buctd_conv3x3_bf16x3_timing_end": (_I, [_P, _PI]),
     "buctd_conv3x3_bf16x3_prep_bytes": (_SZ, [_I, _I, _I]),
     "buctd_conv3x3_bf16x3_prep": (_I, [_I, _I, _P, _I, _P, _P]),
     "buctd_conv3x3_bf16x3_prep_batched": (_I, [_P, _I, _L, _P]),
@@ -66,6 +64,14 @@ SIGNATURES = {
     "buctd_conv3x3_wgrad_bf16x3_supported": (_I, [_I, _I, _I, _I, _I]),
     "buctd_conv3x3_wgrad_bf16x3_workspace": (_SZ, [_I, _I, _I, _I, _I]),
     "buctd_conv3x3_wgrad_bf16x3": (_I, [_I, _I, _I, _I, _I, _P, _P, _P, _I, _P, _SZ, _P]),
+    "buctd_conv3x3_bf16x6_supported": (_I, [_I, _I, _I, _I, _I]),
+    "buctd_conv3x3_bf16x6_stats_groups": (_I, [_I, _I, _I, _I, _I, _PI, _PI]),
+    "buctd_conv3x3_bf16x6_prep_bytes": (_SZ, [_I, _I, _I]),
+    "buctd_conv3x3_bf16x6_prep": (_I, [_I, _I, _P, _I, _P, _P]),
+    "buctd_conv3x3_bf16x6": (_I, [_I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P]),
+    "buctd_conv3x3_wgrad_bf16x6_supported": (_I, [_I, _I, _I, _I, _I]),
+    "buctd_conv3x3_wgrad_bf16x6_workspace": (_SZ, [_I, _I, _I, _I, _I]),
+    "buctd_conv3x3_wgrad_bf16x6": (_I, [_I, _I, _I, _I, _I, _P, _P, _P, _I, _P, _SZ, _P]),
     "buctd_bn_stats": (_I, [_P, _L, _I, _P, _PI, _PI, _P]),
     "buctd_bn_stats_groups": (_I, [_L, _I, _PI, _PI]),
     "buctd_bn_apply": (_I, [_P, _P, _P, _P, _P, _P, _I, _P, _L, _I, _P]),

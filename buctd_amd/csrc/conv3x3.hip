@@ -1,8 +1,12 @@
-// 3x3 / stride 1 / pad 1 NHWC convolution on the bf16 matrix cores with fp32-class accuracy ("bf16x3"):
-// every fp32 operand is split as hi + lo (two bf16), and a*b ~= hi*hi + hi*lo + lo*hi is accumulated in fp32 by
-// three v_mfma_f32_16x16x32_bf16 - ~5x the rate of v_mfma_f32_16x16x4_f32 at ~2^-16 relative product error
-// (whole-network heat-map error 1.4e-4..3.5e-4 of full scale, measured; the fp32 engine in conv.hip stays the
-// exact path and the default for parity tests).
+// 3x3 / stride 1 / pad 1 NHWC convolution on the bf16 matrix cores with split-fp32 operands, fp32 accumulation.
+// Two math modes, selected by the number of bf16 pieces NP an fp32 operand is split into:
+//   NP = 3 ("bf16x6", fp32-class - the default of the engine): x = h + m + l with h = bf16(x), m = bf16(x - h),
+//          l = bf16(x - h - m).  The split is EXACT (24 mantissa bits = 3 x 8) and  a*b = sum of the six piece
+//          products of weight >= 2^-16 (hh, hm, mh, hl, lh, mm), each one exact in the fp32 accumulator; the dropped
+//          terms (ml, lm, ll) are <= 2^-24 |a b| - the size of ONE fp32 rounding, so the result is as accurate as an
+//          fp32 FMA chain.  Six v_mfma_f32_16x16x32_bf16 per product = 2.5 PF / 6 = 417 TFLOP/s-equivalent, against
+//          157 TFLOP/s of the exact fp32 MFMA (conv.hip).
+//   NP = 2 ("bf16x3", optional, reduced precision ~2^-16 per product): hi*hi + hi*lo + lo*hi.
 //
 // This is the workhorse of the path: BasicBlock convs of reference lib/models/pose_hrnet.py:28-57, 214 of the
 // ~300 convolutions of CoAM-W48 and ~75 % of its FLOPs, forward and (with FLIP) data gradient.
@@ -11,32 +15,47 @@
 //   * pixels are addressed in a zero-padded flattened space  p = n*IB + (y+1)*SW + (x+1),  SW = W+2,
 //     IB = (H+1)*SW : one zero column left/right of every row, one zero row between images.  A filter tap is then
 //     a constant shift  (r-1)*SW + (s-1)  of p, valid across row and image boundaries alike;
-//   * a workgroup owns BM consecutive p's and all BN output channels; per 32-channel chunk it stages the
-//     BM + 2*SW + 2 input rows it needs ONCE (fp32 -> bf16 hi|lo, 160-byte rows: stride = 32 mod 64 bytes makes the
-//     four 16-lane groups of ds_read_b128 conflict free) and all 9 taps read shifted rows of that tile;
-//   * weights are split and re-ordered ONCE per weight update by buctd_conv3x3_bf16x3_prep into the exact stage
-//     image the kernel consumes ([step][Co][32 hi | 32 lo] bf16; one (tap, 32-channel chunk) per step), so the
-//     double-buffered B stage is a plain 16-byte copy; the 16-channel tail of C = 48 pairs two taps in one K = 32
-//     MFMA (lanes 0-31 feed tap t, lanes 32-63 tap t+1), so no MFMA lanes are wasted on padding;
-//   * the 4 waves tile the workgroup 4x1 (BN = 48/64) or 2x2 (BN = 96/128): every wave issues its 2*(MF+NF)
-//     ds_read_b128 up front and then MF*NF*3 back-to-back MFMAs; the step loop is fully unrolled per chunk;
+//   * a workgroup owns BM consecutive p's and all BN output channels; per channel chunk it stages the
+//     BM + 2*SW + 2 input rows it needs ONCE (fp32 -> bf16 pieces at store time) and all 9 taps read shifted rows of
+//     that tile.  NP = 2: 32-channel chunks (+ one 16-channel tail), rows [32 hi | 32 lo | pad] = 160 B.
+//     NP = 3: 16-channel chunks, rows [16 h | 16 m | 16 l] = 96 B, two taps per K = 32 MFMA (lanes 0-31 feed tap t,
+//     lanes 32-63 tap t+1; the 10th half-step of a chunk has zero weights).  Both strides are 32 mod 64 bytes, which
+//     makes the four 16-lane groups of ds_read_b128 conflict free (checked exhaustively);
+//   * weights are split and re-ordered ONCE per weight update by buctd_conv3x3_*_prep into the exact stage image the
+//     kernel consumes ([step][Co][NP x 32 k-slots] bf16), so the double-buffered B stage is a plain 16-byte copy;
+//   * the 4 waves tile the workgroup 4x1 (BN = 48/64) or 2x2 (BN = 96/128): every wave issues its fragment reads up
+//     front and then MF*NF*(3 | 6) back-to-back MFMAs, small terms first; the step loop is fully unrolled per chunk;
 //   * workgroups are renumbered so that each XCD (own L2) walks a contiguous run of position tiles;
 //   * epilogue as in conv.hip: bias, Welford BN partials (+ per-group valid-row counts, since pad positions are
 //     skipped), eval-BN scale/shift, residual, ReLU.
 #include "common.h"
-#include <hip/hip_ext.h>
-#include <vector>
 #include "../../include/buctd_hip.h"
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned short u16x4 __attribute__((ext_vector_type(4)));
 
-#define ROWB 160           // bytes per LDS row: 32 bf16 hi | 32 bf16 lo | 32 B pad
-#define CK 32              // channels per chunk
+#define CK 32              // NP = 2: channels per full chunk
+
+// per-mode geometry
+template <int NP> struct Geo;
+template <> struct Geo<2> {
+  static constexpr int ROWB = 160;   // LDS bytes per A row: 32 hi | 32 lo | 32 B pad
+  static constexpr int PST = 64;     // byte stride between the pieces of an A row
+  static constexpr int CPR = 8;      // float4 per staged row (32 channels)
+  static constexpr int BROW = 128;   // global bytes per (step, co) row of the prepared image
+  static constexpr int BLDS = 160;   // LDS stride of a B row
+};
+template <> struct Geo<3> {
+  static constexpr int ROWB = 96;    // 16 h | 16 m | 16 l
+  static constexpr int PST = 32;
+  static constexpr int CPR = 4;      // 16 channels
+  static constexpr int BROW = 192;   // 32 h | 32 m | 32 l k-slots
+  static constexpr int BLDS = 224;   // + 32 B pad: 224 = 32 mod 64
+};
 
 struct C3Args {
   const float* x;
-  const unsigned char* wp;   // prepared weight image: [steps][Co][128 B = 32 bf16 hi | 32 bf16 lo]
+  const unsigned char* wp;   // prepared weight image: [steps][Co][NP pieces x 32 bf16 k-slots]
   float* out;
   const float* bias;
   const float* scale;
@@ -46,7 +65,7 @@ struct C3Args {
   int* counts;
   int N, H, W, Ci, Co;
   int SW, IB, P;       // padded row width, padded image block, total padded positions
-  int relu, na;        // na: 32-row staging passes per chunk = ceil((BM + 2*SW + 2) / 32)
+  int relu, na;        // na: 32-row groups of the staged tile = ceil((BM + 2*SW + 2) / 32)
   unsigned ib_mul, ib_sh, sw_mul, sw_sh;   // n / d == mulhi(n, mul) >> sh for 0 <= n < 2^31 (Granlund-Montgomery)
 };
 
@@ -54,18 +73,20 @@ __device__ __forceinline__ int fast_div(int n, unsigned mul, unsigned sh) {
   return (int)(__umulhi((unsigned)n, mul) >> sh);
 }
 
+// channels c..c+3 of one row -> NP bf16 pieces, piece q at byte q*PST + 2c.  The residual subtractions are exact.
+template <int NP, int PST>
 __device__ __forceinline__ void split_store(unsigned char* row, int c, f32x4 v) {
-  // channels c..c+3 of one row: hi at byte 2c, lo at 64 + 2c
-  u16x4 hi, lo;
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const __bf16 h = (__bf16)v[j];
-    const __bf16 l = (__bf16)(v[j] - (float)h);
-    hi[j] = __builtin_bit_cast(unsigned short, h);
-    lo[j] = __builtin_bit_cast(unsigned short, l);
+  for (int q = 0; q < NP; ++q) {
+    u16x4 pc;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const __bf16 h = (__bf16)v[j];
+      pc[j] = __builtin_bit_cast(unsigned short, h);
+      v[j] -= (float)h;
+    }
+    *reinterpret_cast<u16x4*>(row + q * PST + 2 * c) = pc;
   }
-  *reinterpret_cast<u16x4*>(row + 2 * c) = hi;
-  *reinterpret_cast<u16x4*>(row + 64 + 2 * c) = lo;
 }
 
 #define MAX_SW 75          // W <= 73: the staged tile is at most BM + 152 rows
@@ -73,15 +94,20 @@ __device__ __forceinline__ void split_store(unsigned char* row, int c, f32x4 v) 
 template <int V>
 struct IC { static constexpr int value = V; };
 
-template <int MF, int NF, int WM, int WN>
-__global__ __launch_bounds__(256, 2) void conv3x3_bf16x3_kernel(C3Args p) {
+template <int NP, int MF, int NF, int WM, int WN>
+__global__ __launch_bounds__(256, 2) void conv3x3_split_kernel(C3Args p) {
+  using G = Geo<NP>;
+  constexpr int ROWB = G::ROWB, PST = G::PST, CPR = G::CPR, BROW = G::BROW, BLDS = G::BLDS;
   constexpr int BM = WM * MF * 16, BN = WN * NF * 16;
-  constexpr int PA = (BM + 2 * MAX_SW + 2 + 31) / 32;   // float4 loads per thread for one A chunk (8 per row), max
-  constexpr int PB = (BN * 8 + 255) / 256;              // 16-byte pieces per thread for one B step
+  constexpr int RPP = 256 / CPR;                                 // rows staged per pass (32 | 64)
+  constexpr int PA = (BM + 2 * MAX_SW + 2 + RPP - 1) / RPP;      // float4 loads per thread for one A chunk, max
+  constexpr int BPR = BROW / 16;                                 // 16-byte pieces per B row (8 | 12)
+  constexpr int PB = (BN * BPR + 255) / 256;                     // 16-byte pieces per thread for one B step
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int na = p.na;
+  const int arows = na * 32;
   unsigned char* At = smem;                              // [na*32][ROWB]
-  unsigned char* Bt = smem + (size_t)na * 32 * ROWB;     // [2][BN][ROWB]
+  unsigned char* Bt = smem + (size_t)arows * ROWB;       // [2][BN][BLDS]
 
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int i16 = lane & 15, g = lane >> 4;
@@ -101,16 +127,17 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bf16x3_kernel(C3Args p) {
   }
   const int p0 = bx * BM, n0 = by * BN;
   const int halo = p.SW + 1;
-  const int c4 = (t & 7) * 4;                    // this thread's 4-channel slot inside a 32-channel chunk
+  const int c4 = (t % CPR) * 4;                  // this thread's 4-channel slot inside a chunk
+  const int prow = t / CPR;                      // its row inside a staging pass
 
-  // global element offset (channel 0) of every staged row this thread fills; -1 = zero row
+  // global element offset (channel 0) of every staged row this thread fills; -1 = zero row, -2 = beyond the tile
   int goff[PA];
 #pragma unroll
   for (int q = 0; q < PA; ++q) {
-    const int row = (t >> 3) + 32 * q;
+    const int row = prow + RPP * q;
     const int pp = p0 - halo + row;
-    int o = -1;
-    if (q < na && pp >= 0 && pp < p.P) {
+    int o = row < arows ? -1 : -2;
+    if (row < arows && pp >= 0 && pp < p.P) {
       const int n = fast_div(pp, p.ib_mul, p.ib_sh);
       const int rem = pp - n * p.IB;
       const int yy = fast_div(rem, p.sw_mul, p.sw_sh);   // 0 = pad row above the image
@@ -126,7 +153,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bf16x3_kernel(C3Args p) {
   auto load_a = [&](int c0, int cw) {
 #pragma unroll
     for (int q = 0; q < PA; ++q)
-      if (q < na) {
+      if (RPP * q < arows) {
         const bool ok = goff[q] >= 0 && c4 < cw * 16;
         areg[q] = *reinterpret_cast<const f32x4*>(p.x + (ok ? goff[q] + c0 + c4 : 0));
       }
@@ -134,29 +161,30 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bf16x3_kernel(C3Args p) {
   auto store_a = [&](int cw) {
 #pragma unroll
     for (int q = 0; q < PA; ++q)
-      if (q < na) {
-        const int row = (t >> 3) + 32 * q;
+      if (RPP * q < arows && goff[q] != -2) {
+        const int row = prow + RPP * q;
         const bool ok = goff[q] >= 0 && c4 < cw * 16;
-        split_store(At + (size_t)row * ROWB, c4, ok ? areg[q] : (f32x4){0.f, 0.f, 0.f, 0.f});
+        split_store<NP, PST>(At + (size_t)row * ROWB, c4, ok ? areg[q] : (f32x4){0.f, 0.f, 0.f, 0.f});
       }
   };
-  // B: one step image is [Co][128 B]; this thread copies 16-byte piece (t & 7) of rows (t >> 3) + 32 q
+  // B: one step image is [Co][BROW]; this thread copies 16-byte pieces (row, piece) = divmod(t + 256 q, BPR)
   int bsrc[PB], bdst[PB];
 #pragma unroll
   for (int q = 0; q < PB; ++q) {
-    const int nl = (t >> 3) + 32 * q;
+    const int id = t + 256 * q;
+    const int nl = id / BPR, pc = id - nl * BPR;
     const bool ok = nl < BN;
-    bsrc[q] = ok ? (n0 + nl) * 128 + (t & 7) * 16 : 0;
-    bdst[q] = ok ? nl * ROWB + (t & 7) * 16 : (nl & 15) * ROWB + 128 + (t & 1) * 16;   // idle threads: row pad bytes
+    bsrc[q] = ok ? (n0 + nl) * BROW + pc * 16 : 0;
+    bdst[q] = ok ? nl * BLDS + pc * 16 : (nl & 15) * BLDS + BROW + (t & 1) * 16;   // idle threads: row pad bytes
   }
-  const long step_bytes = (long)p.Co * 128;
+  const long step_bytes = (long)p.Co * BROW;
   auto load_b = [&](int gs) {
     const unsigned char* src = p.wp + gs * step_bytes;
 #pragma unroll
     for (int q = 0; q < PB; ++q) breg[q] = *reinterpret_cast<const f32x4*>(src + bsrc[q]);
   };
   auto store_b = [&](int buf) {
-    unsigned char* dst = Bt + (size_t)buf * BN * ROWB;
+    unsigned char* dst = Bt + (size_t)buf * BN * BLDS;
 #pragma unroll
     for (int q = 0; q < PB; ++q) *reinterpret_cast<f32x4*>(dst + bdst[q]) = breg[q];
   };
@@ -167,10 +195,13 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bf16x3_kernel(C3Args p) {
 #pragma unroll
     for (int nf = 0; nf < NF; ++nf) acc[mf][nf] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  const int nfull = p.Ci / CK, tail = (p.Ci % CK) ? 1 : 0;
-  const int nchunks = nfull + tail, last_step = nfull * 9 + tail * 5 - 1;
+  // chunk plan: NP = 2: Ci/32 chunks of 32 channels (9 steps each) + a 16-channel tail (5 steps);
+  //             NP = 3: Ci/16 chunks of 16 channels (5 steps each)
+  const int nfull = NP == 2 ? p.Ci / CK : 0;
+  const int ntail = NP == 2 ? ((p.Ci % CK) ? 1 : 0) : p.Ci / 16;
+  const int nchunks = nfull + ntail, last_step = nfull * 9 + ntail * 5 - 1;
   const unsigned char* abase = At + (size_t)(wave_m * MF * 16 + i16) * ROWB + (g & 1) * 16;
-  const unsigned char* bbase = Bt + (size_t)(wave_n * NF * 16 + i16) * ROWB + g * 16;
+  const unsigned char* bbase = Bt + (size_t)(wave_n * NF * 16 + i16) * BLDS + g * 16;
   const bool lowk = g < 2;     // lanes feeding reduction slots 0..15 of the K = 32 MFMA
   int gs = 0, buf = 0;
 
@@ -182,34 +213,32 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bf16x3_kernel(C3Args p) {
     for (int s = 0; s < NS; ++s) {
       load_b(gs < last_step ? gs + 1 : last_step);
       const int tap0 = CW == 2 ? s : 2 * s;
-      const int tap1 = CW == 2 ? s : (2 * s + 1 < 9 ? 2 * s + 1 : 2 * s);   // tap 9 of the tail: its weights are zero
+      const int tap1 = CW == 2 ? s : (2 * s + 1 < 9 ? 2 * s + 1 : 2 * s);   // tap 9 of a paired chunk: its weights are zero
       const int o0 = ((tap0 / 3) * p.SW + tap0 % 3) * ROWB;
       const int o1 = ((tap1 / 3) * p.SW + tap1 % 3) * ROWB + (CW == 2 ? 32 : 0);
       const unsigned char* ap = abase + (lowk ? o0 : o1);
-      const unsigned char* bp = bbase + (size_t)buf * BN * ROWB;
-      bf16x8 ah[MF], al[MF], bh[NF], bl[NF];
+      const unsigned char* bp = bbase + (size_t)buf * BN * BLDS;
+      bf16x8 a[NP][MF], b[NP][NF];
 #pragma unroll
-      for (int nf = 0; nf < NF; ++nf) {
-        bh[nf] = *reinterpret_cast<const bf16x8*>(bp + nf * 16 * ROWB);
-        bl[nf] = *reinterpret_cast<const bf16x8*>(bp + nf * 16 * ROWB + 64);
-      }
+      for (int nf = 0; nf < NF; ++nf)
 #pragma unroll
-      for (int mf = 0; mf < MF; ++mf) {
-        ah[mf] = *reinterpret_cast<const bf16x8*>(ap + mf * 16 * ROWB);
-        al[mf] = *reinterpret_cast<const bf16x8*>(ap + mf * 16 * ROWB + 64);
-      }
-      // small terms first, then hi*hi; consecutive MFMAs hit different accumulators
+        for (int q = 0; q < NP; ++q) b[q][nf] = *reinterpret_cast<const bf16x8*>(bp + nf * 16 * BLDS + q * 64);
+#pragma unroll
+      for (int mf = 0; mf < MF; ++mf)
+#pragma unroll
+        for (int q = 0; q < NP; ++q) a[q][mf] = *reinterpret_cast<const bf16x8*>(ap + mf * 16 * ROWB + q * PST);
+      // small terms first, the leading product last; consecutive MFMAs hit different accumulators
 #pragma unroll
       for (int mf = 0; mf < MF; ++mf) {
-#pragma unroll
-        for (int nf = 0; nf < NF; ++nf)
-          acc[mf][nf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[mf], bh[nf], acc[mf][nf], 0, 0, 0);
-#pragma unroll
-        for (int nf = 0; nf < NF; ++nf)
-          acc[mf][nf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[mf], bl[nf], acc[mf][nf], 0, 0, 0);
-#pragma unroll
-        for (int nf = 0; nf < NF; ++nf)
-          acc[mf][nf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[mf], bh[nf], acc[mf][nf], 0, 0, 0);
+#define C3_MMA(qa, qb)                                                                                          \
+  _Pragma("unroll") for (int nf = 0; nf < NF; ++nf) acc[mf][nf] =                                                \
+      __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[qa][mf], b[qb][nf], acc[mf][nf], 0, 0, 0);
+        if constexpr (NP == 3) {
+          C3_MMA(2, 0) C3_MMA(0, 2) C3_MMA(1, 1) C3_MMA(1, 0) C3_MMA(0, 1) C3_MMA(0, 0)
+        } else {
+          C3_MMA(1, 0) C3_MMA(0, 1) C3_MMA(0, 0)
+        }
+#undef C3_MMA
       }
       store_b(buf ^ 1);
       __syncthreads();
@@ -218,17 +247,20 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bf16x3_kernel(C3Args p) {
     }
   };
 
-  load_a(0, nfull > 0 ? 2 : 1);
+  const int cw0 = nfull > 0 ? 2 : 1;
+  load_a(0, cw0);
   load_b(0);
-  store_a(nfull > 0 ? 2 : 1);
+  store_a(cw0);
   store_b(0);
-  if (nchunks > 1) load_a(CK, nfull > 1 ? 2 : 1);   // in flight during the first chunk
+  if (nchunks > 1) load_a(cw0 * 16, nfull > 1 ? 2 : 1);   // in flight during the first chunk
   __syncthreads();
+  int c_next = cw0 * 16;                          // first channel of the chunk whose loads are in flight
   for (int ch = 0; ch < nchunks; ++ch) {
     const int cw = ch < nfull ? 2 : 1;
     if (ch > 0) {
       store_a(cw);                                   // everybody left the previous tile at the last step's barrier
-      if (ch + 1 < nchunks) load_a((ch + 1) * CK, ch + 1 < nfull ? 2 : 1);
+      c_next += cw * 16;
+      if (ch + 1 < nchunks) load_a(c_next, ch + 1 < nfull ? 2 : 1);
       __syncthreads();
     }
     if (cw == 2) run_chunk(IC<2>{});
@@ -358,7 +390,7 @@ __global__ __launch_bounds__(256) void conv3x3_prep_kernel(const float* __restri
       for (int j = 0; j < 4; ++j) v[j] = w[((long)(cc + j) * 9 + (8 - tap)) * Nc + n];
     }
   }
-  split_store(out + rown * 128, c4, v);
+  split_store<2, 64>(out + rown * 128, c4, v);
 }
 
 // the same for many filters in one launch (all prepared images of a model after an optimizer step): items live in
@@ -394,7 +426,30 @@ __global__ __launch_bounds__(256) void conv3x3_prep_batched_kernel(const buctd_c
       for (int j = 0; j < 4; ++j) v[j] = it.w[((long)(cc + j) * 9 + (8 - tap)) * Nc + nn];
     }
   }
-  split_store(reinterpret_cast<unsigned char*>(it.wprep) + rown * 128, c4, v);
+  split_store<2, 64>(reinterpret_cast<unsigned char*>(it.wprep) + rown * 128, c4, v);
+}
+
+// NP = 3 image: out[step][n][piece][32 k-slots] bf16 (192 B per (step, n)); step = (16-channel chunk c, s): k-slots
+// 0-15 = (tap 2s, channels 16c..16c+15), 16-31 = (tap 2s+1, same channels; tap 9 = zero).  One thread = 4 k-slots.
+__global__ __launch_bounds__(256) void conv3x3_prep3_kernel(const float* __restrict__ w, unsigned char* __restrict__ out,
+                                                            int Kc, int Nc, int flip, long items) {
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= items) return;
+  const int k4 = (int)(idx & 7);               // k-slots 4*k4 .. 4*k4+3
+  const long rown = idx >> 3;
+  const int n = (int)(rown % Nc), step = (int)(rown / Nc);
+  const int chunk = step / 5, s = step - chunk * 5;
+  const int tap = 2 * s + (k4 >> 2);
+  const int cc = chunk * 16 + (k4 & 3) * 4;
+  f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
+  if (tap < 9) {
+    if (!flip) v = *reinterpret_cast<const f32x4*>(w + ((long)n * 9 + tap) * Kc + cc);
+    else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[j] = w[((long)(cc + j) * 9 + (8 - tap)) * Nc + n];
+    }
+  }
+  split_store<3, 64>(out + rown * 192, k4 * 4, v);
 }
 
 // ---------------------------------------------------------------------------------------------- host ----
@@ -411,10 +466,11 @@ static void magic_u32(unsigned d, unsigned* mul, unsigned* sh) {
   *sh = l - 1;                                  // mulhi already shifts by 32: total shift 31 + l
 }
 
-static int c3_steps(int Kc) { return (Kc / CK) * 9 + ((Kc % CK) ? 5 : 0); }
+static int c3_steps(int Kc, int np) { return np == 3 ? (Kc / 16) * 5 : (Kc / CK) * 9 + ((Kc % CK) ? 5 : 0); }
 
-static bool c3_plan(int N, int H, int W, int Ci, int Co, C3Plan* pl) {
+static bool c3_plan(int np, int N, int H, int W, int Ci, int Co, C3Plan* pl) {
   if (N <= 0 || H <= 0 || W <= 0 || Ci <= 0 || Co <= 0 || Ci % 16 != 0 || Co % 16 != 0 || W + 2 > MAX_SW) return false;
+  const int rowb = np == 3 ? Geo<3>::ROWB : Geo<2>::ROWB, blds = np == 3 ? Geo<3>::BLDS : Geo<2>::BLDS;
   const long P = (long)N * (H + 1) * (W + 2) + (W + 2);
   int nf, wn;
   if (Co % 96 == 0) { nf = 3; wn = 2; }
@@ -437,45 +493,119 @@ static bool c3_plan(int N, int H, int W, int Ci, int Co, C3Plan* pl) {
   pl->MF = mf; pl->NF = nf; pl->WM = wm; pl->WN = wn; pl->BM = wm * mf * 16; pl->BN = bn;
   pl->na = (pl->BM + 2 * (W + 2) + 2 + 31) / 32;
   const size_t stage = (size_t)4 * (mf >= 2 ? 2 : 1) * 16 * (nf * 16 + 4) * 4 + 4 * 64 * 4;   // epilogue staging + row offsets
-  while ((size_t)pl->na * 32 * ROWB < stage) ++pl->na;
-  pl->lds = (size_t)pl->na * 32 * ROWB + (size_t)2 * pl->BN * ROWB;
+  while ((size_t)pl->na * 32 * rowb < stage) ++pl->na;
+  pl->lds = (size_t)pl->na * 32 * rowb + (size_t)2 * pl->BN * blds;
   return pl->lds <= 160 * 1024;
 }
 
-extern "C" int buctd_conv3x3_bf16x3_supported(int N, int H, int W, int Ci, int Co) {
-  C3Plan pl;
-  return c3_plan(N, H, W, Ci, Co, &pl) ? 1 : 0;
+static bool c3_np_ok(int np) { return np == 2 || np == 3; }
+
+template <int NP, int MF, int NF, int WM, int WN>
+static int c3_launch(const C3Args& a, const C3Plan& pl, hipStream_t st) {
+  static bool attr_set = false;     // idempotent attribute call: a race at first use only repeats it
+  auto fn = conv3x3_split_kernel<NP, MF, NF, WM, WN>;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       160 * 1024);
+    if (e != hipSuccess) {
+      buctd_set_error("conv3x3 (split bf16): cannot raise the dynamic LDS limit: %s", hipGetErrorString(e));
+      return BUCTD_ELAUNCH;
+    }
+    attr_set = true;
+  }
+  dim3 grid(ceil_div(a.P, pl.BM), a.Co / pl.BN);
+  hipLaunchKernelGGL(fn, grid, dim3(256), pl.lds, st, a);
+  BUCTD_CHECK_LAUNCH("buctd_conv3x3 (split bf16)");
+  return BUCTD_OK;
 }
 
-extern "C" int buctd_conv3x3_bf16x3_stats_groups(int N, int H, int W, int Ci, int Co, int* ngroups,
-                                                 int* rows_per_group) {
+template <int NP>
+static int c3_dispatch(const C3Args& a, const C3Plan& pl, hipStream_t st) {
+#define C3_CASE(mf, nf, wm, wn) \
+  if (pl.MF == mf && pl.NF == nf && pl.WN == wn) return c3_launch<NP, mf, nf, wm, wn>(a, pl, st);
+#define C3_MF(nf, wm, wn) C3_CASE(4, nf, wm, wn) C3_CASE(2, nf, wm, wn) C3_CASE(1, nf, wm, wn)
+  C3_MF(1, 4, 1) C3_MF(2, 4, 1) C3_MF(3, 4, 1) C3_MF(3, 2, 2)
+  C3_CASE(2, 4, 4, 1) C3_CASE(1, 4, 4, 1) C3_CASE(2, 4, 2, 2) C3_CASE(1, 4, 2, 2)
+#undef C3_MF
+#undef C3_CASE
+  buctd_set_error("conv3x3 (split bf16): no kernel for MF=%d NF=%d WN=%d", pl.MF, pl.NF, pl.WN);
+  return BUCTD_EINVAL;
+}
+
+static int c3_supported(int np, int N, int H, int W, int Ci, int Co) {
   C3Plan pl;
-  BUCTD_CHECK_ARG(ngroups && rows_per_group && c3_plan(N, H, W, Ci, Co, &pl),
-                  "buctd_conv3x3_bf16x3_stats_groups: unsupported shape");
+  return c3_np_ok(np) && c3_plan(np, N, H, W, Ci, Co, &pl) ? 1 : 0;
+}
+
+static int c3_stats_groups(int np, int N, int H, int W, int Ci, int Co, int* ngroups, int* rows_per_group) {
+  C3Plan pl;
+  BUCTD_CHECK_ARG(ngroups && rows_per_group && c3_np_ok(np) && c3_plan(np, N, H, W, Ci, Co, &pl),
+                  "buctd_conv3x3_*_stats_groups: unsupported shape");
   const long P = (long)N * (H + 1) * (W + 2) + (W + 2);
   *ngroups = ceil_div(P, pl.BM) * pl.WM;
   *rows_per_group = pl.MF * 16;
   return BUCTD_OK;
 }
 
-extern "C" size_t buctd_conv3x3_bf16x3_prep_bytes(int Ci, int Co, int flip) {
-  if (Ci <= 0 || Co <= 0 || Ci % 16 != 0 || Co % 16 != 0) return 0;
+static size_t c3_prep_bytes(int np, int Ci, int Co, int flip) {
+  if (!c3_np_ok(np) || Ci <= 0 || Co <= 0 || Ci % 16 != 0 || Co % 16 != 0) return 0;
   const int Kc = flip ? Co : Ci, Nc = flip ? Ci : Co;
-  return (size_t)c3_steps(Kc) * Nc * 128;
+  return (size_t)c3_steps(Kc, np) * Nc * (np == 3 ? Geo<3>::BROW : Geo<2>::BROW);
 }
 
-extern "C" int buctd_conv3x3_bf16x3_prep(int Ci, int Co, const float* w, int flip, void* wprep, void* stream) {
-  BUCTD_CHECK_ARG(w && wprep, "buctd_conv3x3_bf16x3_prep: null pointer");
-  BUCTD_CHECK_ARG(Ci > 0 && Co > 0 && Ci % 16 == 0 && Co % 16 == 0, "buctd_conv3x3_bf16x3_prep: Ci=%d Co=%d must be multiples of 16",
+static int c3_prep(int np, int Ci, int Co, const float* w, int flip, void* wprep, void* stream) {
+  BUCTD_CHECK_ARG(w && wprep && c3_np_ok(np), "buctd_conv3x3_*_prep: null pointer");
+  BUCTD_CHECK_ARG(Ci > 0 && Co > 0 && Ci % 16 == 0 && Co % 16 == 0, "buctd_conv3x3_*_prep: Ci=%d Co=%d must be multiples of 16",
                   Ci, Co);
   const int Kc = flip ? Co : Ci, Nc = flip ? Ci : Co;
-  const long pieces = (long)c3_steps(Kc) * Nc * 8;
-  hipLaunchKernelGGL(conv3x3_prep_kernel, dim3(ceil_div(pieces, 256)), dim3(256), 0, (hipStream_t)stream, w,
-                     (unsigned char*)wprep, Kc, Nc, flip ? 1 : 0, pieces);
-  BUCTD_CHECK_LAUNCH("buctd_conv3x3_bf16x3_prep");
+  const long pieces = (long)c3_steps(Kc, np) * Nc * 8;
+  if (np == 3)
+    hipLaunchKernelGGL(conv3x3_prep3_kernel, dim3(ceil_div(pieces, 256)), dim3(256), 0, (hipStream_t)stream, w,
+                       (unsigned char*)wprep, Kc, Nc, flip ? 1 : 0, pieces);
+  else
+    hipLaunchKernelGGL(conv3x3_prep_kernel, dim3(ceil_div(pieces, 256)), dim3(256), 0, (hipStream_t)stream, w,
+                       (unsigned char*)wprep, Kc, Nc, flip ? 1 : 0, pieces);
+  BUCTD_CHECK_LAUNCH("buctd_conv3x3_*_prep");
   return BUCTD_OK;
 }
 
+// x: [N][H][W][Ci] -> y: [N][H][W][Co], wprep from the matching prep call.  Forward: prep(Ci, Co, w, 0).
+// Data gradient of a forward conv (CiF -> CoF): x = dy ([N][H][W][CoF]), y = dx ([N][H][W][CiF]), i.e. this call's
+// Ci = CoF, Co = CiF, and wprep = prep(CiF, CoF, w, 1).
+static int c3_run(int np, int N, int H, int W, int Ci, int Co, const float* x, const void* wprep, const float* bias,
+                  const float* scale, const float* shift, const float* residual, int relu, float* y,
+                  float* stats_partials, int* stats_counts, void* stream) {
+  C3Plan pl;
+  BUCTD_CHECK_ARG(x && wprep && y, "buctd_conv3x3 (split bf16): null tensor pointer");
+  BUCTD_CHECK_ARG(c3_np_ok(np) && c3_plan(np, N, H, W, Ci, Co, &pl),
+                  "buctd_conv3x3 (split bf16): unsupported shape N%d H%d W%d Ci%d Co%d", N, H, W, Ci, Co);
+  BUCTD_CHECK_ARG((scale == nullptr) == (shift == nullptr), "buctd_conv3x3 (split bf16): scale and shift go together");
+  BUCTD_CHECK_ARG((stats_partials == nullptr) == (stats_counts == nullptr),
+                  "buctd_conv3x3 (split bf16): stats partials and counts go together");
+  C3Args a;
+  a.x = x; a.wp = (const unsigned char*)wprep; a.out = y; a.bias = bias; a.scale = scale; a.shift = shift;
+  a.res = residual; a.stats = stats_partials; a.counts = stats_counts;
+  a.N = N; a.H = H; a.W = W; a.Ci = Ci; a.Co = Co;
+  a.SW = W + 2; a.IB = (H + 1) * (W + 2);
+  const long P = (long)N * a.IB + a.SW;
+  BUCTD_CHECK_ARG(P < 2147483647L && (long)N * H * W * (Ci > Co ? Ci : Co) < 2147483647L,
+                  "buctd_conv3x3 (split bf16): tensor too large");
+  a.P = (int)P;
+  a.relu = relu; a.na = pl.na;
+  magic_u32((unsigned)a.IB, &a.ib_mul, &a.ib_sh);
+  magic_u32((unsigned)a.SW, &a.sw_mul, &a.sw_sh);
+  return np == 3 ? c3_dispatch<3>(a, pl, (hipStream_t)stream) : c3_dispatch<2>(a, pl, (hipStream_t)stream);
+}
+
+// ---- "bf16x3" (NP = 2) entry points --------------------------------------------------------------------------
+extern "C" int buctd_conv3x3_bf16x3_supported(int N, int H, int W, int Ci, int Co) { return c3_supported(2, N, H, W, Ci, Co); }
+extern "C" int buctd_conv3x3_bf16x3_stats_groups(int N, int H, int W, int Ci, int Co, int* ngroups, int* rows_per_group) {
+  return c3_stats_groups(2, N, H, W, Ci, Co, ngroups, rows_per_group);
+}
+extern "C" size_t buctd_conv3x3_bf16x3_prep_bytes(int Ci, int Co, int flip) { return c3_prep_bytes(2, Ci, Co, flip); }
+extern "C" int buctd_conv3x3_bf16x3_prep(int Ci, int Co, const float* w, int flip, void* wprep, void* stream) {
+  return c3_prep(2, Ci, Co, w, flip, wprep, stream);
+}
 extern "C" int buctd_conv3x3_bf16x3_prep_batched(const buctd_c3_prep_item* items_device, int n, long total_pieces,
                                                  void* stream) {
   BUCTD_CHECK_ARG(items_device && n > 0 && total_pieces > 0, "buctd_conv3x3_bf16x3_prep_batched: bad argument");
@@ -484,112 +614,23 @@ extern "C" int buctd_conv3x3_bf16x3_prep_batched(const buctd_c3_prep_item* items
   BUCTD_CHECK_LAUNCH("buctd_conv3x3_bf16x3_prep_batched");
   return BUCTD_OK;
 }
-
-// Optional live timing of the launches of one shape (bench.py's roofline figure): HIP events attached to the dispatch
-// itself (hipExtLaunchKernelGGL start/stop events) time the kernel exactly as a kernel trace does - events recorded
-// around the launch on the stream would also count marker handling and whatever the stream waits for.
-struct C3Timing {
-  bool on = false;
-  int N = 0, H = 0, W = 0, Ci = 0, Co = 0;
-  std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
-};
-static C3Timing g_c3_timing;
-
-template <int MF, int NF, int WM, int WN>
-static int c3_launch(const C3Args& a, const C3Plan& pl, hipStream_t st) {
-  static bool attr_set = false;
-  auto fn = conv3x3_bf16x3_kernel<MF, NF, WM, WN>;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       160 * 1024);
-    if (e != hipSuccess) {
-      buctd_set_error("conv3x3_bf16x3: cannot raise the dynamic LDS limit: %s", hipGetErrorString(e));
-      return BUCTD_ELAUNCH;
-    }
-    attr_set = true;
-  }
-  dim3 grid(ceil_div(a.P, pl.BM), a.Co / pl.BN);
-  C3Timing& tm = g_c3_timing;
-  if (tm.on && a.N == tm.N && a.H == tm.H && a.W == tm.W && a.Ci == tm.Ci && a.Co == tm.Co) {
-    hipEvent_t e0, e1;
-    if (hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess) {
-      hipExtLaunchKernelGGL(fn, grid, dim3(256), (uint32_t)pl.lds, st, e0, e1, 0, a);
-      tm.events.emplace_back(e0, e1);
-      BUCTD_CHECK_LAUNCH("buctd_conv3x3_bf16x3");
-      return BUCTD_OK;
-    }
-  }
-  hipLaunchKernelGGL(fn, grid, dim3(256), pl.lds, st, a);
-  BUCTD_CHECK_LAUNCH("buctd_conv3x3_bf16x3");
-  return BUCTD_OK;
-}
-
-extern "C" int buctd_conv3x3_bf16x3_timing_begin(int N, int H, int W, int Ci, int Co) {
-  C3Timing& tm = g_c3_timing;
-  for (auto& ev : tm.events) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
-  tm.events.clear();
-  tm.N = N; tm.H = H; tm.W = W; tm.Ci = Ci; tm.Co = Co;
-  tm.on = true;
-  return BUCTD_OK;
-}
-
-extern "C" int buctd_conv3x3_bf16x3_timing_end(double* total_us, int* launches) {
-  BUCTD_CHECK_ARG(total_us && launches, "buctd_conv3x3_bf16x3_timing_end: null pointer");
-  C3Timing& tm = g_c3_timing;
-  tm.on = false;
-  double tot = 0.0;
-  int n = 0;
-  for (auto& ev : tm.events) {
-    float ms = 0.f;
-    if (hipEventSynchronize(ev.second) == hipSuccess && hipEventElapsedTime(&ms, ev.first, ev.second) == hipSuccess) {
-      tot += (double)ms * 1e3;
-      ++n;
-    }
-    (void)hipEventDestroy(ev.first);
-    (void)hipEventDestroy(ev.second);
-  }
-  tm.events.clear();
-  *total_us = tot;
-  *launches = n;
-  return BUCTD_OK;
-}
-
-static int c3_dispatch(const C3Args& a, const C3Plan& pl, hipStream_t st) {
-#define C3_CASE(mf, nf, wm, wn) \
-  if (pl.MF == mf && pl.NF == nf && pl.WN == wn) return c3_launch<mf, nf, wm, wn>(a, pl, st);
-#define C3_MF(nf, wm, wn) C3_CASE(4, nf, wm, wn) C3_CASE(2, nf, wm, wn) C3_CASE(1, nf, wm, wn)
-  C3_MF(1, 4, 1) C3_MF(2, 4, 1) C3_MF(3, 4, 1) C3_MF(3, 2, 2)
-  C3_CASE(2, 4, 4, 1) C3_CASE(1, 4, 4, 1) C3_CASE(2, 4, 2, 2) C3_CASE(1, 4, 2, 2)
-#undef C3_MF
-#undef C3_CASE
-  buctd_set_error("conv3x3_bf16x3: no kernel for MF=%d NF=%d WN=%d", pl.MF, pl.NF, pl.WN);
-  return BUCTD_EINVAL;
-}
-
-// x: [N][H][W][Ci] -> y: [N][H][W][Co], wprep from buctd_conv3x3_bf16x3_prep.  Forward: prep(Ci, Co, w, 0).
-// Data gradient of a forward conv (CiF -> CoF): x = dy ([N][H][W][CoF]), y = dx ([N][H][W][CiF]), i.e. this call's
-// Ci = CoF, Co = CiF, and wprep = prep(CiF, CoF, w, 1).
 extern "C" int buctd_conv3x3_bf16x3(int N, int H, int W, int Ci, int Co, const float* x, const void* wprep,
                                     const float* bias, const float* scale, const float* shift, const float* residual,
                                     int relu, float* y, float* stats_partials, int* stats_counts, void* stream) {
-  C3Plan pl;
-  BUCTD_CHECK_ARG(x && wprep && y, "buctd_conv3x3_bf16x3: null tensor pointer");
-  BUCTD_CHECK_ARG(c3_plan(N, H, W, Ci, Co, &pl), "buctd_conv3x3_bf16x3: unsupported shape N%d H%d W%d Ci%d Co%d", N, H,
-                  W, Ci, Co);
-  BUCTD_CHECK_ARG((scale == nullptr) == (shift == nullptr), "buctd_conv3x3_bf16x3: scale and shift go together");
-  BUCTD_CHECK_ARG((stats_partials == nullptr) == (stats_counts == nullptr),
-                  "buctd_conv3x3_bf16x3: stats partials and counts go together");
-  C3Args a;
-  a.x = x; a.wp = (const unsigned char*)wprep; a.out = y; a.bias = bias; a.scale = scale; a.shift = shift;
-  a.res = residual; a.stats = stats_partials; a.counts = stats_counts;
-  a.N = N; a.H = H; a.W = W; a.Ci = Ci; a.Co = Co;
-  a.SW = W + 2; a.IB = (H + 1) * (W + 2);
-  const long P = (long)N * a.IB + a.SW;
-  BUCTD_CHECK_ARG(P < 2147483647L && (long)N * H * W * (Ci > Co ? Ci : Co) < 2147483647L,
-                  "buctd_conv3x3_bf16x3: tensor too large");
-  a.P = (int)P;
-  a.relu = relu; a.na = pl.na;
-  magic_u32((unsigned)a.IB, &a.ib_mul, &a.ib_sh);
-  magic_u32((unsigned)a.SW, &a.sw_mul, &a.sw_sh);
-  return c3_dispatch(a, pl, (hipStream_t)stream);
+  return c3_run(2, N, H, W, Ci, Co, x, wprep, bias, scale, shift, residual, relu, y, stats_partials, stats_counts, stream);
+}
+
+// ---- "bf16x6" (NP = 3, fp32-class) entry points -----------------------------------------------------------------
+extern "C" int buctd_conv3x3_bf16x6_supported(int N, int H, int W, int Ci, int Co) { return c3_supported(3, N, H, W, Ci, Co); }
+extern "C" int buctd_conv3x3_bf16x6_stats_groups(int N, int H, int W, int Ci, int Co, int* ngroups, int* rows_per_group) {
+  return c3_stats_groups(3, N, H, W, Ci, Co, ngroups, rows_per_group);
+}
+extern "C" size_t buctd_conv3x3_bf16x6_prep_bytes(int Ci, int Co, int flip) { return c3_prep_bytes(3, Ci, Co, flip); }
+extern "C" int buctd_conv3x3_bf16x6_prep(int Ci, int Co, const float* w, int flip, void* wprep, void* stream) {
+  return c3_prep(3, Ci, Co, w, flip, wprep, stream);
+}
+extern "C" int buctd_conv3x3_bf16x6(int N, int H, int W, int Ci, int Co, const float* x, const void* wprep,
+                                    const float* bias, const float* scale, const float* shift, const float* residual,
+                                    int relu, float* y, float* stats_partials, int* stats_counts, void* stream) {
+  return c3_run(3, N, H, W, Ci, Co, x, wprep, bias, scale, shift, residual, relu, y, stats_partials, stats_counts, stream);
 }

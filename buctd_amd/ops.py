@@ -147,24 +147,41 @@ def conv_desc(x_shape, w_shape, stride, pad):
     return ConvDesc(N, H, W, Ci, Co, R, S, stride, pad, Ho, Wo)
 
 
-_conv_math = {"mode": os.environ.get("BUCTD_CONV_MATH", "fp32")}
+_CONV_MATH_MODES = ("fp32", "bf16x6", "bf16x3")
+_conv_math = {"mode": os.environ.get("BUCTD_CONV_MATH", "bf16x6")}
 
 
 def set_conv_math(mode):
-    """'fp32': every convolution on the exact fp32 MFMA path.  'bf16x3': 3x3/stride-1/pad-1 convolutions (forward and
-    data gradient) on the bf16 matrix cores with split-fp32 operands (conv3x3.hip); everything else unchanged."""
-    if mode not in ("fp32", "bf16x3"):
-        raise ValueError("conv math mode must be 'fp32' or 'bf16x3'")
+    """How the 3x3 / stride-1 / pad-1 convolutions (forward, data gradient, weight gradient) are computed:
+    'fp32'   - v_mfma_f32_16x16x4_f32, bitwise an fmaf chain (conv.hip), 157 TFLOP/s peak;
+    'bf16x6' - the default: fp32 operands split EXACTLY into three bf16 pieces, six bf16 MFMAs per product with fp32
+               accumulation (conv3x3.hip); the dropped piece products are below one fp32 rounding, so this is
+               fp32-class arithmetic at 2.5 PF / 6 = 417 TFLOP/s-equivalent;
+    'bf16x3' - optional reduced precision (two pieces, three MFMAs, ~2^-16 per product); also switches the fused
+               CoAM attention to its bf16 variants.  Never used for a parity claim or the headline benchmark.
+    Everything else (1x1, strided, 7x7 convolutions, GEMMs) is fp32 MFMA in every mode."""
+    if mode not in _CONV_MATH_MODES:
+        raise ValueError(f"conv math mode must be one of {_CONV_MATH_MODES}")
     _conv_math["mode"] = mode
+
+
+if _conv_math["mode"] not in _CONV_MATH_MODES:
+    raise ValueError(f"BUCTD_CONV_MATH must be one of {_CONV_MATH_MODES}")
 
 
 def get_conv_math():
     return _conv_math["mode"]
 
 
+def _c3fn(suffix):
+    """libbuctd_hip entry point of the current split mode, e.g. buctd_conv3x3_bf16x6_prep."""
+    return getattr(lib(), "buctd_conv3x3_" + _conv_math["mode"] + suffix)
+
+
 def _bf16x3_ok(d):
-    return (_conv_math["mode"] == "bf16x3" and d.R == 3 and d.S == 3 and d.stride == 1 and d.pad == 1 and
-            lib().buctd_conv3x3_bf16x3_supported(d.N, d.H, d.W, d.Ci, d.Co) == 1)
+    """True when this convolution takes the split-bf16 3x3 kernel in the current math mode."""
+    return (_conv_math["mode"] != "fp32" and d.R == 3 and d.S == 3 and d.stride == 1 and d.pad == 1 and
+            _c3fn("_supported")(d.N, d.H, d.W, d.Ci, d.Co) == 1)
 
 
 _weights_epoch = {"n": 0}
@@ -198,7 +215,9 @@ def _prep_all(device):
         if cache is None or cache[0][0] != w.data_ptr():
             continue
         live.append(ref)
-        if cache[0] == (w.data_ptr(), w._version, epoch):
+        if cache[0] == (w.data_ptr(), w._version, epoch, "bf16x3"):
+            continue
+        if cache[0][3:] != ("bf16x3",):
             continue
         Co, Ci = _wshape(w)[0], _wshape(w)[1]
         for flip in (0, 1):
@@ -207,7 +226,7 @@ def _prep_all(device):
                 continue
             items.append((w.data_ptr(), img.data_ptr(), Ci, Co, flip, 0, total))
             total += img.numel() // 16
-        cache[0] = (w.data_ptr(), w._version, epoch)
+        cache[0] = (w.data_ptr(), w._version, epoch, "bf16x3")
     _prep_registry["weights"] = live
     if not items:
         return
@@ -230,9 +249,10 @@ def _conv3x3_prepared(w, flip):
     import weakref
     Co, Ci = _wshape(w)[0], _wshape(w)[1]
     epoch = _weights_epoch["n"]
-    key = (w.data_ptr(), w._version, epoch)
+    key = (w.data_ptr(), w._version, epoch, _conv_math["mode"])
     cache = getattr(w, "_buctd_prep", None)
-    if cache is not None and cache[0] != key and cache[0][:2] == key[:2] and _PREP_BATCH:
+    if (cache is not None and cache[0] != key and cache[0][:2] == key[:2] and cache[0][3:] == key[3:] and _PREP_BATCH
+            and key[3] == "bf16x3"):
         _prep_all(w.device)       # rewritten in place by the optimizer kernel: batch-refresh all registered images
     if cache is None or cache[0] != key:
         cache = [key, None, None]
@@ -242,9 +262,9 @@ def _conv3x3_prepared(w, flip):
         except (AttributeError, RuntimeError, TypeError):
             pass
     if cache[1 + flip] is None:
-        nbytes = lib().buctd_conv3x3_bf16x3_prep_bytes(Ci, Co, flip)
+        nbytes = _c3fn("_prep_bytes")(Ci, Co, flip)
         img = torch.empty(nbytes, dtype=torch.uint8, device=w.device)
-        check(lib().buctd_conv3x3_bf16x3_prep(Ci, Co, ptr(w), flip, ptr(img), stream_ptr()), "conv3x3_bf16x3_prep")
+        check(_c3fn("_prep")(Ci, Co, ptr(w), flip, ptr(img), stream_ptr()), "conv3x3 prep")
         cache[1 + flip] = img
     ev = _prep_registry["event"]
     if ev is not None:
@@ -262,13 +282,13 @@ def _conv3x3_bf16x3(x, w, flip, cin, cout, bias, scale, shift, residual, relu, s
     part = counts = info = None
     if stats:
         ng, rpg = C.c_int(), C.c_int()
-        check(lib().buctd_conv3x3_bf16x3_stats_groups(N, H, W, cin, cout, C.byref(ng), C.byref(rpg)), "conv3x3 groups")
+        check(_c3fn("_stats_groups")(N, H, W, cin, cout, C.byref(ng), C.byref(rpg)), "conv3x3 groups")
         part = torch.empty((ng.value, cout, 2), dtype=torch.float32, device=x.device)
         counts = torch.empty(ng.value, dtype=torch.int32, device=x.device)
         info = (ng.value, rpg.value, counts)
-    check(lib().buctd_conv3x3_bf16x3(N, H, W, cin, cout, ptr(x), ptr(wp), ptr(bias), ptr(scale), ptr(shift),
-                                     ptr(residual), int(bool(relu)), ptr(y), ptr(part), ptr(counts), stream_ptr()),
-          "conv3x3_bf16x3")
+    check(_c3fn("")(N, H, W, cin, cout, ptr(x), ptr(wp), ptr(bias), ptr(scale), ptr(shift),
+                    ptr(residual), int(bool(relu)), ptr(y), ptr(part), ptr(counts), stream_ptr()),
+          "conv3x3 (split bf16)")
     return (y, part, info) if stats else y
 
 
@@ -299,7 +319,7 @@ def conv_dgrad(dy, w, x_shape, stride=1, pad=0, bias=None, stats=False, residual
     d = conv_desc(x_shape, _wshape(w), stride, pad)
     if tuple(dy.shape) != (d.N, d.Ho, d.Wo, d.Co):
         raise _C.BuctdHipError(f"conv_dgrad: dy shape {tuple(dy.shape)} != {(d.N, d.Ho, d.Wo, d.Co)}")
-    if _bf16x3_ok(d) and lib().buctd_conv3x3_bf16x3_supported(d.N, d.H, d.W, d.Co, d.Ci) == 1:
+    if _bf16x3_ok(d) and _c3fn("_supported")(d.N, d.H, d.W, d.Co, d.Ci) == 1:
         return _conv3x3_bf16x3(dy, w, 1, d.Co, d.Ci, bias, None, None, residual, False, stats)
     if residual is not None and stats:
         raise _C.BuctdHipError("conv_dgrad: residual and stats do not combine")
@@ -326,13 +346,15 @@ def conv_wgrad(x, dy, w_like, stride=1, pad=0, out=None, accumulate=0):
         out = _new_like_weight(w_like)
         accumulate = 0
     weight_rsc(out)
-    if (_conv_math["mode"] == "bf16x3" and d.R == 3 and d.S == 3 and d.stride == 1 and d.pad == 1 and
-            lib().buctd_conv3x3_wgrad_bf16x3_supported(d.N, d.H, d.W, d.Ci, d.Co) == 1):
-        need = lib().buctd_conv3x3_wgrad_bf16x3_workspace(d.N, d.H, d.W, d.Ci, d.Co)
-        ws = workspace(need, x.device)
-        check(lib().buctd_conv3x3_wgrad_bf16x3(d.N, d.H, d.W, d.Ci, d.Co, ptr(x), ptr(dy), ptr(out), int(accumulate),
-                                               ptr(ws), ws.numel(), stream_ptr()), "conv3x3_wgrad_bf16x3")
-        return out
+    mode = _conv_math["mode"]
+    if mode != "fp32" and d.R == 3 and d.S == 3 and d.stride == 1 and d.pad == 1:
+        fn = getattr(lib(), "buctd_conv3x3_wgrad_" + mode)
+        if getattr(lib(), "buctd_conv3x3_wgrad_" + mode + "_supported")(d.N, d.H, d.W, d.Ci, d.Co) == 1:
+            need = getattr(lib(), "buctd_conv3x3_wgrad_" + mode + "_workspace")(d.N, d.H, d.W, d.Ci, d.Co)
+            ws = workspace(need, x.device)
+            check(fn(d.N, d.H, d.W, d.Ci, d.Co, ptr(x), ptr(dy), ptr(out), int(accumulate), ptr(ws), ws.numel(),
+                     stream_ptr()), "conv3x3_wgrad (split bf16)")
+            return out
     need = lib().buctd_conv2d_wgrad_workspace(C.byref(d))
     ws = workspace(need, x.device)
     check(lib().buctd_conv2d_wgrad(C.byref(d), ptr(x), ptr(dy), ptr(out), int(accumulate), ptr(ws), ws.numel(),

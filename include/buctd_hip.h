@@ -58,23 +58,34 @@ size_t buctd_conv2d_wgrad_workspace(const buctd_conv_desc* d);
 int buctd_conv2d_wgrad(const buctd_conv_desc* d, const float* x, const float* dy, float* dw, int accumulate,
                        void* workspace, size_t workspace_bytes, void* stream);
 
-/* 3x3 / stride 1 / pad 1 convolution on the bf16 matrix cores with split-fp32 operands ("bf16x3": hi*hi + hi*lo +
- * lo*hi, fp32 accumulate; ~2^-16 relative product error).  Same epilogue options as buctd_conv2d_fwd.
- * Replaces the BasicBlock convs of pose_hrnet.py:28-57 when the "bf16x3" math mode is selected.
+/* 3x3 / stride 1 / pad 1 convolution on the bf16 matrix cores with split-fp32 operands, fp32 accumulate
+ * (csrc/conv3x3.hip).  Replaces the BasicBlock convs of pose_hrnet.py:28-57 (nn.Conv2d(k=3, s=1, p=1, bias=False)
+ * forward and its autograd data gradient).  Same epilogue options as buctd_conv2d_fwd.  Two families of entry points:
+ *   buctd_conv3x3_bf16x6_*  fp32-class (the engine's default): x = h + m + l exactly (three bf16 pieces), six MFMAs
+ *                           per product; dropped piece products are <= 2^-24 of the product;
+ *   buctd_conv3x3_bf16x3_*  optional reduced precision: two pieces, three MFMAs, ~2^-16 per product.
  *
- * The filter is consumed as a prepared image (bf16 hi|lo halves in the kernel's stage order), produced once per
- * weight update by buctd_conv3x3_bf16x3_prep from the forward filter w = [Co][3][3][Ci]:
+ * The filter is consumed as a prepared image (bf16 pieces in the kernel's stage order), produced once per
+ * weight update by the family's _prep from the forward filter w = [Co][3][3][Ci]:
  *   flip = 0: image for the forward convolution (Ci -> Co);
  *   flip = 1: image for its data gradient (the call below then takes x = dy [N][H][W][Co] with "Ci" = Co and
  *             produces y = dx [N][H][W][Ci] with "Co" = Ci).
+ * A prepared image belongs to the family that made it.
  * stats_counts: ngroups ints (valid rows per group; pad positions of the flattened tile are skipped). */
+int buctd_conv3x3_bf16x6_supported(int N, int H, int W, int Ci, int Co);
+int buctd_conv3x3_bf16x6_stats_groups(int N, int H, int W, int Ci, int Co, int* ngroups, int* rows_per_group);
+size_t buctd_conv3x3_bf16x6_prep_bytes(int Ci, int Co, int flip);
+int buctd_conv3x3_bf16x6_prep(int Ci, int Co, const float* w, int flip, void* wprep, void* stream);
+int buctd_conv3x3_bf16x6(int N, int H, int W, int Ci, int Co, const float* x, const void* wprep, const float* bias,
+                         const float* scale, const float* shift, const float* residual, int relu, float* y,
+                         float* stats_partials, int* stats_counts, void* stream);
 int buctd_conv3x3_bf16x3_supported(int N, int H, int W, int Ci, int Co);
 int buctd_conv3x3_bf16x3_stats_groups(int N, int H, int W, int Ci, int Co, int* ngroups, int* rows_per_group);
 size_t buctd_conv3x3_bf16x3_prep_bytes(int Ci, int Co, int flip);
 int buctd_conv3x3_bf16x3_prep(int Ci, int Co, const float* w, int flip, void* wprep, void* stream);
-/* The same for n filters in ONE launch (every prepared image of a model after an optimizer step).  `items_device` is
- * an array in device memory; piece_begin is the running sum of buctd_conv3x3_bf16x3_prep_bytes(..)/16 over the
- * preceding items and total_pieces the sum over all of them. */
+/* The same for n filters in ONE launch (every prepared image of a model after an optimizer step; bf16x3 only).
+ * `items_device` is an array in device memory; piece_begin is the running sum of
+ * buctd_conv3x3_bf16x3_prep_bytes(..)/16 over the preceding items and total_pieces the sum over all of them. */
 typedef struct {
   const float* w;       /* forward filter [Co][3][3][Ci] */
   void* wprep;          /* destination image */
@@ -82,16 +93,17 @@ typedef struct {
   long piece_begin;
 } buctd_c3_prep_item;
 int buctd_conv3x3_bf16x3_prep_batched(const buctd_c3_prep_item* items_device, int n, long total_pieces, void* stream);
-/* Measurement aid (bench.py roofline): between timing_begin and timing_end every launch of the given shape carries
- * HIP events attached to the dispatch itself; timing_end synchronises on them and returns the summed kernel time. */
-int buctd_conv3x3_bf16x3_timing_begin(int N, int H, int W, int Ci, int Co);
-int buctd_conv3x3_bf16x3_timing_end(double* total_us, int* launches);
 int buctd_conv3x3_bf16x3(int N, int H, int W, int Ci, int Co, const float* x, const void* wprep, const float* bias,
                          const float* scale, const float* shift, const float* residual, int relu, float* y,
                          float* stats_partials, int* stats_counts, void* stream);
 
-/* weight gradient of the same convolution on the bf16 matrix cores (transpose-read fragments from position-major
- * LDS tiles, split over positions through `workspace`): dw (+)= sum_p dy[p] (x) x[p + tap].  dw: [Co][3][3][Ci]. */
+/* weight gradient of the same convolution on the bf16 matrix cores (autograd of nn.Conv2d, pose_hrnet.py:28-57;
+ * transpose-read fragments from position-major LDS tiles, split over positions through `workspace`):
+ * dw (+)= sum_p dy[p] (x) x[p + tap].  dw: [Co][3][3][Ci].  Families as above. */
+int buctd_conv3x3_wgrad_bf16x6_supported(int N, int H, int W, int Ci, int Co);
+size_t buctd_conv3x3_wgrad_bf16x6_workspace(int N, int H, int W, int Ci, int Co);
+int buctd_conv3x3_wgrad_bf16x6(int N, int H, int W, int Ci, int Co, const float* x, const float* dy, float* dw,
+                               int accumulate, void* workspace, size_t workspace_bytes, void* stream);
 int buctd_conv3x3_wgrad_bf16x3_supported(int N, int H, int W, int Ci, int Co);
 size_t buctd_conv3x3_wgrad_bf16x3_workspace(int N, int H, int W, int Ci, int Co);
 int buctd_conv3x3_wgrad_bf16x3(int N, int H, int W, int Ci, int Co, const float* x, const float* dy, float* dw,

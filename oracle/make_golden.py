@@ -7,7 +7,7 @@ seeded state_dict + inputs, asserts agreement, and stores the REFERENCE's output
 vectors.  Nothing from the reference's sources is copied; only inputs/outputs (data) are kept.
 
     python -m oracle.make_golden            # all cases
-    python -m oracle.make_golden --fast     # skip the full-size W48 / W32 cases
+    python -m oracle.make_golden --fast     # skip the full-size cases (BASELINE configs C1-C5)
 """
 import argparse
 import hashlib
@@ -250,7 +250,7 @@ def main():
         target_case()
     small = ["prenet_w16_96x64", "coam_w16_96x64_colored", "coam_w16_96x64_mono_default_att",
              "coam_w16_96x64_stacked_2heads", "transpose_w16_96x64", "resnet18_96x64"]
-    full = ["coam_w48_384x288", "prenet_w32_256x192"]
+    full = ["coam_w48_384x288", "prenet_w32_256x192", "resnet50_256x192", "prenet_w48_384x288", "transpose_a6_256x192"]
     for name in small + ([] if args.fast else full):
         if args.only and args.only != name:
             continue

@@ -1,0 +1,180 @@
+"""The split-bf16 3x3/s1/p1 convolution (buctd_amd/csrc/conv3x3.hip, conv3x3_wgrad.hip) in both of its math modes:
+  bf16x6 - fp32-class (three exact bf16 pieces per operand, six MFMAs per product): a single convolution within
+           2e-6 of an fp64 evaluation relative to the output scale - the accuracy of an fp32 FMA chain (checked next
+           to the exact-fp32 kernel, which has to meet the same bar);
+  bf16x3 - optional reduced precision (two pieces, three MFMAs): within 5e-5.
+Whole networks: the literal north_star bar (abs 1e-3 on unit-scale heat-maps, identical arg-max) in every mode."""
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+TOL = {"bf16x6": 2e-6, "fp32": 2e-6, "bf16x3": 5e-5}
+
+
+def nhwc(t):
+    return t.permute(0, 2, 3, 1).contiguous()
+
+
+def nchw(t):
+    return t.permute(0, 3, 1, 2).contiguous()
+
+
+@pytest.fixture(params=["bf16x6", "bf16x3", "fp32"])
+def mode(request):
+    from buctd_amd import ops
+    old = ops.get_conv_math()
+    ops.set_conv_math(request.param)
+    yield request.param
+    ops.set_conv_math(old)
+
+
+SHAPES = [(2, 24, 18, 48, 48), (3, 12, 9, 384, 384), (2, 17, 13, 96, 96), (2, 20, 14, 64, 64), (4, 6, 5, 192, 192),
+          (2, 10, 8, 16, 16), (2, 9, 7, 32, 128), (2, 13, 11, 48, 96), (8, 96, 72, 48, 48), (2, 11, 10, 64, 256),
+          (1, 1, 1, 48, 48), (2, 3, 73, 32, 32)]
+
+
+@pytest.mark.parametrize("shape", SHAPES)
+def test_conv3x3_fwd_dgrad(dev, mode, shape):
+    from buctd_amd import ops
+    N, H, W, Ci, Co = shape
+    g = torch.Generator().manual_seed(sum(shape))
+    x = torch.randn(N, Ci, H, W, generator=g, dtype=torch.float64).float().double().requires_grad_(True)
+    w = (torch.randn(Co, Ci, 3, 3, generator=g) / math.sqrt(Ci * 9)).double().requires_grad_(True)
+    b = torch.randn(Co, generator=g).double()
+    y_ref = F.conv2d(x, w, b, 1, 1)
+    dy = torch.randn(y_ref.shape, generator=g).double()
+    y_ref.backward(dy)
+    d = ops.conv_desc((N, H, W, Ci), (Co, Ci, 3, 3), 1, 1)
+    if mode != "fp32":
+        assert ops._bf16x3_ok(d), "shape should take the split-bf16 path"
+    xd = nhwc(x.detach().float()).to(dev)
+    wd = w.detach().float().contiguous(memory_format=torch.channels_last).to(dev)
+    y = ops.conv_fwd(xd, wd, b.float().to(dev), 1, 1)
+    sc = y_ref.abs().max().item()
+    err = (nchw(y).cpu().double() - y_ref).abs().max().item()
+    assert err <= TOL[mode] * sc, f"fwd {shape} [{mode}]: {err:.3e} vs scale {sc:.2f}"
+    dx = ops.conv_dgrad(nhwc(dy.float()).to(dev), wd, tuple(xd.shape), 1, 1)
+    sc = x.grad.abs().max().item()
+    err = (nchw(dx).cpu().double() - x.grad).abs().max().item()
+    assert err <= TOL[mode] * sc, f"dgrad {shape} [{mode}]: {err:.3e} vs scale {sc:.2f}"
+    # the skip-connection gradient joins in the data-gradient epilogue
+    res = torch.randn(xd.shape, generator=g)
+    dx2 = ops.conv_dgrad(nhwc(dy.float()).to(dev), wd, tuple(xd.shape), 1, 1, residual=res.to(dev))
+    assert (dx2 - dx - res.to(dev)).abs().max().item() <= 1e-6 * max(1.0, sc)
+
+
+def test_bf16x6_split_is_exact_on_hard_operands(dev):
+    """Operands built to expose a lossy split: values with all 24 mantissa bits set, magnitudes spread over 2^-20..2^20
+    inside one reduction.  The six kept piece products make the result agree with fp64 to fp32 accumulation accuracy."""
+    from buctd_amd import ops
+    old = ops.get_conv_math()
+    ops.set_conv_math("bf16x6")
+    try:
+        g = torch.Generator().manual_seed(5)
+        N, H, W, Ci, Co = 2, 9, 7, 48, 48
+        mant = (torch.randint(0, 2 ** 23, (N, Ci, H, W), generator=g) | 1).float() / 2 ** 23 + 1.0   # odd 24-bit mantissas
+        x = mant * torch.exp2(torch.randint(-20, 21, (N, Ci, H, W), generator=g).float())
+        x = x * (torch.randint(0, 2, x.shape, generator=g).float() * 2 - 1)
+        mw = (torch.randint(0, 2 ** 23, (Co, Ci, 3, 3), generator=g) | 1).float() / 2 ** 23 + 1.0
+        w = mw * torch.exp2(torch.randint(-8, 9, (Co, Ci, 3, 3), generator=g).float())
+        ref = F.conv2d(x.double(), w.double(), None, 1, 1)
+        mag = F.conv2d(x.double().abs(), w.double().abs(), None, 1, 1)      # sum of |products|: the rounding yardstick
+        y = ops.conv_fwd(nhwc(x).to(dev), w.contiguous(memory_format=torch.channels_last).to(dev), None, 1, 1)
+        rel = ((nchw(y).cpu().double() - ref).abs() / mag).max().item()
+        assert rel <= 4e-7, f"bf16x6 error {rel:.3e} of the summed product magnitudes (fp32 FMA chain: ~1e-7)"
+    finally:
+        ops.set_conv_math(old)
+
+
+def test_conv3x3_epilogues(dev, mode):
+    from buctd_amd import ops
+    g = torch.Generator().manual_seed(9)
+    N, H, W, Ci, Co = 3, 13, 11, 48, 96
+    x = torch.randn(N, Ci, H, W, generator=g)
+    w = torch.randn(Co, Ci, 3, 3, generator=g) * 0.05
+    res = torch.randn(N, Co, H, W, generator=g)
+    scale, shift = torch.rand(Co, generator=g) + 0.5, torch.randn(Co, generator=g)
+    zr = F.conv2d(x.double(), w.double(), None, 1, 1)
+    ref = F.relu(zr * scale.double().view(1, -1, 1, 1) + shift.double().view(1, -1, 1, 1) + res.double())
+    xd, wd = nhwc(x).to(dev), w.contiguous(memory_format=torch.channels_last).to(dev)
+    y = ops.conv_fwd(xd, wd, None, 1, 1, scale=scale.to(dev), shift=shift.to(dev), residual=nhwc(res).to(dev), relu=True)
+    assert (nchw(y).cpu().double() - ref).abs().max().item() <= TOL[mode] * ref.abs().max().item()
+    z, part, info = ops.conv_fwd(xd, wd, None, 1, 1, stats=True)
+    if mode != "fp32":
+        assert len(info) == 3 and int(info[2].sum()) == N * H * W, "valid-row counts must add up to N*H*W"
+    rm, rv = torch.zeros(Co, device=dev), torch.ones(Co, device=dev)
+    mean, invstd = ops.bn_finalize(part, info, N * H * W, Co, 1e-5, 0.1, rm, rv)
+    assert (mean.cpu().double() - zr.mean((0, 2, 3))).abs().max().item() <= 2e-5
+    ref_is = 1.0 / torch.sqrt(zr.var((0, 2, 3), unbiased=False) + 1e-5)
+    assert ((invstd.cpu().double() - ref_is).abs() / ref_is).max().item() <= 5e-5
+    rv_ref = 0.9 + 0.1 * zr.var((0, 2, 3), unbiased=True)
+    assert ((rv.cpu().double() - rv_ref).abs() / rv_ref).max().item() <= 5e-5
+
+
+@pytest.mark.parametrize("name", ["prenet_w16_96x64", "coam_w16_96x64_colored", "coam_w48_384x288"])
+def test_networks_in_bf16x3_mode(dev, name):
+    """The optional reduced-precision mode still meets the literal bar on unit-scale heat-maps (not used for any
+    headline number; the default-mode and fp32-mode network tests are in test_gpu_models.py)."""
+    from oracle import recipes
+    from buctd_amd import models, ops
+    old = ops.get_conv_math()
+    ops.set_conv_math("bf16x3")
+    try:
+        gold = np.load(os.path.join(GOLD, f"model_{name}.npz"))
+        ref = gold["out"]
+        cfg, omodel, x, joints = recipes.build(name)
+        m = getattr(models, cfg.MODEL.NAME).get_pose_net(cfg, is_train=False)
+        m.load_state_dict(omodel.state_dict(), strict=True)
+        m = m.to(dev).eval()
+        with torch.no_grad():
+            y = m(x.to(dev)).cpu().numpy()
+        err = np.abs(y - ref).max()
+        print(f"{name} [bf16x3]: |hip - reference| = {err:.3e} (max|y| {np.abs(ref).max():.3f})")
+        assert err <= 1e-3
+        assert np.array_equal(y.reshape(y.shape[0], y.shape[1], -1).argmax(2), gold["argmax"])
+        if "loss" in gold.files:
+            from buctd_amd.core.loss import JointsMSELoss
+            tgt, wt = recipes.make_targets(cfg, joints, 77)
+            m.train()
+            recipes.set_dropout(m, 0.0)
+            loss = JointsMSELoss(True)(m(x.to(dev)), tgt.to(dev), wt.to(dev))
+            loss.backward()
+            assert abs(loss.item() - float(gold["loss"])) <= 1e-3 * abs(float(gold["loss"]))
+    finally:
+        ops.set_conv_math(old)
+
+
+def test_conv3x3_speed_report(dev):
+    """Not a pass/fail bar: prints the stage-4 branch-0 conv timing in every math mode (HIP events)."""
+    from buctd_amd import ops
+    N, H, W, C = 32, 96, 72, 48
+    x = torch.randn(N, H, W, C, device=dev)
+    dy = torch.randn(N, H, W, C, device=dev)
+    w = (torch.randn(C, C, 3, 3, device=dev) * 0.05).contiguous(memory_format=torch.channels_last)
+    flops = 2.0 * N * H * W * C * C * 9
+    old = ops.get_conv_math()
+    try:
+        for mode in ("fp32", "bf16x3", "bf16x6"):
+            ops.set_conv_math(mode)
+            for what, fn in (("fwd+stats", lambda: ops.conv_fwd(x, w, None, 1, 1, stats=True)),
+                             ("dgrad", lambda: ops.conv_dgrad(dy, w, tuple(x.shape), 1, 1)),
+                             ("wgrad", lambda: ops.conv_wgrad(x, dy, w, 1, 1))):
+                for _ in range(3):
+                    fn()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(20):
+                    fn()
+                e1.record()
+                torch.cuda.synchronize()
+                us = e0.elapsed_time(e1) * 1e3 / 20
+                print(f"conv 3x3 48->48 @96x72 N=32 [{mode}] {what}: {us:.1f} us/launch, "
+                      f"{flops / us / 1e6:.1f} TFLOP/s-equivalent, {85.0e6 / us / 1e3:.0f} GB/s algorithmic")
+    finally:
+        ops.set_conv_math(old)
