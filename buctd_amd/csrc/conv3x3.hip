@@ -94,6 +94,110 @@ __device__ __forceinline__ void split_store(unsigned char* row, int c, f32x4 v) 
 template <int V>
 struct IC { static constexpr int value = V; };
 
+// ---- epilogue (shared by both kernels) -----------------------------------------------------------------------
+// accumulator (mf, nf, reg): row = wave_m*MR + mf*16 + (lane>>4)*4 + reg, col = wave_n*NF*16 + nf*16 + (lane&15).
+// Called after a barrier that ends every read of the staged tiles: the tile area of `smem` is reused for staging.
+template <int MF, int NF, int WM, int WN>
+__device__ __forceinline__ void c3_epilogue(const C3Args& p, f32x4 (&acc)[MF][NF], unsigned char* smem, int bx, int by,
+                                            int p0, int n0) {
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int i16 = lane & 15, g = lane >> 4;
+  const int wave_m = wave % WM, wave_n = wave / WM;
+  // The tile goes through LDS (the A tile is dead after the last step's barrier) so that every output row leaves as
+  // 16-byte pieces of one contiguous run instead of 64-byte column slivers of four rows.
+  constexpr int MR = MF * 16;              // rows of this wave's tile
+  constexpr int LD = NF * 16 + 4;          // staging row stride in floats: 4*LD = 16 mod 64 keeps the writes conflict-free
+  constexpr int EP = MF >= 2 ? 2 : 1;      // 16-row fragments staged per pass
+  float* stg = reinterpret_cast<float*>(smem) + wave * (EP * 16 * LD);
+  int* rowoff = reinterpret_cast<int*>(smem) + 4 * EP * 16 * LD + wave * 64;
+  int myoff = -1;                          // lane r: element offset of output row r of this wave (-1: pad position)
+  if (lane < MR) {
+    const int pp = p0 + wave_m * MR + lane;
+    if (pp < p.P) {
+      const int n = fast_div(pp, p.ib_mul, p.ib_sh);
+      const int rem = pp - n * p.IB;
+      const int yy = fast_div(rem, p.sw_mul, p.sw_sh), xx = rem - yy * p.SW;
+      if (n < p.N && yy >= 1 && xx >= 1 && xx <= p.W) myoff = ((n * p.H + yy - 1) * p.W + xx - 1) * p.Co;
+    }
+  }
+  const unsigned long long vmask = __ballot(myoff >= 0);
+  const int cnt = __popcll(vmask);
+  rowoff[lane] = myoff;
+  const int grp = bx * WM + wave_m;
+  if (p.stats && p.counts && by == 0 && wave_n == 0 && lane == 0) p.counts[grp] = cnt;
+  const int ncol0 = n0 + wave_n * NF * 16;
+  float bv[NF];
+#pragma unroll
+  for (int nf = 0; nf < NF; ++nf) bv[nf] = p.bias ? p.bias[ncol0 + nf * 16 + i16] : 0.f;
+  if (p.stats) {
+    const float inv_cnt = cnt > 0 ? 1.f / (float)cnt : 0.f;
+#pragma unroll
+    for (int nf = 0; nf < NF; ++nf) {
+      float s1 = 0.f;
+#pragma unroll
+      for (int mf = 0; mf < MF; ++mf)
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg)
+          s1 += ((vmask >> (mf * 16 + g * 4 + rg)) & 1) ? acc[mf][nf][rg] + bv[nf] : 0.f;
+      s1 += __shfl_xor(s1, 16, 64);
+      s1 += __shfl_xor(s1, 32, 64);
+      const float mean = s1 * inv_cnt;
+      float s2 = 0.f;
+#pragma unroll
+      for (int mf = 0; mf < MF; ++mf)
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) {
+          const float d = acc[mf][nf][rg] + bv[nf] - mean;
+          s2 += ((vmask >> (mf * 16 + g * 4 + rg)) & 1) ? d * d : 0.f;
+        }
+      s2 += __shfl_xor(s2, 16, 64);
+      s2 += __shfl_xor(s2, 32, 64);
+      if (g == 0) {
+        const int n = ncol0 + nf * 16 + i16;
+        *reinterpret_cast<float2*>(p.stats + ((long)grp * p.Co + n) * 2) = make_float2(mean, s2);
+      }
+    }
+  }
+#pragma unroll
+  for (int ps = 0; ps < MF / EP; ++ps) {
+    if (ps) __syncthreads();
+#pragma unroll
+    for (int e = 0; e < EP; ++e)
+#pragma unroll
+      for (int nf = 0; nf < NF; ++nf)
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg)
+          stg[(e * 16 + g * 4 + rg) * LD + nf * 16 + i16] = acc[ps * EP + e][nf][rg] + bv[nf];
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < EP * NF; ++k) {
+      const int item = lane + 64 * k;
+      const int row = item / (NF * 4), c4 = item - row * (NF * 4);
+      f32x4 v = *reinterpret_cast<const f32x4*>(stg + row * LD + c4 * 4);
+      const int off = rowoff[ps * EP * 16 + row];
+      const int n = ncol0 + c4 * 4;
+      if (off >= 0) {
+        if (p.scale) {
+          const f32x4 sc = *reinterpret_cast<const f32x4*>(p.scale + n);
+          const f32x4 sh = *reinterpret_cast<const f32x4*>(p.shift + n);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) v[j] = v[j] * sc[j] + sh[j];
+        }
+        if (p.res) {
+          const f32x4 r = *reinterpret_cast<const f32x4*>(p.res + off + n);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) v[j] += r[j];
+        }
+        if (p.relu) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
+        }
+        *reinterpret_cast<f32x4*>(p.out + off + n) = v;
+      }
+    }
+  }
+}
+
 template <int NP, int MF, int NF, int WM, int WN>
 __global__ __launch_bounds__(256, 2) void conv3x3_split_kernel(C3Args p) {
   using G = Geo<NP>;
@@ -267,101 +371,151 @@ __global__ __launch_bounds__(256, 2) void conv3x3_split_kernel(C3Args p) {
     else run_chunk(IC<1>{});
   }
 
-  // ---- epilogue ---------------------------------------------------------------------------------------
-  // accumulator (mf, nf, reg): row = wave_m*MR + mf*16 + (lane>>4)*4 + reg, col = wave_n*NF*16 + nf*16 + (lane&15).
-  // The tile goes through LDS (the A tile is dead after the last step's barrier) so that every output row leaves as
-  // 16-byte pieces of one contiguous run instead of 64-byte column slivers of four rows.
-  constexpr int MR = MF * 16;              // rows of this wave's tile
-  constexpr int LD = NF * 16 + 4;          // staging row stride in floats: 4*LD = 16 mod 64 keeps the writes conflict-free
-  constexpr int EP = MF >= 2 ? 2 : 1;      // 16-row fragments staged per pass
-  float* stg = reinterpret_cast<float*>(smem) + wave * (EP * 16 * LD);
-  int* rowoff = reinterpret_cast<int*>(smem) + 4 * EP * 16 * LD + wave * 64;
-  int myoff = -1;                          // lane r: element offset of output row r of this wave (-1: pad position)
-  if (lane < MR) {
-    const int pp = p0 + wave_m * MR + lane;
-    if (pp < p.P) {
+  c3_epilogue<MF, NF, WM, WN>(p, acc, smem, bx, by, p0, n0);
+}
+
+// ---- the fp32-class kernel (NP = 3, "bf16x6") ----------------------------------------------------------------------
+// Same tiling and epilogue as conv3x3_split_kernel, different data movement:
+//   * A: 16-channel chunks, rows [16 h | 16 m | 16 l] = 96 B, DOUBLE buffered: the next chunk is split and stored while
+//     the current one is being multiplied (its global loads were issued a chunk earlier), one barrier per chunk;
+//   * B: no LDS stage and no per-step barrier: the prepared image is laid out in MFMA fragment order
+//     ([step][Co/16][piece][lane][16 B]), every wave fetches the 3*NF fragments of a step straight from L2/L1
+//     (1 KB contiguous per fragment; all workgroups read the same few hundred KB) at the top of the step.
+//     With six MFMAs per product the fragment stream needs ~31 B/clk/CU of the 64 B/clk L1 - half of what the
+//     three-MFMA mode would need, which is why that mode keeps its LDS stage.
+// Two taps per K = 32 MFMA (lanes 0-31 feed tap 2s, lanes 32-63 tap 2s+1; the 10th half-step has zero weights).
+template <int MF, int NF, int WM, int WN>
+__global__ __launch_bounds__(256, 2) void conv3x3_x6_kernel(C3Args p) {
+  constexpr int ROWB = Geo<3>::ROWB, PST = Geo<3>::PST, CPR = Geo<3>::CPR;
+  constexpr int BM = WM * MF * 16, BN = WN * NF * 16;
+  constexpr int RPP = 256 / CPR;                                 // 64 rows staged per pass
+  constexpr int PA = (BM + 2 * MAX_SW + 2 + RPP - 1) / RPP;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int arows = p.na * 32;
+  const size_t abytes = (size_t)arows * ROWB;                    // one A buffer; smem = [2][arows][ROWB]
+
+  const int t = threadIdx.x, lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);      // wave-uniform: keeps the B addressing scalar
+  const int i16 = lane & 15, g = lane >> 4;
+  const int wave_m = wave % WM, wave_n = wave / WM;
+  int bx, by;
+  {
+    const unsigned gx = gridDim.x, gy = gridDim.y, total = gx * gy;
+    const unsigned lin = blockIdx.y * gx + blockIdx.x;
+    const unsigned xcd = lin & 7, idx = lin >> 3, per = total >> 3, rem = total & 7;
+    const unsigned L = xcd < rem ? xcd * (per + 1) + idx : rem * (per + 1) + (xcd - rem) * per + idx;
+    bx = (int)(L / gy);
+    by = (int)(L - (unsigned)bx * gy);
+  }
+  const int p0 = bx * BM, n0 = by * BN;
+  const int halo = p.SW + 1;
+  const int c4 = (t % CPR) * 4, prow = t / CPR;
+
+  int goff[PA];        // global element offset (channel 0) of every staged row of this thread; -1 zero row, -2 beyond
+#pragma unroll
+  for (int q = 0; q < PA; ++q) {
+    const int row = prow + RPP * q;
+    const int pp = p0 - halo + row;
+    int o = row < arows ? -1 : -2;
+    if (row < arows && pp >= 0 && pp < p.P) {
       const int n = fast_div(pp, p.ib_mul, p.ib_sh);
       const int rem = pp - n * p.IB;
-      const int yy = fast_div(rem, p.sw_mul, p.sw_sh), xx = rem - yy * p.SW;
-      if (n < p.N && yy >= 1 && xx >= 1 && xx <= p.W) myoff = ((n * p.H + yy - 1) * p.W + xx - 1) * p.Co;
+      const int yy = fast_div(rem, p.sw_mul, p.sw_sh);
+      const int xx = rem - yy * p.SW;
+      if (n < p.N && yy >= 1 && xx >= 1 && xx <= p.W) o = ((n * p.H + yy - 1) * p.W + xx - 1) * p.Ci;
     }
+    goff[q] = o;
   }
-  const unsigned long long vmask = __ballot(myoff >= 0);
-  const int cnt = __popcll(vmask);
-  rowoff[lane] = myoff;
-  const int grp = bx * WM + wave_m;
-  if (p.stats && p.counts && by == 0 && wave_n == 0 && lane == 0) p.counts[grp] = cnt;
-  const int ncol0 = n0 + wave_n * NF * 16;
-  float bv[NF];
+  f32x4 areg[PA];
+  auto load_a = [&](int c0) {
 #pragma unroll
-  for (int nf = 0; nf < NF; ++nf) bv[nf] = p.bias ? p.bias[ncol0 + nf * 16 + i16] : 0.f;
-  if (p.stats) {
-    const float inv_cnt = cnt > 0 ? 1.f / (float)cnt : 0.f;
+    for (int q = 0; q < PA; ++q)
+      if (RPP * q < arows) areg[q] = *reinterpret_cast<const f32x4*>(p.x + (goff[q] >= 0 ? goff[q] + c0 + c4 : 0));
+  };
+  auto store_a = [&](unsigned char* At) {
 #pragma unroll
-    for (int nf = 0; nf < NF; ++nf) {
-      float s1 = 0.f;
+    for (int q = 0; q < PA; ++q)
+      if (RPP * q < arows && goff[q] != -2)
+        split_store<3, PST>(At + (size_t)(prow + RPP * q) * ROWB, c4, goff[q] >= 0 ? areg[q] : (f32x4){0.f, 0.f, 0.f, 0.f});
+  };
+
+  // B fragments of this lane: image [step][Co/16][3][64][16 B]
+  const unsigned char* bptr = p.wp + ((size_t)(n0 / 16 + wave_n * NF) * 3) * 1024;   // scalar base
+  const int blane = lane * 16;                                                        // the only per-lane part
+  const size_t bstep = (size_t)(p.Co / 16) * 3 * 1024;
+  bf16x8 bc[3][NF];
+  auto load_b = [&](int gs, bf16x8 (&dst)[3][NF]) {
+    const unsigned char* src = bptr + (size_t)gs * bstep;
 #pragma unroll
-      for (int mf = 0; mf < MF; ++mf)
+    for (int nf = 0; nf < NF; ++nf)
 #pragma unroll
-        for (int rg = 0; rg < 4; ++rg)
-          s1 += ((vmask >> (mf * 16 + g * 4 + rg)) & 1) ? acc[mf][nf][rg] + bv[nf] : 0.f;
-      s1 += __shfl_xor(s1, 16, 64);
-      s1 += __shfl_xor(s1, 32, 64);
-      const float mean = s1 * inv_cnt;
-      float s2 = 0.f;
+      for (int q = 0; q < 3; ++q) dst[q][nf] = *reinterpret_cast<const bf16x8*>(src + (nf * 3 + q) * 1024 + blane);
+  };
+
+  f32x4 acc[MF][NF];
 #pragma unroll
-      for (int mf = 0; mf < MF; ++mf)
+  for (int mf = 0; mf < MF; ++mf)
 #pragma unroll
-        for (int rg = 0; rg < 4; ++rg) {
-          const float d = acc[mf][nf][rg] + bv[nf] - mean;
-          s2 += ((vmask >> (mf * 16 + g * 4 + rg)) & 1) ? d * d : 0.f;
-        }
-      s2 += __shfl_xor(s2, 16, 64);
-      s2 += __shfl_xor(s2, 32, 64);
-      if (g == 0) {
-        const int n = ncol0 + nf * 16 + i16;
-        *reinterpret_cast<float2*>(p.stats + ((long)grp * p.Co + n) * 2) = make_float2(mean, s2);
+    for (int nf = 0; nf < NF; ++nf) acc[mf][nf] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int nchunks = p.Ci / 16;
+  const size_t aoff = (size_t)(wave_m * MF * 16 + i16) * ROWB + (g & 1) * 16;
+  const bool lowk = g < 2;
+  int gs = 0;
+
+  // one chunk = 5 unrolled steps.  The B fragments of a step are fetched at its top into the one register set (a second
+  // set for a step-ahead prefetch does not fit beside 48 accumulators: it spills); the L2 latency is covered by the
+  // other wave of the SIMD and by the A reads
+  auto run_chunk = [&](int ch) {
+    const unsigned char* abase = smem + (ch & 1) * abytes + aoff;
+#pragma unroll
+    for (int s = 0; s < 5; ++s) {
+      if (s == 2 && ch + 1 < nchunks) {            // next chunk: registers -> pieces -> the other A buffer
+        // done while the fewest registers are live (no B prefetch in flight, no A fragments): the split needs ~60
+        store_a(smem + ((ch + 1) & 1) * abytes);
+        if (ch + 2 < nchunks) load_a((ch + 2) * 16);
+        __builtin_amdgcn_sched_barrier(0);
       }
-    }
-  }
+      load_b(gs, bc);
+      const int tap0 = 2 * s, tap1 = 2 * s + 1 < 9 ? 2 * s + 1 : 2 * s;
+      const int o0 = ((tap0 / 3) * p.SW + tap0 % 3) * ROWB, o1 = ((tap1 / 3) * p.SW + tap1 % 3) * ROWB;
+      const unsigned char* ap = abase + (lowk ? o0 : o1);
+      // A fragments are fetched one 16-row fragment ahead (24 registers live instead of 48): the reads of fragment
+      // mf+1 are issued in front of the 18 MFMAs of fragment mf; the scheduling fences keep the compiler from hoisting
+      // every read of the step to its top (which spills)
+      bf16x8 a[2][3];
 #pragma unroll
-  for (int ps = 0; ps < MF / EP; ++ps) {
-    if (ps) __syncthreads();
+      for (int q = 0; q < 3; ++q) a[0][q] = *reinterpret_cast<const bf16x8*>(ap + q * PST);
 #pragma unroll
-    for (int e = 0; e < EP; ++e)
+      for (int mf = 0; mf < MF; ++mf) {
+        if (mf + 1 < MF) {
 #pragma unroll
-      for (int nf = 0; nf < NF; ++nf)
-#pragma unroll
-        for (int rg = 0; rg < 4; ++rg)
-          stg[(e * 16 + g * 4 + rg) * LD + nf * 16 + i16] = acc[ps * EP + e][nf][rg] + bv[nf];
-    __syncthreads();
-#pragma unroll
-    for (int k = 0; k < EP * NF; ++k) {
-      const int item = lane + 64 * k;
-      const int row = item / (NF * 4), c4 = item - row * (NF * 4);
-      f32x4 v = *reinterpret_cast<const f32x4*>(stg + row * LD + c4 * 4);
-      const int off = rowoff[ps * EP * 16 + row];
-      const int n = ncol0 + c4 * 4;
-      if (off >= 0) {
-        if (p.scale) {
-          const f32x4 sc = *reinterpret_cast<const f32x4*>(p.scale + n);
-          const f32x4 sh = *reinterpret_cast<const f32x4*>(p.shift + n);
-#pragma unroll
-          for (int j = 0; j < 4; ++j) v[j] = v[j] * sc[j] + sh[j];
+          for (int q = 0; q < 3; ++q)
+            a[(mf + 1) & 1][q] = *reinterpret_cast<const bf16x8*>(ap + (mf + 1) * 16 * ROWB + q * PST);
         }
-        if (p.res) {
-          const f32x4 r = *reinterpret_cast<const f32x4*>(p.res + off + n);
-#pragma unroll
-          for (int j = 0; j < 4; ++j) v[j] += r[j];
-        }
-        if (p.relu) {
-#pragma unroll
-          for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
-        }
-        *reinterpret_cast<f32x4*>(p.out + off + n) = v;
+        __builtin_amdgcn_sched_barrier(0);
+        bf16x8 (&ac)[3] = a[mf & 1];
+#define X6_MMA(qa, qb)                                                                                          \
+  _Pragma("unroll") for (int nf = 0; nf < NF; ++nf) acc[mf][nf] =                                                \
+      __builtin_amdgcn_mfma_f32_16x16x32_bf16(ac[qa], bc[qb][nf], acc[mf][nf], 0, 0, 0);
+        X6_MMA(2, 0) X6_MMA(0, 2) X6_MMA(1, 1) X6_MMA(1, 0) X6_MMA(0, 1) X6_MMA(0, 0)
+#undef X6_MMA
+        __builtin_amdgcn_sched_barrier(0);
       }
+      ++gs;
+      __builtin_amdgcn_sched_barrier(0);           // keep the steps apart: cross-step hoisting only costs registers
     }
+  };
+
+  load_a(0);
+  store_a(smem);
+  if (nchunks > 1) load_a(16);
+  __syncthreads();
+  for (int ch = 0; ch < nchunks; ++ch) {
+    run_chunk(ch);
+    __syncthreads();       // chunk ch+1 is complete in its buffer; nobody reads buffer (ch & 1) any more
   }
+  c3_epilogue<MF, NF, WM, WN>(p, acc, smem, bx, by, p0, n0);
 }
 
 // ------------------------------------------------------------------------------------- weight preparation ----
@@ -429,8 +583,9 @@ __global__ __launch_bounds__(256) void conv3x3_prep_batched_kernel(const buctd_c
   split_store<2, 64>(reinterpret_cast<unsigned char*>(it.wprep) + rown * 128, c4, v);
 }
 
-// NP = 3 image: out[step][n][piece][32 k-slots] bf16 (192 B per (step, n)); step = (16-channel chunk c, s): k-slots
-// 0-15 = (tap 2s, channels 16c..16c+15), 16-31 = (tap 2s+1, same channels; tap 9 = zero).  One thread = 4 k-slots.
+// NP = 3 image in MFMA fragment order: out[step][n/16][piece][lane][8 bf16], lane = 16*g + (n & 15) holding k-slots
+// 8g..8g+7 of row n; step = (16-channel chunk c, s): k-slots 0-15 = (tap 2s, channels 16c..16c+15), 16-31 = (tap 2s+1,
+// same channels; tap 9 = zero).  One thread = 4 k-slots of one row.
 __global__ __launch_bounds__(256) void conv3x3_prep3_kernel(const float* __restrict__ w, unsigned char* __restrict__ out,
                                                             int Kc, int Nc, int flip, long items) {
   const long idx = (long)blockIdx.x * 256 + threadIdx.x;
@@ -449,7 +604,10 @@ __global__ __launch_bounds__(256) void conv3x3_prep3_kernel(const float* __restr
       for (int j = 0; j < 4; ++j) v[j] = w[((long)(cc + j) * 9 + (8 - tap)) * Nc + n];
     }
   }
-  split_store<3, 64>(out + rown * 192, k4 * 4, v);
+  const int lane = (k4 >> 1) * 16 + (n & 15);
+  unsigned char* dst = out + (((size_t)step * (Nc / 16) + (n >> 4)) * 3) * 1024 + lane * 16;
+  // pieces 1 KB apart; the 4 k-slots occupy 8 bytes at (k4 & 1) * 8 inside the lane's 16
+  split_store<3, 1024>(dst, (k4 & 1) * 4, v);
 }
 
 // ---------------------------------------------------------------------------------------------- host ----
@@ -493,8 +651,13 @@ static bool c3_plan(int np, int N, int H, int W, int Ci, int Co, C3Plan* pl) {
   pl->MF = mf; pl->NF = nf; pl->WM = wm; pl->WN = wn; pl->BM = wm * mf * 16; pl->BN = bn;
   pl->na = (pl->BM + 2 * (W + 2) + 2 + 31) / 32;
   const size_t stage = (size_t)4 * (mf >= 2 ? 2 : 1) * 16 * (nf * 16 + 4) * 4 + 4 * 64 * 4;   // epilogue staging + row offsets
-  while ((size_t)pl->na * 32 * rowb < stage) ++pl->na;
-  pl->lds = (size_t)pl->na * 32 * rowb + (size_t)2 * pl->BN * blds;
+  if (np == 3) {            // two A buffers, no B stage
+    while ((size_t)2 * pl->na * 32 * rowb < stage) ++pl->na;
+    pl->lds = (size_t)2 * pl->na * 32 * rowb;
+  } else {
+    while ((size_t)pl->na * 32 * rowb < stage) ++pl->na;
+    pl->lds = (size_t)pl->na * 32 * rowb + (size_t)2 * pl->BN * blds;
+  }
   return pl->lds <= 160 * 1024;
 }
 
@@ -503,7 +666,9 @@ static bool c3_np_ok(int np) { return np == 2 || np == 3; }
 template <int NP, int MF, int NF, int WM, int WN>
 static int c3_launch(const C3Args& a, const C3Plan& pl, hipStream_t st) {
   static bool attr_set = false;     // idempotent attribute call: a race at first use only repeats it
-  auto fn = conv3x3_split_kernel<NP, MF, NF, WM, WN>;
+  void (*fn)(C3Args);
+  if constexpr (NP == 3) fn = conv3x3_x6_kernel<MF, NF, WM, WN>;
+  else fn = conv3x3_split_kernel<NP, MF, NF, WM, WN>;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        160 * 1024);

@@ -14,8 +14,11 @@
 // each.  Position ranges are split over the grid; per-split slabs are summed by wg3_reduce.
 // The X tile is a ring of RING rows indexed by (position - first staged position) mod RING: consecutive stages of a
 // workgroup overlap in all but KB rows, so after the first stage only the KB new rows are fetched and split.
-//   NP = 2: KB = 96 positions per stage, RING = 256;  NP = 3: KB = 32, RING = 192 (6 B per element instead of 4:
-//   the smaller stage keeps two workgroups per CU; a stage still carries 126 MFMAs per wave between barriers).
+//   NP = 2: KB = 96 positions per stage;  NP = 3: KB = 64 (6 B per element instead of 4).  Ring size = the R rows of
+//   one stage.  A lane group's 8 positions are {4g..4g+3} u {16+4g..16+4g+3} of the 32-position k-step (any assignment
+//   is legal as long as both operands use the same one): the 32 lanes served in one LDS cycle then touch 8 consecutive
+//   rows = 8 distinct 32-byte bank windows (row stride = 32 mod 64 bytes), where the natural {8g..8g+7} assignment made
+//   rows r and r+8 collide (2-way conflicts on every transpose read: half of all LDS cycles, measured).
 #include "common.h"
 #include "../../include/buctd_hip.h"
 
@@ -27,8 +30,10 @@ typedef unsigned short u16x4 __attribute__((ext_vector_type(4)));
 #define WG_PRO 96          // halo rows fetched per round of the first stage
 
 template <int NP> struct WGeo;
-template <> struct WGeo<2> { static constexpr int KB = 96, RING = 256; };
-template <> struct WGeo<3> { static constexpr int KB = 32, RING = 192; };   // RING >= KB + 2*WG_MAX_SW + 2
+template <> struct WGeo<2> { static constexpr int KB = 96; };
+template <> struct WGeo<3> { static constexpr int KB = 64; };
+// The X ring holds exactly the R = KB + 2*SW + 2 rows a stage needs (a runtime size: W = 72 -> 214 rows at KB = 64, which
+// is what lets two workgroups of the six-byte-per-element mode share a CU's 160 KB).
 
 struct WG3Args {
   const float* x;
@@ -36,7 +41,7 @@ struct WG3Args {
   float* part;          // [nsplit][Co][9][Ci]
   int N, H, W, Ci, Co;
   int SW, IB, P;
-  int pos_per_split;    // multiple of KB
+  int split_q, split_rem;   // stages per split: q, the first split_rem splits q + 1
   unsigned ib_mul, ib_sh, sw_mul, sw_sh;
 };
 
@@ -78,17 +83,13 @@ __device__ __forceinline__ bf16x8 tr_frag2(const unsigned char* p, const unsigne
   return __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
 }
 
-template <int RING>
-__device__ __forceinline__ int ring_slot(int r) {     // r in [0, 3*RING)
-  if constexpr ((RING & (RING - 1)) == 0) return r & (RING - 1);
-  r -= r >= RING ? RING : 0;
-  r -= r >= RING ? RING : 0;
-  return r;
+__device__ __forceinline__ int ring_slot(int r, int ring) {     // r in [0, 2*ring)
+  return r - (r >= ring ? ring : 0);
 }
 
 template <int NP, int CF>   // channel fragments (of 16) per chunk: 3 -> 48 channels, 2 -> 32
 __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_split_kernel(WG3Args p) {
-  constexpr int KB = WGeo<NP>::KB, RING = WGeo<NP>::RING;
+  constexpr int KB = WGeo<NP>::KB;
   constexpr int CH = CF * 16;
   constexpr int LO = CH * 2;                 // byte stride between the pieces of a row
   constexpr int RS = (CH * 2 * NP) % 64 == 32 ? CH * 2 * NP : CH * 2 * NP + 32;   // row stride = 32 mod 64
@@ -99,15 +100,17 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_split_kernel(WG3Args p) 
   constexpr int NW = (NFR + 3) / 4;          // n-fragments per wave
 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const int R = KB + 2 * p.SW + 2;
+  const int R = KB + 2 * p.SW + 2;                   // rows of one stage = ring size
   unsigned char* Dt = smem;                          // dY tile [KB][RS]
-  unsigned char* Xt = smem + (size_t)KB * RS;        // X  ring [RING][RS]
+  unsigned char* Xt = smem + (size_t)KB * RS;        // X  ring [R][RS]
 
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int t16 = lane & 15, g = lane >> 4;
   const int co0 = blockIdx.x * CH, ci0 = blockIdx.y * CH;
-  const int k_begin = blockIdx.z * p.pos_per_split;
-  int k_end = k_begin + p.pos_per_split;
+  // splits get q or q+1 stages (the first `split_rem` ones one more): no split-count rounding loss
+  const int z = blockIdx.z;
+  const int k_begin = (z * p.split_q + (z < p.split_rem ? z : p.split_rem)) * KB;
+  int k_end = k_begin + (p.split_q + (z < p.split_rem ? 1 : 0)) * KB;
   if (k_end > p.P) k_end = p.P;
   const int halo = p.SW + 1;
 
@@ -162,7 +165,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_split_kernel(WG3Args p) 
       const int idx = t + 256 * q;
       const int row = idx / C4, c4 = (idx - row * C4) * 4;
       if (row < KB)
-        wg_split_store<NP, LO>(Xt + (size_t)ring_slot<RING>(slot0 + row) * RS, c4,
+        wg_split_store<NP, LO>(Xt + (size_t)ring_slot(slot0 + row, R) * RS, c4,
                                ((xmask >> q) & 1u) ? xreg[q] : (f32x4){0.f, 0.f, 0.f, 0.f});
     }
   };
@@ -173,14 +176,15 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_split_kernel(WG3Args p) 
 #pragma unroll
     for (int j = 0; j < NW; ++j) acc[mf][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  // transpose-read lane addressing: lane t16 of group g points at row g*8 + (t16>>2), channels 4*(t16&3)..+3
-  const int lane_row = g * 8 + (t16 >> 2), lane_col = (t16 & 3) * 8;
+  // transpose-read lane addressing: lane t16 of group g points at row g*4 + (t16>>2) (second read: + 16), channels
+  // 4*(t16&3)..+3
+  const int lane_row = g * 4 + (t16 >> 2), lane_col = (t16 & 3) * 8;
   const int lane_off = lane_row * RS + lane_col;
 
   // first stage: the first R - KB rows (the halo) go in synchronously, WG_PRO rows per round with all loads of a
   // round in flight together; the last KB rows of the first stage travel through the steady-state registers
   if (k_begin < k_end) {
-    const int pro = R - KB;                  // = 2*SW + 2 <= 152 < RING: slots 0 .. pro-1, no wrap
+    const int pro = R - KB;                  // = 2*SW + 2 < R: slots 0 .. pro-1, no wrap
     for (int r0 = 0; r0 < pro; r0 += WG_PRO) {
       f32x4 preg[PP];
       unsigned pmask = 0;
@@ -204,7 +208,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_split_kernel(WG3Args p) 
     load_d(k_begin);
     load_x(pro);
   }
-  int slot_new = ring_slot<RING>(R - KB);    // ring slot receiving the first of the KB rows held in xreg
+  int slot_new = R - KB;                     // ring slot receiving the first of the KB rows held in xreg
   int slot_base = 0;                         // ring slot of position (k0 - halo), tap shift 0
   int rel_next = R;                          // first row (from k_begin - halo) of the stage after this one
   for (int k0 = k_begin; k0 < k_end; k0 += KB) {
@@ -215,7 +219,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_split_kernel(WG3Args p) 
       load_d(k0 + KB);
       load_x(rel_next);
     }
-    slot_new = ring_slot<RING>(slot_new + KB);
+    slot_new = ring_slot(slot_new + KB, R);
     rel_next += KB;
     __syncthreads();
 #pragma unroll
@@ -225,7 +229,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_split_kernel(WG3Args p) 
       for (int mf = 0; mf < CF; ++mf) {
         const unsigned char* q = Dt + (size_t)ks * 32 * RS + lane_off + mf * 32;
 #pragma unroll
-        for (int pc = 0; pc < NP; ++pc) a[pc][mf] = tr_frag(q + pc * LO, RS);
+        for (int pc = 0; pc < NP; ++pc) a[pc][mf] = tr_frag(q + pc * LO, 4 * RS);   // second read: rows + 16
       }
 #pragma unroll
       for (int j = 0; j < NW; ++j) {
@@ -233,7 +237,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_split_kernel(WG3Args p) 
         if (nf < NFR) {
           const int tap = nf / CF, cf = nf - tap * CF;
           const int shift = (tap / 3) * p.SW + tap % 3;      // X row of position k + shift(tap) (the ring starts at -halo)
-          const int r0 = ring_slot<RING>(slot_base + lane_row + ks * 32 + shift), r1 = ring_slot<RING>(r0 + 4);
+          const int r0 = ring_slot(slot_base + lane_row + ks * 32 + shift, R), r1 = ring_slot(r0 + 16, R);
           const unsigned char* q0 = Xt + (size_t)r0 * RS + lane_col + cf * 32;
           const unsigned char* q1 = Xt + (size_t)r1 * RS + lane_col + cf * 32;
           bf16x8 b[NP];
@@ -251,7 +255,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_split_kernel(WG3Args p) 
         }
       }
     }
-    slot_base = ring_slot<RING>(slot_base + KB);
+    slot_base = ring_slot(slot_base + KB, R);
   }
 
   // partial slab: [split][co][tap][ci]; accumulator (mf, j, reg): co = co0 + mf*16 + g*4 + reg, ci = ci0 + cf*16 + t16
@@ -298,7 +302,7 @@ __global__ __launch_bounds__(256) void wg3_reduce_kernel(const float* __restrict
 }
 
 // ---------------------------------------------------------------------------------------------- host ----
-struct WG3Plan { int CF, nsplit, pps; size_t lds; };
+struct WG3Plan { int CF, nsplit, q, rem; size_t lds; };
 
 static void wg_magic(unsigned d, unsigned* mul, unsigned* sh) {
   unsigned l = 0;
@@ -309,7 +313,7 @@ static void wg_magic(unsigned d, unsigned* mul, unsigned* sh) {
 
 static bool wg3_plan(int np, int N, int H, int W, int Ci, int Co, WG3Plan* pl) {
   if ((np != 2 && np != 3) || W + 2 > WG_MAX_SW || H < 1 || W < 2) return false;
-  const int kb = np == 3 ? WGeo<3>::KB : WGeo<2>::KB, ring = np == 3 ? WGeo<3>::RING : WGeo<2>::RING;
+  const int kb = np == 3 ? WGeo<3>::KB : WGeo<2>::KB;
   int cf;
   if (Ci % 48 == 0 && Co % 48 == 0) cf = 3;
   else if (Ci % 32 == 0 && Co % 32 == 0) cf = 2;
@@ -317,18 +321,19 @@ static bool wg3_plan(int np, int N, int H, int W, int Ci, int Co, WG3Plan* pl) {
   const int ch = cf * 16;
   const long P = (long)N * (H + 1) * (W + 2) + (W + 2);
   const long pairs = (long)(Co / ch) * (Ci / ch);
-  long want = (384 + pairs - 1) / pairs;          // ~1.5 workgroups per CU (measured flat optimum 320..512 inside the
-                                                  // train step): partial-slab traffic grows with the split
+  // two resident workgroups per CU (512 in all) when one (co, ci) chunk pair exists; fewer splits per pair otherwise
+  // (partial-slab traffic grows with the split).  Splits take q or q + 1 stages, so no rounding loss.
+  long want = ((np == 3 ? 512 : 384) + pairs - 1) / pairs;
   const long stages = (P + kb - 1) / kb;
   if (want > stages) want = stages;
   if (want < 1) want = 1;
-  const long per = (stages + want - 1) / want;    // stages per split
   pl->CF = cf;
-  pl->pps = (int)(per * kb);
-  pl->nsplit = (int)((P + pl->pps - 1) / pl->pps);
+  pl->nsplit = (int)want;
+  pl->q = (int)(stages / want);
+  pl->rem = (int)(stages % want);
   int rs = ch * 2 * np;
   if (rs % 64 != 32) rs += 32;
-  pl->lds = (size_t)kb * rs + (size_t)ring * rs;
+  pl->lds = (size_t)(2 * kb + 2 * (W + 2) + 2) * rs;      // dY tile (KB rows) + X ring (KB + 2*SW + 2 rows)
   return pl->lds <= 160 * 1024;
 }
 
@@ -369,7 +374,7 @@ static int wg3_run(int np, int N, int H, int W, int Ci, int Co, const float* x, 
   const long P = (long)N * a.IB + a.SW;
   BUCTD_CHECK_ARG(P < 2147483647L, "buctd_conv3x3_wgrad (split bf16): tensor too large");
   a.P = (int)P;
-  a.pos_per_split = pl.pps;
+  a.split_q = pl.q; a.split_rem = pl.rem;
   wg_magic((unsigned)a.IB, &a.ib_mul, &a.ib_sh);
   wg_magic((unsigned)a.SW, &a.sw_mul, &a.sw_sh);
   hipStream_t st = (hipStream_t)stream;

@@ -14,7 +14,7 @@ import torch.nn.functional as F
 
 pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
-TOL = {"bf16x6": 2e-6, "fp32": 2e-6, "bf16x3": 5e-5}
+TOL = {"bf16x6": 2e-6, "fp32": 1e-5, "bf16x3": 5e-5}   # fp32 kernel: fp32 partial sums over up to 3456 products
 
 
 def nhwc(t):
@@ -85,9 +85,13 @@ def test_bf16x6_split_is_exact_on_hard_operands(dev):
         w = mw * torch.exp2(torch.randint(-8, 9, (Co, Ci, 3, 3), generator=g).float())
         ref = F.conv2d(x.double(), w.double(), None, 1, 1)
         mag = F.conv2d(x.double().abs(), w.double().abs(), None, 1, 1)      # sum of |products|: the rounding yardstick
-        y = ops.conv_fwd(nhwc(x).to(dev), w.contiguous(memory_format=torch.channels_last).to(dev), None, 1, 1)
-        rel = ((nchw(y).cpu().double() - ref).abs() / mag).max().item()
-        assert rel <= 4e-7, f"bf16x6 error {rel:.3e} of the summed product magnitudes (fp32 FMA chain: ~1e-7)"
+        xd, wd = nhwc(x).to(dev), w.contiguous(memory_format=torch.channels_last).to(dev)
+        rel = ((nchw(ops.conv_fwd(xd, wd, None, 1, 1)).cpu().double() - ref).abs() / mag).max().item()
+        ops.set_conv_math("fp32")
+        rel32 = ((nchw(ops.conv_fwd(xd, wd, None, 1, 1)).cpu().double() - ref).abs() / mag).max().item()
+        print(f"error / sum|products|: bf16x6 {rel:.3e}, exact-fp32 MFMA kernel {rel32:.3e}")
+        # an fp32 FMA chain over K = 432 products: <= K * 2^-24 worst case, ~sqrt(K) * 2^-24 = 1.2e-6 typical
+        assert rel <= 2e-6 and rel <= 3 * rel32 + 2e-7, f"bf16x6 {rel:.3e} vs fp32 kernel {rel32:.3e}"
     finally:
         ops.set_conv_math(old)
 

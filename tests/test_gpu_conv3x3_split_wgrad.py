@@ -12,7 +12,7 @@ pytestmark = pytest.mark.gpu
 SHAPES = [(2, 24, 18, 48, 48), (3, 12, 9, 384, 384), (2, 17, 13, 96, 96), (2, 20, 14, 64, 64), (4, 6, 5, 192, 192),
           (2, 9, 7, 32, 128), (2, 13, 11, 48, 96), (8, 96, 72, 48, 48), (2, 11, 10, 64, 256), (32, 12, 9, 96, 48),
           (1, 2, 2, 48, 48), (2, 3, 73, 32, 32)]
-TOL = {"bf16x6": 3e-6, "fp32": 3e-6, "bf16x3": 5e-5}
+TOL = {"bf16x6": 3e-6, "fp32": 1e-5, "bf16x3": 5e-5}
 
 
 @pytest.mark.parametrize("mode", ["bf16x6", "bf16x3", "fp32"])
