@@ -103,26 +103,36 @@ __device__ __forceinline__ void c3_epilogue(const C3Args& p, f32x4 (&acc)[MF][NF
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int i16 = lane & 15, g = lane >> 4;
   const int wave_m = wave % WM, wave_n = wave / WM;
-  // The tile goes through LDS (the A tile is dead after the last step's barrier) so that every output row leaves as
-  // 16-byte pieces of one contiguous run instead of 64-byte column slivers of four rows.
-  constexpr int MR = MF * 16;              // rows of this wave's tile
+  // The tile goes through LDS (the A tile is dead by now) so that every output row leaves as 16-byte pieces of one
+  // contiguous run instead of 64-byte column slivers of four rows.
+  constexpr int MR = MF * 16;              // rows of this wave's tile (<= 128)
+  constexpr int RH = (MR + 63) / 64;       // 64-row halves: lane r owns rows r and r + 64
   constexpr int LD = NF * 16 + 4;          // staging row stride in floats: 4*LD = 16 mod 64 keeps the writes conflict-free
   constexpr int EP = MF >= 2 ? 2 : 1;      // 16-row fragments staged per pass
+  static_assert(MR <= 128, "c3_epilogue: at most 128 rows per wave");
   float* stg = reinterpret_cast<float*>(smem) + wave * (EP * 16 * LD);
-  int* rowoff = reinterpret_cast<int*>(smem) + 4 * EP * 16 * LD + wave * 64;
-  int myoff = -1;                          // lane r: element offset of output row r of this wave (-1: pad position)
-  if (lane < MR) {
-    const int pp = p0 + wave_m * MR + lane;
-    if (pp < p.P) {
-      const int n = fast_div(pp, p.ib_mul, p.ib_sh);
-      const int rem = pp - n * p.IB;
-      const int yy = fast_div(rem, p.sw_mul, p.sw_sh), xx = rem - yy * p.SW;
-      if (n < p.N && yy >= 1 && xx >= 1 && xx <= p.W) myoff = ((n * p.H + yy - 1) * p.W + xx - 1) * p.Co;
+  int* rowoff = reinterpret_cast<int*>(smem) + 4 * EP * 16 * LD + wave * 128;
+  // element offset of output row r of this wave (-1: pad position)
+  unsigned long long vmask[RH];
+  int cnt = 0;
+#pragma unroll
+  for (int h = 0; h < RH; ++h) {
+    int myoff = -1;
+    const int r = lane + 64 * h;
+    if (r < MR) {
+      const int pp = p0 + wave_m * MR + r;
+      if (pp < p.P) {
+        const int n = fast_div(pp, p.ib_mul, p.ib_sh);
+        const int rem = pp - n * p.IB;
+        const int yy = fast_div(rem, p.sw_mul, p.sw_sh), xx = rem - yy * p.SW;
+        if (n < p.N && yy >= 1 && xx >= 1 && xx <= p.W) myoff = ((n * p.H + yy - 1) * p.W + xx - 1) * p.Co;
+      }
     }
+    vmask[h] = __ballot(myoff >= 0);
+    cnt += __popcll(vmask[h]);
+    rowoff[r] = myoff;
   }
-  const unsigned long long vmask = __ballot(myoff >= 0);
-  const int cnt = __popcll(vmask);
-  rowoff[lane] = myoff;
+  auto valid = [&](int row) -> bool { return (vmask[row >> 6] >> (row & 63)) & 1ull; };
   const int grp = bx * WM + wave_m;
   if (p.stats && p.counts && by == 0 && wave_n == 0 && lane == 0) p.counts[grp] = cnt;
   const int ncol0 = n0 + wave_n * NF * 16;
@@ -137,8 +147,7 @@ __device__ __forceinline__ void c3_epilogue(const C3Args& p, f32x4 (&acc)[MF][NF
 #pragma unroll
       for (int mf = 0; mf < MF; ++mf)
 #pragma unroll
-        for (int rg = 0; rg < 4; ++rg)
-          s1 += ((vmask >> (mf * 16 + g * 4 + rg)) & 1) ? acc[mf][nf][rg] + bv[nf] : 0.f;
+        for (int rg = 0; rg < 4; ++rg) s1 += valid(mf * 16 + g * 4 + rg) ? acc[mf][nf][rg] + bv[nf] : 0.f;
       s1 += __shfl_xor(s1, 16, 64);
       s1 += __shfl_xor(s1, 32, 64);
       const float mean = s1 * inv_cnt;
@@ -148,7 +157,7 @@ __device__ __forceinline__ void c3_epilogue(const C3Args& p, f32x4 (&acc)[MF][NF
 #pragma unroll
         for (int rg = 0; rg < 4; ++rg) {
           const float d = acc[mf][nf][rg] + bv[nf] - mean;
-          s2 += ((vmask >> (mf * 16 + g * 4 + rg)) & 1) ? d * d : 0.f;
+          s2 += valid(mf * 16 + g * 4 + rg) ? d * d : 0.f;
         }
       s2 += __shfl_xor(s2, 16, 64);
       s2 += __shfl_xor(s2, 32, 64);
@@ -384,7 +393,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_split_kernel(C3Args p) {
 //     With six MFMAs per product the fragment stream needs ~31 B/clk/CU of the 64 B/clk L1 - half of what the
 //     three-MFMA mode would need, which is why that mode keeps its LDS stage.
 // Two taps per K = 32 MFMA (lanes 0-31 feed tap 2s, lanes 32-63 tap 2s+1; the 10th half-step has zero weights).
-template <int MF, int NF, int WM, int WN>
+template <int MF, int NF, int WM, int WN, bool DBUF>
 __global__ __launch_bounds__(256, 2) void conv3x3_x6_kernel(C3Args p) {
   constexpr int ROWB = Geo<3>::ROWB, PST = Geo<3>::PST, CPR = Geo<3>::CPR;
   constexpr int BM = WM * MF * 16, BN = WN * NF * 16;
@@ -392,7 +401,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_x6_kernel(C3Args p) {
   constexpr int PA = (BM + 2 * MAX_SW + 2 + RPP - 1) / RPP;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int arows = p.na * 32;
-  const size_t abytes = (size_t)arows * ROWB;                    // one A buffer; smem = [2][arows][ROWB]
+  const size_t abytes = DBUF ? (size_t)arows * ROWB : 0;         // one A buffer; smem = [DBUF ? 2 : 1][arows][ROWB]
 
   const int t = threadIdx.x, lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);      // wave-uniform: keeps the B addressing scalar
@@ -443,7 +452,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_x6_kernel(C3Args p) {
   const unsigned char* bptr = p.wp + ((size_t)(n0 / 16 + wave_n * NF) * 3) * 1024;   // scalar base
   const int blane = lane * 16;                                                        // the only per-lane part
   const size_t bstep = (size_t)(p.Co / 16) * 3 * 1024;
-  bf16x8 bc[3][NF];
+  constexpr bool BPF = MF < 8;       // step-ahead B prefetch (36 more registers)
+  bf16x8 bc[3][NF], bn[BPF ? 3 : 1][BPF ? NF : 1];      // fragments of the current step / of the next one (in flight)
   auto load_b = [&](int gs, bf16x8 (&dst)[3][NF]) {
     const unsigned char* src = bptr + (size_t)gs * bstep;
 #pragma unroll
@@ -458,25 +468,33 @@ __global__ __launch_bounds__(256, 2) void conv3x3_x6_kernel(C3Args p) {
 #pragma unroll
     for (int nf = 0; nf < NF; ++nf) acc[mf][nf] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  const int nchunks = p.Ci / 16;
+  const int nchunks = p.Ci / 16, last_step = nchunks * 5 - 1;
   const size_t aoff = (size_t)(wave_m * MF * 16 + i16) * ROWB + (g & 1) * 16;
   const bool lowk = g < 2;
   int gs = 0;
 
-  // one chunk = 5 unrolled steps.  The B fragments of a step are fetched at its top into the one register set (a second
-  // set for a step-ahead prefetch does not fit beside 48 accumulators: it spills); the L2 latency is covered by the
-  // other wave of the SIMD and by the A reads
+  // one chunk = 5 unrolled steps.  The B fragments travel one step ahead: a step first takes over the set fetched
+  // during the previous step (register moves - indexing two sets by step parity made the compiler keep copies of both
+  // and spill), then issues the fetch of the next step's set, whose L2 latency the step's MFMAs cover
   auto run_chunk = [&](int ch) {
     const unsigned char* abase = smem + (ch & 1) * abytes + aoff;
 #pragma unroll
     for (int s = 0; s < 5; ++s) {
-      if (s == 2 && ch + 1 < nchunks) {            // next chunk: registers -> pieces -> the other A buffer
+      if (DBUF && s == 2 && ch + 1 < nchunks) {    // next chunk: registers -> pieces -> the other A buffer
         // done while the fewest registers are live (no B prefetch in flight, no A fragments): the split needs ~60
         store_a(smem + ((ch + 1) & 1) * abytes);
         if (ch + 2 < nchunks) load_a((ch + 2) * 16);
         __builtin_amdgcn_sched_barrier(0);
       }
-      load_b(gs, bc);
+      if constexpr (BPF) {
+#pragma unroll
+        for (int nf = 0; nf < NF; ++nf)
+#pragma unroll
+          for (int q = 0; q < 3; ++q) bc[q][nf] = bn[q][nf];
+        load_b(gs < last_step ? gs + 1 : last_step, bn);
+      } else {
+        load_b(gs, bc);          // 144 MFMAs per step: the fetch latency is small against them, the registers are not
+      }
       const int tap0 = 2 * s, tap1 = 2 * s + 1 < 9 ? 2 * s + 1 : 2 * s;
       const int o0 = ((tap0 / 3) * p.SW + tap0 % 3) * ROWB, o1 = ((tap1 / 3) * p.SW + tap1 % 3) * ROWB;
       const unsigned char* ap = abase + (lowk ? o0 : o1);
@@ -508,12 +526,18 @@ __global__ __launch_bounds__(256, 2) void conv3x3_x6_kernel(C3Args p) {
   };
 
   load_a(0);
+  if constexpr (BPF) load_b(0, bn);
   store_a(smem);
   if (nchunks > 1) load_a(16);
   __syncthreads();
   for (int ch = 0; ch < nchunks; ++ch) {
+    if (!DBUF && ch > 0) {   // single buffer (the largest position tiles): restage between two barriers
+      store_a(smem);
+      if (ch + 1 < nchunks) load_a((ch + 1) * 16);
+      __syncthreads();
+    }
     run_chunk(ch);
-    __syncthreads();       // chunk ch+1 is complete in its buffer; nobody reads buffer (ch & 1) any more
+    __syncthreads();       // DBUF: chunk ch+1 is complete in its buffer; nobody reads this chunk's buffer any more
   }
   c3_epilogue<MF, NF, WM, WN>(p, acc, smem, bx, by, p0, n0);
 }
@@ -648,12 +672,20 @@ static bool c3_plan(int np, int N, int H, int W, int Ci, int Co, C3Plan* pl) {
     const long blocks = ((P + wm * cand[i] * 16 - 1) / (wm * cand[i] * 16)) * (Co / bn);
     if (blocks >= 320) { mf = cand[i]; break; }
   }
+  bool single = false;
+  if (np == 3 && nf == 3 && wn == 1 && Co == bn) {
+    // 512-position tiles in ONE round of workgroups (2 resident per CU = 512 slots) instead of 1.75 rounds of
+    // 256-position tiles: the 48-channel branch at N*H*W >= ~115k positions (single A buffer: 64.5 KB at W = 72)
+    const long b8 = (P + 511) / 512;
+    if (b8 > 256 && b8 <= 512) { mf = 8; single = true; }
+  }
   pl->MF = mf; pl->NF = nf; pl->WM = wm; pl->WN = wn; pl->BM = wm * mf * 16; pl->BN = bn;
   pl->na = (pl->BM + 2 * (W + 2) + 2 + 31) / 32;
-  const size_t stage = (size_t)4 * (mf >= 2 ? 2 : 1) * 16 * (nf * 16 + 4) * 4 + 4 * 64 * 4;   // epilogue staging + row offsets
-  if (np == 3) {            // two A buffers, no B stage
-    while ((size_t)2 * pl->na * 32 * rowb < stage) ++pl->na;
-    pl->lds = (size_t)2 * pl->na * 32 * rowb;
+  const size_t stage = (size_t)4 * (mf >= 2 ? 2 : 1) * 16 * (nf * 16 + 4) * 4 + 4 * 128 * 4;   // epilogue staging + row offsets
+  if (np == 3) {            // two A buffers (one for the 512-position tiles), no B stage
+    const int nb = single ? 1 : 2;
+    while ((size_t)nb * pl->na * 32 * rowb < stage) ++pl->na;
+    pl->lds = (size_t)nb * pl->na * 32 * rowb;
   } else {
     while ((size_t)pl->na * 32 * rowb < stage) ++pl->na;
     pl->lds = (size_t)pl->na * 32 * rowb + (size_t)2 * pl->BN * blds;
@@ -667,8 +699,8 @@ template <int NP, int MF, int NF, int WM, int WN>
 static int c3_launch(const C3Args& a, const C3Plan& pl, hipStream_t st) {
   static bool attr_set = false;     // idempotent attribute call: a race at first use only repeats it
   void (*fn)(C3Args);
-  if constexpr (NP == 3) fn = conv3x3_x6_kernel<MF, NF, WM, WN>;
-  else fn = conv3x3_split_kernel<NP, MF, NF, WM, WN>;
+  if constexpr (NP == 3) fn = MF >= 8 ? conv3x3_x6_kernel<MF, NF, WM, WN, false> : conv3x3_x6_kernel<MF, NF, WM, WN, true>;
+  else fn = conv3x3_split_kernel<NP, (MF > 4 ? 4 : MF), NF, WM, WN>;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        160 * 1024);
@@ -689,6 +721,7 @@ static int c3_dispatch(const C3Args& a, const C3Plan& pl, hipStream_t st) {
 #define C3_CASE(mf, nf, wm, wn) \
   if (pl.MF == mf && pl.NF == nf && pl.WN == wn) return c3_launch<NP, mf, nf, wm, wn>(a, pl, st);
 #define C3_MF(nf, wm, wn) C3_CASE(4, nf, wm, wn) C3_CASE(2, nf, wm, wn) C3_CASE(1, nf, wm, wn)
+  if constexpr (NP == 3) { C3_CASE(8, 3, 4, 1) }
   C3_MF(1, 4, 1) C3_MF(2, 4, 1) C3_MF(3, 4, 1) C3_MF(3, 2, 2)
   C3_CASE(2, 4, 4, 1) C3_CASE(1, 4, 4, 1) C3_CASE(2, 4, 2, 2) C3_CASE(1, 4, 2, 2)
 #undef C3_MF

@@ -277,23 +277,35 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_split_kernel(WG3Args p) 
   }
 }
 
-// slab reduction: 32 float4 columns x 8 split-lanes per workgroup, so even the 48x432 gradient (5184 float4)
-// spreads over 162 workgroups and every split slab is read by 8 independent lanes
+// slab reduction: 16 float4 columns x 16 split-lanes per workgroup: the 48x432 gradient (5184 float4) spreads over 324
+// workgroups, every split slab is read by 16 independent lanes with four loads in flight each (the 512 slabs of the
+// six-MFMA mode are 42 MB: at 8 split-lanes and 162 workgroups this pass took 27 us)
 __global__ __launch_bounds__(256) void wg3_reduce_kernel(const float* __restrict__ part, float* __restrict__ out, long n,
                                                          int nsplit, int accumulate) {
-  __shared__ f32x4 sm[8][32];
+  __shared__ f32x4 sm[16][16];
   const long n4 = n >> 2;
-  const int col = threadIdx.x & 31, zl = threadIdx.x >> 5;
-  for (long base = (long)blockIdx.x * 32; base < n4; base += (long)gridDim.x * 32) {
+  const int col = threadIdx.x & 15, zl = threadIdx.x >> 4;
+  for (long base = (long)blockIdx.x * 16; base < n4; base += (long)gridDim.x * 16) {
     const long i = base + col;
-    f32x4 s = (f32x4){0.f, 0.f, 0.f, 0.f};
-    if (i < n4)
-      for (int z = zl; z < nsplit; z += 8) s += reinterpret_cast<const f32x4*>(part + (long)z * n)[i];
-    sm[zl][col] = s;
+    f32x4 s0 = (f32x4){0.f, 0.f, 0.f, 0.f}, s1 = s0, s2 = s0, s3 = s0;
+    if (i < n4) {
+      const f32x4* src = reinterpret_cast<const f32x4*>(part) + i;
+      const long zs = n4;                         // float4 stride between slabs
+      int z = zl;
+      for (; z + 48 < nsplit; z += 64) {
+        s0 += src[(long)z * zs];
+        s1 += src[(long)(z + 16) * zs];
+        s2 += src[(long)(z + 32) * zs];
+        s3 += src[(long)(z + 48) * zs];
+      }
+      for (; z < nsplit; z += 16) s0 += src[(long)z * zs];
+    }
+    sm[zl][col] = (s0 + s1) + (s2 + s3);
     __syncthreads();
     if (zl == 0 && i < n4) {
+      f32x4 s = sm[0][col];
 #pragma unroll
-      for (int k = 1; k < 8; ++k) s += sm[k][col];
+      for (int k = 1; k < 16; ++k) s += sm[k][col];
       if (accumulate) s += reinterpret_cast<const f32x4*>(out)[i];
       reinterpret_cast<f32x4*>(out)[i] = s;
     }
@@ -383,7 +395,7 @@ static int wg3_run(int np, int N, int H, int W, int Ci, int Co, const float* x, 
   else rc = pl.CF == 3 ? wg3_launch<2, 3>(a, pl, st) : wg3_launch<2, 2>(a, pl, st);
   if (rc) return rc;
   const long n = (long)Co * 9 * Ci;
-  int blocks = ceil_div(n / 4, 32);
+  int blocks = ceil_div(n / 4, 16);
   if (blocks > 4096) blocks = 4096;
   hipLaunchKernelGGL(wg3_reduce_kernel, dim3(blocks), dim3(256), 0, st, (const float*)workspace, dw, n, pl.nsplit,
                      accumulate);

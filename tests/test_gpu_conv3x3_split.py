@@ -36,7 +36,7 @@ def mode(request):
 
 SHAPES = [(2, 24, 18, 48, 48), (3, 12, 9, 384, 384), (2, 17, 13, 96, 96), (2, 20, 14, 64, 64), (4, 6, 5, 192, 192),
           (2, 10, 8, 16, 16), (2, 9, 7, 32, 128), (2, 13, 11, 48, 96), (8, 96, 72, 48, 48), (2, 11, 10, 64, 256),
-          (1, 1, 1, 48, 48), (2, 3, 73, 32, 32)]
+          (1, 1, 1, 48, 48), (2, 3, 73, 32, 32), (20, 96, 72, 48, 48)]   # the last one takes the 512-position tiles
 
 
 @pytest.mark.parametrize("shape", SHAPES)
