@@ -261,6 +261,20 @@ int buctd_flipback_avg(const float* a, const float* b, const int32_t* perm, int 
 int buctd_adam_step(float* p, const float* g, float* m, float* v, long n, float lr, float beta1, float beta2,
                     float eps, int step, float gscale, void* stream);
 
+/* ------------------------------------------------------------------- NMS --- */
+/* Greedy box NMS - replaces _nms(int* keep_out, int* num_out, const float* boxes_host, int boxes_num, int boxes_dim,
+ * float nms_overlap_thresh, int device_id) of lib/nms/gpu_nms.hpp:1-2 / nms_kernel.cu:94-143 (kernel 33-77).
+ * Differences of form, not of result: `boxes` ([boxes_num][boxes_dim], x1 y1 x2 y2 first, sorted by descending score
+ * like gpu_nms.pyx:27-30 does before the call) is a DEVICE pointer, so are keep_out ([boxes_num] ints) and num_out;
+ * the suppression mask lives in caller-provided workspace and the greedy sweep runs on the device as well.
+ * A box is suppressed when IoU (with the +1 pixel convention) with an earlier kept box is > thresh. */
+size_t buctd_nms_workspace(int boxes_num);
+int buctd_nms(int* keep_out, int* num_out, const float* boxes, int boxes_num, int boxes_dim, float thresh,
+              void* workspace, size_t workspace_bytes, void* stream);
+/* cpu_nms(dets [n][5] float32, thresh) of lib/nms/cpu_nms.pyx:20-71 as plain host C++ (suppression at IoU >= thresh);
+ * order = argsort of the scores, descending, computed by the caller like the .pyx does with numpy. */
+int buctd_cpu_nms(const float* dets, int n, const int* order, float thresh, int* keep_out, int* num_out);
+
 #ifdef __cplusplus
 }
 #endif

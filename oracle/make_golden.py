@@ -232,6 +232,48 @@ def target_case():
     print("  target: generate_target (executed reference body) == oracle, incl. out-of-bounds joints")
 
 
+def nms_case():
+    """lib/nms/nms.py imported from the reference (its two Cython extension modules stubbed - they cannot be built
+    here: np.float / np.int in the .pyx sources) vs the oracle restatement; the reference's outputs become nms.npz."""
+    for name in ("nms.cpu_nms", "nms.gpu_nms"):
+        m = types.ModuleType(name)
+        m.cpu_nms = m.gpu_nms = None
+        sys.modules[name] = m
+    from nms import nms as rn
+    from oracle import nms as on
+    rec = {}
+    for tag, n, seed, thr in (("a", 300, 1, 0.3), ("b", 1000, 2, 0.5), ("c", 65, 3, 0.1)):
+        d = on.make_boxes(n, seed)
+        keep = [int(i) for i in rn.nms(d, thr)]
+        assert keep == on.nms(d, thr), "nms " + tag
+        # cpu_nms.pyx differs from nms.py only in >= vs > and float32 arithmetic: same keep list unless an overlap
+        # lands within rounding of the threshold (checked not to happen on these inputs)
+        assert keep == on.nms(d, thr, strict=False), "cpu_nms restatement " + tag
+        rec[f"boxes_{tag}"], rec[f"thr_{tag}"], rec[f"keep_{tag}"] = d, np.float64(thr), np.array(keep, np.int64)
+    for tag, n, k, seed in (("p", 40, 17, 2), ("q", 64, 14, 5)):
+        db = on.make_poses(n, k, seed)
+        sig = None if k == 17 else np.array([.79, .79, .72, .72, .62, .62, 1.07, 1.07, .87, .87, .89, .89, .79, .79]) / 10.0
+        kp = np.array([p["keypoints"].flatten() for p in db])
+        ar = np.array([p["area"] for p in db])
+        iou_r = rn.oks_iou(kp[0], kp[1:], ar[0], ar[1:], sig)
+        iou_v = rn.oks_iou(kp[0], kp[1:], ar[0], ar[1:], sig, 0.3)
+        assert np.allclose(iou_r, on.oks_iou(kp[0], kp[1:], ar[0], ar[1:], sig), atol=1e-15)
+        assert np.allclose(iou_v, on.oks_iou(kp[0], kp[1:], ar[0], ar[1:], sig, 0.3), atol=1e-15)
+        k1 = [int(i) for i in rn.oks_nms(db, 0.6, sig)]
+        k2 = [int(i) for i in rn.oks_nms(db, 0.6, sig, 0.3)]
+        k3 = [int(i) for i in rn.soft_oks_nms(db, 0.6, sig)]
+        assert k1 == [int(i) for i in on.oks_nms(db, 0.6, sig)] and k2 == [int(i) for i in on.oks_nms(db, 0.6, sig, 0.3)]
+        assert k3 == [int(i) for i in on.soft_oks_nms(db, 0.6, sig)]
+        assert 0 < len(k1) < n, "the pose set must exercise suppression"
+        rec.update({f"kpts_{tag}": kp, f"areas_{tag}": ar, f"scores_{tag}": np.array([p["score"] for p in db]),
+                    f"oks_{tag}": iou_r, f"oksvis_{tag}": iou_v, f"oksnms_{tag}": np.array(k1, np.int64),
+                    f"oksnmsvis_{tag}": np.array(k2, np.int64), f"softnms_{tag}": np.array(k3, np.int64)})
+        if sig is not None:
+            rec[f"sigmas_{tag}"] = sig
+    np.savez_compressed(os.path.join(OUT, "nms.npz"), **rec)
+    print("  nms: nms / oks_iou / oks_nms / soft_oks_nms of the reference == oracle (+ cpu_nms restatement)")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--fast", action="store_true")
@@ -248,6 +290,7 @@ def main():
     if not args.only:
         core_cases()
         target_case()
+        nms_case()
     small = ["prenet_w16_96x64", "coam_w16_96x64_colored", "coam_w16_96x64_mono_default_att",
              "coam_w16_96x64_stacked_2heads", "transpose_w16_96x64", "resnet18_96x64"]
     full = ["coam_w48_384x288", "prenet_w32_256x192", "resnet50_256x192", "prenet_w48_384x288", "transpose_a6_256x192"]
