@@ -103,6 +103,8 @@ SIGNATURES = {
     "buctd_layernorm_bwd": (_I, [_P, _P, _P, _P, _P, _L, _I, _P, _P, _P, _I, _P, _SZ, _P]),
     "buctd_joints_mse": (_I, [_P, _P, _P, _I, _I, _I, _P, _P, _F, _P, _SZ, _P]),
     "buctd_argmax_decode": (_I, [_P, _I, _I, _I, _P, _P, _P, _P]),
+    "buctd_warp_affine_norm": (_I, [_P, _I, _I, _I, _P, _P, _P, _L, _P, _P]),
+    "buctd_cond_render_into": (_I, [_P, _I, _P, _I, _I, _I, _I, _I, _I, _P, _L, _P, _SZ, _P]),
     "buctd_nms_workspace": (_SZ, [_I]),
     "buctd_nms": (_I, [_P, _P, _P, _I, _I, _F, _P, _SZ, _P]),
     "buctd_cpu_nms": (_I, [_P, _I, _P, _F, _P, _P]),

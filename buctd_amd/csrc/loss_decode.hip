@@ -249,7 +249,7 @@ __global__ __launch_bounds__(256) void cond_render_kernel(const float* __restric
 }
 __global__ __launch_bounds__(256) void cond_normalise_kernel(const float* __restrict__ raw,
                                                              const float* __restrict__ maxbuf, long per_img,
-                                                             int truncate, float* __restrict__ cond) {
+                                                             int truncate, float* __restrict__ cond, long cond_stride) {
   const int b = blockIdx.y;
   const float am = maxbuf[b];
   // heatmap /= am / 255  (skipped when the image is empty)
@@ -257,7 +257,7 @@ __global__ __launch_bounds__(256) void cond_normalise_kernel(const float* __rest
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < per_img; i += (long)gridDim.x * 256) {
     const float v = raw[b * per_img + i];
     const float o = am == 0.f ? v : v / div;
-    cond[b * per_img + i] = truncate ? truncf(o) : o;
+    cond[b * cond_stride + i] = truncate ? truncf(o) : o;
   }
 }
 extern "C" size_t buctd_cond_render_workspace(int B, int Cc, int H, int W) {
@@ -265,6 +265,13 @@ extern "C" size_t buctd_cond_render_workspace(int B, int Cc, int H, int W) {
 }
 extern "C" int buctd_cond_render(const float* joints, int js, const float* colors, int B, int K, int Cc, int H, int W,
                                  int truncate, float* cond, void* workspace, size_t workspace_bytes, void* stream) {
+  return buctd_cond_render_into(joints, js, colors, B, K, Cc, H, W, truncate, cond, (long)Cc * H * W, workspace,
+                                workspace_bytes, stream);
+}
+extern "C" int buctd_cond_render_into(const float* joints, int js, const float* colors, int B, int K, int Cc, int H,
+                                      int W, int truncate, float* cond, long cond_batch_stride, void* workspace,
+                                      size_t workspace_bytes, void* stream) {
+  BUCTD_CHECK_ARG(cond_batch_stride >= (long)Cc * H * W, "buctd_cond_render_into: batch stride smaller than one image");
   BUCTD_CHECK_ARG(joints && cond && B > 0 && K > 0 && K <= 64 && Cc >= 1 && Cc <= 4 && H > 0 && W > 0 && js >= 2,
                   "buctd_cond_render: bad argument (K<=64, 1<=Cc<=4)");
   const size_t need = buctd_cond_render_workspace(B, Cc, H, W);
@@ -296,7 +303,7 @@ extern "C" int buctd_cond_render(const float* joints, int js, const float* color
   const long per_img = (long)Cc * H * W;
   dim3 grid2(ceil_div(per_img, 256 * 4), B);
   hipLaunchKernelGGL(cond_normalise_kernel, grid2, dim3(256), 0, st, (const float*)raw, (const float*)maxbuf, per_img,
-                     truncate, cond);
+                     truncate, cond, cond_batch_stride);
   BUCTD_CHECK_LAUNCH("buctd_cond_render(normalise)");
   return BUCTD_OK;
 }

@@ -261,6 +261,28 @@ int buctd_flipback_avg(const float* a, const float* b, const int32_t* perm, int 
 int buctd_adam_step(float* p, const float* g, float* m, float* v, long n, float lr, float beta1, float beta2,
                     float eps, int step, float gscale, void* stream);
 
+/* ------------------------------------------------------- sample pipeline --- */
+/* Person crop of the per-sample pipeline (dataset/JointsDataset.py:287-294): cv2.warpAffine(img_u8, M, (w, h),
+ * flags=INTER_LINEAR) restated bit for bit (OpenCV's fixed-point bilinear, BORDER_CONSTANT 0), fused with
+ * transforms.ToTensor + Normalize(mean, std); written into channels [0, 3) of the NCHW network input
+ * (out + b * out_batch_stride).  flip: the source is mirrored horizontally first (JointsDataset.py:244);
+ * rw > 0: source pixels outside the rectangle (rx, ry, rw, rh) read as zero (NEW_AUGMENTATION, 272-285).
+ * crop_u8 (NULL ok): the 8-bit crop [B][h][w][3] (meta['input_img']).  items live in device memory. */
+typedef struct {
+  const unsigned char* src; /* uint8 [H][W][3], device memory */
+  int H, W;
+  int flip;
+  int rx, ry, rw, rh;
+  double m[6];              /* 2x3 forward matrix (source -> crop), as utils.transforms.get_affine_transform returns it */
+} buctd_warp_item;
+int buctd_warp_affine_norm(const buctd_warp_item* items_device, int B, int dst_h, int dst_w, const float* mean3,
+                           const float* std3, float* out, long out_batch_stride, unsigned char* crop_u8, void* stream);
+/* buctd_cond_render with a destination batch stride (in floats): renders straight into channels [3, 3+Cc) of the
+ * network input. */
+int buctd_cond_render_into(const float* joints, int js, const float* colors, int B, int K, int Cc, int H, int W,
+                           int truncate, float* cond, long cond_batch_stride, void* workspace, size_t workspace_bytes,
+                           void* stream);
+
 /* ------------------------------------------------------------------- NMS --- */
 /* Greedy box NMS - replaces _nms(int* keep_out, int* num_out, const float* boxes_host, int boxes_num, int boxes_dim,
  * float nms_overlap_thresh, int device_id) of lib/nms/gpu_nms.hpp:1-2 / nms_kernel.cu:94-143 (kernel 33-77).

@@ -84,6 +84,11 @@ def get_affine_transform(center, scale, rot, output_size, shift=np.array([0, 0],
     return np.linalg.solve(A, b.astype(np.float64)).T  # 2x3
 
 
+def affine_transform(pt, t):
+    """reference lib/utils/transforms.py:121-124."""
+    return np.dot(t, np.array([pt[0], pt[1], 1.]).T)[:2]
+
+
 def transform_preds(coords, center, scale, output_size):
     """reference lib/utils/transforms.py:78-83."""
     out = np.zeros(coords.shape)
