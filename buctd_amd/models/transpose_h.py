@@ -31,7 +31,14 @@ class MultiheadAttention(nn.Module):
     def forward(self, qin, src):
         """q = k = qin (src + pos), v = src; returns the attention output [B, T, d]."""
         qk, v = ops_seq.InProjection.apply(qin, src, self.in_proj_weight, self.in_proj_bias)
-        out = ops.PositionAttention.apply(qk, None, v, self.num_heads, float(self.dropout), self.training)
+        p_eff = float(self.dropout) if self.training else 0.0
+        needs_grad = torch.is_grad_enabled() and (qk.requires_grad or v.requires_grad)
+        if p_eff == 0.0 and not needs_grad and ops.mha_fused_ok(qk.shape[1], self.embed_dim, self.num_heads):
+            # inference (BASELINE config C5): flash-style fused attention, no T x T matrix in HBM
+            out = ops.mha_fwd(qk, v)
+        else:
+            # training: materialised soft-max with the counter-hash attention dropout and its backward
+            out = ops.PositionAttention.apply(qk, None, v, self.num_heads, float(self.dropout), self.training)
         return self.out_proj(out)
 
 

@@ -1055,6 +1055,26 @@ class PositionAttention(torch.autograd.Function):
         return dq, (None if packed else dkk), dvv, None, None, None
 
 
+def mha_fused_ok(T, d, h=1):
+    """True when the fused flash-style self-attention forward (attn_mha.hip) covers this shape."""
+    return h == 1 and lib().buctd_mha_fwd_supported(int(T), int(d)) == 1
+
+
+def mha_fwd(qk, v, scale=None):
+    """softmax(scale * q k^T) v for one head without the T x T matrix.  qk [B, T, 2d] = q | k side by side (the packed
+    nn.MultiheadAttention input projection), v [B, T, d] -> [B, T, d].  Inference / no-dropout path."""
+    _f32(qk, "mha qk")
+    _f32(v, "mha v")
+    B, T, two_d = qk.shape
+    d = two_d // 2
+    out = torch.empty((B, T, d), dtype=torch.float32, device=qk.device)
+    kptr = C.c_void_p(qk.data_ptr() + 4 * d)
+    check(lib().buctd_mha_fwd(B, T, d, ptr(qk), kptr, ptr(v), two_d, v.shape[2],
+                              (1.0 / math.sqrt(d)) if scale is None else float(scale), ptr(out), None, stream_ptr()),
+          "mha_fwd")
+    return out
+
+
 def attn_smallqk_ok(T, d_in, C, h=1):
     """True when the fused narrow-contraction attention (attn_smallqk.hip) covers this shape."""
     if h != 1 or d_in + 1 > 20:

@@ -261,6 +261,15 @@ int buctd_flipback_avg(const float* a, const float* b, const int32_t* perm, int 
 int buctd_adam_step(float* p, const float* g, float* m, float* v, long n, float lr, float beta1, float beta2,
                     float eps, int step, float gscale, void* stream);
 
+/* Fused single-head self-attention forward (flash style, exact fp32) - nn.MultiheadAttention of the TransPose encoder
+ * layer, transpose_h.py:192-197, in eval mode / without attention dropout: out[b][i] = softmax_j(scale * q_i . k_j) v_j.
+ * q, k: [B][T][.] rows of stride ldqk floats (q and k may be the two halves of one packed projection: k = q + d);
+ * v: [B][T][.] stride ldv; out: [B][T][d] contiguous; lse (NULL ok): [B][T] log-sum-exp of the scaled logits.
+ * T % 128 == 0, d % 16 == 0, d <= 128. */
+int buctd_mha_fwd_supported(int T, int d);
+int buctd_mha_fwd(int B, int T, int d, const float* q, const float* k, const float* v, int ldqk, int ldv, float scale,
+                  float* out, float* lse, void* stream);
+
 /* ------------------------------------------------------- sample pipeline --- */
 /* Person crop of the per-sample pipeline (dataset/JointsDataset.py:287-294): cv2.warpAffine(img_u8, M, (w, h),
  * flags=INTER_LINEAR) restated bit for bit (OpenCV's fixed-point bilinear, BORDER_CONSTANT 0), fused with
@@ -282,6 +291,25 @@ int buctd_warp_affine_norm(const buctd_warp_item* items_device, int B, int dst_h
 int buctd_cond_render_into(const float* joints, int js, const float* colors, int B, int K, int Cc, int H, int W,
                            int truncate, float* cond, long cond_batch_stride, void* workspace, size_t workspace_bytes,
                            void* stream);
+
+/* Generative pose synthesis (dataset/pose_synthesis.py:234-817, called from JointsDataset.py:202-215): for every person
+ * and joint one of the error types jitter / miss / inversion / swap / good is drawn and a key point proposed
+ * accordingly.  joints, estimated [B][K][3] and near_joints [B][M][K][3] (neighbours; visibility 0 = absent) are float64
+ * device arrays, area [B] float64, num_overlap [B] int; out [B][K][3].  Randomness: a counter-based generator keyed by
+ * (seed, person, joint) - pass a fresh seed per batch.  tables: per-dataset constants (host struct, copied). */
+typedef struct {
+  double sigmas[32];
+  int pair[32];                /* symmetric partner of a joint, -1 = none (kps_symmetry) */
+  int jitter_cls[32], miss_cls[32], inv_cls[32], swap_cls[32];
+  double jitter_p[2][3];       /* [num_valid <= 10 | else][class] */
+  double miss_p[3][3];         /* [num_valid <= 5 | <= 10 | else][class] */
+  double inv_p[3];
+  double swap_p[2][3];         /* [crowded | else][class] */
+  double out_vis;              /* third column of a synthesized joint: 1 (coco) / 0 (crowdpose) */
+} buctd_synth_tables;
+int buctd_synthesize_pose(const buctd_synth_tables* tables, const double* joints, const double* estimated,
+                          const double* near_joints, const double* area, const int* num_overlap, int B, int K, int M,
+                          unsigned long long seed, double* out, void* stream);
 
 /* ------------------------------------------------------------------- NMS --- */
 /* Greedy box NMS - replaces _nms(int* keep_out, int* num_out, const float* boxes_host, int boxes_num, int boxes_dim,

@@ -274,6 +274,47 @@ def nms_case():
     print("  nms: nms / oks_iou / oks_nms / soft_oks_nms of the reference == oracle (+ cpu_nms restatement)")
 
 
+def pose_synthesis_case(runs=1500):
+    """lib/dataset/pose_synthesis.py imported from the reference (pure numpy / random): its outputs on a fixed scene,
+    classified geometrically into the five error types, against the counter-RNG restatement - frequencies per joint
+    must agree within sampling noise.  The reference's class counts become tests/golden/pose_synthesis.npz."""
+    import importlib.util
+    import random
+    from oracle import pose_synthesis as P
+    spec = importlib.util.spec_from_file_location("ref_pose_synthesis", os.path.join(REF, "lib/dataset/pose_synthesis.py"))
+    ps = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ps)
+
+    class C(dict):
+        __getattr__ = dict.__getitem__
+    rec = {}
+    for dataset in ("crowdpose", "coco"):
+        K = 17 if dataset == "coco" else 14
+        cfg = C(MODEL=C(NUM_JOINTS=K), DATASET=C(DATASET=dataset))
+        joints, est, near, area = P.make_scene(dataset, 7)
+        np.random.seed(11)
+        random.seed(11)
+        ref = np.zeros((K, 6), dtype=np.int64)          # 5 classes + "dropped" (all-zero output)
+        orc = np.zeros((K, 6), dtype=np.int64)
+        for it in range(runs):
+            o = ps.synthesize_pose(cfg, joints.copy(), est.copy(), near.copy(), area, 0)
+            q = P.synthesize_pose(dataset, joints, est, near, area, 0, seed=1000 + it)
+            for j in range(K):
+                ref[j, 5 if not o[j, :2].any() else P.classify(o[j], joints, est, near, area, dataset, j)] += 1
+                orc[j, 5 if not q[j, :2].any() else P.classify(q[j], joints, est, near, area, dataset, j)] += 1
+            if it == 0:
+                assert np.array_equal(o[:, 2], q[:, 2]), "visibility column convention"
+        fr, fo = ref / runs, orc / runs
+        tol = 4.0 * np.sqrt(np.maximum(fr * (1 - fr), 1e-3) * 2 / runs) + 0.004
+        bad = np.abs(fr - fo) > tol
+        assert not bad.any(), f"{dataset}: class frequencies differ from the reference at {np.argwhere(bad).tolist()}:\n" \
+                              f"{fr[bad]} vs {fo[bad]}"
+        rec[f"{dataset}_ref_counts"], rec[f"{dataset}_runs"] = ref, np.int64(runs)
+        print(f"  pose_synthesis[{dataset}]: {runs} runs, max class-frequency gap to the reference "
+              f"{np.abs(fr - fo).max():.4f} (good/jitter/inv/swap/miss/dropped)")
+    np.savez_compressed(os.path.join(OUT, "pose_synthesis.npz"), **rec)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--fast", action="store_true")
@@ -291,6 +332,7 @@ def main():
         core_cases()
         target_case()
         nms_case()
+        pose_synthesis_case()
     small = ["prenet_w16_96x64", "coam_w16_96x64_colored", "coam_w16_96x64_mono_default_att",
              "coam_w16_96x64_stacked_2heads", "transpose_w16_96x64", "resnet18_96x64"]
     full = ["coam_w48_384x288", "prenet_w32_256x192", "resnet50_256x192", "prenet_w48_384x288", "transpose_a6_256x192"]

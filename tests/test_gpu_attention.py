@@ -69,3 +69,23 @@ def test_channel_attention(dev, B, T, C, h):
     o2 = ops.ChannelAttention.apply(qd, yd, Wd, bd, h, 0.1, False)
     o2.backward(dout.float().to(dev))
     assert _e(Wd.grad, 2 * W.grad) <= 2e-5 and _e(bd.grad, 2 * bias.grad) <= 2e-5
+
+
+@pytest.mark.parametrize("B,T,d", [(2, 384, 48), (1, 3072, 112), (3, 128, 16), (2, 256, 128)])
+def test_fused_mha_forward_vs_fp64(dev, B, T, d):
+    """attn_mha.hip (TransPose encoder self-attention, eval): softmax(q k^T / sqrt(d)) v against an fp64 evaluation and
+    against the materialised HIP path; logits spread wide enough to exercise the online rescaling."""
+    from buctd_amd import ops
+    g = torch.Generator().manual_seed(B * T + d)
+    qk = torch.randn(B, T, 2 * d, generator=g) * 1.5
+    qk[:, ::7, :d] *= 4.0                       # a few peaked rows
+    v = torch.randn(B, T, d, generator=g)
+    q64, k64, v64 = qk[..., :d].double(), qk[..., d:].double(), v.double()
+    ref = torch.softmax(q64 @ k64.transpose(1, 2) / math.sqrt(d), dim=-1) @ v64
+    assert ops.mha_fused_ok(T, d)
+    out = ops.mha_fwd(qk.to(dev), v.to(dev))
+    err = (out.cpu().double() - ref).abs().max().item() / ref.abs().max().item()
+    assert err <= 2e-5, f"fused MHA (B{B} T{T} d{d}): rel err {err:.2e}"
+    mat = ops.PositionAttention.apply(qk.to(dev), None, v.to(dev), 1, 0.0, False)
+    assert (mat - out).abs().max().item() <= 2e-5 * ref.abs().max().item()
+    assert not ops.mha_fused_ok(100, d) and not ops.mha_fused_ok(T, 20)
