@@ -261,11 +261,136 @@ def cpu_baseline(limit_s=300):
     return {"value": None, "unit": "images/s", "cores": _host_cores(), "kind": "port", "sample": note}
 
 
+COCO_COLORS = [[127, 0, 255], [97, 46, 254], [67, 91, 252], [37, 134, 249], [7, 173, 245], [22, 206, 239],
+               [52, 232, 231], [82, 248, 222], [112, 254, 212], [142, 249, 201], [172, 233, 188], [202, 207, 174],
+               [232, 174, 159], [255, 135, 142], [255, 92, 126], [255, 47, 108], [255, 0, 90]]
+
+
+def transpose_a6_cfg(batch):
+    from buctd_amd.config import cfg as base, hrnet_extra
+    c = base.clone()
+    c.defrost()
+    c.MODEL.NAME = "transpose_h"
+    c.MODEL.NUM_JOINTS = 17
+    c.MODEL.IMAGE_SIZE = [192, 256]
+    c.MODEL.HEATMAP_SIZE = [48, 64]
+    c.MODEL.SIGMA = 2
+    c.MODEL.PRETRAINED = ""
+    c.MODEL.CONDITIONAL_TOPDOWN = True
+    c.MODEL.EXTRA = hrnet_extra(48, use_attention=True)
+    c.DATASET.DATASET = "coco"
+    c.DATASET.COLORED = True
+    c.TEST.BATCH_SIZE_PER_GPU = batch
+    c.freeze()
+    return c
+
+
+def bench_infer_c5(args, rank, world, device):
+    """BASELINE config C5: BUCTD-TransPose-H-A6 256x192, 3x iterative-refinement inference, persons/s:
+    one step = three chained passes, each forward -> device arg-max decode -> colored condition re-rendered from the
+    decoded key points (crop coordinates) -> next forward, on 32 persons resident in HBM; eval mode."""
+    from buctd_amd import models, ops
+    cfg = transpose_a6_cfg(args.batch)
+    torch.manual_seed(1234)
+    net = models.transpose_h.get_pose_net(cfg, is_train=False).to(device).eval()
+    w, h = cfg.MODEL.IMAGE_SIZE
+    k = cfg.MODEL.NUM_JOINTS
+    g = torch.Generator(device="cpu").manual_seed(7 + rank)
+    rgb = torch.randn(args.batch, 3, h, w, generator=g).to(device)
+    joints0 = (torch.rand(args.batch, k, 2, generator=g) * torch.tensor([w - 1.0, h - 1.0])).to(device).contiguous()
+    colors = torch.tensor(COCO_COLORS[:k], dtype=torch.float32, device=device)
+    x = torch.empty(args.batch, 6, h, w, device=device)
+    x[:, :3] = rgb
+    mha = {"pairs": [], "on": False}
+    raw_mha = ops.mha_fwd
+
+    def timed_mha(qk, v, scale=None):
+        if not mha["on"]:
+            return raw_mha(qk, v, scale)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        out = raw_mha(qk, v, scale)
+        e1.record()
+        mha["pairs"].append((e0, e1))
+        return out
+
+    ops.mha_fwd = timed_mha
+
+    @torch.no_grad()
+    def step():
+        joints = joints0
+        for _ in range(3):
+            need = ops.lib().buctd_cond_render_workspace(args.batch, 3, h, w)
+            ws = ops.workspace(need, device)
+            ops.check(ops.lib().buctd_cond_render_into(ops.ptr(joints), 2, ops.ptr(colors), args.batch, k, 3, h, w, 0,
+                                                       ops.C.c_void_p(x[:, 3:].data_ptr()), x.stride(0), ops.ptr(ws),
+                                                       ws.numel(), ops.stream_ptr()), "cond_render_into")
+            out = net(x)
+            preds, _, _ = ops.argmax_decode(out)
+            joints = ops.scale(preds, alpha=4.0)          # heat-map -> crop coordinates (stride 4)
+        return joints
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    mha["on"] = not args.no_kernel_timer
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    dt = time.perf_counter() - t0
+    mha["on"] = False
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    if rank != 0:
+        return
+    persons = args.batch * world * args.steps
+    out = {"metric": "persons/sec (3x iterative-refinement inference) BUCTD-TransPose-H-A6 256x192",
+           "value": round(persons / dt, 3), "unit": "persons/s", "n_gpus": world, "steps": args.steps,
+           "warmup": args.warmup, "ms_per_step": round(1000 * dt / args.steps, 3), "higher_is_better": True,
+           "scaling": "weak", "vs_baseline": None,
+           "dtype": "f32 (3x3 convs bf16x6 = fp32-class; attention exact fp32 MFMA)" if args.conv_math == "bf16x6"
+           else "f32", "data": "synthetic",
+           "config": {"workload": "BUCTD-TransPose-H-A6 (transpose_h, W48 trunk, d_model 96+16, 6 encoder layers, "
+                                  "T = 3072) 256x192 COCO-17kpt, eval: 3 chained passes per person (forward -> arg-max "
+                                  "decode -> colored condition re-render -> forward)",
+                      "global_batch": args.batch * world, "batch_per_gpu": args.batch, "input": "N x 6 x 256 x 192 fp32",
+                      "params": sum(p.numel() for p in net.parameters()), "parallelism": f"dp{world} (replicas)",
+                      "conv_math": args.conv_math, "forwards_per_step": 3}}
+    if mha["pairs"]:
+        us = 1e3 * sum(a.elapsed_time(b) for a, b in mha["pairs"]) / len(mha["pairs"])
+        T, d = (h // 4) * (w // 4), 112
+        flops = 4.0 * args.batch * T * T * d
+        bytes_ = 4.0 * args.batch * T * d * 4          # q, k, v read + o written once
+        tf = flops / us / 1e6
+        out["roofline"] = {"kernel": f"mha_fwd_kernel<7>: fused self-attention forward, T={T} d={d} N={args.batch} "
+                                     "(TransPose encoder layer)", "bound": "mfma", "achieved": round(tf, 2),
+                           "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / PEAK_FP32_MFMA_TFLOPS, 4),
+                           "traffic": None, "algorithmic_flops": flops, "algorithmic_bytes": bytes_,
+                           "avg_launch_us": round(us, 1), "launches_timed": len(mha["pairs"]),
+                           "hbm_frac": round(bytes_ / us / 1e3 / PEAK_HBM_GBPS, 4),
+                           "timing": "HIP events on the launching stream around every launch in the timed steps "
+                                     "(single stream: no co-runners)",
+                           "note": "exact fp32 MFMA (v_mfma_f32_16x16x4_f32, 157.3 TFLOP/s peak) binds: 4 T^2 d FLOP "
+                                   "against 4 T d floats of HBM traffic per image"}
+    print(json.dumps(out), flush=True)
+
+
 def main():
     if os.environ.get("BUCTD_BENCH_CPU_WORKER") == "1":
         print(json.dumps(_cpu_baseline_worker()))
         return
     ap = argparse.ArgumentParser()
+    ap.add_argument("--workload", default="train_c4", choices=["train_c4", "infer_c5"],
+                    help="train_c4 (default): the headline metric, CoAM-W48 384x288 training images/s; infer_c5: "
+                         "TransPose-H-A6 256x192 3x iterative-refinement inference persons/s (BASELINE config C5)")
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
@@ -288,8 +413,14 @@ def main():
         raise SystemExit("bench.py needs a ROCm device: buctd_amd has no CPU path")
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
-    cfg = coam_w48_cfg(args.batch)
     ops.set_conv_math(args.conv_math)
+    if args.workload == "infer_c5":
+        bench_infer_c5(args, rank, world, device)
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
+    cfg = coam_w48_cfg(args.batch)
     torch.manual_seed(1234)
     ops.manual_seed(1234 + rank)
     net = models.pose_hrnet_coam.get_pose_net(cfg, is_train=True).to(device)
