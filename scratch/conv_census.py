@@ -3,7 +3,8 @@ import collections, os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench
 from buctd_amd import engine, models, ops
-ops.set_conv_math("bf16x3")
+ops.set_conv_math("bf16x6")
+import buctd_amd.ops as _o; _o._side["on"] = False; _o._branch["on"] = False   # serial streams: event brackets = kernel time
 dev = torch.device("cuda:0")
 cfg = bench.coam_w48_cfg(32)
 model = models.pose_hrnet_coam.get_pose_net(cfg, is_train=True).to(dev).train()

@@ -122,6 +122,16 @@ def test_train_step_matches_reference(dev, name):
         e_cpu.append((g32[k].double() - g64[k]).norm().item() / den)
         assert abs(g.norm().item() - gn) <= 5e-2 * max(gn, 1e-6), \
             f"{name}: grad norm of {k}: {g.norm().item()} vs reference {gn}"
+    if name.startswith("transpose"):
+        # The encoder (LayerNorm, in/out projections, FFN, attention soft-max) sits downstream of every ReLU of the trunk
+        # in the backward pass, so its gradients are free of the ReLU-flip chaos described below: they must be as
+        # accurate as the fp32 CPU path.  (Round 1 saw "40x worse than CPU fp32" on this network: scratch/diag_transpose.py
+        # localises it to ONE BatchNorm layer of the HRNet trunk whose position changes with the input seed - a flipped
+        # ReLU - while every encoder tensor sits at 3e-6..2e-5 against the CPU's 1e-6..6e-6.)
+        kept = [k for k, gn in zip(names, gold["grad_norms"]) if g64[k].norm().item() > 1e-6 * gmax]
+        for k, eh, ec in zip(kept, e_hip, e_cpu):
+            if k.startswith(("global_encoder", "final_layer", "reduce", "trans_cond")):
+                assert eh <= 5 * ec + 2e-5, f"{name}: encoder gradient {k}: hip {eh:.2e} vs fp32 CPU {ec:.2e}"
     med_h, med_c = float(np.median(e_hip)), float(np.median(e_cpu))
     worst, worst_ref = max(e_hip), max(e_cpu)
     # A single ReLU whose pre-activation sits within fp32 round-off of zero flips between implementations and shifts
