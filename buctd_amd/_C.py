@@ -69,6 +69,8 @@ SIGNATURES = {
     "buctd_conv3x3_bf16x6_prep_bytes": (_SZ, [_I, _I, _I]),
     "buctd_conv3x3_bf16x6_prep": (_I, [_I, _I, _P, _I, _P, _P]),
     "buctd_conv3x3_bf16x6": (_I, [_I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P]),
+    "buctd_conv3x3_bf16x6_bnin": (_I, [_I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _I, _P]),
+    "buctd_conv3x3_wgrad_bf16x6_bnin": (_I, [_I, _I, _I, _I, _I, _P, _P, _P, _I, _P, _P, _P, _P, _I, _P, _SZ, _P]),
     "buctd_conv3x3_wgrad_bf16x6_supported": (_I, [_I, _I, _I, _I, _I]),
     "buctd_conv3x3_wgrad_bf16x6_workspace": (_SZ, [_I, _I, _I, _I, _I]),
     "buctd_conv3x3_wgrad_bf16x6": (_I, [_I, _I, _I, _I, _I, _P, _P, _P, _I, _P, _SZ, _P]),

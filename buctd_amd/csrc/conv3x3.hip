@@ -66,6 +66,14 @@ struct C3Args {
   int N, H, W, Ci, Co;
   int SW, IB, P;       // padded row width, padded image block, total padded positions
   int relu, na;        // na: 32-row groups of the staged tile = ceil((BM + 2*SW + 2) / 32)
+  // optional BatchNorm(+ReLU) of the PRODUCER applied to the input while it is staged (bf16x6 kernel only): the input
+  // tensor is the producer's raw convolution output z and the kernel consumes relu((z - mean) * (invstd * gamma) + beta),
+  // the exact expression of bn_apply_kernel - the normalised tensor never exists in HBM
+  const float* in_mean;
+  const float* in_invstd;
+  const float* in_gamma;
+  const float* in_beta;
+  int in_relu;
   unsigned ib_mul, ib_sh, sw_mul, sw_sh;   // n / d == mulhi(n, mul) >> sh for 0 <= n < 2^31 (Granlund-Montgomery)
 };
 
@@ -441,11 +449,29 @@ __global__ __launch_bounds__(256, 2) void conv3x3_x6_kernel(C3Args p) {
     for (int q = 0; q < PA; ++q)
       if (RPP * q < arows) areg[q] = *reinterpret_cast<const f32x4*>(p.x + (goff[q] >= 0 ? goff[q] + c0 + c4 : 0));
   };
-  auto store_a = [&](unsigned char* At) {
+  auto store_a = [&](unsigned char* At, int c0) {
+    f32x4 mu, sc, be;
+    if (p.in_mean) {
+      mu = *reinterpret_cast<const f32x4*>(p.in_mean + c0 + c4);
+      const f32x4 is = *reinterpret_cast<const f32x4*>(p.in_invstd + c0 + c4);
+      const f32x4 ga = *reinterpret_cast<const f32x4*>(p.in_gamma + c0 + c4);
+      be = *reinterpret_cast<const f32x4*>(p.in_beta + c0 + c4);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) sc[j] = is[j] * ga[j];
+    }
 #pragma unroll
     for (int q = 0; q < PA; ++q)
-      if (RPP * q < arows && goff[q] != -2)
-        split_store<3, PST>(At + (size_t)(prow + RPP * q) * ROWB, c4, goff[q] >= 0 ? areg[q] : (f32x4){0.f, 0.f, 0.f, 0.f});
+      if (RPP * q < arows && goff[q] != -2) {
+        f32x4 v = goff[q] >= 0 ? areg[q] : (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (p.in_mean && goff[q] >= 0) {             // zero padding stays zero: it pads the NORMALISED tensor
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            v[j] = (v[j] - mu[j]) * sc[j] + be[j];
+            if (p.in_relu) v[j] = fmaxf(v[j], 0.f);
+          }
+        }
+        split_store<3, PST>(At + (size_t)(prow + RPP * q) * ROWB, c4, v);
+      }
   };
 
   // B fragments of this lane: image [step][Co/16][3][64][16 B]
@@ -482,7 +508,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_x6_kernel(C3Args p) {
     for (int s = 0; s < 5; ++s) {
       if (DBUF && s == 2 && ch + 1 < nchunks) {    // next chunk: registers -> pieces -> the other A buffer
         // done while the fewest registers are live (no B prefetch in flight, no A fragments): the split needs ~60
-        store_a(smem + ((ch + 1) & 1) * abytes);
+        store_a(smem + ((ch + 1) & 1) * abytes, (ch + 1) * 16);
         if (ch + 2 < nchunks) load_a((ch + 2) * 16);
         __builtin_amdgcn_sched_barrier(0);
       }
@@ -527,12 +553,12 @@ __global__ __launch_bounds__(256, 2) void conv3x3_x6_kernel(C3Args p) {
 
   load_a(0);
   if constexpr (BPF) load_b(0, bn);
-  store_a(smem);
+  store_a(smem, 0);
   if (nchunks > 1) load_a(16);
   __syncthreads();
   for (int ch = 0; ch < nchunks; ++ch) {
     if (!DBUF && ch > 0) {   // single buffer (the largest position tiles): restage between two barriers
-      store_a(smem);
+      store_a(smem, ch * 16);
       if (ch + 1 < nchunks) load_a((ch + 1) * 16);
       __syncthreads();
     }
@@ -770,9 +796,11 @@ static int c3_prep(int np, int Ci, int Co, const float* w, int flip, void* wprep
 // x: [N][H][W][Ci] -> y: [N][H][W][Co], wprep from the matching prep call.  Forward: prep(Ci, Co, w, 0).
 // Data gradient of a forward conv (CiF -> CoF): x = dy ([N][H][W][CoF]), y = dx ([N][H][W][CiF]), i.e. this call's
 // Ci = CoF, Co = CiF, and wprep = prep(CiF, CoF, w, 1).
+struct C3InBn { const float* mean; const float* invstd; const float* gamma; const float* beta; int relu; };
+
 static int c3_run(int np, int N, int H, int W, int Ci, int Co, const float* x, const void* wprep, const float* bias,
                   const float* scale, const float* shift, const float* residual, int relu, float* y,
-                  float* stats_partials, int* stats_counts, void* stream) {
+                  float* stats_partials, int* stats_counts, void* stream, const C3InBn* in_bn = nullptr) {
   C3Plan pl;
   BUCTD_CHECK_ARG(x && wprep && y, "buctd_conv3x3 (split bf16): null tensor pointer");
   BUCTD_CHECK_ARG(c3_np_ok(np) && c3_plan(np, N, H, W, Ci, Co, &pl),
@@ -790,6 +818,14 @@ static int c3_run(int np, int N, int H, int W, int Ci, int Co, const float* x, c
                   "buctd_conv3x3 (split bf16): tensor too large");
   a.P = (int)P;
   a.relu = relu; a.na = pl.na;
+  a.in_mean = a.in_invstd = a.in_gamma = a.in_beta = nullptr;
+  a.in_relu = 0;
+  if (in_bn && in_bn->mean) {
+    BUCTD_CHECK_ARG(np == 3 && in_bn->invstd && in_bn->gamma && in_bn->beta,
+                    "buctd_conv3x3: fused input BatchNorm needs the bf16x6 kernel and all four statistics arrays");
+    a.in_mean = in_bn->mean; a.in_invstd = in_bn->invstd; a.in_gamma = in_bn->gamma; a.in_beta = in_bn->beta;
+    a.in_relu = in_bn->relu;
+  }
   magic_u32((unsigned)a.IB, &a.ib_mul, &a.ib_sh);
   magic_u32((unsigned)a.SW, &a.sw_mul, &a.sw_sh);
   return np == 3 ? c3_dispatch<3>(a, pl, (hipStream_t)stream) : c3_dispatch<2>(a, pl, (hipStream_t)stream);
@@ -831,4 +867,12 @@ extern "C" int buctd_conv3x3_bf16x6(int N, int H, int W, int Ci, int Co, const f
                                     const float* bias, const float* scale, const float* shift, const float* residual,
                                     int relu, float* y, float* stats_partials, int* stats_counts, void* stream) {
   return c3_run(3, N, H, W, Ci, Co, x, wprep, bias, scale, shift, residual, relu, y, stats_partials, stats_counts, stream);
+}
+extern "C" int buctd_conv3x3_bf16x6_bnin(int N, int H, int W, int Ci, int Co, const float* x, const void* wprep,
+                                         const float* bias, const float* scale, const float* shift,
+                                         const float* residual, int relu, float* y, float* stats_partials,
+                                         int* stats_counts, const float* in_mean, const float* in_invstd,
+                                         const float* in_gamma, const float* in_beta, int in_relu, void* stream) {
+  C3InBn b{in_mean, in_invstd, in_gamma, in_beta, in_relu};
+  return c3_run(3, N, H, W, Ci, Co, x, wprep, bias, scale, shift, residual, relu, y, stats_partials, stats_counts, stream, &b);
 }

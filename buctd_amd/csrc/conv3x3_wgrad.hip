@@ -42,6 +42,13 @@ struct WG3Args {
   int N, H, W, Ci, Co;
   int SW, IB, P;
   int split_q, split_rem;   // stages per split: q, the first split_rem splits q + 1
+  // optional BatchNorm(+ReLU) of the producer applied to X while it is staged (X = the producer's raw conv output):
+  // relu((x - mean) * (invstd * gamma) + beta), the expression of bn_apply_kernel
+  const float* x_mean;
+  const float* x_invstd;
+  const float* x_gamma;
+  const float* x_beta;
+  int x_relu;
   unsigned ib_mul, ib_sh, sw_mul, sw_sh;
 };
 
@@ -124,6 +131,20 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_split_kernel(WG3Args p) 
     return ((n * p.H + yy - 1) * p.W + xx - 1) * C;
   };
 
+  auto bn_in = [&](f32x4 v, int c) -> f32x4 {    // channels ci0 + c .. + 3 of a real pixel
+    if (!p.x_mean) return v;
+    const f32x4 mu = *reinterpret_cast<const f32x4*>(p.x_mean + ci0 + c);
+    const f32x4 is = *reinterpret_cast<const f32x4*>(p.x_invstd + ci0 + c);
+    const f32x4 ga = *reinterpret_cast<const f32x4*>(p.x_gamma + ci0 + c);
+    const f32x4 be = *reinterpret_cast<const f32x4*>(p.x_beta + ci0 + c);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      v[j] = (v[j] - mu[j]) * (is[j] * ga[j]) + be[j];
+      if (p.x_relu) v[j] = fmaxf(v[j], 0.f);
+    }
+    return v;
+  };
+
   f32x4 dreg[PD], xreg[PD];
   unsigned dmask = 0, xmask = 0;             // bit q: the row loaded in pass q is a real pixel (else zero row)
   auto load_d = [&](int k0) {
@@ -166,7 +187,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_split_kernel(WG3Args p) 
       const int row = idx / C4, c4 = (idx - row * C4) * 4;
       if (row < KB)
         wg_split_store<NP, LO>(Xt + (size_t)ring_slot(slot0 + row, R) * RS, c4,
-                               ((xmask >> q) & 1u) ? xreg[q] : (f32x4){0.f, 0.f, 0.f, 0.f});
+                               ((xmask >> q) & 1u) ? bn_in(xreg[q], c4) : (f32x4){0.f, 0.f, 0.f, 0.f});
     }
   };
 
@@ -202,7 +223,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_split_kernel(WG3Args p) 
         const int row = idx / C4, c4 = (idx - row * C4) * 4;
         if (row < WG_PRO && r0 + row < pro)
           wg_split_store<NP, LO>(Xt + (size_t)(r0 + row) * RS, c4,
-                                 ((pmask >> q) & 1u) ? preg[q] : (f32x4){0.f, 0.f, 0.f, 0.f});
+                                 ((pmask >> q) & 1u) ? bn_in(preg[q], c4) : (f32x4){0.f, 0.f, 0.f, 0.f});
       }
     }
     load_d(k_begin);
@@ -368,8 +389,10 @@ static int wg3_launch(const WG3Args& a, const WG3Plan& pl, hipStream_t st) {
   return BUCTD_OK;
 }
 
+struct WG3InBn { const float* mean; const float* invstd; const float* gamma; const float* beta; int relu; };
+
 static int wg3_run(int np, int N, int H, int W, int Ci, int Co, const float* x, const float* dy, float* dw,
-                   int accumulate, void* workspace, size_t workspace_bytes, void* stream) {
+                   int accumulate, void* workspace, size_t workspace_bytes, void* stream, const WG3InBn* x_bn = nullptr) {
   WG3Plan pl;
   BUCTD_CHECK_ARG(x && dy && dw, "buctd_conv3x3_wgrad (split bf16): null tensor pointer");
   BUCTD_CHECK_ARG(wg3_plan(np, N, H, W, Ci, Co, &pl),
@@ -387,6 +410,13 @@ static int wg3_run(int np, int N, int H, int W, int Ci, int Co, const float* x, 
   BUCTD_CHECK_ARG(P < 2147483647L, "buctd_conv3x3_wgrad (split bf16): tensor too large");
   a.P = (int)P;
   a.split_q = pl.q; a.split_rem = pl.rem;
+  a.x_mean = a.x_invstd = a.x_gamma = a.x_beta = nullptr;
+  a.x_relu = 0;
+  if (x_bn && x_bn->mean) {
+    BUCTD_CHECK_ARG(x_bn->invstd && x_bn->gamma && x_bn->beta, "buctd_conv3x3_wgrad: fused input BatchNorm needs all four arrays");
+    a.x_mean = x_bn->mean; a.x_invstd = x_bn->invstd; a.x_gamma = x_bn->gamma; a.x_beta = x_bn->beta;
+    a.x_relu = x_bn->relu;
+  }
   wg_magic((unsigned)a.IB, &a.ib_mul, &a.ib_sh);
   wg_magic((unsigned)a.SW, &a.sw_mul, &a.sw_sh);
   hipStream_t st = (hipStream_t)stream;
@@ -432,4 +462,11 @@ extern "C" int buctd_conv3x3_wgrad_bf16x6(int N, int H, int W, int Ci, int Co, c
                                           float* dw, int accumulate, void* workspace, size_t workspace_bytes,
                                           void* stream) {
   return wg3_run(3, N, H, W, Ci, Co, x, dy, dw, accumulate, workspace, workspace_bytes, stream);
+}
+extern "C" int buctd_conv3x3_wgrad_bf16x6_bnin(int N, int H, int W, int Ci, int Co, const float* x, const float* dy,
+                                               float* dw, int accumulate, const float* x_mean, const float* x_invstd,
+                                               const float* x_gamma, const float* x_beta, int x_relu, void* workspace,
+                                               size_t workspace_bytes, void* stream) {
+  WG3InBn b{x_mean, x_invstd, x_gamma, x_beta, x_relu};
+  return wg3_run(3, N, H, W, Ci, Co, x, dy, dw, accumulate, workspace, workspace_bytes, stream, &b);
 }

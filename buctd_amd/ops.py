@@ -275,7 +275,7 @@ def _conv3x3_prepared(w, flip):
     return cache[1 + flip]
 
 
-def _conv3x3_bf16x3(x, w, flip, cin, cout, bias, scale, shift, residual, relu, stats):
+def _conv3x3_bf16x3(x, w, flip, cin, cout, bias, scale, shift, residual, relu, stats, in_bn=None):
     N, H, W = x.shape[0], x.shape[1], x.shape[2]
     wp = _conv3x3_prepared(w, flip)
     y = torch.empty((N, H, W, cout), dtype=torch.float32, device=x.device)
@@ -286,18 +286,43 @@ def _conv3x3_bf16x3(x, w, flip, cin, cout, bias, scale, shift, residual, relu, s
         part = torch.empty((ng.value, cout, 2), dtype=torch.float32, device=x.device)
         counts = torch.empty(ng.value, dtype=torch.int32, device=x.device)
         info = (ng.value, rpg.value, counts)
+    if in_bn is not None:
+        mean, invstd, gamma, beta, in_relu = in_bn
+        check(lib().buctd_conv3x3_bf16x6_bnin(N, H, W, cin, cout, ptr(x), ptr(wp), ptr(bias), ptr(scale), ptr(shift),
+                                              ptr(residual), int(bool(relu)), ptr(y), ptr(part), ptr(counts), ptr(mean),
+                                              ptr(invstd), ptr(gamma), ptr(beta), int(bool(in_relu)), stream_ptr()),
+              "conv3x3_bf16x6_bnin")
+        return (y, part, info) if stats else y
     check(_c3fn("")(N, H, W, cin, cout, ptr(x), ptr(wp), ptr(bias), ptr(scale), ptr(shift),
                     ptr(residual), int(bool(relu)), ptr(y), ptr(part), ptr(counts), stream_ptr()),
           "conv3x3 (split bf16)")
     return (y, part, info) if stats else y
 
 
-def conv_fwd(x, w, bias=None, stride=1, pad=0, scale=None, shift=None, residual=None, relu=False, stats=False):
+def bn_in_fusable(x_shape, w):
+    """True when a 3x3/s1/p1 convolution of this shape can apply its producer's BatchNorm(+ReLU) while staging its
+    input (bf16x6 kernel): conv_fwd(..., in_bn=...) and conv_wgrad(..., x_bn=...)."""
+    if _conv_math["mode"] != "bf16x6" or os.environ.get("BUCTD_FUSE_BN_IN", "1") != "1":
+        return False
+    ws = _wshape(w)
+    if ws[2] != 3 or ws[3] != 3:
+        return False
+    d = conv_desc(x_shape, ws, 1, 1)
+    return (lib().buctd_conv3x3_bf16x6_supported(d.N, d.H, d.W, d.Ci, d.Co) == 1 and
+            lib().buctd_conv3x3_wgrad_bf16x6_supported(d.N, d.H, d.W, d.Ci, d.Co) == 1)
+
+
+def conv_fwd(x, w, bias=None, stride=1, pad=0, scale=None, shift=None, residual=None, relu=False, stats=False,
+             in_bn=None):
+    """in_bn = (mean, invstd, gamma, beta, relu): x is the raw output of the producing convolution and its BatchNorm
+    (+ReLU) is applied while the input is staged (only where bn_in_fusable() says so)."""
     _f32(x, "conv input")
     weight_rsc(w)
     d = conv_desc(x.shape, _wshape(w), stride, pad)
+    if in_bn is not None and not (_conv_math["mode"] == "bf16x6" and _bf16x3_ok(d)):
+        raise _C.BuctdHipError("conv_fwd: in_bn needs the bf16x6 3x3 kernel (check bn_in_fusable first)")
     if _bf16x3_ok(d):
-        return _conv3x3_bf16x3(x, w, 0, d.Ci, d.Co, bias, scale, shift, residual, relu, stats)
+        return _conv3x3_bf16x3(x, w, 0, d.Ci, d.Co, bias, scale, shift, residual, relu, stats, in_bn)
     y = torch.empty((d.N, d.Ho, d.Wo, d.Co), dtype=torch.float32, device=x.device)
     part = None
     info = None
@@ -338,7 +363,8 @@ def conv_dgrad(dy, w, x_shape, stride=1, pad=0, bias=None, stats=False, residual
     return (dx, part, info) if stats else dx
 
 
-def conv_wgrad(x, dy, w_like, stride=1, pad=0, out=None, accumulate=0):
+def conv_wgrad(x, dy, w_like, stride=1, pad=0, out=None, accumulate=0, x_bn=None):
+    """x_bn = (mean, invstd, gamma, beta, relu): like conv_fwd's in_bn, for the X operand of the weight gradient."""
     _f32(x, "conv wgrad x")
     _f32(dy, "conv wgrad dy")
     d = conv_desc(x.shape, _wshape(w_like), stride, pad)
@@ -352,9 +378,20 @@ def conv_wgrad(x, dy, w_like, stride=1, pad=0, out=None, accumulate=0):
         if getattr(lib(), "buctd_conv3x3_wgrad_" + mode + "_supported")(d.N, d.H, d.W, d.Ci, d.Co) == 1:
             need = getattr(lib(), "buctd_conv3x3_wgrad_" + mode + "_workspace")(d.N, d.H, d.W, d.Ci, d.Co)
             ws = workspace(need, x.device)
+            if x_bn is not None:
+                if mode != "bf16x6":
+                    raise _C.BuctdHipError("conv_wgrad: x_bn needs the bf16x6 kernel")
+                mean, invstd, gamma, beta, x_relu = x_bn
+                check(lib().buctd_conv3x3_wgrad_bf16x6_bnin(d.N, d.H, d.W, d.Ci, d.Co, ptr(x), ptr(dy), ptr(out),
+                                                            int(accumulate), ptr(mean), ptr(invstd), ptr(gamma), ptr(beta),
+                                                            int(bool(x_relu)), ptr(ws), ws.numel(), stream_ptr()),
+                      "conv3x3_wgrad_bf16x6_bnin")
+                return out
             check(fn(d.N, d.H, d.W, d.Ci, d.Co, ptr(x), ptr(dy), ptr(out), int(accumulate), ptr(ws), ws.numel(),
                      stream_ptr()), "conv3x3_wgrad (split bf16)")
             return out
+    if x_bn is not None:
+        raise _C.BuctdHipError("conv_wgrad: x_bn needs the bf16x6 3x3 kernel (check bn_in_fusable first)")
     need = lib().buctd_conv2d_wgrad_workspace(C.byref(d))
     ws = workspace(need, x.device)
     check(lib().buctd_conv2d_wgrad(C.byref(d), ptr(x), ptr(dy), ptr(out), int(accumulate), ptr(ws), ws.numel(),
@@ -485,19 +522,22 @@ def _queue_join():
         _join_side()
 
 
-def conv_wgrad_async(x, dy, w_like, stride, pad, out, accumulate):
+def conv_wgrad_async(x, dy, w_like, stride, pad, out, accumulate, x_bn=None):
     """conv_wgrad on the side stream (backward passes only: the join rides on the autograd engine's final callback)."""
     if not (_side["on"] and x.is_cuda):
         if x.is_cuda and _branch["on"]:
             _queue_join()     # parameter gradients may be written on branch streams: still join them at the end
-        return conv_wgrad(x, dy, w_like, stride, pad, out=out, accumulate=accumulate)
+        return conv_wgrad(x, dy, w_like, stride, pad, out=out, accumulate=accumulate, x_bn=x_bn)
     main = torch.cuda.current_stream(x.device)
     side = _side_stream(x.device)
     side.wait_stream(main)
     with torch.cuda.stream(side):
-        conv_wgrad(x, dy, w_like, stride, pad, out=out, accumulate=accumulate)
+        conv_wgrad(x, dy, w_like, stride, pad, out=out, accumulate=accumulate, x_bn=x_bn)
     x.record_stream(side)
     dy.record_stream(side)
+    if x_bn is not None:
+        x_bn[0].record_stream(side)
+        x_bn[1].record_stream(side)
     _queue_join()
     return out
 
@@ -861,27 +901,38 @@ class BasicBlockFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, w1, bn1, w2, bn2):
-        saved = []
-        y = x
-        for w, bn, res in ((w1, bn1, None), (w2, bn2, x)):
+        # In the bf16x6 mode conv2 applies bn1 + ReLU while it stages its input: the tensor y1 = relu(bn1(conv1(x)))
+        # never exists in HBM (one kernel and two tensor passes less per block; conv2's weight gradient rebuilds it the
+        # same way).  Bit-identical to the unfused sequence: the staged value is bn_apply's own expression.
+        fuse = bn_in_fusable(tuple(x.shape), w2)
+        stats = []
+        for w, bn in ((w1, bn1), (w2, bn2)):
             momentum = 0.1 if bn.momentum is None else bn.momentum
-            z, part, info = conv_fwd(y, w, None, 1, 1, stats=True)
+            if w is w1:
+                z, part, info = conv_fwd(x, w, None, 1, 1, stats=True)
+            elif fuse:
+                z, part, info = conv_fwd(stats[0][0], w, None, 1, 1, stats=True,
+                                         in_bn=(stats[0][1], stats[0][2], bn1.weight, bn1.bias, True))
+            else:
+                z, part, info = conv_fwd(y1, w, None, 1, 1, stats=True)
             Cn = z.shape[-1]
             track = bn.track_running_stats
             mean, invstd = bn_finalize(part, info, z.numel() // Cn, Cn, bn.eps, momentum,
                                        bn.running_mean if track else None, bn.running_var if track else None)
             if track:
                 bn.count_batch() if hasattr(bn, "count_batch") else bn.num_batches_tracked.add_(1)
-            yin = y
-            y = bn_apply(z, mean, invstd, bn.weight, bn.bias, res, True)
-            saved += [yin, z, mean, invstd]
-        ctx.meta = (w1, bn1, w2, bn2)
-        ctx.save_for_backward(*saved, y)
+            stats.append((z, mean, invstd))
+            if w is w1 and not fuse:
+                y1 = bn_apply(z, mean, invstd, bn.weight, bn.bias, None, True)
+        (z1, mean1, invstd1), (z2, mean2, invstd2) = stats
+        y = bn_apply(z2, mean2, invstd2, bn2.weight, bn2.bias, x, True)
+        ctx.meta = (w1, bn1, w2, bn2, fuse)
+        ctx.save_for_backward(x, z1, mean1, invstd1, None if fuse else y1, z2, mean2, invstd2, y)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        w1, bn1, w2, bn2 = ctx.meta
+        w1, bn1, w2, bn2, fuse = ctx.meta
         x, z1, mean1, invstd1, y1, z2, mean2, invstd2, y2 = ctx.saved_tensors
         dy = _contig(dy)
         # conv2 / bn2 (+ skip): dres = masked upstream gradient
@@ -889,9 +940,12 @@ class BasicBlockFn(torch.autograd.Function):
         db, acc_b = grad_target(bn2.bias)
         assert acc_g == acc_b
         dz2, dres = bn_bwd(dy, y2, z2, mean2, invstd2, bn2.weight, True, True, dg, db, acc_g)
-        dy1 = conv_dgrad(dz2, w2, tuple(y1.shape), 1, 1)
+        dy1 = conv_dgrad(dz2, w2, tuple(z1.shape), 1, 1)
         dw, acc_w = grad_target(w2)
-        conv_wgrad_async(y1, dz2, w2, 1, 1, dw, acc_w)
+        if fuse:
+            conv_wgrad_async(z1, dz2, w2, 1, 1, dw, acc_w, x_bn=(mean1, invstd1, bn1.weight, bn1.bias, True))
+        else:
+            conv_wgrad_async(y1, dz2, w2, 1, 1, dw, acc_w)
         grad_done(bn2.weight, bn2.bias, w2)
         # conv1 / bn1: ReLU mask rebuilt from z1; the skip gradient joins in the dgrad epilogue
         dg, acc_g = grad_target(bn1.weight)

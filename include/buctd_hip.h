@@ -79,6 +79,14 @@ int buctd_conv3x3_bf16x6_prep(int Ci, int Co, const float* w, int flip, void* wp
 int buctd_conv3x3_bf16x6(int N, int H, int W, int Ci, int Co, const float* x, const void* wprep, const float* bias,
                          const float* scale, const float* shift, const float* residual, int relu, float* y,
                          float* stats_partials, int* stats_counts, void* stream);
+/* buctd_conv3x3_bf16x6 with the BatchNorm(+ReLU) of the PRODUCING layer applied to the input while it is staged: x is
+ * the producer's raw convolution output z, the kernel convolves relu((z - mean) * (invstd * gamma) + beta) - bitwise
+ * what buctd_bn_apply would have written - so the tensor between bn1/relu and conv2 of a BasicBlock
+ * (pose_hrnet.py:44-49) never exists in HBM.  in_* are [Ci] arrays. */
+int buctd_conv3x3_bf16x6_bnin(int N, int H, int W, int Ci, int Co, const float* x, const void* wprep, const float* bias,
+                              const float* scale, const float* shift, const float* residual, int relu, float* y,
+                              float* stats_partials, int* stats_counts, const float* in_mean, const float* in_invstd,
+                              const float* in_gamma, const float* in_beta, int in_relu, void* stream);
 int buctd_conv3x3_bf16x3_supported(int N, int H, int W, int Ci, int Co);
 int buctd_conv3x3_bf16x3_stats_groups(int N, int H, int W, int Ci, int Co, int* ngroups, int* rows_per_group);
 size_t buctd_conv3x3_bf16x3_prep_bytes(int Ci, int Co, int flip);
@@ -104,6 +112,11 @@ int buctd_conv3x3_wgrad_bf16x6_supported(int N, int H, int W, int Ci, int Co);
 size_t buctd_conv3x3_wgrad_bf16x6_workspace(int N, int H, int W, int Ci, int Co);
 int buctd_conv3x3_wgrad_bf16x6(int N, int H, int W, int Ci, int Co, const float* x, const float* dy, float* dw,
                                int accumulate, void* workspace, size_t workspace_bytes, void* stream);
+/* the weight gradient with the same on-the-fly BatchNorm(+ReLU) of its X operand (x = the producer's raw output) */
+int buctd_conv3x3_wgrad_bf16x6_bnin(int N, int H, int W, int Ci, int Co, const float* x, const float* dy, float* dw,
+                                    int accumulate, const float* x_mean, const float* x_invstd, const float* x_gamma,
+                                    const float* x_beta, int x_relu, void* workspace, size_t workspace_bytes,
+                                    void* stream);
 int buctd_conv3x3_wgrad_bf16x3_supported(int N, int H, int W, int Ci, int Co);
 size_t buctd_conv3x3_wgrad_bf16x3_workspace(int N, int H, int W, int Ci, int Co);
 int buctd_conv3x3_wgrad_bf16x3(int N, int H, int W, int Ci, int Co, const float* x, const float* dy, float* dw,

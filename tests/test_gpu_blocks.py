@@ -85,3 +85,40 @@ def test_high_resolution_module(dev, nb, mso):
     o = om.HighResolutionModule(nb, om.BasicBlock, [1] * nb, list(ch), list(ch), "SUM", mso)
     p = hc.HighResolutionModule(nb, hc.BasicBlock, [1] * nb, list(ch), list(ch), "SUM", mso)
     _run(dev, f"hr{nb}", o, p, [torch.randn(3, ch[i], 24 >> i, 16 >> i) for i in range(nb)])
+
+
+@pytest.mark.parametrize("shape", [(2, 24, 18, 48), (3, 12, 9, 96), (20, 96, 72, 48)])
+def test_basic_block_input_bn_fusion_is_bit_identical(dev, shape, monkeypatch):
+    """bf16x6 mode: conv2 of a BasicBlock applies bn1 + ReLU while staging its input, and its weight gradient rebuilds
+    that input the same way (buctd_conv3x3_*_bnin).  Same bits as the unfused sequence conv1 -> bn_apply -> conv2:
+    output, input gradient and every parameter gradient."""
+    import torch.nn as tnn
+    from buctd_amd import ops
+    N, H, W, Cn = shape
+    assert ops.get_conv_math() == "bf16x6"
+    g = torch.Generator().manual_seed(H + Cn)
+    x = torch.randn(N, H, W, Cn, generator=g).to(dev)
+    w1 = tnn.Parameter((torch.randn(Cn, Cn, 3, 3, generator=g) * 0.08).contiguous(memory_format=torch.channels_last).to(dev))
+    w2 = tnn.Parameter((torch.randn(Cn, Cn, 3, 3, generator=g) * 0.08).contiguous(memory_format=torch.channels_last).to(dev))
+    dy = torch.randn(N, H, W, Cn, generator=g).to(dev)
+    res = {}
+    for flag in ("1", "0"):
+        monkeypatch.setenv("BUCTD_FUSE_BN_IN", flag)
+        assert ops.bn_in_fusable((N, H, W, Cn), w2) == (flag == "1")
+        bns = []
+        for s in (1, 2):
+            bn = tnn.BatchNorm2d(Cn).to(dev).train()
+            with torch.no_grad():
+                bn.weight.copy_(torch.rand(Cn, generator=torch.Generator().manual_seed(s)) + 0.5)
+                bn.bias.copy_(torch.randn(Cn, generator=torch.Generator().manual_seed(10 + s)) * 0.2)
+            bns.append(bn)
+        for p in (w1, w2):
+            p.grad = None
+        xi = x.clone().requires_grad_(True)
+        y = ops.BasicBlockFn.apply(xi, w1, bns[0], w2, bns[1])
+        y.backward(dy)
+        torch.cuda.synchronize()
+        res[flag] = [y.detach().clone(), xi.grad.clone(), w1.grad.clone(), w2.grad.clone(), bns[0].weight.grad.clone(),
+                     bns[0].bias.grad.clone(), bns[1].weight.grad.clone(), bns[1].running_var.clone()]
+    for a, b in zip(res["1"], res["0"]):
+        assert torch.equal(a, b), f"fused vs unfused differ by {(a - b).abs().max().item():.3e}"

@@ -103,10 +103,12 @@ def test_validate_is_sharded_over_ranks(tmp_path):
         "    import torch.distributed as dist\n"
         "    dist.barrier(); dist.destroy_process_group()\n")
     outs = []
-    for tag, cmd, extra in (("one", [sys.executable, str(script)], {}),
+    # OMP_NUM_THREADS=1 in both launches (torchrun's default for its workers): the recipe calibrates the oracle's BatchNorm
+    # statistics on the CPU, and torch's parallel reductions round differently with the thread count
+    for tag, cmd, extra in (("one", [sys.executable, str(script)], {"OMP_NUM_THREADS": "1"}),
                             ("two", [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
                                      "--master-addr", "127.0.0.1", "--master-port", "29535", str(script)],
-                             {"BUCTD_DIST_BACKEND": "gloo", "BUCTD_SINGLE_DEVICE": "1"})):
+                             {"BUCTD_DIST_BACKEND": "gloo", "BUCTD_SINGLE_DEVICE": "1", "OMP_NUM_THREADS": "1"})):
         out = str(tmp_path / f"{tag}.npz")
         r = subprocess.run(cmd + [out, str(tmp_path)], env=_env(**extra), capture_output=True, text=True, timeout=900)
         assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-2500:]
