@@ -29,6 +29,7 @@
 //   * epilogue as in conv.hip: bias, Welford BN partials (+ per-group valid-row counts, since pad positions are
 //     skipped), eval-BN scale/shift, residual, ReLU.
 #include "common.h"
+#include <stdlib.h>
 #include "../../include/buctd_hip.h"
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -401,8 +402,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_split_kernel(C3Args p) {
 //     With six MFMAs per product the fragment stream needs ~31 B/clk/CU of the 64 B/clk L1 - half of what the
 //     three-MFMA mode would need, which is why that mode keeps its LDS stage.
 // Two taps per K = 32 MFMA (lanes 0-31 feed tap 2s, lanes 32-63 tap 2s+1; the 10th half-step has zero weights).
-template <int MF, int NF, int WM, int WN, bool DBUF>
-__global__ __launch_bounds__(256, 2) void conv3x3_x6_kernel(C3Args p) {
+template <int MF, int NF, int WM, int WN, bool DBUF, bool BPF_, int WPS>
+__global__ __launch_bounds__(256, WPS) void conv3x3_x6_kernel(C3Args p) {
   constexpr int ROWB = Geo<3>::ROWB, PST = Geo<3>::PST, CPR = Geo<3>::CPR;
   constexpr int BM = WM * MF * 16, BN = WN * NF * 16;
   constexpr int RPP = 256 / CPR;                                 // 64 rows staged per pass
@@ -427,6 +428,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_x6_kernel(C3Args p) {
   const int p0 = bx * BM, n0 = by * BN;
   const int halo = p.SW + 1;
   const int c4 = (t % CPR) * 4, prow = t / CPR;
+
 
   int goff[PA];        // global element offset (channel 0) of every staged row of this thread; -1 zero row, -2 beyond
 #pragma unroll
@@ -478,7 +480,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_x6_kernel(C3Args p) {
   const unsigned char* bptr = p.wp + ((size_t)(n0 / 16 + wave_n * NF) * 3) * 1024;   // scalar base
   const int blane = lane * 16;                                                        // the only per-lane part
   const size_t bstep = (size_t)(p.Co / 16) * 3 * 1024;
-  constexpr bool BPF = MF < 8;       // step-ahead B prefetch (36 more registers)
+  constexpr bool BPF = BPF_;         // step-ahead B prefetch (36 more registers)
   bf16x8 bc[3][NF], bn[BPF ? 3 : 1][BPF ? NF : 1];      // fragments of the current step / of the next one (in flight)
   auto load_b = [&](int gs, bf16x8 (&dst)[3][NF]) {
     const unsigned char* src = bptr + (size_t)gs * bstep;
@@ -598,7 +600,10 @@ __global__ __launch_bounds__(256) void conv3x3_prep_kernel(const float* __restri
 }
 
 // the same for many filters in one launch (all prepared images of a model after an optimizer step): items live in
-// device memory, thread -> item by binary search over the running piece count
+// device memory, thread -> item by binary search over the running piece count; item.reserved = 3 selects the
+// fragment-order image of the six-MFMA mode (conv3x3_prep3 layout), anything else the two-piece stage image
+__device__ __forceinline__ void prep3_piece(const float* __restrict__ w, unsigned char* __restrict__ out, int Kc, int Nc,
+                                            int flip, long idx);
 __global__ __launch_bounds__(256) void conv3x3_prep_batched_kernel(const buctd_c3_prep_item* __restrict__ items, int n,
                                                                    long total) {
   const long idx = (long)blockIdx.x * 256 + threadIdx.x;
@@ -612,6 +617,10 @@ __global__ __launch_bounds__(256) void conv3x3_prep_batched_kernel(const buctd_c
   const buctd_c3_prep_item it = items[lo];
   const long local = idx - it.piece_begin;
   const int Kc = it.flip ? it.Co : it.Ci, Nc = it.flip ? it.Ci : it.Co;
+  if (it.reserved == 3) {
+    prep3_piece(it.w, reinterpret_cast<unsigned char*>(it.wprep), Kc, Nc, it.flip, local);
+    return;
+  }
   const int k4 = (int)(local & 7);
   const long rown = local >> 3;
   const int nn = (int)(rown % Nc), step = (int)(rown / Nc);
@@ -636,10 +645,8 @@ __global__ __launch_bounds__(256) void conv3x3_prep_batched_kernel(const buctd_c
 // NP = 3 image in MFMA fragment order: out[step][n/16][piece][lane][8 bf16], lane = 16*g + (n & 15) holding k-slots
 // 8g..8g+7 of row n; step = (16-channel chunk c, s): k-slots 0-15 = (tap 2s, channels 16c..16c+15), 16-31 = (tap 2s+1,
 // same channels; tap 9 = zero).  One thread = 4 k-slots of one row.
-__global__ __launch_bounds__(256) void conv3x3_prep3_kernel(const float* __restrict__ w, unsigned char* __restrict__ out,
-                                                            int Kc, int Nc, int flip, long items) {
-  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
-  if (idx >= items) return;
+__device__ __forceinline__ void prep3_piece(const float* __restrict__ w, unsigned char* __restrict__ out, int Kc, int Nc,
+                                            int flip, long idx) {
   const int k4 = (int)(idx & 7);               // k-slots 4*k4 .. 4*k4+3
   const long rown = idx >> 3;
   const int n = (int)(rown % Nc), step = (int)(rown / Nc);
@@ -659,9 +666,15 @@ __global__ __launch_bounds__(256) void conv3x3_prep3_kernel(const float* __restr
   // pieces 1 KB apart; the 4 k-slots occupy 8 bytes at (k4 & 1) * 8 inside the lane's 16
   split_store<3, 1024>(dst, (k4 & 1) * 4, v);
 }
+__global__ __launch_bounds__(256) void conv3x3_prep3_kernel(const float* __restrict__ w, unsigned char* __restrict__ out,
+                                                            int Kc, int Nc, int flip, long items) {
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= items) return;
+  prep3_piece(w, out, Kc, Nc, flip, idx);
+}
 
 // ---------------------------------------------------------------------------------------------- host ----
-struct C3Plan { int MF, NF, WM, WN, BM, BN, na; size_t lds; };
+struct C3Plan { int MF, NF, WM, WN, BM, BN, na, lean; size_t lds; };
 
 // magic for unsigned division of n < 2^31 by d (2 <= d < 2^31): q = mulhi(n, mul) >> sh
 static void magic_u32(unsigned d, unsigned* mul, unsigned* sh) {
@@ -699,17 +712,20 @@ static bool c3_plan(int np, int N, int H, int W, int Ci, int Co, C3Plan* pl) {
     if (blocks >= 320) { mf = cand[i]; break; }
   }
   bool single = false;
+  pl->lean = 0;
   if (np == 3 && nf == 3 && wn == 1 && Co == bn) {
     // 512-position tiles in ONE round of workgroups (2 resident per CU = 512 slots) instead of 1.75 rounds of
     // 256-position tiles: the 48-channel branch at N*H*W >= ~115k positions (single A buffer: 64.5 KB at W = 72)
     const long b8 = (P + 511) / 512;
     if (b8 > 256 && b8 <= 512) { mf = 8; single = true; }
+    static const int lean_env = getenv("BUCTD_C3_LEAN") ? atoi(getenv("BUCTD_C3_LEAN")) : 0;
+    if (lean_env && mf == 8) { mf = 4; pl->lean = 1; }      // experiment: 3 lean workgroups per CU instead
   }
   pl->MF = mf; pl->NF = nf; pl->WM = wm; pl->WN = wn; pl->BM = wm * mf * 16; pl->BN = bn;
   pl->na = (pl->BM + 2 * (W + 2) + 2 + 31) / 32;
   const size_t stage = (size_t)4 * (mf >= 2 ? 2 : 1) * 16 * (nf * 16 + 4) * 4 + 4 * 128 * 4;   // epilogue staging + row offsets
   if (np == 3) {            // two A buffers (one for the 512-position tiles), no B stage
-    const int nb = single ? 1 : 2;
+    const int nb = (single || pl->lean) ? 1 : 2;
     while ((size_t)nb * pl->na * 32 * rowb < stage) ++pl->na;
     pl->lds = (size_t)nb * pl->na * 32 * rowb;
   } else {
@@ -723,10 +739,16 @@ static bool c3_np_ok(int np) { return np == 2 || np == 3; }
 
 template <int NP, int MF, int NF, int WM, int WN>
 static int c3_launch(const C3Args& a, const C3Plan& pl, hipStream_t st) {
-  static bool attr_set = false;     // idempotent attribute call: a race at first use only repeats it
+  static bool attr_done[3] = {false, false, false};   // idempotent attribute call: a race at first use only repeats it
   void (*fn)(C3Args);
-  if constexpr (NP == 3) fn = MF >= 8 ? conv3x3_x6_kernel<MF, NF, WM, WN, false> : conv3x3_x6_kernel<MF, NF, WM, WN, true>;
+  int variant = 0;
+  if constexpr (NP == 3) {
+    if (MF >= 8) fn = conv3x3_x6_kernel<MF, NF, WM, WN, false, false, 2>;
+    else if (pl.lean) { fn = conv3x3_x6_kernel<MF, NF, WM, WN, false, false, 3>; variant = 1; }
+    else { fn = conv3x3_x6_kernel<MF, NF, WM, WN, true, true, 2>; variant = 2; }
+  }
   else fn = conv3x3_split_kernel<NP, (MF > 4 ? 4 : MF), NF, WM, WN>;
+  bool& attr_set = attr_done[variant];
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        160 * 1024);

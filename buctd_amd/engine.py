@@ -109,7 +109,8 @@ class FusedAdam(torch.optim.Optimizer):
         g = self.param_groups[0]
         ops.adam_step(self.flat.flat, self.flat.grad, self.exp_avg, self.exp_avg_sq, g["lr"], g["betas"][0],
                       g["betas"][1], g["eps"], self.step_count, gscale)
-        ops.weights_updated()  # the kernel wrote the parameters through raw pointers: drop prepared filter images
+        ops.weights_updated()  # the kernel wrote the parameters through raw pointers: prepared filter images are stale
+        ops.refresh_prepared(self.flat.flat.device)   # ... and are rebuilt here, by one launch behind the Adam kernel
 
     def zero_grad(self, set_to_none=True):
         for p in self.flat.params:

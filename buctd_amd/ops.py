@@ -185,15 +185,22 @@ def _bf16x3_ok(d):
 
 
 _weights_epoch = {"n": 0}
-# one batched refresh launch instead of ~430 small ones per train step: fewer launches (CPU side) but the small ones
-# overlap with other streams' work and measured 1.5 ms/step faster while the step is GPU-bound; off by default
-_PREP_BATCH = os.environ.get("BUCTD_PREP_BATCH", "0") == "1"
+# After an optimizer step every prepared filter image of the model is rebuilt by ONE launch on the stream of the step
+# (refresh_prepared, called by FusedAdam) instead of ~430 small launches in front of the convolutions that need them:
+# off the critical path of the next forward / backward, 430 launches less per step.  BUCTD_PREP_BATCH=0: lazy refresh.
+_PREP_BATCH = os.environ.get("BUCTD_PREP_BATCH", "1") == "1"
 _prep_registry = {"weights": [], "table": None, "table_key": None, "event": None, "stream": None, "waited": set()}
 
 
 def weights_updated():
     """Called by whoever rewrites parameters through raw pointers (FusedAdam): invalidates prepared filter images."""
     _weights_epoch["n"] += 1
+
+
+def refresh_prepared(device):
+    """Rebuild all registered prepared filter images now (one launch on the current stream)."""
+    if _PREP_BATCH and _conv_math["mode"] != "fp32":
+        _prep_all(device)
 
 
 class _PrepItem(C.Structure):
@@ -204,8 +211,10 @@ class _PrepItem(C.Structure):
 def _prep_all(device):
     """Refresh every registered prepared image whose filter was rewritten in place (same storage, new epoch) with ONE
     launch instead of one per filter and direction (~430 per CoAM-W48 train step)."""
-    import weakref
     epoch = _weights_epoch["n"]
+    mode = _conv_math["mode"]
+    np_pieces = 3 if mode == "bf16x6" else 2
+    unit = 24 if np_pieces == 3 else 16          # image bytes per piece of the batched kernel
     items, live, total = [], [], 0
     for ref in _prep_registry["weights"]:
         w = ref()
@@ -215,18 +224,16 @@ def _prep_all(device):
         if cache is None or cache[0][0] != w.data_ptr():
             continue
         live.append(ref)
-        if cache[0] == (w.data_ptr(), w._version, epoch, "bf16x3"):
-            continue
-        if cache[0][3:] != ("bf16x3",):
+        if cache[0] == (w.data_ptr(), w._version, epoch, mode) or cache[0][3] != mode:
             continue
         Co, Ci = _wshape(w)[0], _wshape(w)[1]
         for flip in (0, 1):
             img = cache[1 + flip]
             if img is None:
                 continue
-            items.append((w.data_ptr(), img.data_ptr(), Ci, Co, flip, 0, total))
-            total += img.numel() // 16
-        cache[0] = (w.data_ptr(), w._version, epoch, "bf16x3")
+            items.append((w.data_ptr(), img.data_ptr(), Ci, Co, flip, np_pieces, total))
+            total += img.numel() // unit
+        cache[0] = (w.data_ptr(), w._version, epoch, mode)
     _prep_registry["weights"] = live
     if not items:
         return
@@ -237,7 +244,7 @@ def _prep_all(device):
         _prep_registry["table"] = host.to(device)
         _prep_registry["table_key"] = key
     check(lib().buctd_conv3x3_bf16x3_prep_batched(ptr(_prep_registry["table"]), len(items), total, stream_ptr()),
-          "conv3x3_bf16x3_prep_batched")
+          "conv3x3 prep_batched")
     ev = torch.cuda.Event()
     ev.record()
     _prep_registry["event"], _prep_registry["stream"] = ev, torch.cuda.current_stream(device).cuda_stream
@@ -251,8 +258,7 @@ def _conv3x3_prepared(w, flip):
     epoch = _weights_epoch["n"]
     key = (w.data_ptr(), w._version, epoch, _conv_math["mode"])
     cache = getattr(w, "_buctd_prep", None)
-    if (cache is not None and cache[0] != key and cache[0][:2] == key[:2] and cache[0][3:] == key[3:] and _PREP_BATCH
-            and key[3] == "bf16x3"):
+    if cache is not None and cache[0] != key and cache[0][:2] == key[:2] and cache[0][3:] == key[3:] and _PREP_BATCH:
         _prep_all(w.device)       # rewritten in place by the optimizer kernel: batch-refresh all registered images
     if cache is None or cache[0] != key:
         cache = [key, None, None]

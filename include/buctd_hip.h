@@ -91,9 +91,10 @@ int buctd_conv3x3_bf16x3_supported(int N, int H, int W, int Ci, int Co);
 int buctd_conv3x3_bf16x3_stats_groups(int N, int H, int W, int Ci, int Co, int* ngroups, int* rows_per_group);
 size_t buctd_conv3x3_bf16x3_prep_bytes(int Ci, int Co, int flip);
 int buctd_conv3x3_bf16x3_prep(int Ci, int Co, const float* w, int flip, void* wprep, void* stream);
-/* The same for n filters in ONE launch (every prepared image of a model after an optimizer step; bf16x3 only).
- * `items_device` is an array in device memory; piece_begin is the running sum of
- * buctd_conv3x3_bf16x3_prep_bytes(..)/16 over the preceding items and total_pieces the sum over all of them. */
+/* The same for n filters in ONE launch (every prepared image of a model after an optimizer step), either family:
+ * item.reserved = 3 writes the bf16x6 image, anything else the bf16x3 one.  `items_device` is an array in device
+ * memory; an item has steps * Nc * 8 pieces (= prep_bytes / 16 for bf16x3, / 24 for bf16x6); piece_begin is the running
+ * sum over the preceding items and total_pieces the sum over all of them. */
 typedef struct {
   const float* w;       /* forward filter [Co][3][3][Ci] */
   void* wprep;          /* destination image */

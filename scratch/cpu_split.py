@@ -3,7 +3,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench
 from buctd_amd import engine, models, ops
 from buctd_amd.core.loss import JointsMSELoss
-ops.set_conv_math("bf16x3")
+ops.set_conv_math("bf16x6")
 dev = torch.device("cuda:0")
 B = int(os.environ.get("BATCH", "2"))
 cfg = bench.coam_w48_cfg(B)
