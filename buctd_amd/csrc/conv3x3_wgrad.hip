@@ -20,6 +20,7 @@
 //   rows = 8 distinct 32-byte bank windows (row stride = 32 mod 64 bytes), where the natural {8g..8g+7} assignment made
 //   rows r and r+8 collide (2-way conflicts on every transpose read: half of all LDS cycles, measured).
 #include "common.h"
+#include <stdlib.h>
 #include "../../include/buctd_hip.h"
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -356,7 +357,8 @@ static bool wg3_plan(int np, int N, int H, int W, int Ci, int Co, WG3Plan* pl) {
   const long pairs = (long)(Co / ch) * (Ci / ch);
   // two resident workgroups per CU (512 in all) when one (co, ci) chunk pair exists; fewer splits per pair otherwise
   // (partial-slab traffic grows with the split).  Splits take q or q + 1 stages, so no rounding loss.
-  long want = ((np == 3 ? 512 : 384) + pairs - 1) / pairs;
+  static const int split_env = getenv("BUCTD_WG3_SPLIT") ? atoi(getenv("BUCTD_WG3_SPLIT")) : 0;
+  long want = ((split_env > 0 ? split_env : (np == 3 ? 512 : 384)) + pairs - 1) / pairs;
   const long stages = (P + kb - 1) / kb;
   if (want > stages) want = stages;
   if (want < 1) want = 1;
