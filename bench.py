@@ -165,8 +165,10 @@ def roofline_entry(math, batch, kind, in_step, solo, traffic):
         peak = PEAK_BF16_MFMA_TFLOPS / k
         unit_note = (f"dense bf16 MFMA peak 2500 TFLOP/s / {k} MFMAs per fp32 product (split operands) = "
                      f"{peak:.1f} TFLOP/s-equivalent")
-        kernel = ("conv3x3_split_kernel<NP=%d,4,3,4,1>" if kind == "fwd" else "conv3x3_wgrad_split_kernel<NP=%d,3>") % \
-            (3 if math == "bf16x6" else 2)
+        kernel = {("bf16x6", "fwd"): "conv3x3_x6_kernel<MF=8,NF=3,WM=4,WN=1> (512-position tiles)",
+                  ("bf16x3", "fwd"): "conv3x3_split_kernel<NP=2,4,3,4,1>"}.get(
+                      (math, "fwd" if kind == "fwd" else "wgrad"),
+                      "conv3x3_wgrad_split_kernel<NP=%d,3> + wg3_reduce_kernel" % (3 if math == "bf16x6" else 2))
     hbm_us = bytes_ / (PEAK_HBM_GBPS * 1e3)
     mfma_us = flops / (peak * 1e6)
     bound = "mfma" if mfma_us >= hbm_us else "hbm"
@@ -479,7 +481,7 @@ def main():
             ops.conv_fwd(xs, wsel, None, 1, 1, stats=True)
             ops.conv_dgrad(dys, wsel, tuple(xs.shape), 1, 1)
             ops.conv_wgrad(xs, dys, wsel, 1, 1, out=gw, accumulate=0)
-            torch.cuda.synchronize()
+        torch.cuda.synchronize()
         timer.enabled = False
         solo = {k: timer.mean_us(k) for k in ("fwd", "dgrad", "wgrad")}
     state["pending"].resolve(losses, acc)
