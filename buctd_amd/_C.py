@@ -81,6 +81,7 @@ SIGNATURES = {
     "buctd_bn_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _L, _I, _P, _P, _P, _P, _I, _P, _SZ, _P]),
     "buctd_bn_fold": (_I, [_P, _P, _P, _P, _F, _I, _P, _P, _P]),
     "buctd_add": (_I, [_P, _P, _P, _L, _I, _P]),
+    "buctd_mul": (_I, [_P, _P, _P, _L, _P]),
     "buctd_scale": (_I, [_P, _P, _F, _P, _L, _P]),
     "buctd_copy_channels": (_I, [_P, _L, _I, _I, _P, _I, _I, _I, _P]),
     "buctd_add_bcast": (_I, [_P, _P, _P, _L, _L, _P]),

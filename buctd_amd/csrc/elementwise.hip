@@ -34,6 +34,15 @@ __global__ __launch_bounds__(256) void add_kernel(const float* __restrict__ a, c
   }
 }
 
+__global__ __launch_bounds__(256) void mul_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                  float* __restrict__ out, long n) {
+  const long n4 = n >> 2;
+  const long step = (long)gridDim.x * 256;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += step)
+    reinterpret_cast<f32x4*>(out)[i] = reinterpret_cast<const f32x4*>(a)[i] * reinterpret_cast<const f32x4*>(b)[i];
+  for (long i = n4 * 4 + (long)blockIdx.x * 256 + threadIdx.x; i < n; i += step) out[i] = a[i] * b[i];
+}
+
 __global__ __launch_bounds__(256) void relu_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y,
                                                        float* __restrict__ dx, long n) {
   const long n4 = n >> 2;
@@ -103,6 +112,12 @@ extern "C" int buctd_add(const float* a, const float* b, float* out, long n, int
   BUCTD_CHECK_ARG(a && out && n > 0, "buctd_add: bad argument");
   hipLaunchKernelGGL(add_kernel, dim3(stream_grid((n + 3) / 4)), dim3(256), 0, (hipStream_t)stream, a, b, out, n, relu);
   BUCTD_CHECK_LAUNCH("buctd_add");
+  return BUCTD_OK;
+}
+extern "C" int buctd_mul(const float* a, const float* b, float* out, long n, void* stream) {
+  BUCTD_CHECK_ARG(a && b && out && n > 0, "buctd_mul: bad argument");
+  hipLaunchKernelGGL(mul_kernel, dim3(stream_grid((n + 3) / 4)), dim3(256), 0, (hipStream_t)stream, a, b, out, n);
+  BUCTD_CHECK_LAUNCH("buctd_mul");
   return BUCTD_OK;
 }
 extern "C" int buctd_relu_bwd(const float* dy, const float* y, float* dx, long n, void* stream) {

@@ -67,11 +67,13 @@ class DAModule(nn.Module):
     def parts(self):
         """the independent attention cores of this module, as callables (input, cond) -> [B, T, C]"""
         if self.channel_only:
-            raise NotImplementedError("MODEL.ATT_CHANNEL_ONLY (input * c_out) is not used by any BUCTD recipe")
+            return [self.channel_attention_module]
         return [self.channel_attention_module, self.position_attention_module]
 
     def combine(self, input, outs):
         b, h, w, c = input.shape
+        if self.channel_only:  # MODEL.ATT_CHANNEL_ONLY: the channel core gates the input (pose_hrnet_coam.py:716-717)
+            return ops.Mul.apply(input, outs[0].view(b, h, w, c))
         c_out, p_out = outs
         return ops.AddN.apply(input, p_out.view(b, h, w, c), c_out.view(b, h, w, c))
 
@@ -110,6 +112,9 @@ class CoAMBlock(nn.Module):
 
         def chan():
             return [self.att_layers[i].parts()[0](y_list[i], conds[i]) for i in range(n)]
+
+        if self.att_layers[0].channel_only:
+            return [self.att_layers[i].combine(y_list[i], chan()) for i in range(n)]
 
         def pos():
             return [self.att_layers[i].parts()[1](y_list[i], conds[i]) for i in range(n)]

@@ -623,6 +623,29 @@ def add(a, b=None, relu=False, out=None):
     return out
 
 
+def mul(a, b, out=None):
+    if out is None:
+        out = torch.empty_like(a)
+    check(lib().buctd_mul(ptr(a), ptr(b), ptr(out), a.numel(), stream_ptr()), "mul")
+    return out
+
+
+class Mul(torch.autograd.Function):
+    """out = a * b, DAModule's channel-only gate `input * c_out` (pose_hrnet_coam.py:716-717)."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        a, b = _contig(a), _contig(b)
+        ctx.save_for_backward(a, b)
+        return mul(a, b)
+
+    @staticmethod
+    def backward(ctx, dy):
+        a, b = ctx.saved_tensors
+        dy = _contig(dy)
+        return mul(dy, b), mul(dy, a)
+
+
 def scale(x, dev_scalar=None, alpha=1.0, out=None):
     if out is None:
         out = torch.empty_like(x)

@@ -171,6 +171,8 @@ int buctd_bn_fold(const float* gamma, const float* beta, const float* running_me
 /* ----------------------------------------------------------- elementwise --- */
 /* out[i] = a[i] + b[i] (b may be NULL -> copy); relu optional */
 int buctd_add(const float* a, const float* b, float* out, long n, int relu, void* stream);
+/* out[i] = a[i] * b[i]: DAModule with MODEL.ATT_CHANNEL_ONLY, `input * c_out` (pose_hrnet_coam.py:716-717) */
+int buctd_mul(const float* a, const float* b, float* out, long n, void* stream);
 /* out[i] = x[i] * alpha * (*dev_scalar) ; dev_scalar is a device pointer or NULL (chain rule through
  * the scalar loss without a host sync: loss.backward() hands d(loss) over as a device scalar) */
 int buctd_scale(const float* x, const float* dev_scalar, float alpha, float* out, long n, void* stream);
