@@ -402,6 +402,17 @@ __global__ __launch_bounds__(256, 2) void conv3x3_split_kernel(C3Args p) {
 //     With six MFMAs per product the fragment stream needs ~31 B/clk/CU of the 64 B/clk L1 - half of what the
 //     three-MFMA mode would need, which is why that mode keeps its LDS stage.
 // Two taps per K = 32 MFMA (lanes 0-31 feed tap 2s, lanes 32-63 tap 2s+1; the 10th half-step has zero weights).
+#ifndef C3_PRIO
+#define C3_PRIO 0
+#endif
+constexpr bool PRIO = C3_PRIO != 0;
+#ifdef C3_TRACE
+__device__ unsigned long long c3_trace_buf[8][64];
+__device__ unsigned long long c3_trace_wall[4096][2];   // wall clock (100 MHz) at start / end of every workgroup, dispatch order
+#define C3_TR(k) do { if (tr_on) c3_trace_buf[tr_slot][(k)] = clock64(); } while (0)
+#else
+#define C3_TR(k) do {} while (0)
+#endif
 template <int MF, int NF, int WM, int WN, bool DBUF, bool BPF_, int WPS>
 __global__ __launch_bounds__(256, WPS) void conv3x3_x6_kernel(C3Args p) {
   constexpr int ROWB = Geo<3>::ROWB, PST = Geo<3>::PST, CPR = Geo<3>::CPR;
@@ -430,6 +441,11 @@ __global__ __launch_bounds__(256, WPS) void conv3x3_x6_kernel(C3Args p) {
   const int c4 = (t % CPR) * 4, prow = t / CPR;
 
 
+#ifdef C3_TRACE
+  const int tr_stride = (gridDim.x + 7) / 8;
+  const bool tr_on = t == 0 && by == 0 && bx % tr_stride == 0;
+  const int tr_slot = bx / tr_stride;
+#endif
   int goff[PA];        // global element offset (channel 0) of every staged row of this thread; -1 zero row, -2 beyond
 #pragma unroll
   for (int q = 0; q < PA; ++q) {
@@ -504,15 +520,29 @@ __global__ __launch_bounds__(256, WPS) void conv3x3_x6_kernel(C3Args p) {
   // one chunk = 5 unrolled steps.  The B fragments travel one step ahead: a step first takes over the set fetched
   // during the previous step (register moves - indexing two sets by step parity made the compiler keep copies of both
   // and spill), then issues the fetch of the next step's set, whose L2 latency the step's MFMAs cover
+  constexpr int AD = MF >= 2 ? 2 : 1;      // fragment prefetch distance
+  bf16x8 a[AD + 1][3];
+  auto read_a = [&](const unsigned char* abase, int i, bf16x8 (&dst)[3]) {     // fragment i = (step, mf) of the chunk
+    const int st = i / MF, mf = i % MF;
+    const int tap0 = 2 * st, tap1 = 2 * st + 1 < 9 ? 2 * st + 1 : 2 * st;
+    const int o0 = ((tap0 / 3) * p.SW + tap0 % 3) * ROWB, o1 = ((tap1 / 3) * p.SW + tap1 % 3) * ROWB;
+    const unsigned char* ap = abase + (lowk ? o0 : o1) + mf * 16 * ROWB;
+#pragma unroll
+    for (int q = 0; q < 3; ++q) dst[q] = *reinterpret_cast<const bf16x8*>(ap + q * PST);
+  };
   auto run_chunk = [&](int ch) {
     const unsigned char* abase = smem + (ch & 1) * abytes + aoff;
 #pragma unroll
+    for (int i = 0; i < AD; ++i) read_a(abase, i, a[i]);
+#pragma unroll
     for (int s = 0; s < 5; ++s) {
+      if (ch == 1) C3_TR(50 + s);
       if (DBUF && s == 2 && ch + 1 < nchunks) {    // next chunk: registers -> pieces -> the other A buffer
         // done while the fewest registers are live (no B prefetch in flight, no A fragments): the split needs ~60
+        if (ch == 1) C3_TR(56);
         store_a(smem + ((ch + 1) & 1) * abytes, (ch + 1) * 16);
-        if (ch + 2 < nchunks) load_a((ch + 2) * 16);
         __builtin_amdgcn_sched_barrier(0);
+        if (ch == 1) C3_TR(57);
       }
       if constexpr (BPF) {
 #pragma unroll
@@ -523,28 +553,28 @@ __global__ __launch_bounds__(256, WPS) void conv3x3_x6_kernel(C3Args p) {
       } else {
         load_b(gs, bc);          // 144 MFMAs per step: the fetch latency is small against them, the registers are not
       }
-      const int tap0 = 2 * s, tap1 = 2 * s + 1 < 9 ? 2 * s + 1 : 2 * s;
-      const int o0 = ((tap0 / 3) * p.SW + tap0 % 3) * ROWB, o1 = ((tap1 / 3) * p.SW + tap1 % 3) * ROWB;
-      const unsigned char* ap = abase + (lowk ? o0 : o1);
-      // A fragments are fetched one 16-row fragment ahead (24 registers live instead of 48): the reads of fragment
-      // mf+1 are issued in front of the 18 MFMAs of fragment mf; the scheduling fences keep the compiler from hoisting
-      // every read of the step to its top (which spills)
-      bf16x8 a[2][3];
-#pragma unroll
-      for (int q = 0; q < 3; ++q) a[0][q] = *reinterpret_cast<const bf16x8*>(ap + q * PST);
+      if (DBUF && s == 2 && ch + 2 < nchunks) {
+        // the global loads of chunk ch+2 go out BEHIND this step's B prefetch: vector loads return in order, so the next
+        // step's wait for its B fragments (older) leaves them in flight, and only the wait two steps on needs them -
+        // issued in front of the prefetch they put their whole HBM latency into the very next step
+        __builtin_amdgcn_sched_barrier(0);
+        load_a((ch + 2) * 16);
+        __builtin_amdgcn_sched_barrier(0);
+        if (ch == 1) C3_TR(58);
+      }
+      // A fragments travel AD 16-row fragments ahead of their MFMAs through a ring of AD + 1 register sets, across the
+      // step boundaries of the chunk (flat index i = s * MF + mf): with eight waves reading, a ds_read_b128 triple takes
+      // longer than the 18 MFMAs of one fragment (cycle stamps: ~650 idle cycles per 72-MFMA step with AD = 1 and a
+      // cold start at every step).  The scheduling fences keep the compiler from hoisting every read to the top.
 #pragma unroll
       for (int mf = 0; mf < MF; ++mf) {
-        if (mf + 1 < MF) {
-#pragma unroll
-          for (int q = 0; q < 3; ++q)
-            a[(mf + 1) & 1][q] = *reinterpret_cast<const bf16x8*>(ap + (mf + 1) * 16 * ROWB + q * PST);
-        }
+        const int i = s * MF + mf;
+        if (i + AD < 5 * MF) read_a(abase, i + AD, a[(i + AD) % (AD + 1)]);
         __builtin_amdgcn_sched_barrier(0);
-        bf16x8 (&ac)[3] = a[mf & 1];
-#define X6_MMA(qa, qb)                                                                                          \
-  _Pragma("unroll") for (int nf = 0; nf < NF; ++nf) acc[mf][nf] =                                                \
-      __builtin_amdgcn_mfma_f32_16x16x32_bf16(ac[qa], bc[qb][nf], acc[mf][nf], 0, 0, 0);
-        X6_MMA(2, 0) X6_MMA(0, 2) X6_MMA(1, 1) X6_MMA(1, 0) X6_MMA(0, 1) X6_MMA(0, 0)
+        bf16x8 (&ac)[3] = a[i % (AD + 1)];
+#define X6_MMA(qa, qb) acc[mf][nf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ac[qa], bc[qb][nf], acc[mf][nf], 0, 0, 0);
+#pragma unroll
+        for (int nf = 0; nf < NF; ++nf) { X6_MMA(2, 0) X6_MMA(0, 2) X6_MMA(1, 1) X6_MMA(1, 0) X6_MMA(0, 1) X6_MMA(0, 0) }
 #undef X6_MMA
         __builtin_amdgcn_sched_barrier(0);
       }
@@ -553,21 +583,48 @@ __global__ __launch_bounds__(256, WPS) void conv3x3_x6_kernel(C3Args p) {
     }
   };
 
+  C3_TR(0);
+#ifdef C3_TRACE
+  if (tr_on) c3_trace_buf[tr_slot][62] = wall_clock64();
+  const unsigned tr_lin = blockIdx.y * gridDim.x + blockIdx.x;
+  if (t == 0 && tr_lin < 4096) c3_trace_wall[tr_lin][0] = wall_clock64();
+#endif
   load_a(0);
   if constexpr (BPF) load_b(0, bn);
   store_a(smem, 0);
   if (nchunks > 1) load_a(16);
   __syncthreads();
+  C3_TR(1);
   for (int ch = 0; ch < nchunks; ++ch) {
     if (!DBUF && ch > 0) {   // single buffer (the largest position tiles): restage between two barriers
       store_a(smem, ch * 16);
       if (ch + 1 < nchunks) load_a((ch + 1) * 16);
       __syncthreads();
     }
+    if (ch < 24) C3_TR(2 + 2 * ch);
+    if (PRIO) {
+      // the two workgroups of a CU are not served alike: the instruction arbiter favours the older wave, so the first
+      // workgroup finishes a third ahead and the second runs its last chunks alone at half the throughput (cycle stamps:
+      // lifetimes 35 / 47 us).  Priority by progress quartile - whoever is behind wins - keeps them level.
+      switch (4 * ch / nchunks) {
+        case 0: __builtin_amdgcn_s_setprio(3); break;
+        case 1: __builtin_amdgcn_s_setprio(2); break;
+        case 2: __builtin_amdgcn_s_setprio(1); break;
+        default: __builtin_amdgcn_s_setprio(0); break;
+      }
+    }
     run_chunk(ch);
+    if (ch < 24) C3_TR(3 + 2 * ch);
     __syncthreads();       // DBUF: chunk ch+1 is complete in its buffer; nobody reads this chunk's buffer any more
   }
+  C3_TR(60);
+  if (PRIO) __builtin_amdgcn_s_setprio(0);
   c3_epilogue<MF, NF, WM, WN>(p, acc, smem, bx, by, p0, n0);
+  C3_TR(61);
+#ifdef C3_TRACE
+  if (tr_on) c3_trace_buf[tr_slot][63] = wall_clock64();
+  if (t == 0 && tr_lin < 4096) c3_trace_wall[tr_lin][1] = wall_clock64();
+#endif
 }
 
 // ------------------------------------------------------------------------------------- weight preparation ----
@@ -709,7 +766,9 @@ static bool c3_plan(int np, int N, int H, int W, int Ci, int Co, C3Plan* pl) {
   const int cand[2] = {4, 2};
   for (int i = (nf == 4 ? 1 : 0); i < 2; ++i) {   // 64-row x 64-column wave tiles would spill
     const long blocks = ((P + wm * cand[i] * 16 - 1) / (wm * cand[i] * 16)) * (Co / bn);
-    if (blocks >= 320) { mf = cand[i]; break; }
+    // bf16x6 fetches its B fragments per wave, one step ahead: a 16-row wave tile (MF = 1) leaves 18 MFMAs to cover an
+    // L2 round trip, so the smallest maps (384 ch @12x9: 288 workgroups at MF = 2) prefer the larger tile (measured)
+    if (blocks >= (np == 3 ? 256 : 320)) { mf = cand[i]; break; }
   }
   bool single = false;
   pl->lean = 0;
@@ -720,6 +779,12 @@ static bool c3_plan(int np, int N, int H, int W, int Ci, int Co, C3Plan* pl) {
     if (b8 > 256 && b8 <= 512) { mf = 8; single = true; }
     static const int lean_env = getenv("BUCTD_C3_LEAN") ? atoi(getenv("BUCTD_C3_LEAN")) : 0;
     if (lean_env && mf == 8) { mf = 4; pl->lean = 1; }      // experiment: 3 lean workgroups per CU instead
+  }
+  if (const char* f = getenv("BUCTD_C3_FORCE")) {   // experiment: "mf,wn" for the 48/96-column tiles
+    int fm = 0, fw = 0;
+    if (np == 3 && nf == 3 && sscanf(f, "%d,%d", &fm, &fw) == 2 && (fw == 1 || (fw == 2 && Co % 96 == 0))) {
+      mf = fm; wn = fw; wm = 4 / wn; bn = wn * nf * 16; single = mf == 8; pl->lean = 0;
+    }
   }
   pl->MF = mf; pl->NF = nf; pl->WM = wm; pl->WN = wn; pl->BM = wm * mf * 16; pl->BN = bn;
   pl->na = (pl->BM + 2 * (W + 2) + 2 + 31) / 32;
@@ -769,7 +834,7 @@ static int c3_dispatch(const C3Args& a, const C3Plan& pl, hipStream_t st) {
 #define C3_CASE(mf, nf, wm, wn) \
   if (pl.MF == mf && pl.NF == nf && pl.WN == wn) return c3_launch<NP, mf, nf, wm, wn>(a, pl, st);
 #define C3_MF(nf, wm, wn) C3_CASE(4, nf, wm, wn) C3_CASE(2, nf, wm, wn) C3_CASE(1, nf, wm, wn)
-  if constexpr (NP == 3) { C3_CASE(8, 3, 4, 1) }
+  if constexpr (NP == 3) { C3_CASE(8, 3, 4, 1) C3_CASE(8, 3, 2, 2) }
   C3_MF(1, 4, 1) C3_MF(2, 4, 1) C3_MF(3, 4, 1) C3_MF(3, 2, 2)
   C3_CASE(2, 4, 4, 1) C3_CASE(1, 4, 4, 1) C3_CASE(2, 4, 2, 2) C3_CASE(1, 4, 2, 2)
 #undef C3_MF
@@ -777,6 +842,15 @@ static int c3_dispatch(const C3Args& a, const C3Plan& pl, hipStream_t st) {
   buctd_set_error("conv3x3 (split bf16): no kernel for MF=%d NF=%d WN=%d", pl.MF, pl.NF, pl.WN);
   return BUCTD_EINVAL;
 }
+
+#ifdef C3_TRACE
+extern "C" int buctd_debug_c3_wall(unsigned long long* host_out) {
+  return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(c3_trace_wall), sizeof(unsigned long long) * 4096 * 2);
+}
+extern "C" int buctd_debug_c3_trace(unsigned long long* host_out) {
+  return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(c3_trace_buf), sizeof(unsigned long long) * 8 * 64);
+}
+#endif
 
 static int c3_supported(int np, int N, int H, int W, int Ci, int Co) {
   C3Plan pl;
