@@ -75,6 +75,7 @@ struct C3Args {
   const float* in_gamma;
   const float* in_beta;
   int in_relu;
+  int col_major;       // bf16x6 kernel: consecutive workgroups of an XCD share the COLUMN tile (see the kernel)
   unsigned ib_mul, ib_sh, sw_mul, sw_sh;   // n / d == mulhi(n, mul) >> sh for 0 <= n < 2^31 (Granlund-Montgomery)
 };
 
@@ -433,8 +434,16 @@ __global__ __launch_bounds__(256, WPS) void conv3x3_x6_kernel(C3Args p) {
     const unsigned lin = blockIdx.y * gx + blockIdx.x;
     const unsigned xcd = lin & 7, idx = lin >> 3, per = total >> 3, rem = total & 7;
     const unsigned L = xcd < rem ? xcd * (per + 1) + idx : rem * (per + 1) + (xcd - rem) * per + idx;
-    bx = (int)(L / gy);
-    by = (int)(L - (unsigned)bx * gy);
+    if (p.col_major) {
+      // large filters (384 -> 384: 8 MB of prepared B, two L2s' worth): an XCD's run of workgroups walks the position
+      // tiles of ONE column tile, so its L2 keeps that column tile's 1/gy of B for all of them; position-major order
+      // streams the whole image through every L2 and each B fetch pays a MALL / HBM round trip
+      by = (int)(L / gx);
+      bx = (int)(L - (unsigned)by * gx);
+    } else {
+      bx = (int)(L / gy);
+      by = (int)(L - (unsigned)bx * gy);
+    }
   }
   const int p0 = bx * BM, n0 = by * BN;
   const int halo = p.SW + 1;
@@ -496,8 +505,12 @@ __global__ __launch_bounds__(256, WPS) void conv3x3_x6_kernel(C3Args p) {
   const unsigned char* bptr = p.wp + ((size_t)(n0 / 16 + wave_n * NF) * 3) * 1024;   // scalar base
   const int blane = lane * 16;                                                        // the only per-lane part
   const size_t bstep = (size_t)(p.Co / 16) * 3 * 1024;
-  constexpr bool BPF = BPF_;         // step-ahead B prefetch (36 more registers)
+  constexpr bool BPF = BPF_;         // step-ahead B prefetch (36 more registers per step of distance)
+  // small wave tiles (MF <= 2: at most 36 MFMAs = 576 cycles per step) cannot cover an L2 round trip (~1000 cycles, cycle
+  // stamps on the 384-channel 12x9 maps) with one step of distance: their fragments travel two steps ahead
+  constexpr bool BPF2 = BPF && MF <= 2 && NF <= 3;
   bf16x8 bc[3][NF], bn[BPF ? 3 : 1][BPF ? NF : 1];      // fragments of the current step / of the next one (in flight)
+  bf16x8 bn2[BPF2 ? 3 : 1][BPF2 ? NF : 1];              // ... and of the one after
   auto load_b = [&](int gs, bf16x8 (&dst)[3][NF]) {
     const unsigned char* src = bptr + (size_t)gs * bstep;
 #pragma unroll
@@ -548,8 +561,12 @@ __global__ __launch_bounds__(256, WPS) void conv3x3_x6_kernel(C3Args p) {
 #pragma unroll
         for (int nf = 0; nf < NF; ++nf)
 #pragma unroll
-          for (int q = 0; q < 3; ++q) bc[q][nf] = bn[q][nf];
-        load_b(gs < last_step ? gs + 1 : last_step, bn);
+          for (int q = 0; q < 3; ++q) {
+            bc[q][nf] = bn[q][nf];
+            if constexpr (BPF2) bn[q][nf] = bn2[q][nf];
+          }
+        if constexpr (BPF2) load_b(gs + 2 < last_step ? gs + 2 : last_step, bn2);
+        else load_b(gs < last_step ? gs + 1 : last_step, bn);
       } else {
         load_b(gs, bc);          // 144 MFMAs per step: the fetch latency is small against them, the registers are not
       }
@@ -591,6 +608,7 @@ __global__ __launch_bounds__(256, WPS) void conv3x3_x6_kernel(C3Args p) {
 #endif
   load_a(0);
   if constexpr (BPF) load_b(0, bn);
+  if constexpr (BPF2) load_b(last_step > 0 ? 1 : 0, bn2);
   store_a(smem, 0);
   if (nchunks > 1) load_a(16);
   __syncthreads();
@@ -759,7 +777,11 @@ static bool c3_plan(int np, int N, int H, int W, int Ci, int Co, C3Plan* pl) {
   else { nf = 1; wn = 1; }
   // wide column tiles (2x2 waves, BN = 96) only pay while they still fill the machine: the low-resolution branches
   // (192 ch @24x18, 384 ch @12x9) run faster as 4x1 waves with BN = 48 and twice as many workgroups (measured)
-  if (Co % 96 == 0 && ((P + 127) / 128) * (Co / 96) < 320) { nf = 3; wn = 1; }
+  if (np == 2 && Co % 96 == 0 && ((P + 127) / 128) * (Co / 96) < 320) { nf = 3; wn = 1; }
+  // bf16x6 (B fragments per wave from L2): the 192-channel 24x18 maps keep the 128 x 96 workgroup tile (252 workgroups,
+  // one per CU: 53.6 us against 57.2 for 504 half-width tiles); the smallest maps (384 ch @12x9, 36 tiles of 128
+  // positions) go to 32-column tiles - 432 workgroups instead of 288 that load 32 CUs twice (71 us against 95)
+  if (np == 3 && Co % 32 == 0 && ((P + 127) / 128) * ((Co + 95) / 96) < 200) { nf = 2; wn = 1; }
   int wm = 4 / wn, bn = wn * nf * 16;
   // largest position tile that still gives every CU work (256 CUs, 2 resident workgroups each)
   int mf = 1;
@@ -768,7 +790,7 @@ static bool c3_plan(int np, int N, int H, int W, int Ci, int Co, C3Plan* pl) {
     const long blocks = ((P + wm * cand[i] * 16 - 1) / (wm * cand[i] * 16)) * (Co / bn);
     // bf16x6 fetches its B fragments per wave, one step ahead: a 16-row wave tile (MF = 1) leaves 18 MFMAs to cover an
     // L2 round trip, so the smallest maps (384 ch @12x9: 288 workgroups at MF = 2) prefer the larger tile (measured)
-    if (blocks >= (np == 3 ? 256 : 320)) { mf = cand[i]; break; }
+    if (blocks >= (np == 3 ? 240 : 320)) { mf = cand[i]; break; }
   }
   bool single = false;
   pl->lean = 0;
@@ -780,10 +802,10 @@ static bool c3_plan(int np, int N, int H, int W, int Ci, int Co, C3Plan* pl) {
     static const int lean_env = getenv("BUCTD_C3_LEAN") ? atoi(getenv("BUCTD_C3_LEAN")) : 0;
     if (lean_env && mf == 8) { mf = 4; pl->lean = 1; }      // experiment: 3 lean workgroups per CU instead
   }
-  if (const char* f = getenv("BUCTD_C3_FORCE")) {   // experiment: "mf,wn" for the 48/96-column tiles
-    int fm = 0, fw = 0;
-    if (np == 3 && nf == 3 && sscanf(f, "%d,%d", &fm, &fw) == 2 && (fw == 1 || (fw == 2 && Co % 96 == 0))) {
-      mf = fm; wn = fw; wm = 4 / wn; bn = wn * nf * 16; single = mf == 8; pl->lean = 0;
+  if (const char* f = getenv("BUCTD_C3_FORCE")) {   // experiment: "mf,nf,wn"
+    int fm = 0, fn = 0, fw = 0;
+    if (np == 3 && sscanf(f, "%d,%d,%d", &fm, &fn, &fw) == 3 && (fw == 1 || fw == 2) && Co % (fn * 16 * fw) == 0) {
+      mf = fm; nf = fn; wn = fw; wm = 4 / wn; bn = wn * nf * 16; single = mf == 8; pl->lean = 0;
     }
   }
   pl->MF = mf; pl->NF = nf; pl->WM = wm; pl->WN = wn; pl->BM = wm * mf * 16; pl->BN = bn;
@@ -922,6 +944,8 @@ static int c3_run(int np, int N, int H, int W, int Ci, int Co, const float* x, c
     a.in_mean = in_bn->mean; a.in_invstd = in_bn->invstd; a.in_gamma = in_bn->gamma; a.in_beta = in_bn->beta;
     a.in_relu = in_bn->relu;
   }
+  a.col_major = (np == 3 && Co / pl.BN >= 2 && (size_t)c3_steps(Ci, 3) * Co * Geo<3>::BROW > ((size_t)3 << 20)) ? 1 : 0;
+  if (const char* f = getenv("BUCTD_C3_COLMAJOR")) a.col_major = np == 3 && atoi(f) != 0;     // experiment
   magic_u32((unsigned)a.IB, &a.ib_mul, &a.ib_sh);
   magic_u32((unsigned)a.SW, &a.sw_mul, &a.sw_sh);
   return np == 3 ? c3_dispatch<3>(a, pl, (hipStream_t)stream) : c3_dispatch<2>(a, pl, (hipStream_t)stream);
