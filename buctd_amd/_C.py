@@ -80,6 +80,10 @@ SIGNATURES = {
     "buctd_bn_bwd_workspace": (_SZ, [_L, _I]),
     "buctd_bn_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _L, _I, _P, _P, _P, _P, _I, _P, _SZ, _P]),
     "buctd_bn_fold": (_I, [_P, _P, _P, _P, _F, _I, _P, _P, _P]),
+    "buctd_x6_image_dims": (_I, [_I, _I, _I, _P, _P]),
+    "buctd_x6_image_bytes": (C.c_size_t, [_I, _I, _I]),
+    "buctd_x6_image": (_I, [_P, _I, _I, _I, _L, _L, _I, _L, _L, _I, _P, _P]),
+    "buctd_x6_gemm": (_I, [_I, _I, _I, _P, _P, _P, _I, _F, _P, _L, _I, _L, _P]),
     "buctd_add": (_I, [_P, _P, _P, _L, _I, _P]),
     "buctd_mul": (_I, [_P, _P, _P, _L, _P]),
     "buctd_scale": (_I, [_P, _P, _F, _P, _L, _P]),

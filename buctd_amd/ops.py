@@ -563,6 +563,52 @@ def matmul(A, B, Cout, *, batch, M, N, K, a_layout, b_layout, lda, ldb, ldc, str
     return Cout
 
 
+def x6_image(src, V, K, role, *, vs, ks, vg=0, vgs=0, kg=0, kgs=0, off=0, out=None):
+    """Prepared bf16x6 image of the logical matrix X[v][k] = src.flat[off + (v // vg) * vgs + (v % vg) * vs +
+    (k // kg) * kgs + (k % kg) * ks] (vg / kg = 0: plain strides); role 0: A operand (rows of C), 1: B operand."""
+    need = lib().buctd_x6_image_bytes(V, K, role)
+    if out is None or out.numel() < need:
+        out = torch.empty(need, dtype=torch.uint8, device=src.device)
+    check(lib().buctd_x6_image(C.c_void_p(src.data_ptr() + 4 * off), V, K, vg, vgs, vs, kg, kgs, ks, role, ptr(out),
+                               stream_ptr()), "x6_image")
+    return out
+
+
+def x6_gemm(a_image, b_image, Cout, M, N, K, *, ldc, Nc=0, gsc=0, bias=None, bias_axis=0, alpha=1.0, c_off=0):
+    """Cout(m, n) = alpha * sum_k A(m, k) B(k, n) (+ bias) from two prepared images (bf16x6 arithmetic)."""
+    check(lib().buctd_x6_gemm(M, N, K, ptr(a_image), ptr(b_image), ptr(bias), bias_axis, alpha,
+                              C.c_void_p(Cout.data_ptr() + 4 * c_off), ldc, Nc, gsc, stream_ptr()), "x6_gemm")
+    return Cout
+
+
+def _x6_weight_image(w, V, K, transposed):
+    """bf16x6 image of a Linear weight w [V or K rows] as the A operand, cached on the tensor until it changes
+    (version / optimizer epoch).  transposed: the logical matrix is w^T (X[v][k] = w[k][v])."""
+    key = (w.data_ptr(), w._version, _weights_epoch["n"])
+    cache = getattr(w, "_buctd_x6img", None)
+    if cache is None or cache["key"] != key:
+        cache = {"key": key}
+        try:
+            w._buctd_x6img = cache
+        except (AttributeError, RuntimeError, TypeError):
+            pass
+    tag = "t" if transposed else "n"
+    if tag not in cache:
+        ld = w.shape[1]
+        cache[tag] = x6_image(w, V, K, 0, vs=1, ks=ld) if transposed else x6_image(w, V, K, 0, vs=ld, ks=1)
+        cache[tag + "_ev"] = torch.cuda.Event()
+        cache[tag + "_ev"].record()
+        cache[tag + "_stream"] = torch.cuda.current_stream(w.device).cuda_stream
+    elif torch.cuda.current_stream(w.device).cuda_stream != cache[tag + "_stream"]:
+        torch.cuda.current_stream(w.device).wait_event(cache[tag + "_ev"])
+    return cache[tag]
+
+
+def fc_o_x6_ok(T, rows):
+    """the bf16x6 GEMM pays once the product is large (its images are padded to 128 x 192 x 128 tiles)"""
+    return _conv_math["mode"] == "bf16x6" and T >= 512 and rows >= 192 and os.environ.get("BUCTD_FC_O_X6", "1") != "0"
+
+
 def bn_finalize(part, info, rows, Cn, eps, momentum, running_mean, running_var):
     """info = (ngroups, rows_per_group[, per-group valid-row counts tensor])."""
     mean = torch.empty(Cn, dtype=torch.float32, device=part.device)
@@ -1268,8 +1314,13 @@ class ChannelAttention(torch.autograd.Function):
                    c_off=i * dk * Cn)
         # fc_o over the token axis for all images at once: out[b][t'][c] = sum_t W[t'][t] on[b][t][c] + bias[t']
         out = torch.empty_like(on)
-        matmul(fc_w, on, out, batch=1, M=T, N=B * Cn, K=T, a_layout=0, b_layout=1, lda=T, ldb=Cn, ldc=Cn,
-               Nc=Cn, gsbn=T * Cn, gsc=T * Cn, bias=fc_b, bias_axis=1)
+        if fc_o_x6_ok(T, B * Cn):
+            x6_gemm(_x6_weight_image(fc_w, T, T, False),
+                    x6_image(on, B * Cn, T, 1, vg=Cn, vgs=T * Cn, vs=1, ks=Cn), out, T, B * Cn, T, ldc=Cn, Nc=Cn,
+                    gsc=T * Cn, bias=fc_b, bias_axis=1)
+        else:
+            matmul(fc_w, on, out, batch=1, M=T, N=B * Cn, K=T, a_layout=0, b_layout=1, lda=T, ldb=Cn, ldc=Cn,
+                   Nc=Cn, gsbn=T * Cn, gsc=T * Cn, bias=fc_b, bias_axis=1)
         ctx.meta = (fc_w, fc_b, h, dk, scale, p_eff, seed)
         ctx.save_for_backward(qn, yn, A, Ad if p_eff > 0 else None, on)
         return out
@@ -1287,8 +1338,12 @@ class ChannelAttention(torch.autograd.Function):
         if fc_w.requires_grad:
             dw, acc = grad_target(fc_w)
             tgt = dw if not acc else torch.empty_like(dw)
-            matmul(dout, on, tgt, batch=1, M=T, N=T, K=B * Cn, a_layout=0, b_layout=0, lda=Cn, ldb=Cn, ldc=T,
-                   Kc=Cn, gsa=T * Cn, gsbk=T * Cn)
+            if fc_o_x6_ok(T, B * Cn):
+                x6_gemm(x6_image(dout, T, B * Cn, 0, vs=Cn, ks=1, kg=Cn, kgs=T * Cn),
+                        x6_image(on, T, B * Cn, 1, vs=Cn, ks=1, kg=Cn, kgs=T * Cn), tgt, T, T, B * Cn, ldc=T)
+            else:
+                matmul(dout, on, tgt, batch=1, M=T, N=T, K=B * Cn, a_layout=0, b_layout=0, lda=Cn, ldb=Cn, ldc=T,
+                       Kc=Cn, gsa=T * Cn, gsbk=T * Cn)
             if acc:
                 add(dw, tgt, out=dw)
         if fc_b is not None and fc_b.requires_grad:
@@ -1302,8 +1357,13 @@ class ChannelAttention(torch.autograd.Function):
         grad_done(fc_w, fc_b)
         # d_on[b][t][c] = sum_t' W[t'][t] dout[b][t'][c]
         don = torch.empty_like(on)
-        matmul(fc_w, dout, don, batch=1, M=T, N=B * Cn, K=T, a_layout=1, b_layout=1, lda=T, ldb=Cn, ldc=Cn,
-               Nc=Cn, gsbn=T * Cn, gsc=T * Cn)
+        if fc_o_x6_ok(T, B * Cn):
+            x6_gemm(_x6_weight_image(fc_w, T, T, True),
+                    x6_image(dout, B * Cn, T, 1, vg=Cn, vgs=T * Cn, vs=1, ks=Cn), don, T, B * Cn, T, ldc=Cn, Nc=Cn,
+                    gsc=T * Cn)
+        else:
+            matmul(fc_w, dout, don, batch=1, M=T, N=B * Cn, K=T, a_layout=1, b_layout=1, lda=T, ldb=Cn, ldc=Cn,
+                   Nc=Cn, gsbn=T * Cn, gsc=T * Cn)
         dAd = torch.empty_like(A)
         dyn_v = torch.empty_like(yn)
         for i in range(h):

@@ -271,6 +271,22 @@ int buctd_cond_render(const float* joints, int js, const float* colors, int B, i
 int buctd_flipback_avg(const float* a, const float* b, const int32_t* perm, int N, int K, int H, int W, int shift,
                        float* out, void* stream);
 
+/* ------------------------------------------------------------ bf16x6 GEMM --- */
+/* C = alpha * A * B (+ bias) in the bf16x6 arithmetic of the 3x3 convolutions (fp32 operands split exactly into three
+ * bf16 pieces, six bf16 MFMAs per product, fp32 accumulate) for the large plain GEMMs of the path - fc_o =
+ * nn.Linear(T, T) of the CoAM channel attention (self_attention.py:150-159) forward, data and weight gradient.
+ * Both operands are handed over as prepared images (fragment order, 6 bytes per element):
+ *   image of a logical matrix X[v][k] (v: row of C for the A operand, column of C for the B operand; k: reduction
+ *   index) whose element sits at src[(v / vg) * vgs + (v % vg) * vs + (k / kg) * kgs + (k % kg) * ks]
+ *   (vg or kg = 0: no grouping, plain strides vs / ks).  role 0 = A operand, 1 = B operand (they differ in padding).
+ * C(m, n) = C[m * ldc + (n / Nc) * gsc + n % Nc] (Nc <= 0: no grouping); bias_axis 0: bias[n], 1: bias[m]. */
+int buctd_x6_image_dims(int V, int K, int role, int* Vpad, int* Kpad);
+size_t buctd_x6_image_bytes(int V, int K, int role);
+int buctd_x6_image(const float* src, int V, int K, int vg, long vgs, long vs, int kg, long kgs, long ks, int role,
+                   void* image, void* stream);
+int buctd_x6_gemm(int M, int N, int K, const void* a_image, const void* b_image, const float* bias, int bias_axis,
+                  float alpha, float* C, long ldc, int Nc, long gsc, void* stream);
+
 /* -------------------------------------------------------------- optimizer --- */
 /* torch.optim.Adam step (utils/utils.py:268-272: betas .9/.999, eps 1e-8, no weight decay, no amsgrad)
  * on flat fp32 buffers; gscale multiplies the gradient first (1/world for averaged all-reduce). */

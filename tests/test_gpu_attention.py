@@ -36,7 +36,8 @@ def test_position_attention(dev, B, T, C, h):
         assert err <= 2e-5, f"position attention {name} (B{B} T{T} C{C} h{h}): rel err {err:.2e}"
 
 
-@pytest.mark.parametrize("B,T,C,h", [(2, 96, 16, 1), (3, 6, 128, 1), (2, 24, 64, 2), (2, 384, 32, 2), (2, 1728, 48, 1)])
+@pytest.mark.parametrize("B,T,C,h", [(2, 96, 16, 1), (3, 6, 128, 1), (2, 24, 64, 2), (2, 384, 32, 2), (2, 1728, 48, 1),
+                                     (4, 1728, 48, 1), (2, 576, 96, 1)])   # the last two: fc_o on the bf16x6 GEMM
 def test_channel_attention(dev, B, T, C, h):
     from buctd_amd import ops
     g = torch.Generator().manual_seed(B * 77 + T)
