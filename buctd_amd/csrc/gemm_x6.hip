@@ -15,6 +15,7 @@
 // up conflict-free), double buffered, one barrier per two steps; the B fragments come straight from L2 one step
 // ahead, as in the convolution kernel.  LDS 96 KB -> one workgroup (two waves per SIMD) per CU.
 #include "common.h"
+#include <stdlib.h>
 #include "../../include/buctd_hip.h"
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -37,6 +38,7 @@ struct GxArgs {
   int Nc;
   float alpha;
   int bias_axis;
+  int row_major;
 };
 
 struct GxImg {
@@ -97,15 +99,21 @@ __global__ __launch_bounds__(512, 1) void x6_gemm_kernel(GxArgs p) {
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
   const int wave_m = wave % GX_WM, wave_n = wave / GX_WM;
   const int i16 = lane & 15, g = lane >> 4;
-  // XCD-aware order: the workgroups of one XCD walk the row tiles of a few column tiles, whose B blocks stay in its L2
+  // XCD-aware order: the workgroups of one XCD walk the tiles that share the LARGER operand's blocks back to back, so
+  // that operand streams from HBM once and the smaller one is re-read from L2 / the Infinity Cache
   int bx, by;
   {
     const unsigned gx = gridDim.x, gy = gridDim.y, total = gx * gy;
     const unsigned lin = blockIdx.y * gx + blockIdx.x;
     const unsigned xcd = lin & 7, idx = lin >> 3, per = total >> 3, rem = total & 7;
     const unsigned L = xcd < rem ? xcd * (per + 1) + idx : rem * (per + 1) + (xcd - rem) * per + idx;
-    by = (int)(L / gx);
-    bx = (int)(L - (unsigned)by * gx);
+    if (p.row_major) {        // consecutive workgroups share the ROW tile: the larger operand is A (fc_o: 287 MB of weights)
+      bx = (int)(L / gy);
+      by = (int)(L - (unsigned)bx * gy);
+    } else {
+      by = (int)(L / gx);
+      bx = (int)(L - (unsigned)by * gx);
+    }
   }
   const int mb0 = bx * (GX_BM / 16), nb0 = by * (GX_BN / 16);
   const int nchunks = p.KB / CH;
@@ -269,6 +277,8 @@ extern "C" int buctd_x6_gemm(int M, int N, int K, const void* a_image, const voi
   p.a = (const unsigned char*)a_image; p.b = (const unsigned char*)b_image; p.c = C; p.bias = bias;
   p.M = M; p.N = N; p.KB = pad_to(K, GX_KPAD) / 32; p.ldc = ldc; p.gsc = gsc; p.Nc = Nc; p.alpha = alpha;
   p.bias_axis = bias_axis;
+  p.row_major = (size_t)pad_to(M, GX_BM) > (size_t)pad_to(N, GX_BN) ? 1 : 0;     // image bytes ~ V x Kpad
+  if (const char* f = getenv("BUCTD_GX_ROWMAJOR")) p.row_major = atoi(f) != 0;     // experiment
   dim3 grid(pad_to(M, GX_BM) / GX_BM, pad_to(N, GX_BN) / GX_BN);
   hipLaunchKernelGGL(x6_gemm_kernel, grid, dim3(512), 2 * GX_ABUF, (hipStream_t)stream, p);
   BUCTD_CHECK_LAUNCH("buctd_x6_gemm");
