@@ -45,7 +45,7 @@ struct AttnArgs {
   float* out;         // fwd: O ; bwd_q: dq' ; bwd_kv: dk'
   float* out2;        // bwd_kv: dV
   int T, C;
-  int b3;               // 1: bf16x3 kernels
+  int b3;               // split-operand kernels: 0 none (fp32 MFMA), 2 = two bf16 pieces (bf16x3), 3 = three (bf16x6)
   float scale, scale2, p_drop, inv_keep;   // scale2 = scale * log2(e): logits are formed in the exp2 domain
   uint32_t s0, s1, thr;
 };
@@ -171,19 +171,22 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef unsigned short u16x4 __attribute__((ext_vector_type(4)));
 
-// channels c..c+3 of one LDS row -> bf16 hi at byte 2c, lo at LO + 2c
-template <int LO>
+// channels c..c+3 of one LDS row -> NP bf16 pieces (exact residual chain), piece q at byte q * LO + 2c
+template <int LO, int NP>
 __device__ __forceinline__ void split_store4(unsigned char* row, int c, f32x4 v) {
-  u16x4 hi, lo;
+  u16x4 pc[NP];
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
-    const __bf16 h = (__bf16)v[j];
-    const __bf16 l = (__bf16)(v[j] - (float)h);
-    hi[j] = __builtin_bit_cast(unsigned short, h);
-    lo[j] = __builtin_bit_cast(unsigned short, l);
+    float r = v[j];
+#pragma unroll
+    for (int q = 0; q < NP; ++q) {
+      const __bf16 h = (__bf16)r;
+      pc[q][j] = __builtin_bit_cast(unsigned short, h);
+      r -= (float)h;
+    }
   }
-  *reinterpret_cast<u16x4*>(row + 2 * c) = hi;
-  *reinterpret_cast<u16x4*>(row + LO + 2 * c) = lo;
+#pragma unroll
+  for (int q = 0; q < NP; ++q) *reinterpret_cast<u16x4*>(row + q * LO + 2 * c) = pc[q];
 }
 // gfx950 transpose read: the 16 lanes of a group address 4 rows x 16 bf16; lane c receives the 4 rows of column c.
 // Two of them (rows +0..3 at p, rows +0..3 at q) give the 8 reduction slots of one MFMA operand.
@@ -193,29 +196,51 @@ __device__ __forceinline__ bf16x8 tr_pair(const unsigned char* p, const unsigned
   const bf16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)q);
   return __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
 }
-__device__ __forceinline__ void split8(const float (&x)[8], bf16x8& h, bf16x8& l) {
+template <int NP>
+__device__ __forceinline__ void split8(const float (&x)[8], bf16x8 (&pc)[NP]) {
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
-    const __bf16 hh = (__bf16)x[e];
-    h[e] = hh;
-    l[e] = (__bf16)(x[e] - (float)hh);
+    float r = x[e];
+#pragma unroll
+    for (int q = 0; q < NP; ++q) {
+      const __bf16 h = (__bf16)r;
+      pc[q][e] = h;
+      r -= (float)h;
+    }
   }
 }
-#define MFMA_B3(acc, ah, al, bh, bl)                                          \
-  do {                                                                        \
-    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh, acc, 0, 0, 0);      \
-    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl, acc, 0, 0, 0);      \
-    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh, acc, 0, 0, 0);      \
-  } while (0)
+// acc += a . b on split operands, smallest terms first.  NP = 2: the three terms of weight >= 2^-8 (bf16x3, product
+// error ~2^-16); NP = 3: the six terms of weight >= 2^-16 (bf16x6, fp32 class - see conv3x3.hip)
+template <int NP>
+__device__ __forceinline__ void mfma_split(f32x4& acc, const bf16x8 (&a)[NP], const bf16x8 (&b)[NP]) {
+  if constexpr (NP == 2) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1], b[0], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], b[1], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], b[0], acc, 0, 0, 0);
+  } else {
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[2], b[0], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], b[2], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1], b[1], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1], b[0], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], b[1], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], b[0], acc, 0, 0, 0);
+  }
+}
+// LDS tile row of C channels in NP bf16 pieces, padded to 32 mod 64 bytes (conflict-free 16-byte row reads)
+template <int C, int NP>
+struct SplitRow {
+  static constexpr int LO = C * 2;
+  static constexpr int RS = C * 2 * NP + (((C * 2 * NP) % 64 == 32) ? 0 : 32);
+};
 
 // forward: workgroup = 64 query rows (16 per wave); per 32-key step lane (row i16, g) generates the probabilities of
 // keys 8g..8g+7 - exactly the A operand of the K = 32 MFMA - and the V fragments (lane = channel, 8 keys) come out of
 // the key-major bf16 tile through the transpose read.  The soft-max statistics are computed on the fly (running row
 // maximum, accumulators rescaled when it moves - rare after the first tiles), so the separate statistics pass of the
 // fp32 path is gone; m and 1/l are written at the end for the backward kernels.
-template <int R4, int CF, bool DROP>
+template <int R4, int CF, bool DROP, int NP>
 __global__ __launch_bounds__(256) void attn_fwd_b3_kernel(AttnArgs p) {
-  constexpr int C = CF * 16, LO = C * 2, RS = C * 4 + 32;   // V rows: C bf16 hi | C bf16 lo | 32 B pad (= 32 mod 64)
+  constexpr int C = CF * 16, LO = SplitRow<C, NP>::LO, RS = SplitRow<C, NP>::RS;   // V rows: NP pieces of C bf16 | pad
   __shared__ __attribute__((aligned(16))) float ks[64 * R4];
   __shared__ __attribute__((aligned(16))) unsigned char vt[64 * RS];
   __shared__ uint32_t cks[64];
@@ -249,7 +274,7 @@ __global__ __launch_bounds__(256) void attn_fwd_b3_kernel(AttnArgs p) {
 #pragma unroll
     for (int q = 0; q < CF; ++q) {
       const int e = t + 256 * q, r = e / (C / 4), c4 = e - r * (C / 4);
-      split_store4<LO>(vt + r * RS, c4 * 4, vreg[q]);
+      split_store4<LO, NP>(vt + r * RS, c4 * 4, vreg[q]);
     }
     if (DROP && t < 64) cks[t] = colkey(p.s1, (uint32_t)(j0 + t));
   };
@@ -288,14 +313,15 @@ __global__ __launch_bounds__(256) void attn_fwd_b3_kernel(AttnArgs p) {
         lrun += pv[e];
         if (DROP) pv[e] *= keepf(rk, cks[32 * kstep + 8 * g + e], p.thr, p.inv_keep);
       }
-      bf16x8 ph, pl;
-      split8(pv, ph, pl);
+      bf16x8 pp[NP];
+      split8<NP>(pv, pp);
       const unsigned char* vb = vt + 32 * kstep * RS + tr_off;
 #pragma unroll
       for (int nf = 0; nf < CF; ++nf) {
-        const bf16x8 bh = tr_pair(vb + nf * 32, vb + nf * 32 + 4 * RS);
-        const bf16x8 bl = tr_pair(vb + nf * 32 + LO, vb + nf * 32 + LO + 4 * RS);
-        MFMA_B3(acc[nf], ph, pl, bh, bl);
+        bf16x8 bb[NP];
+#pragma unroll
+        for (int q = 0; q < NP; ++q) bb[q] = tr_pair(vb + nf * 32 + q * LO, vb + nf * 32 + q * LO + 4 * RS);
+        mfma_split<NP>(acc[nf], pp, bb);
       }
     }
   }
@@ -315,8 +341,9 @@ __global__ __launch_bounds__(256) void attn_fwd_b3_kernel(AttnArgs p) {
   }
 }
 
-// 8 consecutive channels [c0, c0+8) of one fp32 row as bf16 hi / lo MFMA operands (zeros past channel C)
-__device__ __forceinline__ void load_split8(const float* row, int c0, int C, bf16x8& h, bf16x8& l) {
+// 8 consecutive channels [c0, c0+8) of one fp32 row as NP bf16-piece MFMA operands (zeros past channel C)
+template <int NP>
+__device__ __forceinline__ void load_split8(const float* row, int c0, int C, bf16x8 (&pc)[NP]) {
   float x[8];
   if (c0 < C) {
     const f32x4 a = *reinterpret_cast<const f32x4*>(row + c0);
@@ -326,14 +353,14 @@ __device__ __forceinline__ void load_split8(const float* row, int c0, int C, bf1
 #pragma unroll
     for (int e = 0; e < 8; ++e) x[e] = 0.f;
   }
-  split8(x, h, l);
+  split8<NP>(x, pc);
 }
 
 // dq' pass: dP = dO V^T with the channel contraction on the bf16 MFMA (dO fragments live in registers for the whole
 // kernel, V rows come out of the bf16 tile with plain 16-byte reads); everything else as attn_bwd_q_kernel.
-template <int R4, int CF, bool DROP>
+template <int R4, int CF, bool DROP, int NP>
 __global__ __launch_bounds__(256) void attn_bwd_q_b3_kernel(AttnArgs p) {
-  constexpr int C = CF * 16, CS = C / 4, LO = C * 2, RS = C * 4 + 32, NK = (C + 31) / 32;
+  constexpr int C = CF * 16, CS = C / 4, LO = SplitRow<C, NP>::LO, RS = SplitRow<C, NP>::RS, NK = (C + 31) / 32;
   __shared__ __attribute__((aligned(16))) float ks[64 * R4];
   __shared__ __attribute__((aligned(16))) unsigned char vt[64 * RS];
   __shared__ uint32_t cks[64];
@@ -358,9 +385,9 @@ __global__ __launch_bounds__(256) void attn_bwd_q_b3_kernel(AttnArgs p) {
   dpart += __shfl_xor(dpart, 32, 64);
   if (kq == 0) p.dvec[rowbase + r0 + i16] = dpart;
   // A operand: dO[row r0 + i16][32 kk + 8 kq .. +7]
-  bf16x8 ah[NK], al[NK];
+  bf16x8 aa[NK][NP];
 #pragma unroll
-  for (int kk = 0; kk < NK; ++kk) load_split8(p.dout + (rowbase + r0 + i16) * C, 32 * kk + 8 * kq, C, ah[kk], al[kk]);
+  for (int kk = 0; kk < NK; ++kk) load_split8<NP>(p.dout + (rowbase + r0 + i16) * C, 32 * kk + 8 * kq, C, aa[kk]);
   float qrow[4][R4], mrow[4], lrow[4], drow[4];
   uint32_t rkrow[4];
 #pragma unroll
@@ -401,7 +428,7 @@ __global__ __launch_bounds__(256) void attn_bwd_q_b3_kernel(AttnArgs p) {
 #pragma unroll
     for (int q = 0; q < CF; ++q) {
       const int e = t + 256 * q, r = e / (C / 4), c4 = e - r * (C / 4);
-      split_store4<LO>(vt + r * RS, c4 * 4, vreg[q]);
+      split_store4<LO, NP>(vt + r * RS, c4 * 4, vreg[q]);
     }
     if (DROP && t < 64) cks[t] = colkey(p.s1, (uint32_t)(j0 + t));
   };
@@ -417,9 +444,10 @@ __global__ __launch_bounds__(256) void attn_bwd_q_b3_kernel(AttnArgs p) {
       const unsigned char* vrow = vt + (16 * f + i16) * RS;    // B(k = channel, n = key 16f + i16)
 #pragma unroll
       for (int kk = 0; kk < NK; ++kk) {
-        const bf16x8 bh = *reinterpret_cast<const bf16x8*>(vrow + boff[kk]);
-        const bf16x8 bl = *reinterpret_cast<const bf16x8*>(vrow + boff[kk] + LO);
-        MFMA_B3(dp4, ah[kk], al[kk], bh, bl);
+        bf16x8 bb[NP];
+#pragma unroll
+        for (int q = 0; q < NP; ++q) bb[q] = *reinterpret_cast<const bf16x8*>(vrow + boff[kk] + q * LO);
+        mfma_split<NP>(dp4, aa[kk], bb);
       }
       const int j = 16 * f + i16;
       float kv[R4];
@@ -449,9 +477,9 @@ __global__ __launch_bounds__(256) void attn_bwd_q_b3_kernel(AttnArgs p) {
 // eight dropped probabilities of its key - the A operand of ONE K = 32 MFMA of dV += Pd^T dO when the reduction slot
 // e of lane group g is enumerated as query 16 (e >> 2) + 4 g + (e & 3); the dO fragments in that enumeration come
 // out of the query-major bf16 tile through two transpose reads.
-template <int R4, int CF, bool DROP>
+template <int R4, int CF, bool DROP, int NP>
 __global__ __launch_bounds__(256) void attn_bwd_kv_b3_kernel(AttnArgs p) {
-  constexpr int C = CF * 16, LO = C * 2, RS = C * 4 + 32, NK = (C + 31) / 32;
+  constexpr int C = CF * 16, LO = SplitRow<C, NP>::LO, RS = SplitRow<C, NP>::RS, NK = (C + 31) / 32;
   __shared__ __attribute__((aligned(16))) float qs[64 * R4];
   __shared__ __attribute__((aligned(16))) unsigned char dt[64 * RS];     // dO tile: [query][hi C | lo C]
   __shared__ float ms[64], ls[64], dsm[64];
@@ -465,12 +493,12 @@ __global__ __launch_bounds__(256) void attn_bwd_kv_b3_kernel(AttnArgs p) {
   float ka[R4];
   loadr<R4>(ka, p.k + (rowbase + j0 + i16) * R4);
   // B operand of dP: V[key j0 + i16][32 kk + 8 kq .. +7]
-  bf16x8 vh[NK], vl[NK];
+  bf16x8 vv[NK][NP];
   int boff[NK];
 #pragma unroll
   for (int kk = 0; kk < NK; ++kk) {
     const int c0 = 32 * kk + 8 * kq;
-    load_split8(p.v + (rowbase + j0 + i16) * C, c0, C, vh[kk], vl[kk]);
+    load_split8<NP>(p.v + (rowbase + j0 + i16) * C, c0, C, vv[kk]);
     boff[kk] = (c0 < C ? c0 : 0) * 2;
   }
   f32x4 dv[CF];
@@ -501,7 +529,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kv_b3_kernel(AttnArgs p) {
 #pragma unroll
     for (int q = 0; q < CF; ++q) {
       const int e = t + 256 * q, r = e / (C / 4), c4 = e - r * (C / 4);
-      split_store4<LO>(dt + r * RS, c4 * 4, dreg[q]);
+      split_store4<LO, NP>(dt + r * RS, c4 * 4, dreg[q]);
     }
     if (t < 64) {
       ms[t] = mreg;
@@ -527,13 +555,16 @@ __global__ __launch_bounds__(256) void attn_bwd_kv_b3_kernel(AttnArgs p) {
         const unsigned char* drow = dt + (16 * f + i16) * RS;
 #pragma unroll
         for (int kk = 0; kk < NK; ++kk) {
-          bf16x8 ah = *reinterpret_cast<const bf16x8*>(drow + boff[kk]);
-          bf16x8 al = *reinterpret_cast<const bf16x8*>(drow + boff[kk] + LO);
-          if (32 * kk + 8 * kq >= C) {       // zero-padded tail of the channel contraction
+          bf16x8 aa[NP];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) { ah[e] = (__bf16)0.f; al[e] = (__bf16)0.f; }
+          for (int q = 0; q < NP; ++q) {
+            aa[q] = *reinterpret_cast<const bf16x8*>(drow + boff[kk] + q * LO);
+            if (32 * kk + 8 * kq >= C) {       // zero-padded tail of the channel contraction
+#pragma unroll
+              for (int e = 0; e < 8; ++e) aa[q][e] = (__bf16)0.f;
+            }
           }
-          MFMA_B3(dp4, ah, al, vh[kk], vl[kk]);
+          mfma_split<NP>(dp4, aa, vv[kk]);
         }
 #pragma unroll
         for (int rg = 0; rg < 4; ++rg) {
@@ -549,14 +580,15 @@ __global__ __launch_bounds__(256) void attn_bwd_kv_b3_kernel(AttnArgs p) {
           pd[4 * fb + rg] = pv * keep;
         }
       }
-      bf16x8 ph, pl;
-      split8(pd, ph, pl);
+      bf16x8 pp[NP];
+      split8<NP>(pd, pp);
       const unsigned char* db = dt + 32 * h * RS + tr_off;
 #pragma unroll
       for (int nf = 0; nf < CF; ++nf) {
-        const bf16x8 bh = tr_pair(db + nf * 32, db + nf * 32 + 16 * RS);
-        const bf16x8 bl = tr_pair(db + nf * 32 + LO, db + nf * 32 + LO + 16 * RS);
-        MFMA_B3(dv[nf], ph, pl, bh, bl);
+        bf16x8 bb[NP];
+#pragma unroll
+        for (int q = 0; q < NP; ++q) bb[q] = tr_pair(db + nf * 32 + q * LO, db + nf * 32 + q * LO + 16 * RS);
+        mfma_split<NP>(dv[nf], pp, bb);
       }
     }
   }
@@ -777,18 +809,26 @@ template <int R4, int CF>
 static void attn_launch(int which, const AttnArgs& a, int B, hipStream_t st) {
   const dim3 grid(a.T / 64, B);
   const bool drop = a.p_drop > 0.f;
+#define ATTN_SPLIT(kern)                                                                                         \
+  do {                                                                                                           \
+    if (a.b3 == 3) {                                                                                             \
+      if (drop) hipLaunchKernelGGL((kern<R4 <= 8 ? R4 : 4, CF, true, 3>), grid, dim3(256), 0, st, a);            \
+      else hipLaunchKernelGGL((kern<R4 <= 8 ? R4 : 4, CF, false, 3>), grid, dim3(256), 0, st, a);                \
+    } else {                                                                                                     \
+      if (drop) hipLaunchKernelGGL((kern<R4 <= 8 ? R4 : 4, CF, true, 2>), grid, dim3(256), 0, st, a);            \
+      else hipLaunchKernelGGL((kern<R4 <= 8 ? R4 : 4, CF, false, 2>), grid, dim3(256), 0, st, a);                \
+    }                                                                                                            \
+  } while (0)
   if (which == 1 && a.b3 && R4 <= 8) {
-    if (drop) hipLaunchKernelGGL((attn_fwd_b3_kernel<R4 <= 8 ? R4 : 4, CF, true>), grid, dim3(256), 0, st, a);
-    else hipLaunchKernelGGL((attn_fwd_b3_kernel<R4 <= 8 ? R4 : 4, CF, false>), grid, dim3(256), 0, st, a);
+    ATTN_SPLIT(attn_fwd_b3_kernel);
   } else if (which == 1) {
     if (drop) hipLaunchKernelGGL((attn_fwd_kernel<R4, CF, true>), grid, dim3(256), 0, st, a);
     else hipLaunchKernelGGL((attn_fwd_kernel<R4, CF, false>), grid, dim3(256), 0, st, a);
   } else if (which == 2 && a.b3 && R4 <= 8) {
-    if (drop) hipLaunchKernelGGL((attn_bwd_q_b3_kernel<R4 <= 8 ? R4 : 4, CF, true>), grid, dim3(256), 0, st, a);
-    else hipLaunchKernelGGL((attn_bwd_q_b3_kernel<R4 <= 8 ? R4 : 4, CF, false>), grid, dim3(256), 0, st, a);
+    ATTN_SPLIT(attn_bwd_q_b3_kernel);
   } else if (which == 3 && a.b3 && R4 <= 8) {
-    if (drop) hipLaunchKernelGGL((attn_bwd_kv_b3_kernel<R4 <= 8 ? R4 : 4, CF, true>), grid, dim3(256), 0, st, a);
-    else hipLaunchKernelGGL((attn_bwd_kv_b3_kernel<R4 <= 8 ? R4 : 4, CF, false>), grid, dim3(256), 0, st, a);
+    ATTN_SPLIT(attn_bwd_kv_b3_kernel);
+#undef ATTN_SPLIT
   } else if (which == 2) {
     if (drop) hipLaunchKernelGGL((attn_bwd_q_kernel<R4, CF, true>), grid, dim3(256), 0, st, a);
     else hipLaunchKernelGGL((attn_bwd_q_kernel<R4, CF, false>), grid, dim3(256), 0, st, a);
@@ -824,6 +864,10 @@ static void attn_dispatch(int which, const AttnArgs& a, int R4, int B, hipStream
   else attn_dispatch_c<20>(which, a, B, st);
 }
 
+// flag of the C ABI -> pieces per operand: 0 fp32 MFMA kernels, 1 -> two bf16 pieces, 2 -> three (bf16x6; its 192-channel
+// tile rows would need 77 KB of static LDS, so that width stays on the fp32 kernels)
+static int attn_split_mode(int flag, int C) { return flag == 2 ? (C <= 128 ? 3 : 0) : (flag ? 2 : 0); }
+
 static AttnArgs attn_args(int T, int C, float scale, float p_drop, uint64_t seed) {
   AttnArgs a;
   memset(&a, 0, sizeof(a));
@@ -842,7 +886,7 @@ extern "C" int buctd_attn_smallqk_fwd(int B, int T, int R4, int C, const float* 
   BUCTD_CHECK_ARG(attn_shape_ok(T, R4, C), "buctd_attn_smallqk_fwd: unsupported T=%d R4=%d C=%d", T, R4, C);
   BUCTD_CHECK_ARG(p_drop >= 0.f && p_drop < 1.f && (long)B * T < 2147483647L, "buctd_attn_smallqk_fwd: bad p_drop / size");
   AttnArgs a = attn_args(T, C, scale, p_drop, seed);
-  a.q = q; a.k = k; a.v = v; a.m = m; a.linv = linv; a.out = out; a.b3 = bf16x3 ? 1 : 0;
+  a.q = q; a.k = k; a.v = v; a.m = m; a.linv = linv; a.out = out; a.b3 = attn_split_mode(bf16x3, C);
   if (!(a.b3 && R4 <= 8)) {            // the bf16x3 forward kernel computes the soft-max statistics on the fly
     attn_dispatch(0, a, R4, B, (hipStream_t)stream);
     BUCTD_CHECK_LAUNCH("buctd_attn_smallqk_fwd(stats)");
@@ -861,7 +905,7 @@ extern "C" int buctd_attn_smallqk_bwd(int B, int T, int R4, int C, const float* 
   BUCTD_CHECK_ARG(attn_shape_ok(T, R4, C), "buctd_attn_smallqk_bwd: unsupported T=%d R4=%d C=%d", T, R4, C);
   AttnArgs a = attn_args(T, C, scale, p_drop, seed);
   a.q = q; a.k = k; a.v = v; a.o = o; a.dout = dout;
-  a.m = const_cast<float*>(m); a.linv = const_cast<float*>(linv); a.dvec = dvec_workspace; a.b3 = bf16x3 ? 1 : 0;
+  a.m = const_cast<float*>(m); a.linv = const_cast<float*>(linv); a.dvec = dvec_workspace; a.b3 = attn_split_mode(bf16x3, C);
   a.out = dq;
   attn_dispatch(2, a, R4, B, (hipStream_t)stream);
   BUCTD_CHECK_LAUNCH("buctd_attn_smallqk_bwd(q)");

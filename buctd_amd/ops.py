@@ -1245,7 +1245,11 @@ class SmallQKAttention(torch.autograd.Function):
         out = torch.empty((B, T, Cn), dtype=torch.float32, device=dev)
         m = torch.empty((B, T), dtype=torch.float32, device=dev)
         linv = torch.empty((B, T), dtype=torch.float32, device=dev)
-        b3 = 1 if _conv_math["mode"] == "bf16x3" else 0
+        # contractions over T and C on the bf16 matrix cores: two pieces per operand in the bf16x3 mode, three (fp32
+        # class) in the default bf16x6 mode, the exact fp32 MFMA kernels in the fp32 mode
+        b3 = {"bf16x3": 1, "bf16x6": 2}.get(_conv_math["mode"], 0)
+        if os.environ.get("BUCTD_ATTN_X6", "1") == "0" and b3 == 2:
+            b3 = 0
         check(lib().buctd_attn_smallqk_fwd(B, T, R4, Cn, ptr(qp), ptr(kp), ptr(v), scale, p_eff, seed, b3, ptr(out), ptr(m),
                                            ptr(linv), stream_ptr()), "attn_smallqk_fwd")
         ctx.meta = (d, R4, scale, p_eff, seed, b3)

@@ -223,8 +223,9 @@ int buctd_softmax_dropout_bwd(const float* dpd, const float* p, long rows, int L
  * m / linv [B][T] receive the row max and reciprocal row sum (saved for the backward).  The dropout mask is a
  * counter hash of (seed, b*T + i, j), rebuilt by the backward.  Shapes: T % 64 == 0, R4 in {4,8,16,20},
  * C in {16,32,48,64,96,128,192} (buctd_attn_smallqk_supported).  bf16x3 != 0 selects the variants whose T- and
- * C-contractions run on the bf16 matrix cores with split-fp32 operands (same accuracy class as
- * buctd_conv3x3_bf16x3; R4 <= 8 only, wider contractions silently use the fp32 kernels). */
+ * C-contractions run on the bf16 matrix cores with split-fp32 operands: 1 = two pieces per operand (accuracy class of
+ * buctd_conv3x3_bf16x3), 2 = three pieces, six MFMAs per product (fp32 class, as buctd_conv3x3_bf16x6; C <= 128).
+ * R4 <= 8 only; wider contractions silently use the fp32 kernels. */
 int buctd_attn_smallqk_supported(int T, int R4, int C);
 int buctd_attn_smallqk_fwd(int B, int T, int R4, int C, const float* q, const float* k, const float* v, float scale,
                            float p_drop, uint64_t seed, int bf16x3, float* out, float* m, float* linv, void* stream);

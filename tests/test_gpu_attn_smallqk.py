@@ -51,33 +51,43 @@ SHAPES = [(2, 128, 3, 48), (2, 384, 1, 16), (1, 1728, 3, 48), (2, 192, 7, 32), (
           (1, 128, 14, 128), (1, 64, 3, 192)]
 
 
+@pytest.mark.parametrize("mode", ["bf16x6", "fp32"])
 @pytest.mark.parametrize("B,T,d,C", SHAPES)
-def test_smallqk_vs_fp64(dev, B, T, d, C):
+def test_smallqk_vs_fp64(dev, B, T, d, C, mode):
+    """default mode (bf16x6: three bf16 pieces per operand, six MFMAs per product - the narrow-query shapes; wider ones
+    and C = 192 run the fp32 kernels) and the exact fp32 MFMA kernels: the same fp32-class bar"""
     from buctd_amd import ops
     assert ops.attn_smallqk_ok(T, d, C)
-    args = _inputs(B, T, d, C, B * 1000 + T + d)
-    ref_o, ref_g = _reference(*args)
-    o, grads = _run(dev, *args, 0.1, False)
-    names = ["out", "dyq", "dwq", "dbq", "dk", "dv"]
-    for name, a, b in zip(names, [o] + grads, [ref_o] + ref_g):
-        err = _e(a, b)
-        assert err <= 2e-5, f"smallqk {name} (B{B} T{T} d{d} C{C}): rel err {err:.2e}"
+    old = ops.get_conv_math()
+    ops.set_conv_math(mode)
+    try:
+        args = _inputs(B, T, d, C, B * 1000 + T + d)
+        ref_o, ref_g = _reference(*args)
+        o, grads = _run(dev, *args, 0.1, False)
+        names = ["out", "dyq", "dwq", "dbq", "dk", "dv"]
+        for name, a, b in zip(names, [o] + grads, [ref_o] + ref_g):
+            err = _e(a, b)
+            assert err <= 2e-5, f"smallqk[{mode}] {name} (B{B} T{T} d{d} C{C}): rel err {err:.2e}"
+    finally:
+        ops.set_conv_math(old)
 
 
+@pytest.mark.parametrize("mode,bar", [("bf16x3", 5e-5), ("bf16x6", 2e-5)])
 @pytest.mark.parametrize("B,T,d,C", [(2, 128, 3, 48), (2, 384, 1, 16), (1, 1728, 3, 96), (2, 192, 7, 32), (2, 64, 5, 64),
                                      (1, 64, 3, 192), (1, 128, 2, 128)])
-def test_smallqk_bf16x3_vs_fp64(dev, B, T, d, C):
-    """bf16x3 math mode: T- and C-contractions on the bf16 matrix cores with split operands; bar 5e-5 relative."""
+def test_smallqk_bf16x3_vs_fp64(dev, B, T, d, C, mode, bar):
+    """split-operand kernels: T- and C-contractions on the bf16 matrix cores; two pieces per operand (bf16x3 mode, bar
+    5e-5 relative) or three (bf16x6, fp32 class); incl. the dropout mask agreement of forward and backward."""
     from buctd_amd import ops
     old = ops.get_conv_math()
-    ops.set_conv_math("bf16x3")
+    ops.set_conv_math(mode)
     try:
         args = _inputs(B, T, d, C, B * 1000 + T + d)
         ref_o, ref_g = _reference(*args)
         o, grads = _run(dev, *args, 0.1, False)
         for name, a, b in zip(["out", "dyq", "dwq", "dbq", "dk", "dv"], [o] + grads, [ref_o] + ref_g):
             err = _e(a, b)
-            assert err <= 5e-5, f"smallqk[bf16x3] {name} (B{B} T{T} d{d} C{C}): rel err {err:.2e}"
+            assert err <= bar, f"smallqk[{mode}] {name} (B{B} T{T} d{d} C{C}): rel err {err:.2e}"
         # dropout: forward and backward must still agree on the mask (v = I exposes it)
         if C == 64 and T == 64:
             yq, wq, bq, k, v, dout = args
@@ -89,7 +99,7 @@ def test_smallqk_bf16x3_vs_fp64(dev, B, T, d, C):
             o, grads = _run(dev, yq, wq, bq, k, v, dout, 0.3, True)
             ref_o, ref_g = _reference(yq, wq, bq, k, v, dout, mask, 0.3)
             for name, a, b in zip(["out", "dyq", "dwq", "dbq", "dk", "dv"], [o] + grads, [ref_o] + ref_g):
-                assert _e(a, b) <= 5e-5, f"smallqk[bf16x3]+dropout {name}: rel err {_e(a, b):.2e}"
+                assert _e(a, b) <= bar, f"smallqk[{mode}]+dropout {name}: rel err {_e(a, b):.2e}"
     finally:
         ops.set_conv_math(old)
 
