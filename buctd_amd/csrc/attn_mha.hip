@@ -151,6 +151,222 @@ __global__ __launch_bounds__(512, 1) void mha_fwd_kernel(const float* __restrict
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// The same attention in the bf16x6 arithmetic of the convolutions (operands split exactly into three bf16 pieces, six
+// v_mfma_f32_16x16x32_bf16 per product, fp32 accumulate - fp32 class, conv3x3.hip): 417 TFLOP/s-equivalent of matrix
+// peak instead of 157.
+//   * S^T = K (scale Q)^T, not S: the accumulator of a 16-key block then gives lane (query i16, group g) the logits of
+//     keys 4g..4g+3 of ITS query, so two blocks are - with the reduction slot e of group g enumerated as key
+//     16 (e >> 2) + 4 g + (e & 3) - exactly the A operand of one K = 32 MFMA of O += P V: the probabilities never leave
+//     the registers (the fp32 kernel sends them through LDS to change layout);
+//   * K and V tiles are staged key-major as [64][d h | d m | d l] (row stride 6 d bytes = 32 mod 64: conflict-free
+//     16-byte row reads for the A operand of S^T; the V fragments in the enumeration above come out of the same layout
+//     through two ds_read_b64_tr_b16 transpose reads each);
+//   * Q is split once into registers (B operand of S^T), pre-multiplied by scale * log2(e): soft-max in the exp2 domain.
+typedef __bf16 mbf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 mbf16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned short mu16x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ mbf16x8 mha_tr_pair(const unsigned char* p, const unsigned char* q) {
+  typedef __attribute__((address_space(3))) mbf16x4 lds_bf16x4;
+  const mbf16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)p);
+  const mbf16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)q);
+  return __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+__device__ __forceinline__ void mha_split8(const float (&x)[8], mbf16x8 (&pc)[3]) {
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    float r = x[e];
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+      const __bf16 h = (__bf16)r;
+      pc[q][e] = h;
+      r -= (float)h;
+    }
+  }
+}
+__device__ __forceinline__ void mha_mma6(f32x4& acc, const mbf16x8 (&a)[3], const mbf16x8 (&b)[3]) {
+  acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[2], b[0], acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], b[2], acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1], b[1], acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1], b[0], acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], b[1], acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], b[0], acc, 0, 0, 0);
+}
+
+template <int DF>
+__global__ __launch_bounds__(512, 1) void mha_fwd_x6_kernel(const float* __restrict__ q, const float* __restrict__ k,
+                                                            const float* __restrict__ v, int T, int ldqk, int ldv,
+                                                            float scale, float* __restrict__ out,
+                                                            float* __restrict__ lse) {
+  constexpr int D = DF * 16, LO = D * 2, RS = D * 6 + (((D * 6) % 64 == 32) ? 0 : 32), NK = (D + 31) / 32;
+  constexpr int C4 = D / 4, PL = (MHA_BK * C4 + 511) / 512;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smx[];
+  unsigned char* kt = smx;                    // [64 keys][RS]
+  unsigned char* vt = smx + MHA_BK * RS;      // [64 keys][RS]
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int i16 = lane & 15, g = lane >> 4;
+  const int b = blockIdx.y, q0 = blockIdx.x * MHA_BQ + wave * 16;
+  const float* qb = q + ((long)b * T) * ldqk;
+  const float* kb = k + ((long)b * T) * ldqk;
+  const float* vb = v + ((long)b * T) * ldv;
+
+  // B operand of S^T: lane (query i16, group g) holds Q[q0 + i16][32 kk + 8 g .. +8] (zeros past d), pre-scaled
+  mbf16x8 qq[NK][3];
+  const float s2 = scale * 1.44269504088896340736f;
+#pragma unroll
+  for (int kk = 0; kk < NK; ++kk) {
+    const int c0 = 32 * kk + 8 * g;
+    float x[8];
+    if (c0 < D) {
+      const f32x4 a = *reinterpret_cast<const f32x4*>(qb + (long)(q0 + i16) * ldqk + c0);
+      const f32x4 c = *reinterpret_cast<const f32x4*>(qb + (long)(q0 + i16) * ldqk + c0 + 4);
+      x[0] = a.x * s2; x[1] = a.y * s2; x[2] = a.z * s2; x[3] = a.w * s2;
+      x[4] = c.x * s2; x[5] = c.y * s2; x[6] = c.z * s2; x[7] = c.w * s2;
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) x[e] = 0.f;
+    }
+    mha_split8(x, qq[kk]);
+  }
+  f32x4 o[DF];
+#pragma unroll
+  for (int n = 0; n < DF; ++n) o[n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  float mrun = -INFINITY, lrun = 0.f;      // query i16: running maximum (same in its 4 lanes), this lane's share of the sum
+  int koff[NK];                            // byte offset of this lane's 8 channels in a K tile row (clamped in the pad)
+#pragma unroll
+  for (int kk = 0; kk < NK; ++kk) {
+    const int c0 = 32 * kk + 8 * g;
+    koff[kk] = (c0 < D ? c0 : 0) * 2;
+  }
+  const int tr_off = (4 * g + (i16 >> 2)) * RS + (i16 & 3) * 8;   // keys 4g .. 4g+3 of a 16-key block, this lane's column
+
+  f32x4 kreg[PL], vreg[PL];
+  auto load_kv = [&](int k0) {
+#pragma unroll
+    for (int p = 0; p < PL; ++p) {
+      const int id = t + 512 * p;
+      const int row = id / C4, c4 = (id - row * C4) * 4;
+      if (row < MHA_BK) {
+        kreg[p] = *reinterpret_cast<const f32x4*>(kb + (long)(k0 + row) * ldqk + c4);
+        vreg[p] = *reinterpret_cast<const f32x4*>(vb + (long)(k0 + row) * ldv + c4);
+      }
+    }
+  };
+  auto split_row4 = [&](unsigned char* row, int c, f32x4 val) {
+    mu16x4 pc[3];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float r = val[j];
+#pragma unroll
+      for (int qp = 0; qp < 3; ++qp) {
+        const __bf16 h = (__bf16)r;
+        pc[qp][j] = __builtin_bit_cast(unsigned short, h);
+        r -= (float)h;
+      }
+    }
+#pragma unroll
+    for (int qp = 0; qp < 3; ++qp) *reinterpret_cast<mu16x4*>(row + qp * LO + 2 * c) = pc[qp];
+  };
+  auto store_kv = [&]() {
+#pragma unroll
+    for (int p = 0; p < PL; ++p) {
+      const int id = t + 512 * p;
+      const int row = id / C4, c4 = (id - row * C4) * 4;
+      if (row < MHA_BK) {
+        split_row4(kt + row * RS, c4, kreg[p]);
+        split_row4(vt + row * RS, c4, vreg[p]);
+      }
+    }
+  };
+
+  load_kv(0);
+  for (int k0 = 0; k0 < T; k0 += MHA_BK) {
+    __syncthreads();                      // everyone is done with the previous block
+    store_kv();
+    if (k0 + MHA_BK < T) load_kv(k0 + MHA_BK);
+    __syncthreads();
+    // S^T blocks: st[f][rg] = logit of (key 16 f + 4 g + rg, query i16), exp2 domain
+    f32x4 st[4];
+#pragma unroll
+    for (int f = 0; f < 4; ++f) {
+      st[f] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      const unsigned char* krow = kt + (16 * f + i16) * RS;
+#pragma unroll
+      for (int kk = 0; kk < NK; ++kk) {
+        mbf16x8 aa[3];
+#pragma unroll
+        for (int qp = 0; qp < 3; ++qp) {
+          aa[qp] = *reinterpret_cast<const mbf16x8*>(krow + koff[kk] + qp * LO);
+          if (32 * kk + 8 * g >= D) {            // zero-padded tail of the channel contraction
+#pragma unroll
+            for (int e = 0; e < 8; ++e) aa[qp][e] = (__bf16)0.f;
+          }
+        }
+        mha_mma6(st[f], aa, qq[kk]);
+      }
+    }
+    // online soft-max of query i16 (its 64 logits of this tile sit in the four lanes i16 + 16 g)
+    float mx = -INFINITY;
+#pragma unroll
+    for (int f = 0; f < 4; ++f)
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg) mx = fmaxf(mx, st[f][rg]);
+    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float mnew = fmaxf(mrun, mx);
+    if (__any(mnew > mrun)) {
+      const float fac = __builtin_amdgcn_exp2f(mrun - mnew);   // 1 where the maximum stayed, 0 on the first tile
+      lrun *= fac;
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg) {
+        const float fr = __shfl(fac, g * 4 + rg, 64);          // accumulator rows of O are queries g*4 + rg
+#pragma unroll
+        for (int n = 0; n < DF; ++n) o[n][rg] *= fr;
+      }
+      mrun = mnew;
+    }
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {            // 32 keys per MFMA: blocks 2h, 2h + 1
+      float pv[8];
+#pragma unroll
+      for (int fb = 0; fb < 2; ++fb)
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) {
+          const float e2 = __builtin_amdgcn_exp2f(st[2 * h + fb][rg] - mrun);
+          pv[4 * fb + rg] = e2;
+          lrun += e2;
+        }
+      mbf16x8 pp[3];
+      mha_split8(pv, pp);
+      const unsigned char* vbase = vt + 32 * h * RS + tr_off;
+#pragma unroll
+      for (int n = 0; n < DF; ++n) {
+        mbf16x8 bb[3];
+#pragma unroll
+        for (int qp = 0; qp < 3; ++qp) bb[qp] = mha_tr_pair(vbase + n * 32 + qp * LO, vbase + n * 32 + qp * LO + 16 * RS);
+        mha_mma6(o[n], pp, bb);
+      }
+    }
+  }
+  lrun += __shfl_xor(lrun, 16, 64);
+  lrun += __shfl_xor(lrun, 32, 64);
+  const float linv = 1.f / lrun;
+  if (lse && g == 0) lse[(long)b * T + q0 + i16] = (mrun + __builtin_amdgcn_logf(lrun)) * 0.69314718055994530942f;
+#pragma unroll
+  for (int rg = 0; rg < 4; ++rg) {
+    const float fl = __shfl(linv, g * 4 + rg, 64);
+    float* op = out + ((long)b * T + q0 + g * 4 + rg) * (long)D;
+#pragma unroll
+    for (int n = 0; n < DF; ++n) op[16 * n + i16] = o[n][rg] * fl;
+  }
+}
+
+static size_t mha_x6_lds(int d) {
+  const int rs = d * 6 + (((d * 6) % 64 == 32) ? 0 : 32);
+  return (size_t)2 * MHA_BK * rs;
+}
+
 static size_t mha_lds(int d) {
   return ((size_t)MHA_BK * (d + 8) + (size_t)d * (MHA_BK + 8) + (size_t)8 * 16 * (MHA_BK + 8)) * sizeof(float);
 }
@@ -161,10 +377,12 @@ extern "C" int buctd_mha_fwd_supported(int T, int d) {
 
 template <int DF>
 static int mha_launch(int B, int T, const float* q, const float* k, const float* v, int ldqk, int ldv, float scale,
-                      float* out, float* lse, hipStream_t st) {
-  static bool attr_set = false;     // idempotent attribute call: a race at first use only repeats it
-  auto fn = mha_fwd_kernel<DF>;
-  const size_t lds = mha_lds(DF * 16);
+                      float* out, float* lse, int x6, hipStream_t st) {
+  static bool attr_done[2] = {false, false};     // idempotent attribute call: a race at first use only repeats it
+  void (*fn)(const float*, const float*, const float*, int, int, int, float, float*, float*) =
+      x6 ? mha_fwd_x6_kernel<DF> : mha_fwd_kernel<DF>;
+  const size_t lds = x6 ? mha_x6_lds(DF * 16) : mha_lds(DF * 16);
+  bool& attr_set = attr_done[x6 ? 1 : 0];
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        160 * 1024);
@@ -179,18 +397,28 @@ static int mha_launch(int B, int T, const float* q, const float* k, const float*
   return BUCTD_OK;
 }
 
-extern "C" int buctd_mha_fwd(int B, int T, int d, const float* q, const float* k, const float* v, int ldqk, int ldv,
-                             float scale, float* out, float* lse, void* stream) {
+static int mha_run(int B, int T, int d, const float* q, const float* k, const float* v, int ldqk, int ldv, float scale,
+                   float* out, float* lse, int x6, void* stream) {
   BUCTD_CHECK_ARG(q && k && v && out && B > 0, "buctd_mha_fwd: null pointer");
   BUCTD_CHECK_ARG(buctd_mha_fwd_supported(T, d), "buctd_mha_fwd: unsupported shape T%d d%d (T %% 128 == 0, d %% 16 == 0, d <= 128)",
                   T, d);
   BUCTD_CHECK_ARG(ldqk >= d && ldv >= d && ldqk % 4 == 0 && ldv % 4 == 0, "buctd_mha_fwd: row strides must be >= d and 16-byte aligned");
   hipStream_t st = (hipStream_t)stream;
   switch (d / 16) {
-#define MHA_CASE(n) case n: return mha_launch<n>(B, T, q, k, v, ldqk, ldv, scale, out, lse, st);
+#define MHA_CASE(n) case n: return mha_launch<n>(B, T, q, k, v, ldqk, ldv, scale, out, lse, x6, st);
     MHA_CASE(1) MHA_CASE(2) MHA_CASE(3) MHA_CASE(4) MHA_CASE(5) MHA_CASE(6) MHA_CASE(7) MHA_CASE(8)
 #undef MHA_CASE
   }
   buctd_set_error("buctd_mha_fwd: no kernel for d=%d", d);
   return BUCTD_EINVAL;
+}
+
+extern "C" int buctd_mha_fwd(int B, int T, int d, const float* q, const float* k, const float* v, int ldqk, int ldv,
+                             float scale, float* out, float* lse, void* stream) {
+  return mha_run(B, T, d, q, k, v, ldqk, ldv, scale, out, lse, 0, stream);
+}
+
+extern "C" int buctd_mha_fwd_bf16x6(int B, int T, int d, const float* q, const float* k, const float* v, int ldqk,
+                                    int ldv, float scale, float* out, float* lse, void* stream) {
+  return mha_run(B, T, d, q, k, v, ldqk, ldv, scale, out, lse, 1, stream);
 }

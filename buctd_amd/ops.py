@@ -1198,9 +1198,11 @@ def mha_fwd(qk, v, scale=None):
     d = two_d // 2
     out = torch.empty((B, T, d), dtype=torch.float32, device=qk.device)
     kptr = C.c_void_p(qk.data_ptr() + 4 * d)
-    check(lib().buctd_mha_fwd(B, T, d, ptr(qk), kptr, ptr(v), two_d, v.shape[2],
-                              (1.0 / math.sqrt(d)) if scale is None else float(scale), ptr(out), None, stream_ptr()),
-          "mha_fwd")
+    # default math mode: both products in bf16x6 (fp32 class on the bf16 matrix cores); fp32 mode: exact fp32 MFMA
+    fn = lib().buctd_mha_fwd_bf16x6 if (_conv_math["mode"] == "bf16x6" and os.environ.get("BUCTD_MHA_X6", "1") != "0") \
+        else lib().buctd_mha_fwd
+    check(fn(B, T, d, ptr(qk), kptr, ptr(v), two_d, v.shape[2],
+             (1.0 / math.sqrt(d)) if scale is None else float(scale), ptr(out), None, stream_ptr()), "mha_fwd")
     return out
 
 

@@ -302,6 +302,10 @@ int buctd_adam_step(float* p, const float* g, float* m, float* v, long n, float 
 int buctd_mha_fwd_supported(int T, int d);
 int buctd_mha_fwd(int B, int T, int d, const float* q, const float* k, const float* v, int ldqk, int ldv, float scale,
                   float* out, float* lse, void* stream);
+/* the same in the bf16x6 arithmetic of the convolutions (three bf16 pieces per operand, six MFMAs per product, fp32
+ * accumulate: fp32 class on the bf16 matrix cores); probabilities stay in registers (S^T formulation). */
+int buctd_mha_fwd_bf16x6(int B, int T, int d, const float* q, const float* k, const float* v, int ldqk, int ldv,
+                         float scale, float* out, float* lse, void* stream);
 
 /* ------------------------------------------------------- sample pipeline --- */
 /* Person crop of the per-sample pipeline (dataset/JointsDataset.py:287-294): cv2.warpAffine(img_u8, M, (w, h),

@@ -72,8 +72,9 @@ def test_channel_attention(dev, B, T, C, h):
     assert _e(Wd.grad, 2 * W.grad) <= 2e-5 and _e(bd.grad, 2 * bias.grad) <= 2e-5
 
 
-@pytest.mark.parametrize("B,T,d", [(2, 384, 48), (1, 3072, 112), (3, 128, 16), (2, 256, 128)])
-def test_fused_mha_forward_vs_fp64(dev, B, T, d):
+@pytest.mark.parametrize("mode", ["bf16x6", "fp32"])
+@pytest.mark.parametrize("B,T,d", [(2, 384, 48), (1, 3072, 112), (3, 128, 16), (2, 256, 128), (2, 256, 96)])
+def test_fused_mha_forward_vs_fp64(dev, B, T, d, mode):
     """attn_mha.hip (TransPose encoder self-attention, eval): softmax(q k^T / sqrt(d)) v against an fp64 evaluation and
     against the materialised HIP path; logits spread wide enough to exercise the online rescaling."""
     from buctd_amd import ops
@@ -84,9 +85,14 @@ def test_fused_mha_forward_vs_fp64(dev, B, T, d):
     q64, k64, v64 = qk[..., :d].double(), qk[..., d:].double(), v.double()
     ref = torch.softmax(q64 @ k64.transpose(1, 2) / math.sqrt(d), dim=-1) @ v64
     assert ops.mha_fused_ok(T, d)
-    out = ops.mha_fwd(qk.to(dev), v.to(dev))
+    old = ops.get_conv_math()
+    ops.set_conv_math(mode)        # bf16x6 (default): split-operand bf16 MFMA kernel; fp32: exact fp32 MFMA kernel
+    try:
+        out = ops.mha_fwd(qk.to(dev), v.to(dev))
+    finally:
+        ops.set_conv_math(old)
     err = (out.cpu().double() - ref).abs().max().item() / ref.abs().max().item()
-    assert err <= 2e-5, f"fused MHA (B{B} T{T} d{d}): rel err {err:.2e}"
+    assert err <= 2e-5, f"fused MHA[{mode}] (B{B} T{T} d{d}): rel err {err:.2e}"
     mat = ops.PositionAttention.apply(qk.to(dev), None, v.to(dev), 1, 0.0, False)
     assert (mat - out).abs().max().item() <= 2e-5 * ref.abs().max().item()
     assert not ops.mha_fused_ok(100, d) and not ops.mha_fused_ok(T, 20)
