@@ -114,7 +114,8 @@ class CoAMBlock(nn.Module):
             return [self.att_layers[i].parts()[0](y_list[i], conds[i]) for i in range(n)]
 
         if self.att_layers[0].channel_only:
-            return [self.att_layers[i].combine(y_list[i], chan()) for i in range(n)]
+            c_outs = chan()
+            return [self.att_layers[i].combine(y_list[i], [c_outs[i]]) for i in range(n)]
 
         def pos():
             return [self.att_layers[i].parts()[1](y_list[i], conds[i]) for i in range(n)]

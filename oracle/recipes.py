@@ -192,13 +192,20 @@ def _transpose_full():
 # input: a power of two, so the scaling itself is exact and the recipe stays a pure function of its seed.
 FINAL_SCALE_LOG2 = {
     "prenet_w16_96x64": 6, "coam_w16_96x64_colored": 6, "coam_w16_96x64_mono_default_att": 7,
-    "coam_w16_96x64_stacked_2heads": 5, "coam_w16_96x64_channel_only": 8, "transpose_w16_96x64": 2, "resnet18_96x64": 3, "coam_w48_384x288": 6,
+    "coam_w16_96x64_stacked_2heads": 5, "coam_w16_96x64_channel_only": 9, "transpose_w16_96x64": 2, "resnet18_96x64": 3, "coam_w48_384x288": 6,
     "prenet_w32_256x192": 7, "resnet50_256x192": 3, "prenet_w48_384x288": 7, "transpose_a6_256x192": 3,
 }
 
 
-def build(name, seed=1234, final_scale_log2=None):
+# recipe seeds other than the default: the channel-only net at seed 1234 has a ReLU pre-activation within fp32 round-off
+# of zero in its train step (the fp32 CPU oracle itself sits 4e-3 from its fp64 evaluation there, against 2e-5 at seed 1)
+SEEDS = {"coam_w16_96x64_channel_only": 1}
+
+
+def build(name, seed=None, final_scale_log2=None):
     """-> cfg, oracle model (eval mode, randomised, unit-scale heat-maps), input x [B,3+Cc,H,W], joints [B,K,2]."""
+    if seed is None:
+        seed = SEEDS.get(name, 1234)
     c, batch, cond_channels = CASES[name]()
     torch.manual_seed(seed)
     model = omodels.get_pose_net(c, is_train=False)
