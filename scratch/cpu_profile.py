@@ -4,7 +4,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench
 from buctd_amd import engine, models, ops
 from buctd_amd.core.loss import JointsMSELoss
-ops.set_conv_math("bf16x3")
+ops.set_conv_math("bf16x6")
 dev = torch.device("cuda:0")
 cfg = bench.coam_w48_cfg(2)
 net = models.pose_hrnet_coam.get_pose_net(cfg, is_train=True).to(dev).train()
