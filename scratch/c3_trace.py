@@ -4,7 +4,7 @@ import os, sys, ctypes as C
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import buctd_amd._C as _C
-_C.LIB_PATH = _C.LIB_PATH.replace("libbuctd_hip.so", "libbuctd_hip_trace.so")
+_C.LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libbuctd_hip_trace.so")
 from buctd_amd import ops
 from buctd_amd._C import lib, ptr, stream_ptr
 N, H, W, Ci, Co = [int(v) for v in sys.argv[1:6]] if len(sys.argv) > 5 else (32, 96, 72, 48, 48)
