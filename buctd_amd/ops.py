@@ -653,6 +653,33 @@ def bn_bwd(dy, y, z, mean, invstd, gamma, relu, want_dres, dgamma, dbeta, accumu
     return dz, dres
 
 
+def bn_fold_cached(bn, gamma, beta, eps):
+    """eval-mode scale / shift of a BatchNorm module, folded once and kept on the module until a parameter, a running
+    statistic (tensor versions) or the optimizer epoch changes - inference runs the same 146 folds on every forward
+    otherwise (4.4 us each: 0.64 ms of a 37 ms TransPose step)."""
+    rm, rv = bn.running_mean, bn.running_var
+    # the train path updates the running statistics through raw pointers (no version bump): it counts batches on the
+    # module (nn.BatchNorm2d.count_batch) or bumps num_batches_tracked - both are part of the key
+    nbt = bn.num_batches_tracked
+    key = (gamma.data_ptr(), gamma._version, beta._version, rm.data_ptr(), rm._version, rv._version, _weights_epoch["n"],
+           float(eps), getattr(bn, "_pending_batches", 0), nbt._version if nbt is not None else 0)
+    cache = getattr(bn, "_buctd_fold", None)
+    cur = torch.cuda.current_stream(gamma.device)
+    if cache is None or cache[0] != key:
+        scale, shift = bn_fold(gamma, beta, rm, rv, eps)
+        ev = torch.cuda.Event()
+        ev.record()
+        cache = (key, scale, shift, ev, cur.cuda_stream, set())
+        try:
+            object.__setattr__(bn, "_buctd_fold", cache)
+        except (AttributeError, TypeError):
+            return scale, shift
+    elif cur.cuda_stream != cache[4] and cur.cuda_stream not in cache[5]:
+        cur.wait_event(cache[3])            # folded on another stream: order this stream behind it, once
+        cache[5].add(cur.cuda_stream)
+    return cache[1], cache[2]
+
+
 def bn_fold(gamma, beta, rm, rv, eps):
     Cn = gamma.numel()
     scale = torch.empty(Cn, dtype=torch.float32, device=gamma.device)
@@ -921,7 +948,7 @@ class ConvBnAct(torch.autograd.Function):
             # without a residual the ReLU mask is rebuilt from z in the backward kernels: y is not kept (nor re-read)
             ctx.save_for_backward(x, z, mean, invstd, y if (relu and ctx.has_res) else None)
             return y
-        scale, shift = bn_fold(gamma, beta, bn.running_mean, bn.running_var, eps)
+        scale, shift = bn_fold_cached(bn, gamma, beta, eps)
         if transposed_shape is None:
             y = conv_fwd(x, conv_w, conv_b, stride, pad, scale=scale, shift=shift, residual=residual, relu=relu)
         else:

@@ -122,3 +122,36 @@ def test_basic_block_input_bn_fusion_is_bit_identical(dev, shape, monkeypatch):
                      bns[0].bias.grad.clone(), bns[1].weight.grad.clone(), bns[1].running_var.clone()]
     for a, b in zip(res["1"], res["0"]):
         assert torch.equal(a, b), f"fused vs unfused differ by {(a - b).abs().max().item():.3e}"
+
+
+def test_eval_bn_fold_cache_follows_training_updates(dev):
+    """eval-mode scale / shift are folded once per BatchNorm and cached; a train-mode forward (running statistics updated
+    through raw pointers) or a parameter update must invalidate them."""
+    from buctd_amd import nn as bnn
+    import torch.nn.functional as F
+    torch.manual_seed(3)
+    conv = bnn.Conv2d(16, 32, 3, 1, 1, bias=False).to(dev)
+    bn = bnn.BatchNorm2d(32).to(dev)
+    bnn.prepare_module(conv)
+    x = torch.randn(2, 16, 12, 10, device=dev)
+
+    def run(train):
+        from buctd_amd import ops
+        y = ops.ConvBnAct.apply(ops.nchw_to_nhwc(x, 0, 16), conv.weight, None, bn, None, True, 1, 1, train, None)
+        return ops.nhwc_to_nchw(y)
+
+    def ref():
+        z = F.conv2d(x, conv.weight, None, 1, 1)
+        return F.relu(F.batch_norm(z, bn.running_mean, bn.running_var, bn.weight, bn.bias, False, 0.0, bn.eps))
+
+    with torch.no_grad():
+        a = run(False)
+        assert (a - ref()).abs().max().item() <= 1e-4
+        b = run(False)                       # served from the cache
+        assert torch.equal(a, b)
+        run(True)                            # running statistics move
+        c = run(False)
+        assert (c - ref()).abs().max().item() <= 1e-4 and not torch.equal(a, c)
+        bn.weight.mul_(1.5)                  # parameter update (version bump)
+        d = run(False)
+        assert (d - ref()).abs().max().item() <= 1e-4 and not torch.equal(c, d)
