@@ -170,3 +170,47 @@ def test_full_size_baseline_configs_forward(dev, name):
     assert 0.4 <= top <= 1.0
     assert err <= BAR, f"{name}: full-size forward differs from the reference by {err:.3e}"
     assert np.array_equal(y.reshape(y.shape[0], y.shape[1], -1).argmax(2), gold["argmax"])
+
+
+def test_full_size_c4_train_step_vs_oracle(dev):
+    """BASELINE config C4 at full size (CoAM-W48 384x288, the bench workload) in TRAIN mode: the kernels only this size
+    reaches - 512-position conv tiles, fc_o on the bf16x6 GEMM at T = 6912, the position attention at T = 6912 - inside
+    one forward + loss + backward, against the fp32 and fp64 CPU oracle evaluated here.  Batch 2 (the recipe's image
+    and a scaled copy) so that the batch statistics are not degenerate."""
+    from oracle import recipes
+    from buctd_amd.core.loss import JointsMSELoss
+    cfg, omodel, x, joints = recipes.build("coam_w48_384x288")
+    x = torch.cat([x, x.flip(3) * 0.9], 0)
+    joints = torch.cat([joints, joints], 0)
+    tgt, wt = recipes.make_targets(cfg, joints, 77)
+    m = product_model(cfg, omodel, dev).train()
+    recipes.set_dropout(m, 0.0)
+    y = m(x.to(dev))
+    loss = JointsMSELoss(True)(y, tgt.to(dev), wt.to(dev))
+    loss.backward()
+    import copy
+    from oracle import core as ocore
+    o32 = copy.deepcopy(omodel).train()
+    recipes.set_dropout(o32, 0.0)
+    y32 = o32(x)
+    l32 = ocore.JointsMSELoss(True)(y32, tgt, wt)
+    l32.backward()
+    g64 = _oracle_grads(omodel, x, tgt, wt, torch.float64)
+    g32 = {k: p.grad.detach() for k, p in o32.named_parameters() if p.grad is not None}
+    top = float(y32.detach().abs().max())
+    err = float((y.detach().cpu() - y32.detach()).abs().max())
+    print(f"C4 full size train: max|y| {top:.3f}, |hip - oracle| {err:.3e}, loss hip {loss.item():.6f} oracle {l32.item():.6f}")
+    assert err <= BAR * max(1.0, top)
+    assert rel(loss.item(), l32.item()) <= 1e-4
+    params = dict(m.named_parameters())
+    gmax = max(v.norm().item() for v in g64.values())
+    e_hip, e_cpu = [], []
+    for k, g in g64.items():
+        den = g.norm().item()
+        if den <= 1e-6 * gmax:
+            continue
+        e_hip.append((params[k].grad.detach().cpu().double() - g).norm().item() / den)
+        e_cpu.append((g32[k].double() - g).norm().item() / den)
+    med_h, med_c, worst, worst_ref = float(np.median(e_hip)), float(np.median(e_cpu)), max(e_hip), max(e_cpu)
+    print(f"C4 full size: grad rel err vs fp64 - median hip {med_h:.2e} / cpu32 {med_c:.2e}; max hip {worst:.2e} / cpu32 {worst_ref:.2e}")
+    assert med_h <= max(3 * med_c, 2e-3) and worst <= max(3 * worst_ref, 5e-2)
