@@ -79,9 +79,6 @@ class DeviceSamplePipeline:
         self.std = np.asarray(std, dtype=np.float32)
         self.np_rng = np.random.RandomState(seed)
         self.py_rng = random.Random(seed)
-        if self.stacked:
-            raise NotImplementedError("stacked conditions (one blurred channel per joint) are rendered by the host "
-                                      "loader; the device pipeline covers the colored / mono recipes")
 
     # ---- host-side scalar geometry (reference expressions, float64) -----------------------------------------
     def half_body_transform(self, joints, joints_vis):
@@ -161,7 +158,7 @@ class DeviceSamplePipeline:
         dev = images[0].device
         B, K = len(images), self.num_joints
         W, H = int(self.image_size[0]), int(self.image_size[1])
-        cc = 3 if self.conditional else 0
+        cc = (K if self.stacked else 3) if self.conditional else 0      # stacked: one condition channel per joint
         x = torch.empty((B, 3 + cc, H, W), dtype=torch.float32, device=dev)
         items = (_WarpItem * B)()
         for b, (img, g) in enumerate(zip(images, geos)):
@@ -198,8 +195,15 @@ class DeviceSamplePipeline:
             colors = None
             if self.colored:
                 colors = torch.from_numpy(np.ascontiguousarray(self.kpt_colors[:K])).to(dev)
-            ws = ops.workspace(lib().buctd_cond_render_workspace(B, 3, H, W), dev)
-            if self.colored:
+            ws = ops.workspace(lib().buctd_cond_render_workspace(B * K if self.stacked else B, 3, H, W), dev)
+            if self.stacked:
+                # get_stacked_condition (JointsDataset.py:471-498): every joint is its own single-impulse image, blurred
+                # and peak-normalised on its own - B * K one-joint "images" of one channel for the render kernel
+                tmp = torch.empty((B * K, 1, H, W), dtype=torch.float32, device=dev)
+                check(lib().buctd_cond_render_into(ptr(cjt), 2, None, B * K, 1, 1, H, W, 0, ptr(tmp), tmp.stride(0), ptr(ws),
+                                                   ws.numel(), stream_ptr()), "cond_render_into")
+                x[:, 3:] = tmp.view(B, K, H, W)
+            elif self.colored:
                 check(lib().buctd_cond_render_into(ptr(cjt), 2, ptr(colors), B, K, 3, H, W, 0,
                                                    C.c_void_p(x[:, 3:].data_ptr()), x.stride(0), ptr(ws), ws.numel(),
                                                    stream_ptr()), "cond_render_into")

@@ -260,6 +260,19 @@ def get_condition_image_colored(kpts, size, colors):
     return generate_heatmap(z)
 
 
+def get_stacked_condition(kpts, size):
+    """reference lib/dataset/JointsDataset.py:471-498. size = (H, W) -> (H, W, K) float64: one blurred impulse per joint,
+    every channel peak-normalised on its own (zero channel for a joint outside the crop)."""
+    kpts = np.array(kpts).astype(int)
+    chans = []
+    for kpt in kpts:
+        z = np.zeros(size)
+        if 0 < kpt[0] < size[1] and 0 < kpt[1] < size[0]:
+            z[kpt[1] - 1][kpt[0] - 1] = 255
+        chans.append(generate_heatmap(z))
+    return np.moveaxis(np.array(chans), 0, -1)
+
+
 def get_condition_image(kpts, size):
     """reference lib/dataset/JointsDataset.py:500-516. size = (H, W) -> (3, H, W) int."""
     kpts = np.array(kpts).astype(int)

@@ -100,7 +100,7 @@ def box_from_keypoints(kp, margin, img_w, img_h):
 
 
 def make_sample(image_u8, joints, joints_vis, cond_joints, cond_joints_vis, center, scale, rot, flip, image_size,
-                heatmap_size, sigma, flip_pairs, mean, std, colors=None, mono=False):
+                heatmap_size, sigma, flip_pairs, mean, std, colors=None, mono=False, stacked=False):
     """One sample after the random draws (center / scale / rot / flip are the post-augmentation values of
     JointsDataset.py:233-251): returns input [3+3, H, W] float32, target, target_weight, joints, cond_joints (crop)."""
     joints, joints_vis = joints.copy(), joints_vis.copy()
@@ -121,7 +121,9 @@ def make_sample(image_u8, joints, joints_vis, cond_joints, cond_joints_vis, cent
             cond_joints[i, 0:2] = ocore.affine_transform(cond_joints[i, 0:2], trans)
     target, weight = ocore.generate_target(joints, joints_vis, joints.shape[0], heatmap_size, image_size, sigma)
     h, w = int(image_size[1]), int(image_size[0])
-    if mono:
+    if stacked:
+        cond = ocore.get_stacked_condition(cond_joints[:, :2], (h, w)).transpose(2, 0, 1).astype(np.float32)
+    elif mono:
         cond = ocore.get_condition_image(cond_joints, (h, w)).astype(np.float32)
     else:
         cond = ocore.get_condition_image_colored(cond_joints, (h, w, 3), colors).transpose(2, 0, 1).astype(np.float32)

@@ -108,11 +108,15 @@ def test_host_geometry_matches_oracle():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("colored", [True, False])
+@pytest.mark.parametrize("colored", [True, False, "stacked"])
 def test_device_pipeline_matches_oracle(dev, colored):
+    """colored / mono (x3, int-truncated) / stacked (one peak-normalised channel per joint, JointsDataset.py:471-498)"""
     from oracle import core as oc, sample as S
     from buctd_amd.dataset.pipeline import DeviceSamplePipeline
+    stacked = colored == "stacked"
+    colored = bool(colored) and not stacked
     cfg = _cfg(colored)
+    cfg.DATASET.STACKED_CONDITION = stacked
     pipe = DeviceSamplePipeline(cfg, oc.CROWDPOSE_FLIP_PAIRS, range(8), oc.CROWDPOSE_KPT_COLORS, MEAN, STD, is_train=True)
     recs = _records(5, 11)
     augs = [(r["center"] + np.float32(i), r["scale"] * np.float32(1 + 0.07 * i), [0, 17.5, -33, 0, 45][i], bool(i % 2))
@@ -126,13 +130,15 @@ def test_device_pipeline_matches_oracle(dev, colored):
         xo, to, wo, jo, cjo, cropo = S.make_sample(r["image_np"], r["joints_3d"], r["joints_3d_vis"], r["cond_joints"],
                                                    r["cond_joints_vis"], a[0], a[1], a[2], a[3], [64, 96], [16, 24], 2,
                                                    oc.CROWDPOSE_FLIP_PAIRS, MEAN, STD, oc.CROWDPOSE_KPT_COLORS[:14],
-                                                   mono=not colored)
+                                                   mono=not colored, stacked=stacked)
+        assert x.shape[1] == (3 + 14 if stacked else 6)
         assert np.array_equal(crop[i].cpu().numpy(), cropo), f"sample {i}: 8-bit crop differs"
         assert np.array_equal(x[i, :3].cpu().numpy(), xo[:3]), f"sample {i}: normalised crop differs"
         assert np.abs(target[i].cpu().numpy() - to).max() <= 2e-7 and np.array_equal(weight[i].cpu().numpy(), wo)
-        tol = 2e-3 if colored else 1.0        # mono is int-truncated: a value within 2e-3 of an integer may land below it
+        exact = colored or stacked
+        tol = 2e-3 if exact else 1.0          # mono is int-truncated: a value within 2e-3 of an integer may land below it
         dc = np.abs(x[i, 3:].cpu().numpy() - xo[3:])
-        assert dc.max() <= tol and (dc > 2e-3).mean() <= (0.0 if colored else 1e-3), \
+        assert dc.max() <= tol and (dc > 2e-3).mean() <= (0.0 if exact else 1e-3), \
             f"sample {i}: condition differs by {dc.max()}"
 
 
