@@ -62,7 +62,7 @@ CROWDPOSE_COLORS = [[245, 53, 53], [245, 125, 45], [253, 206, 20], [206, 244, 54
 
 
 def synthetic_batch(cfg, batch, device, seed):
-    """RGB ~ N(0,1); colored condition rendered from uniform key points (GT + jitter); Gaussian
+    """RGB ~ N(0,1); colored condition rendered from synthesized key points (GT + generative noise); Gaussian
     targets sigma 3; target_weight ~ Bernoulli(0.8). Generated on the device, outside the timed region."""
     from buctd_amd import ops
     g = torch.Generator(device="cpu").manual_seed(seed)
@@ -70,8 +70,15 @@ def synthetic_batch(cfg, batch, device, seed):
     k = cfg.MODEL.NUM_JOINTS
     rgb = torch.randn(batch, 3, h, w, generator=g).to(device)
     gt = torch.rand(batch, k, 2, generator=g) * torch.tensor([w - 1.0, h - 1.0])
-    jitter = torch.randn(batch, k, 2, generator=g) * 4.0  # generative-noise stand-in for pose_synthesis.py
-    cond_j = (gt + jitter).to(device).contiguous()
+    # generative-noise condition: the device port of lib/dataset/pose_synthesis.py perturbs the ground
+    # truth (jitter / miss / inversion / swap with a neighbouring person's joints), as the "generative sampling" recipes do
+    from buctd_amd.dataset.pose_synthesis import synthesize_pose_batch
+    j3 = torch.cat([gt, torch.ones(batch, k, 1)], 2).double()
+    near = torch.cat([(gt + torch.randn(batch, k, 2, generator=g) * 40.0), torch.ones(batch, k, 1)], 2).double()[:, None]
+    area = torch.full((batch,), float(w * h) * 0.5, dtype=torch.float64)
+    syn = synthesize_pose_batch(cfg.DATASET.DATASET, j3.numpy(), j3.numpy(), near.numpy(), area.numpy(),
+                                [1] * batch, seed, device=device)
+    cond_j = syn[:, :, :2].float().contiguous()
     colors = torch.tensor(CROWDPOSE_COLORS[:k], dtype=torch.float32, device=device)
     cond = ops.cond_render(cond_j, colors, h, w)
     x = torch.cat([rgb, cond], 1).contiguous()
@@ -362,7 +369,7 @@ def bench_infer_c5(args, rank, world, device):
            "scaling": "weak", "vs_baseline": None,
            "dtype": "f32 (3x3 convs and attention products bf16x6: operands split exactly into 3 bf16 pieces, 6 bf16 MFMAs "
                     "per product, fp32 accumulate - fp32-class)" if args.conv_math == "bf16x6" else "f32",
-           "data": "synthetic",
+           "data": "synthetic (N(0,1) RGB; condition = device pose synthesis of uniform ground-truth key points; Gaussian targets)",
            "config": {"workload": "BUCTD-TransPose-H-A6 (transpose_h, W48 trunk, d_model 96+16, 6 encoder layers, "
                                   "T = 3072) 256x192 COCO-17kpt, eval: 3 chained passes per person (forward -> arg-max "
                                   "decode -> colored condition re-render -> forward)",
@@ -505,7 +512,7 @@ def main():
                                 "per product, fp32 accumulate - fp32-class)",
                       "bf16x3": "f32 with REDUCED-PRECISION 3x3 convs (2 bf16 pieces, ~2^-16 per product) - not a "
                                 "headline mode"}[args.conv_math],
-            "data": "synthetic",
+            "data": "synthetic (N(0,1) RGB; condition = device pose synthesis of uniform ground-truth key points; Gaussian targets)",
             "config": {"workload": "BUCTD-CoAM-W48 (pose_hrnet_coam, ATT_MODULES [F,T,F,F], colored condition) "
                                    "384x288 CrowdPose-14kpt full train step: fwd + JointsMSE + bwd + grad all-reduce + "
                                    "Adam + arg-max accuracy decode",
