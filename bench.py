@@ -369,7 +369,7 @@ def bench_infer_c5(args, rank, world, device):
            "scaling": "weak", "vs_baseline": None,
            "dtype": "f32 (3x3 convs and attention products bf16x6: operands split exactly into 3 bf16 pieces, 6 bf16 MFMAs "
                     "per product, fp32 accumulate - fp32-class)" if args.conv_math == "bf16x6" else "f32",
-           "data": "synthetic (N(0,1) RGB; condition = device pose synthesis of uniform ground-truth key points; Gaussian targets)",
+           "data": "synthetic (N(0,1) RGB; first condition from uniform key points, later ones from the decoded predictions)",
            "config": {"workload": "BUCTD-TransPose-H-A6 (transpose_h, W48 trunk, d_model 96+16, 6 encoder layers, "
                                   "T = 3072) 256x192 COCO-17kpt, eval: 3 chained passes per person (forward -> arg-max "
                                   "decode -> colored condition re-render -> forward)",
