@@ -56,6 +56,40 @@ def coam_w48_cfg(batch):
     return c
 
 
+def prenet_cfg(batch, width, image_size):
+    """BASELINE configs C2 (W32 256x192) / C3 (W48 384x288): BUCTD-preNet HRNet, COCO 17 key points, colored condition
+    stacked on the RGB crop (experiments/coco/hrnet/*prenet*: USE_PRE_NET)."""
+    from buctd_amd.config import cfg as base, hrnet_extra
+    c = base.clone()
+    c.defrost()
+    c.MODEL.NAME = "pose_hrnet"
+    c.MODEL.NUM_JOINTS = 17
+    c.MODEL.IMAGE_SIZE = list(image_size)
+    c.MODEL.HEATMAP_SIZE = [image_size[0] // 4, image_size[1] // 4]
+    c.MODEL.SIGMA = 3 if image_size[1] >= 384 else 2
+    c.MODEL.PRETRAINED = ""
+    c.MODEL.CONDITIONAL_TOPDOWN = True
+    c.MODEL.EXTRA = hrnet_extra(width, use_pre_net=True)
+    c.DATASET.DATASET = "coco"
+    c.DATASET.COLORED = True
+    c.TRAIN.BATCH_SIZE_PER_GPU = batch
+    c.TRAIN.LR = 0.001
+    c.freeze()
+    return c
+
+
+# workload -> (cfg builder, model module, metric, description, roofline shape (C, H, W) = stage-2..4 branch 0)
+TRAIN_WORKLOADS = {
+    "train_c4": (lambda b: coam_w48_cfg(b), "pose_hrnet_coam", "images/sec (train) BUCTD-CoAM-W48 384x288",
+                 "BUCTD-CoAM-W48 (pose_hrnet_coam, ATT_MODULES [F,T,F,F], colored condition) 384x288 CrowdPose-14kpt",
+                 (48, 96, 72)),
+    "train_c3": (lambda b: prenet_cfg(b, 48, (288, 384)), "pose_hrnet", "images/sec (train) BUCTD-preNet-W48 384x288",
+                 "BUCTD-preNet HRNet-W48 (pose_hrnet, USE_PRE_NET, colored condition) 384x288 COCO-17kpt", (48, 96, 72)),
+    "train_c2": (lambda b: prenet_cfg(b, 32, (192, 256)), "pose_hrnet", "images/sec (train) BUCTD-preNet-W32 256x192",
+                 "BUCTD-preNet HRNet-W32 (pose_hrnet, USE_PRE_NET, colored condition) 256x192 COCO-17kpt", (32, 64, 48)),
+}
+
+
 CROWDPOSE_COLORS = [[245, 53, 53], [245, 125, 45], [253, 206, 20], [206, 244, 54], [118, 253, 27], [47, 254, 47],
                     [25, 245, 113], [15, 243, 197], [14, 199, 245], [44, 126, 249], [13, 13, 249], [128, 47, 249],
                     [205, 38, 247], [245, 48, 206]]
@@ -79,7 +113,7 @@ def synthetic_batch(cfg, batch, device, seed):
     syn = synthesize_pose_batch(cfg.DATASET.DATASET, j3.numpy(), j3.numpy(), near.numpy(), area.numpy(),
                                 [1] * batch, seed, device=device)
     cond_j = syn[:, :, :2].float().contiguous()
-    colors = torch.tensor(CROWDPOSE_COLORS[:k], dtype=torch.float32, device=device)
+    colors = torch.tensor((CROWDPOSE_COLORS * 2)[:k], dtype=torch.float32, device=device)
     cond = ops.cond_render(cond_j, colors, h, w)
     x = torch.cat([rgb, cond], 1).contiguous()
     joints3 = torch.cat([gt, torch.zeros(batch, k, 1)], 2).to(device).contiguous()
@@ -93,13 +127,15 @@ class KernelTimer:
     of the roofline shape - the 3x3 48 -> 48 convolution at 96x72 (HRNet stage-2/3/4 branch 0) - during the timed
     steps: forward, data-gradient and weight-gradient launches are kept apart."""
 
-    def __init__(self, batch):
+    def __init__(self, batch, shape=(48, 96, 72)):
         self.batch = batch
+        self.shape = shape
         self.pairs = {"fwd": [], "dgrad": [], "wgrad": []}
         self.enabled = False
 
     def match(self, d):
-        return (d.R == 3 and d.stride == 1 and d.pad == 1 and d.Ci == 48 and d.Co == 48 and d.H == 96 and d.W == 72
+        c, h, w = self.shape
+        return (d.R == 3 and d.stride == 1 and d.pad == 1 and d.Ci == c and d.Co == c and d.H == h and d.W == w
                 and d.N == self.batch)
 
     def timed(self, kind, fn):
@@ -151,15 +187,16 @@ def install_timer(timer):
     ops.conv_fwd, ops.conv_dgrad, ops.conv_wgrad = conv_fwd, conv_dgrad, conv_wgrad
 
 
-def roofline_entry(math, batch, kind, in_step, solo, traffic):
-    """One roofline object.  Algorithmic work of one launch (SURVEY 8d x batch): 2*N*96*72*48*48*9 FLOP and
-    fp32 bytes in + out + weights.  in_step / solo = (average launch us, launches)."""
+def roofline_entry(math, batch, kind, in_step, solo, traffic, shape=(48, 96, 72)):
+    """One roofline object.  Algorithmic work of one launch (SURVEY 8d x batch): 2*N*H*W*C*C*9 FLOP (C4: 96x72, 48
+    channels) and fp32 bytes in + out + weights.  in_step / solo = (average launch us, launches)."""
     n = batch
-    flops = 2.0 * n * 96 * 72 * 48 * 48 * 9
+    cw, hh, ww = shape
+    flops = 2.0 * n * hh * ww * cw * cw * 9
     if kind == "wgrad":
-        bytes_ = 4.0 * (2 * n * 48 * 96 * 72) + 4.0 * 9 * 48 * 48       # read x and dy once, write dW
+        bytes_ = 4.0 * (2 * n * cw * hh * ww) + 4.0 * 9 * cw * cw       # read x and dy once, write dW
     else:
-        bytes_ = 4.0 * (2 * n * 48 * 96 * 72) + 4.0 * 9 * 48 * 48       # read x, write y, read W
+        bytes_ = 4.0 * (2 * n * cw * hh * ww) + 4.0 * 9 * cw * cw       # read x, write y, read W
     t_head = in_step[0] if in_step[0] else solo[0]
     if not t_head:
         return None
@@ -185,7 +222,9 @@ def roofline_entry(math, batch, kind, in_step, solo, traffic):
 
     tf = flops / t_head / 1e6
     gbps = bytes_ / t_head / 1e3
-    return {"kernel": f"{kernel}: 3x3 48->48 @96x72 N={n} (HRNet branch 0), {names[kind]}",
+    if shape != (48, 96, 72):
+        kernel = kernel.split("<")[0] + "<...>"
+    return {"kernel": f"{kernel}: 3x3 {cw}->{cw} @{hh}x{ww} N={n} (HRNet branch 0), {names[kind]}",
             "bound": bound,
             "achieved": round(tf, 2) if bound == "mfma" else round(gbps, 1),
             "peak": round(peak, 1) if bound == "mfma" else PEAK_HBM_GBPS,
@@ -403,9 +442,10 @@ def main():
         print(json.dumps(_cpu_baseline_worker()))
         return
     ap = argparse.ArgumentParser()
-    ap.add_argument("--workload", default="train_c4", choices=["train_c4", "infer_c5"],
-                    help="train_c4 (default): the headline metric, CoAM-W48 384x288 training images/s; infer_c5: "
-                         "TransPose-H-A6 256x192 3x iterative-refinement inference persons/s (BASELINE config C5)")
+    ap.add_argument("--workload", default="train_c4", choices=["train_c4", "train_c3", "train_c2", "infer_c5"],
+                    help="train_c4 (default): the headline metric, CoAM-W48 384x288 training images/s; train_c3 / train_c2: "
+                         "the preNet configs (HRNet-W48 384x288, HRNet-W32 256x192); infer_c5: TransPose-H-A6 256x192 3x "
+                         "iterative-refinement inference persons/s (BASELINE config C5)")
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
@@ -435,17 +475,18 @@ def main():
             dist.barrier()
             dist.destroy_process_group()
         return
-    cfg = coam_w48_cfg(args.batch)
+    make_cfg, module, metric, describe, rshape = TRAIN_WORKLOADS[args.workload]
+    cfg = make_cfg(args.batch)
     torch.manual_seed(1234)
     ops.manual_seed(1234 + rank)
-    net = models.pose_hrnet_coam.get_pose_net(cfg, is_train=True).to(device)
+    net = getattr(models, module).get_pose_net(cfg, is_train=True).to(device)
     model = engine.DataParallel(net)
     optimizer = engine.get_optimizer(cfg, model)
     if world == 1:
         model.flatten()
     criterion = JointsMSELoss(cfg.LOSS.USE_TARGET_WEIGHT)
     x, target, weight = synthetic_batch(cfg, args.batch, device, seed=100 + rank)
-    timer = KernelTimer(args.batch)
+    timer = KernelTimer(args.batch, rshape)
     if not args.no_kernel_timer:
         install_timer(timer)
     losses, acc = AverageMeter(), AverageMeter()
@@ -483,9 +524,9 @@ def main():
         # the same kernels alone on the GPU: 30 launches each on a stage-4-branch-0 sized activation with one of the
         # model's own 48 -> 48 filters (forward with the BN-statistics epilogue, as in the step)
         timer.reset()
-        wsel = next(p for p in net.parameters() if tuple(p.shape) == (48, 48, 3, 3))
-        xs = torch.randn(args.batch, 96, 72, 48, device=device)
-        dys = torch.randn(args.batch, 96, 72, 48, device=device)
+        wsel = next(p for p in net.parameters() if tuple(p.shape) == (rshape[0], rshape[0], 3, 3))
+        xs = torch.randn(args.batch, rshape[1], rshape[2], rshape[0], device=device)
+        dys = torch.randn(args.batch, rshape[1], rshape[2], rshape[0], device=device)
         gw = torch.empty_like(wsel)
         for it in range(35):
             timer.enabled = it >= 5
@@ -505,7 +546,7 @@ def main():
         global_batch = args.batch * world
         value = global_batch * args.steps / dt
         out = {
-            "metric": "images/sec (train) BUCTD-CoAM-W48 384x288", "value": round(value, 3), "unit": "images/s",
+            "metric": metric, "value": round(value, 3), "unit": "images/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1000 * dt / args.steps, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": {"fp32": "f32", "bf16x6": "f32 (3x3 convs: operands split exactly into 3 bf16 pieces, 6 bf16 MFMAs "
@@ -513,10 +554,10 @@ def main():
                       "bf16x3": "f32 with REDUCED-PRECISION 3x3 convs (2 bf16 pieces, ~2^-16 per product) - not a "
                                 "headline mode"}[args.conv_math],
             "data": "synthetic (N(0,1) RGB; condition = device pose synthesis of uniform ground-truth key points; Gaussian targets)",
-            "config": {"workload": "BUCTD-CoAM-W48 (pose_hrnet_coam, ATT_MODULES [F,T,F,F], colored condition) "
-                                   "384x288 CrowdPose-14kpt full train step: fwd + JointsMSE + bwd + grad all-reduce + "
-                                   "Adam + arg-max accuracy decode",
-                       "global_batch": global_batch, "batch_per_gpu": args.batch, "input": "N x 6 x 384 x 288 fp32",
+            "config": {"workload": describe + " full train step: fwd + JointsMSE + bwd + grad all-reduce + Adam + arg-max "
+                                              "accuracy decode",
+                       "global_batch": global_batch, "batch_per_gpu": args.batch,
+                       "input": f"N x 6 x {cfg.MODEL.IMAGE_SIZE[1]} x {cfg.MODEL.IMAGE_SIZE[0]} fp32",
                        "params": sum(p.numel() for p in net.parameters()), "parallelism": f"dp{world}",
                        "conv_math": args.conv_math, "loss": round(losses.avg, 6)},
         }
@@ -524,15 +565,15 @@ def main():
             n = a[1] + b[1]
             return ((a[0] * a[1] + b[0] * b[1]) / n, n) if n else (None, 0)
 
-        traffic = PMC_TRAFFIC_BYTES_N32.get(args.conv_math, {}) if args.batch == 32 else {}
+        traffic = PMC_TRAFFIC_BYTES_N32.get(args.conv_math, {}) if (args.batch == 32 and rshape == (48, 96, 72)) else {}
         main = roofline_entry(args.conv_math, args.batch, "fwd", merge(in_step["fwd"], in_step["dgrad"]),
-                              merge(solo["fwd"], solo["dgrad"]), traffic.get("fwd"))
-        wg = roofline_entry(args.conv_math, args.batch, "wgrad", in_step["wgrad"], solo["wgrad"], traffic.get("wgrad"))
+                              merge(solo["fwd"], solo["dgrad"]), traffic.get("fwd"), rshape)
+        wg = roofline_entry(args.conv_math, args.batch, "wgrad", in_step["wgrad"], solo["wgrad"], traffic.get("wgrad"), rshape)
         if main is not None:
             out["roofline"] = main
         if wg is not None:
             out["roofline_wgrad"] = wg
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and args.workload == "train_c4":
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)
     if world > 1:
