@@ -18,6 +18,7 @@
 // for dgrad).  HBM->register loads for stage t+1 are issued before the MFMAs of
 // stage t and written to the other LDS buffer afterwards (one barrier / stage).
 #include "gemm_core.h"
+#include <stdlib.h>
 #include "../../include/buctd_hip.h"
 
 struct ConvArgs {
@@ -593,6 +594,136 @@ extern "C" int buctd_conv2d_dgrad(const buctd_conv_desc* d, const float* dy, con
   return BUCTD_OK;
 }
 
+// ---- thin weight gradient -----------------------------------------------------
+// Weight gradient of the stride-1 'same' convolutions with three channels on one side - the full-resolution preNet of
+// BUCTD-preNet (pose_hrnet.py:431-442: 3 -> 64 3x3, 64 -> 3 7x7, 3 -> 3 7x7 on the 384x288 crop).  The implicit-GEMM
+// kernel pads the 3-channel side to a 64-wide tile and loads it scalar: 9.2 ms per launch, 27 ms of a 114 ms step.
+// Here a thread owns work items (tap, group of 4 channels of the wide side) and a 4 x 4 block of dW per item and chunk;
+// the workgroup walks 8 x 32 pixel tiles: the tile of the wide operand (16 channels at a time) and of the thin one sit
+// in LDS, every pixel costs two 16-byte LDS reads (one of them a broadcast) and 16 FMAs per item.  VALU bound
+// (64 FMA/clk/CU): ~2 ms for the 7x7 64 -> 3 filter at N = 32.  Partial sums per workgroup go to slabs of the usual
+// [split][Co][R][S][Ci] layout, reduced by splitk_reduce_kernel.
+struct ThinArgs {
+  const float* x;
+  const float* dy;
+  float* part;
+  int N, H, W, Ci, Co, tiles_y, tiles_x, ntiles;
+};
+
+constexpr int THIN_TH = 8, THIN_TW = 32, THIN_SPLITS = 1024;
+
+template <int R, bool WIDE_DY>
+__global__ __launch_bounds__(256) void conv_wgrad_thin_kernel(ThinArgs p) {
+  constexpr int PADR = R / 2, XH = THIN_TH + R - 1, XW = THIN_TW + R - 1;
+  constexpr int XC = WIDE_DY ? 4 : 16, DC = WIDE_DY ? 16 : 4;          // channels per LDS pixel of the two tiles
+  __shared__ __attribute__((aligned(16))) float xs[XH * XW * XC];
+  __shared__ __attribute__((aligned(16))) float ds[THIN_TH * THIN_TW * DC];
+  const int t = threadIdx.x;
+  const int wide = WIDE_DY ? p.Co : p.Ci;
+  const int nchunks = (wide + 15) / 16;
+  // item of this thread: tap (r, s) and 4-channel group g of the current 16-channel chunk
+  const int groups = wide >= 16 ? 4 : (wide + 3) / 4;
+  const int nitems = R * R * groups;
+  const bool active = t < nitems;
+  const int tap = active ? t / groups : 0, g = active ? t - tap * groups : 0;
+  const int r = tap / R, sx = tap - r * R;
+  const int xoff = (r * XW + sx) * XC + (WIDE_DY ? 0 : g * 4);
+  const int doff = WIDE_DY ? g * 4 : 0;
+  float acc[4][16];                        // [chunk][dy channel i (4)][x channel j (4)]
+#pragma unroll
+  for (int c = 0; c < 4; ++c)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[c][e] = 0.f;
+
+  for (int tile = blockIdx.x; tile < p.ntiles; tile += gridDim.x) {
+    const int n = tile / (p.tiles_y * p.tiles_x);
+    const int rem = tile - n * p.tiles_y * p.tiles_x;
+    const int y0 = (rem / p.tiles_x) * THIN_TH, x0 = (rem - (rem / p.tiles_x) * p.tiles_x) * THIN_TW;
+#pragma unroll 1
+    for (int c = 0; c < nchunks; ++c) {
+      __syncthreads();                     // previous chunk / tile consumed
+      // stage the x tile (halo, zero outside the image) and the dy tile; the thin side once per tile (c == 0)
+      if (!WIDE_DY || c == 0) {
+        const int xc0 = WIDE_DY ? 0 : c * 16;
+        for (int i = t; i < XH * XW * (XC / 4); i += 256) {
+          const int pix = i / (XC / 4), q = i - pix * (XC / 4);
+          const int yy = y0 + pix / XW - PADR, xx = x0 + pix % XW - PADR;
+          f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
+          if (yy >= 0 && yy < p.H && xx >= 0 && xx < p.W) {
+            const float* src = p.x + ((long)(n * p.H + yy) * p.W + xx) * p.Ci + xc0 + q * 4;
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              if (xc0 + q * 4 + e < p.Ci) v[e] = src[e];
+          }
+          *reinterpret_cast<f32x4*>(xs + pix * XC + q * 4) = v;
+        }
+      }
+      if (WIDE_DY || c == 0) {
+        const int dc0 = WIDE_DY ? c * 16 : 0;
+        for (int i = t; i < THIN_TH * THIN_TW * (DC / 4); i += 256) {
+          const int pix = i / (DC / 4), q = i - pix * (DC / 4);
+          const int yy = y0 + pix / THIN_TW, xx = x0 + pix % THIN_TW;
+          f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
+          if (yy < p.H && xx < p.W) {
+            const float* src = p.dy + ((long)(n * p.H + yy) * p.W + xx) * p.Co + dc0 + q * 4;
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              if (dc0 + q * 4 + e < p.Co) v[e] = src[e];
+          }
+          *reinterpret_cast<f32x4*>(ds + pix * DC + q * 4) = v;
+        }
+      }
+      __syncthreads();
+      if (active && c * 16 + g * 4 < wide) {
+        float a16[16];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) a16[e] = acc[c][e];
+        for (int py = 0; py < THIN_TH; ++py) {
+          const float* xr = xs + xoff + py * XW * XC;
+          const float* dr = ds + doff + py * THIN_TW * DC;
+#pragma unroll 4
+          for (int px = 0; px < THIN_TW; ++px) {
+            const f32x4 xv = *reinterpret_cast<const f32x4*>(xr + px * XC);
+            const f32x4 dv = *reinterpret_cast<const f32x4*>(dr + px * DC);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+              for (int j = 0; j < 4; ++j) a16[i * 4 + j] = __builtin_fmaf(dv[i], xv[j], a16[i * 4 + j]);
+          }
+        }
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[c][e] = a16[e];
+      }
+    }
+  }
+  // slab [split][Co][R][S][Ci]: accumulator (c, i, j) = (co, ci) pair of this item's tap
+  if (active) {
+    float* outp = p.part + (size_t)blockIdx.x * p.Co * R * R * p.Ci;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      if (c >= nchunks) break;
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int co = WIDE_DY ? c * 16 + g * 4 + i : i;
+          const int ci = WIDE_DY ? j : c * 16 + g * 4 + j;
+          if (co < p.Co && ci < p.Ci) outp[((size_t)co * R * R + tap) * p.Ci + ci] = acc[c][i * 4 + j];
+        }
+    }
+  }
+}
+
+static bool wgrad_thin_ok(const buctd_conv_desc* d) {
+  static const bool off = getenv("BUCTD_WGRAD_THIN") && atoi(getenv("BUCTD_WGRAD_THIN")) == 0;   // experiment switch
+  if (off) return false;
+  const int thin = d->Ci < d->Co ? d->Ci : d->Co, wide = d->Ci < d->Co ? d->Co : d->Ci;
+  // 3x3 with the thin side on x (3 -> 64): the implicit-GEMM kernel is faster there (0.8 against 1.2 ms at 384x288)
+  if (d->R == 3 && d->Co > d->Ci) return false;
+  return d->stride == 1 && d->R == d->S && (d->R == 3 || d->R == 7) && d->pad == d->R / 2 && thin <= 4 && wide <= 64 &&
+         d->Ho == d->H && d->Wo == d->W && (long)d->N * d->H * d->W >= 65536;
+}
+
 // ---- wgrad ------------------------------------------------------------------
 static void wgrad_plan(const buctd_conv_desc* d, int* bm, int* bn, int* nsplit, int* pps) {
   const int co = d->Co;
@@ -614,6 +745,7 @@ static void wgrad_plan(const buctd_conv_desc* d, int* bm, int* bn, int* nsplit, 
 
 extern "C" size_t buctd_conv2d_wgrad_workspace(const buctd_conv_desc* d) {
   if (check_desc(d, "buctd_conv2d_wgrad_workspace")) return 0;
+  if (wgrad_thin_ok(d)) return (size_t)THIN_SPLITS * d->Co * d->R * d->S * d->Ci * sizeof(float);
   int bm, bn, ns, pps;
   wgrad_plan(d, &bm, &bn, &ns, &pps);
   return (size_t)ns * d->Co * d->R * d->S * d->Ci * sizeof(float);
@@ -632,10 +764,29 @@ extern "C" int buctd_conv2d_wgrad(const buctd_conv_desc* d, const float* x, cons
   BUCTD_CHECK_ARG(x && dy && dw, "buctd_conv2d_wgrad: null tensor pointer");
   int bm, bn, ns, pps;
   wgrad_plan(d, &bm, &bn, &ns, &pps);
+  const bool thin = wgrad_thin_ok(d);
+  if (thin) ns = THIN_SPLITS;
   const size_t need = (size_t)ns * d->Co * d->R * d->S * d->Ci * sizeof(float);
   if (workspace == nullptr || workspace_bytes < need) {
     buctd_set_error("buctd_conv2d_wgrad: workspace %zu bytes < required %zu", workspace_bytes, need);
     return BUCTD_EWORKSPACE;
+  }
+  if (thin) {
+    ThinArgs ta;
+    ta.x = x; ta.dy = dy; ta.part = (float*)workspace;
+    ta.N = d->N; ta.H = d->H; ta.W = d->W; ta.Ci = d->Ci; ta.Co = d->Co;
+    ta.tiles_y = ceil_div(d->H, THIN_TH); ta.tiles_x = ceil_div(d->W, THIN_TW);
+    ta.ntiles = d->N * ta.tiles_y * ta.tiles_x;
+    hipStream_t tst = (hipStream_t)stream;
+    const bool wide_dy = d->Co > d->Ci;
+    if (d->R == 7) {
+      if (wide_dy) hipLaunchKernelGGL((conv_wgrad_thin_kernel<7, true>), dim3(THIN_SPLITS), dim3(256), 0, tst, ta);
+      else hipLaunchKernelGGL((conv_wgrad_thin_kernel<7, false>), dim3(THIN_SPLITS), dim3(256), 0, tst, ta);
+    } else {
+      if (wide_dy) hipLaunchKernelGGL((conv_wgrad_thin_kernel<3, true>), dim3(THIN_SPLITS), dim3(256), 0, tst, ta);
+      else hipLaunchKernelGGL((conv_wgrad_thin_kernel<3, false>), dim3(THIN_SPLITS), dim3(256), 0, tst, ta);
+    }
+    BUCTD_CHECK_LAUNCH("buctd_conv2d_wgrad(thin)");
   }
   WgradArgs a;
   a.x = x; a.dy = dy; a.part = (float*)workspace;
@@ -644,7 +795,8 @@ extern "C" int buctd_conv2d_wgrad(const buctd_conv_desc* d, const float* x, cons
   a.Mpix = d->N * d->Ho * d->Wo; a.Ncols = d->R * d->S * d->Ci; a.pix_per_split = pps;
   hipStream_t st = (hipStream_t)stream;
   const bool vec = (d->Ci % 4 == 0) && (d->Co % 4 == 0);
-  if (!vec) launch_wgrad<TileCfg<2, 2, 2, 2>, false>(a, ns, st);          // 64x64 generic
+  if (thin) {}                                                             // launched above
+  else if (!vec) launch_wgrad<TileCfg<2, 2, 2, 2>, false>(a, ns, st);     // 64x64 generic
   else if (bm == 48) launch_wgrad<TileCfg<1, 4, 3, 1>, true>(a, ns, st);  // 48x64
   else if (bm == 96) launch_wgrad<TileCfg<2, 2, 3, 2>, true>(a, ns, st);  // 96x64
   else if (bm == 64) launch_wgrad<TileCfg<2, 2, 2, 2>, true>(a, ns, st);  // 64x64
