@@ -48,6 +48,7 @@ SIGNATURES = {
     "buctd_version": (_I, []),
     "buctd_last_error": (C.c_char_p, []),
     "buctd_conv2d_fwd": (_I, [_PD, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P]),
+    "buctd_conv2d_fwd_thin": (_I, [_PD]),
     "buctd_conv2d_dgrad": (_I, [_PD, _P, _P, _P, _P, _P, _P]),
     "buctd_conv2d_stats_groups": (_I, [_PD, _I, _PI, _PI]),
     "buctd_conv2d_wgrad_workspace": (_SZ, [_PD]),

@@ -540,6 +540,88 @@ static void dispatch_conv(const ConvArgs& a, bool vec, hipStream_t st) {
 static bool fwd_vec_ok(const buctd_conv_desc* d) { return d->Ci % 16 == 0; }
 static bool dgrad_vec_ok(const buctd_conv_desc* d) { return d->Co % 16 == 0 && d->Ci % 4 == 0; }
 
+constexpr int THIN_TH = 8, THIN_TW = 32, THIN_SPLITS = 1024;
+
+// ---- thin forward ---------------------------------------------------------------
+// Forward of the same preNet convolutions with at most 4 OUTPUT channels (64 -> 3 and 3 -> 3 7x7, stride 1, 'same'): the
+// implicit-GEMM kernel computes a 16-wide column tile for 3 columns (7.8 ms at 384x288, N = 32).  One thread per output
+// pixel of an 8 x 32 tile, three accumulators; the input tile (16 channels at a time, halo included) and the filter chunk
+// sit in LDS, a tap costs one 16-byte read of the pixel's channels and broadcast reads of the filter: VALU bound.
+struct ThinFwdArgs {
+  const float* x;
+  const float* w;      // [Co][R][R][Ci]
+  const float* bias;
+  float* y;
+  int N, H, W, Ci, Co, tiles_y, tiles_x;
+};
+
+template <int R>
+__global__ __launch_bounds__(256) void conv_fwd_thin_kernel(ThinFwdArgs p) {
+  constexpr int PADR = R / 2, XH = THIN_TH + R - 1, XW = THIN_TW + R - 1;
+  __shared__ __attribute__((aligned(16))) float xs[XH * XW * 16];
+  __shared__ __attribute__((aligned(16))) float ws[R * R * 4 * 16];      // [tap][co (4)][16 channels]
+  const int t = threadIdx.x;
+  const int tile = blockIdx.x;
+  const int n = tile / (p.tiles_y * p.tiles_x);
+  const int rem = tile - n * p.tiles_y * p.tiles_x;
+  const int y0 = (rem / p.tiles_x) * THIN_TH, x0 = (rem - (rem / p.tiles_x) * p.tiles_x) * THIN_TW;
+  const int py = t / THIN_TW, px = t - py * THIN_TW;
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  const int nchunks = (p.Ci + 15) / 16;
+  for (int c = 0; c < nchunks; ++c) {
+    const int c0 = c * 16;
+    __syncthreads();
+    for (int i = t; i < XH * XW * 4; i += 256) {
+      const int pix = i >> 2, q = i & 3;
+      const int yy = y0 + pix / XW - PADR, xx = x0 + pix % XW - PADR;
+      f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
+      if (yy >= 0 && yy < p.H && xx >= 0 && xx < p.W) {
+        const float* src = p.x + ((long)(n * p.H + yy) * p.W + xx) * p.Ci + c0 + q * 4;
+        if (c0 + q * 4 + 4 <= p.Ci && (p.Ci & 3) == 0) v = *reinterpret_cast<const f32x4*>(src);
+        else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (c0 + q * 4 + e < p.Ci) v[e] = src[e];
+        }
+      }
+      *reinterpret_cast<f32x4*>(xs + pix * 16 + q * 4) = v;
+    }
+    for (int i = t; i < R * R * 4 * 16; i += 256) {
+      const int ch = i & 15, co = (i >> 4) & 3, tap = i >> 6;
+      ws[i] = (co < p.Co && c0 + ch < p.Ci) ? p.w[((long)co * R * R + tap) * p.Ci + c0 + ch] : 0.f;
+    }
+    __syncthreads();
+    const int qn = (p.Ci - c0 >= 16) ? 4 : (p.Ci - c0 + 3) / 4;
+    for (int r = 0; r < R; ++r) {
+      const float* xr = xs + ((py + r) * XW + px) * 16;
+      const float* wr = ws + r * R * 64;
+#pragma unroll
+      for (int sx = 0; sx < R; ++sx) {
+        for (int q = 0; q < qn; ++q) {
+          const f32x4 xv = *reinterpret_cast<const f32x4*>(xr + sx * 16 + q * 4);
+#pragma unroll
+          for (int co = 0; co < 4; ++co) {
+            const f32x4 wv = *reinterpret_cast<const f32x4*>(wr + sx * 64 + co * 16 + q * 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[co] = __builtin_fmaf(xv[e], wv[e], acc[co]);
+          }
+        }
+      }
+    }
+  }
+  const int yy = y0 + py, xx = x0 + px;
+  if (yy < p.H && xx < p.W) {
+    float* o = p.y + ((long)(n * p.H + yy) * p.W + xx) * p.Co;
+    for (int co = 0; co < p.Co; ++co) o[co] = acc[co] + (p.bias ? p.bias[co] : 0.f);
+  }
+}
+
+static bool fwd_thin_ok(const buctd_conv_desc* d) {
+  static const bool off = getenv("BUCTD_FWD_THIN") && atoi(getenv("BUCTD_FWD_THIN")) == 0;   // experiment switch
+  return !off && d->stride == 1 && d->R == 7 && d->S == 7 && d->pad == 3 && d->Co <= 4 && d->Ci <= 64 && d->Ho == d->H &&
+         d->Wo == d->W && (long)d->N * d->H * d->W >= 65536;
+}
+
 extern "C" int buctd_conv2d_stats_groups(const buctd_conv_desc* d, int transposed, int* ngroups,
                                          int* rows_per_group) {
   int rc = check_desc(d, "buctd_conv2d_stats_groups");
@@ -553,6 +635,10 @@ extern "C" int buctd_conv2d_stats_groups(const buctd_conv_desc* d, int transpose
   return BUCTD_OK;
 }
 
+extern "C" int buctd_conv2d_fwd_thin(const buctd_conv_desc* d) {
+  return (d && check_desc(d, "buctd_conv2d_fwd_thin") == BUCTD_OK && fwd_thin_ok(d)) ? 1 : 0;
+}
+
 extern "C" int buctd_conv2d_fwd(const buctd_conv_desc* d, const float* x, const float* w, const float* bias,
                                 const float* scale, const float* shift, const float* residual, int relu, float* y,
                                 float* stats_partials, void* stream) {
@@ -560,6 +646,15 @@ extern "C" int buctd_conv2d_fwd(const buctd_conv_desc* d, const float* x, const 
   if (rc) return rc;
   BUCTD_CHECK_ARG(x && w && y, "buctd_conv2d_fwd: null tensor pointer");
   BUCTD_CHECK_ARG((scale == nullptr) == (shift == nullptr), "buctd_conv2d_fwd: scale and shift go together");
+  if (fwd_thin_ok(d) && !scale && !residual && !relu && !stats_partials) {     // plain conv (+ bias), <= 4 output channels
+    ThinFwdArgs ta;
+    ta.x = x; ta.w = w; ta.bias = bias; ta.y = y;
+    ta.N = d->N; ta.H = d->H; ta.W = d->W; ta.Ci = d->Ci; ta.Co = d->Co;
+    ta.tiles_y = ceil_div(d->H, THIN_TH); ta.tiles_x = ceil_div(d->W, THIN_TW);
+    hipLaunchKernelGGL((conv_fwd_thin_kernel<7>), dim3(d->N * ta.tiles_y * ta.tiles_x), dim3(256), 0, (hipStream_t)stream, ta);
+    BUCTD_CHECK_LAUNCH("buctd_conv2d_fwd(thin)");
+    return BUCTD_OK;
+  }
   ConvArgs a;
   a.src = x; a.w = w; a.out = y; a.bias = bias; a.scale = scale; a.shift = shift; a.res = residual;
   a.stats = stats_partials;
@@ -610,7 +705,6 @@ struct ThinArgs {
   int N, H, W, Ci, Co, tiles_y, tiles_x, ntiles;
 };
 
-constexpr int THIN_TH = 8, THIN_TW = 32, THIN_SPLITS = 1024;
 
 template <int R, bool WIDE_DY>
 __global__ __launch_bounds__(256) void conv_wgrad_thin_kernel(ThinArgs p) {

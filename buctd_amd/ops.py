@@ -332,6 +332,13 @@ def conv_fwd(x, w, bias=None, stride=1, pad=0, scale=None, shift=None, residual=
     y = torch.empty((d.N, d.Ho, d.Wo, d.Co), dtype=torch.float32, device=x.device)
     part = None
     info = None
+    if stats and scale is None and residual is None and not relu and lib().buctd_conv2d_fwd_thin(C.byref(d)) == 1:
+        # <= 4 output channels at full resolution (preNet 7x7): the thin kernel has no fused epilogue; the BatchNorm
+        # partials of its 3-channel result are one cheap extra pass
+        check(lib().buctd_conv2d_fwd(C.byref(d), ptr(x), ptr(w), ptr(bias), None, None, None, 0, ptr(y), None, stream_ptr()),
+              "conv2d_fwd")
+        part, info = bn_stats(y)
+        return y, part, info
     if stats:
         ng, rpg = C.c_int(), C.c_int()
         check(lib().buctd_conv2d_stats_groups(C.byref(d), 0, C.byref(ng), C.byref(rpg)), "conv2d_stats_groups")

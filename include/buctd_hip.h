@@ -43,6 +43,10 @@ typedef struct {
  *   residual      != NULL  : y += residual ; relu != 0 : y = max(y,0).
  * Replaces nn.Conv2d(+BatchNorm2d+ReLU+residual): pose_hrnet.py:28-98, pose_hrnet_coam.py:44-60,
  * nn.Linear on token tensors (R=S=1): self_attention.py:74-76,87. */
+/* 1 when buctd_conv2d_fwd runs this shape on the thin-output kernel (stride-1 'same' 7x7 with <= 4 output channels: the
+ * full-resolution preNet convolutions, pose_hrnet.py:431-442) - it then takes no fused epilogue: call it with bias
+ * only and run buctd_bn_stats on the (3-channel) result for a train-mode BatchNorm. */
+int buctd_conv2d_fwd_thin(const buctd_conv_desc* d);
 int buctd_conv2d_fwd(const buctd_conv_desc* d, const float* x, const float* w, const float* bias,
                      const float* scale, const float* shift, const float* residual, int relu, float* y,
                      float* stats_partials, void* stream);

@@ -31,3 +31,33 @@ def test_thin_wgrad_vs_fp64(Ci, Co, k, N, H, W):
     ops.conv_wgrad(xd, dyd, wd, 1, k // 2, out=acc, accumulate=1)
     err = (acc.cpu().double() - (base.cpu().double() + ref)).abs().max().item() / ref.abs().max().item()
     assert err <= 2e-5
+
+
+@pytest.mark.parametrize("Ci,Co,N,H,W", [(64, 3, 2, 192, 256), (3, 3, 3, 160, 144), (32, 2, 1, 300, 250), (17, 4, 2, 181, 203)])
+def test_thin_forward_vs_fp64(Ci, Co, N, H, W):
+    """7x7 'same' convolutions with <= 4 output channels (preNet): forward incl. bias and the BatchNorm partials"""
+    from buctd_amd import ops
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(Ci * 10 + Co)
+    x = torch.randn(N, Ci, H, W, generator=g, dtype=torch.float64)
+    w = torch.randn(Co, Ci, 7, 7, generator=g, dtype=torch.float64) * (49 * Ci) ** -0.5
+    b = torch.randn(Co, generator=g, dtype=torch.float64)
+    ref = F.conv2d(x, w, b, 1, 3).permute(0, 2, 3, 1)
+    xd = x.float().permute(0, 2, 3, 1).contiguous().to(dev)
+    wd = w.float().contiguous(memory_format=torch.channels_last).to(dev)
+    bd = b.float().to(dev)
+    d = ops.conv_desc(xd.shape, ops._wshape(wd), 1, 3)
+    import ctypes as C
+    from buctd_amd._C import lib
+    assert lib().buctd_conv2d_fwd_thin(C.byref(d)) == 1
+    y = ops.conv_fwd(xd, wd, bd, 1, 3)
+    err = (y.cpu().double() - ref).abs().max().item() / ref.abs().max().item()
+    assert err <= 2e-6, f"thin forward {Ci}->{Co}: rel err {err:.2e}"
+    y2, part, info = ops.conv_fwd(xd, wd, bd, 1, 3, stats=True)
+    assert torch.equal(y, y2)
+    rows = N * H * W
+    mean, invstd = ops.bn_finalize(part, info, rows, Co, 1e-5, 0.1, None, None)
+    rm = ref.reshape(-1, Co).mean(0)
+    rv = ref.reshape(-1, Co).var(0, unbiased=False)
+    assert (mean.cpu().double() - rm).abs().max().item() <= 1e-5
+    assert ((invstd.cpu().double() - (rv + 1e-5).rsqrt()).abs() / (rv + 1e-5).rsqrt()).max().item() <= 1e-5
