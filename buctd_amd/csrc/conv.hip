@@ -616,10 +616,94 @@ __global__ __launch_bounds__(256) void conv_fwd_thin_kernel(ThinFwdArgs p) {
   }
 }
 
+// Data gradient of the same convolutions (<= 4 OUTPUT channels of the forward conv: dy is thin, dx wide): one thread per
+// dx pixel, 16 input channels per pass; dy tile (halo) in LDS, filter chunk [tap][co][16 ci] read as broadcasts.
+struct ThinDgradArgs {
+  const float* dy;
+  const float* w;      // [Co][R][R][Ci]
+  float* dx;
+  int N, H, W, Ci, Co, tiles_y, tiles_x;
+};
+
+template <int R>
+__global__ __launch_bounds__(256) void conv_dgrad_thin_kernel(ThinDgradArgs p) {
+  constexpr int PADR = R / 2, XH = THIN_TH + R - 1, XW = THIN_TW + R - 1;
+  __shared__ __attribute__((aligned(16))) float ds[XH * XW * 4];
+  __shared__ __attribute__((aligned(16))) float ws[R * R * 4 * 16];      // [tap][co (4)][16 input channels]
+  const int t = threadIdx.x;
+  const int tile = blockIdx.x;
+  const int n = tile / (p.tiles_y * p.tiles_x);
+  const int rem = tile - n * p.tiles_y * p.tiles_x;
+  const int y0 = (rem / p.tiles_x) * THIN_TH, x0 = (rem - (rem / p.tiles_x) * p.tiles_x) * THIN_TW;
+  const int py = t / THIN_TW, px = t - py * THIN_TW;
+  for (int i = t; i < XH * XW; i += 256) {
+    const int yy = y0 + i / XW - PADR, xx = x0 + i % XW - PADR;
+    f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (yy >= 0 && yy < p.H && xx >= 0 && xx < p.W) {
+      const float* src = p.dy + ((long)(n * p.H + yy) * p.W + xx) * p.Co;
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (e < p.Co) v[e] = src[e];
+    }
+    *reinterpret_cast<f32x4*>(ds + i * 4) = v;
+  }
+  const int nchunks = (p.Ci + 15) / 16;
+  const int yy = y0 + py, xx = x0 + px;
+  for (int c = 0; c < nchunks; ++c) {
+    const int c0 = c * 16;
+    __syncthreads();
+    for (int i = t; i < R * R * 4 * 16; i += 256) {
+      const int ch = i & 15, co = (i >> 4) & 3, tap = i >> 6;
+      ws[i] = (co < p.Co && c0 + ch < p.Ci) ? p.w[((long)co * R * R + tap) * p.Ci + c0 + ch] : 0.f;
+    }
+    __syncthreads();
+    f32x4 acc[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) acc[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int r = 0; r < R; ++r) {
+      const float* dr = ds + ((py + R - 1 - r) * XW + px + R - 1) * 4;
+      const float* wr = ws + r * R * 64;
+#pragma unroll
+      for (int sx = 0; sx < R; ++sx) {
+        const f32x4 dv = *reinterpret_cast<const f32x4*>(dr - sx * 4);
+#pragma unroll
+        for (int co = 0; co < 3; ++co) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const f32x4 wv = *reinterpret_cast<const f32x4*>(wr + sx * 64 + co * 16 + q * 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[q][e] = __builtin_fmaf(dv[co], wv[e], acc[q][e]);
+          }
+        }
+        if (p.Co > 3) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const f32x4 wv = *reinterpret_cast<const f32x4*>(wr + sx * 64 + 48 + q * 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[q][e] = __builtin_fmaf(dv[3], wv[e], acc[q][e]);
+          }
+        }
+      }
+    }
+    if (yy < p.H && xx < p.W) {
+      float* o = p.dx + ((long)(n * p.H + yy) * p.W + xx) * p.Ci + c0;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        if (c0 + q * 4 + 4 <= p.Ci && (p.Ci & 3) == 0) *reinterpret_cast<f32x4*>(o + q * 4) = acc[q];
+        else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (c0 + q * 4 + e < p.Ci) o[q * 4 + e] = acc[q][e];
+        }
+      }
+    }
+  }
+}
+
 static bool fwd_thin_ok(const buctd_conv_desc* d) {
   static const bool off = getenv("BUCTD_FWD_THIN") && atoi(getenv("BUCTD_FWD_THIN")) == 0;   // experiment switch
   return !off && d->stride == 1 && d->R == 7 && d->S == 7 && d->pad == 3 && d->Co <= 4 && d->Ci <= 64 && d->Ho == d->H &&
-         d->Wo == d->W && (long)d->N * d->H * d->W >= 65536;
+         d->Wo == d->W && (long)d->N * d->H * d->W >= 4096;
 }
 
 extern "C" int buctd_conv2d_stats_groups(const buctd_conv_desc* d, int transposed, int* ngroups,
@@ -674,6 +758,15 @@ extern "C" int buctd_conv2d_dgrad(const buctd_conv_desc* d, const float* dy, con
   int rc = check_desc(d, "buctd_conv2d_dgrad");
   if (rc) return rc;
   BUCTD_CHECK_ARG(dy && w && dx, "buctd_conv2d_dgrad: null tensor pointer");
+  if (fwd_thin_ok(d) && !bias && !stats_partials) {      // the preNet 7x7 with <= 4 output channels: thin dy, wide dx
+    ThinDgradArgs ta;
+    ta.dy = dy; ta.w = w; ta.dx = dx;
+    ta.N = d->N; ta.H = d->H; ta.W = d->W; ta.Ci = d->Ci; ta.Co = d->Co;
+    ta.tiles_y = ceil_div(d->H, THIN_TH); ta.tiles_x = ceil_div(d->W, THIN_TW);
+    hipLaunchKernelGGL((conv_dgrad_thin_kernel<7>), dim3(d->N * ta.tiles_y * ta.tiles_x), dim3(256), 0, (hipStream_t)stream, ta);
+    BUCTD_CHECK_LAUNCH("buctd_conv2d_dgrad(thin)");
+    return BUCTD_OK;
+  }
   ConvArgs a;
   a.src = dy; a.w = w; a.out = dx; a.bias = bias; a.scale = nullptr; a.shift = nullptr; a.res = nullptr;
   a.stats = stats_partials;
@@ -815,7 +908,12 @@ static bool wgrad_thin_ok(const buctd_conv_desc* d) {
   // 3x3 with the thin side on x (3 -> 64): the implicit-GEMM kernel is faster there (0.8 against 1.2 ms at 384x288)
   if (d->R == 3 && d->Co > d->Ci) return false;
   return d->stride == 1 && d->R == d->S && (d->R == 3 || d->R == 7) && d->pad == d->R / 2 && thin <= 4 && wide <= 64 &&
-         d->Ho == d->H && d->Wo == d->W && (long)d->N * d->H * d->W >= 65536;
+         d->Ho == d->H && d->Wo == d->W && (long)d->N * d->H * d->W >= 4096;
+}
+
+static int thin_splits(const buctd_conv_desc* d) {      // one slab per workgroup; small inputs get fewer
+  const long tiles = (long)d->N * ceil_div(d->H, THIN_TH) * ceil_div(d->W, THIN_TW);
+  return (int)(tiles < THIN_SPLITS ? tiles : THIN_SPLITS);
 }
 
 // ---- wgrad ------------------------------------------------------------------
@@ -839,7 +937,7 @@ static void wgrad_plan(const buctd_conv_desc* d, int* bm, int* bn, int* nsplit, 
 
 extern "C" size_t buctd_conv2d_wgrad_workspace(const buctd_conv_desc* d) {
   if (check_desc(d, "buctd_conv2d_wgrad_workspace")) return 0;
-  if (wgrad_thin_ok(d)) return (size_t)THIN_SPLITS * d->Co * d->R * d->S * d->Ci * sizeof(float);
+  if (wgrad_thin_ok(d)) return (size_t)thin_splits(d) * d->Co * d->R * d->S * d->Ci * sizeof(float);
   int bm, bn, ns, pps;
   wgrad_plan(d, &bm, &bn, &ns, &pps);
   return (size_t)ns * d->Co * d->R * d->S * d->Ci * sizeof(float);
@@ -859,7 +957,7 @@ extern "C" int buctd_conv2d_wgrad(const buctd_conv_desc* d, const float* x, cons
   int bm, bn, ns, pps;
   wgrad_plan(d, &bm, &bn, &ns, &pps);
   const bool thin = wgrad_thin_ok(d);
-  if (thin) ns = THIN_SPLITS;
+  if (thin) ns = thin_splits(d);
   const size_t need = (size_t)ns * d->Co * d->R * d->S * d->Ci * sizeof(float);
   if (workspace == nullptr || workspace_bytes < need) {
     buctd_set_error("buctd_conv2d_wgrad: workspace %zu bytes < required %zu", workspace_bytes, need);
@@ -874,11 +972,11 @@ extern "C" int buctd_conv2d_wgrad(const buctd_conv_desc* d, const float* x, cons
     hipStream_t tst = (hipStream_t)stream;
     const bool wide_dy = d->Co > d->Ci;
     if (d->R == 7) {
-      if (wide_dy) hipLaunchKernelGGL((conv_wgrad_thin_kernel<7, true>), dim3(THIN_SPLITS), dim3(256), 0, tst, ta);
-      else hipLaunchKernelGGL((conv_wgrad_thin_kernel<7, false>), dim3(THIN_SPLITS), dim3(256), 0, tst, ta);
+      if (wide_dy) hipLaunchKernelGGL((conv_wgrad_thin_kernel<7, true>), dim3(ns), dim3(256), 0, tst, ta);
+      else hipLaunchKernelGGL((conv_wgrad_thin_kernel<7, false>), dim3(ns), dim3(256), 0, tst, ta);
     } else {
-      if (wide_dy) hipLaunchKernelGGL((conv_wgrad_thin_kernel<3, true>), dim3(THIN_SPLITS), dim3(256), 0, tst, ta);
-      else hipLaunchKernelGGL((conv_wgrad_thin_kernel<3, false>), dim3(THIN_SPLITS), dim3(256), 0, tst, ta);
+      if (wide_dy) hipLaunchKernelGGL((conv_wgrad_thin_kernel<3, true>), dim3(ns), dim3(256), 0, tst, ta);
+      else hipLaunchKernelGGL((conv_wgrad_thin_kernel<3, false>), dim3(ns), dim3(256), 0, tst, ta);
     }
     BUCTD_CHECK_LAUNCH("buctd_conv2d_wgrad(thin)");
   }

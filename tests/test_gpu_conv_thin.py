@@ -61,3 +61,20 @@ def test_thin_forward_vs_fp64(Ci, Co, N, H, W):
     rv = ref.reshape(-1, Co).var(0, unbiased=False)
     assert (mean.cpu().double() - rm).abs().max().item() <= 1e-5
     assert ((invstd.cpu().double() - (rv + 1e-5).rsqrt()).abs() / (rv + 1e-5).rsqrt()).max().item() <= 1e-5
+
+
+@pytest.mark.parametrize("Ci,Co,N,H,W", [(64, 3, 2, 192, 256), (3, 3, 3, 160, 144), (32, 2, 1, 300, 250), (17, 4, 2, 181, 203)])
+def test_thin_dgrad_vs_fp64(Ci, Co, N, H, W):
+    from buctd_amd import ops
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(Ci * 7 + Co)
+    dy = torch.randn(N, Co, H, W, generator=g, dtype=torch.float64)
+    w = torch.randn(Co, Ci, 7, 7, generator=g, dtype=torch.float64) * (49 * Co) ** -0.5
+    x = torch.zeros(N, Ci, H, W, dtype=torch.float64, requires_grad=True)
+    F.conv2d(x, w, None, 1, 3).backward(dy)
+    ref = x.grad.permute(0, 2, 3, 1)
+    dyd = dy.float().permute(0, 2, 3, 1).contiguous().to(dev)
+    wd = w.float().contiguous(memory_format=torch.channels_last).to(dev)
+    dx = ops.conv_dgrad(dyd, wd, (N, H, W, Ci), 1, 3)
+    err = (dx.cpu().double() - ref).abs().max().item() / ref.abs().max().item()
+    assert err <= 2e-6, f"thin dgrad {Ci}->{Co}: rel err {err:.2e}"
