@@ -701,7 +701,11 @@ __global__ __launch_bounds__(256) void conv_dgrad_thin_kernel(ThinDgradArgs p) {
 }
 
 static bool fwd_thin_ok(const buctd_conv_desc* d) {
-  static const bool off = getenv("BUCTD_FWD_THIN") && atoi(getenv("BUCTD_FWD_THIN")) == 0;   // experiment switch
+#ifdef BUCTD_TUNING      // experiment builds only: BUCTD_FWD_THIN=0 routes back to the implicit-GEMM kernel
+  static const bool off = getenv("BUCTD_FWD_THIN") && atoi(getenv("BUCTD_FWD_THIN")) == 0;
+#else
+  constexpr bool off = false;
+#endif
   return !off && d->stride == 1 && d->R == 7 && d->S == 7 && d->pad == 3 && d->Co <= 4 && d->Ci <= 64 && d->Ho == d->H &&
          d->Wo == d->W && (long)d->N * d->H * d->W >= 4096;
 }
@@ -902,8 +906,10 @@ __global__ __launch_bounds__(256) void conv_wgrad_thin_kernel(ThinArgs p) {
 }
 
 static bool wgrad_thin_ok(const buctd_conv_desc* d) {
-  static const bool off = getenv("BUCTD_WGRAD_THIN") && atoi(getenv("BUCTD_WGRAD_THIN")) == 0;   // experiment switch
+#ifdef BUCTD_TUNING      // experiment builds only
+  static const bool off = getenv("BUCTD_WGRAD_THIN") && atoi(getenv("BUCTD_WGRAD_THIN")) == 0;
   if (off) return false;
+#endif
   const int thin = d->Ci < d->Co ? d->Ci : d->Co, wide = d->Ci < d->Co ? d->Co : d->Ci;
   // 3x3 with the thin side on x (3 -> 64): the implicit-GEMM kernel is faster there (0.8 against 1.2 ms at 384x288)
   if (d->R == 3 && d->Co > d->Ci) return false;

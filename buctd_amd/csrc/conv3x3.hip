@@ -799,15 +799,19 @@ static bool c3_plan(int np, int N, int H, int W, int Ci, int Co, C3Plan* pl) {
     // 256-position tiles: the 48-channel branch at N*H*W >= ~115k positions (single A buffer: 64.5 KB at W = 72)
     const long b8 = (P + 511) / 512;
     if (b8 > 256 && b8 <= 512) { mf = 8; single = true; }
+#ifdef BUCTD_TUNING      // experiment builds only (scratch/build_trace_lib.sh): 3 lean workgroups per CU instead
     static const int lean_env = getenv("BUCTD_C3_LEAN") ? atoi(getenv("BUCTD_C3_LEAN")) : 0;
-    if (lean_env && mf == 8) { mf = 4; pl->lean = 1; }      // experiment: 3 lean workgroups per CU instead
+    if (lean_env && mf == 8) { mf = 4; pl->lean = 1; }
+#endif
   }
-  if (const char* f = getenv("BUCTD_C3_FORCE")) {   // experiment: "mf,nf,wn"
+#ifdef BUCTD_TUNING      // experiment builds only: BUCTD_C3_FORCE="mf,nf,wn" (scratch/sweep_c3_plan.py)
+  if (const char* f = getenv("BUCTD_C3_FORCE")) {
     int fm = 0, fn = 0, fw = 0;
     if (np == 3 && sscanf(f, "%d,%d,%d", &fm, &fn, &fw) == 3 && (fw == 1 || fw == 2) && Co % (fn * 16 * fw) == 0) {
       mf = fm; nf = fn; wn = fw; wm = 4 / wn; bn = wn * nf * 16; single = mf == 8; pl->lean = 0;
     }
   }
+#endif
   pl->MF = mf; pl->NF = nf; pl->WM = wm; pl->WN = wn; pl->BM = wm * mf * 16; pl->BN = bn;
   pl->na = (pl->BM + 2 * (W + 2) + 2 + 31) / 32;
   const size_t stage = (size_t)4 * (mf >= 2 ? 2 : 1) * 16 * (nf * 16 + 4) * 4 + 4 * 128 * 4;   // epilogue staging + row offsets
@@ -945,7 +949,9 @@ static int c3_run(int np, int N, int H, int W, int Ci, int Co, const float* x, c
     a.in_relu = in_bn->relu;
   }
   a.col_major = (np == 3 && Co / pl.BN >= 2 && (size_t)c3_steps(Ci, 3) * Co * Geo<3>::BROW > ((size_t)3 << 20)) ? 1 : 0;
-  if (const char* f = getenv("BUCTD_C3_COLMAJOR")) a.col_major = np == 3 && atoi(f) != 0;     // experiment
+#ifdef BUCTD_TUNING
+  if (const char* f = getenv("BUCTD_C3_COLMAJOR")) a.col_major = np == 3 && atoi(f) != 0;
+#endif
   magic_u32((unsigned)a.IB, &a.ib_mul, &a.ib_sh);
   magic_u32((unsigned)a.SW, &a.sw_mul, &a.sw_sh);
   return np == 3 ? c3_dispatch<3>(a, pl, (hipStream_t)stream) : c3_dispatch<2>(a, pl, (hipStream_t)stream);

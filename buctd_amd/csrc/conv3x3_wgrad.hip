@@ -357,7 +357,11 @@ static bool wg3_plan(int np, int N, int H, int W, int Ci, int Co, WG3Plan* pl) {
   const long pairs = (long)(Co / ch) * (Ci / ch);
   // two resident workgroups per CU (512 in all) when one (co, ci) chunk pair exists; fewer splits per pair otherwise
   // (partial-slab traffic grows with the split).  Splits take q or q + 1 stages, so no rounding loss.
+#ifdef BUCTD_TUNING      // experiment builds only
   static const int split_env = getenv("BUCTD_WG3_SPLIT") ? atoi(getenv("BUCTD_WG3_SPLIT")) : 0;
+#else
+  constexpr int split_env = 0;
+#endif
   long want = ((split_env > 0 ? split_env : (np == 3 ? 512 : 384)) + pairs - 1) / pairs;
   const long stages = (P + kb - 1) / kb;
   if (want > stages) want = stages;

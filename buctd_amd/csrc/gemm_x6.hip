@@ -278,7 +278,9 @@ extern "C" int buctd_x6_gemm(int M, int N, int K, const void* a_image, const voi
   p.M = M; p.N = N; p.KB = pad_to(K, GX_KPAD) / 32; p.ldc = ldc; p.gsc = gsc; p.Nc = Nc; p.alpha = alpha;
   p.bias_axis = bias_axis;
   p.row_major = (size_t)pad_to(M, GX_BM) > (size_t)pad_to(N, GX_BN) ? 1 : 0;     // image bytes ~ V x Kpad
-  if (const char* f = getenv("BUCTD_GX_ROWMAJOR")) p.row_major = atoi(f) != 0;     // experiment
+#ifdef BUCTD_TUNING      // experiment builds only
+  if (const char* f = getenv("BUCTD_GX_ROWMAJOR")) p.row_major = atoi(f) != 0;
+#endif
   dim3 grid(pad_to(M, GX_BM) / GX_BM, pad_to(N, GX_BN) / GX_BN);
   hipLaunchKernelGGL(x6_gemm_kernel, grid, dim3(512), 2 * GX_ABUF, (hipStream_t)stream, p);
   BUCTD_CHECK_LAUNCH("buctd_x6_gemm");

@@ -1,6 +1,9 @@
 """Sweep the (MF, WN) tile plan of the bf16x6 3x3 conv on the HRNet-W48 branch shapes (BUCTD_C3_FORCE)."""
 import os, sys, ctypes as C, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import buctd_amd._C as _C_sel
+if os.environ.get('BUCTD_TUNING_LIB', '1') == '1' and os.path.isfile(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'libbuctd_hip_trace.so')):
+    _C_sel.LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'libbuctd_hip_trace.so')   # experiment switches live in the tuning build
 from buctd_amd import ops
 from buctd_amd._C import lib, ptr, stream_ptr
 dev = torch.device("cuda:0")

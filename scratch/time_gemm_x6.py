@@ -1,6 +1,9 @@
 """fc_o GEMMs of CoAM-W48 (T = 6912, N = 32 x 48) in bf16x6: image preparation and product timings vs the fp32 kernel"""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import buctd_amd._C as _C_sel
+if os.environ.get('BUCTD_TUNING_LIB', '1') == '1' and os.path.isfile(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'libbuctd_hip_trace.so')):
+    _C_sel.LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'libbuctd_hip_trace.so')   # experiment switches live in the tuning build
 from buctd_amd import ops
 dev = torch.device("cuda:0")
 Bn, T, Cn = 32, int(os.environ.get("T", "6912")), 48

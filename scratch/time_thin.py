@@ -1,6 +1,9 @@
 """preNet weight gradients: thin kernel vs the implicit-GEMM kernel (BUCTD_WGRAD_THIN=0) at the C2 / C3 input sizes"""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import buctd_amd._C as _C_sel
+if os.environ.get('BUCTD_TUNING_LIB', '1') == '1' and os.path.isfile(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'libbuctd_hip_trace.so')):
+    _C_sel.LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'libbuctd_hip_trace.so')   # experiment switches live in the tuning build
 from buctd_amd import ops
 dev = torch.device("cuda:0")
 def tm(fn, n=5):
