@@ -137,14 +137,36 @@ def grad_target(p):
 # --------------------------------------------------------------------------------------
 # raw ops
 # --------------------------------------------------------------------------------------
+# Host-side memo of pure per-shape facts (descriptor structs, "does kernel X take this shape", statistics grouping): a
+# train step asks the library the same ~60 questions 1500 times; a dict lookup is 20x cheaper than the ctypes call.
+_desc_cache = {}
+_shape_memo = {}
+
+
 def conv_desc(x_shape, w_shape, stride, pad):
+    key = (tuple(x_shape), tuple(w_shape), stride, pad)
+    d = _desc_cache.get(key)
+    if d is not None:
+        return d
     N, H, W, Ci = x_shape
     Co, Ci2, R, S = w_shape
     if Ci2 != Ci:
         raise _C.BuctdHipError(f"conv: input has {Ci} channels, weight expects {Ci2}")
     Ho = (H + 2 * pad - R) // stride + 1
     Wo = (W + 2 * pad - S) // stride + 1
-    return ConvDesc(N, H, W, Ci, Co, R, S, stride, pad, Ho, Wo)
+    d = ConvDesc(N, H, W, Ci, Co, R, S, stride, pad, Ho, Wo)
+    if len(_desc_cache) < 4096:
+        _desc_cache[key] = d          # read-only by convention: every consumer passes it by reference to the library
+    return d
+
+
+def _memo(key, fn):
+    v = _shape_memo.get(key)
+    if v is None:
+        v = fn()
+        if len(_shape_memo) < 16384:
+            _shape_memo[key] = v
+    return v
 
 
 _CONV_MATH_MODES = ("fp32", "bf16x6", "bf16x3")
@@ -180,8 +202,11 @@ def _c3fn(suffix):
 
 def _bf16x3_ok(d):
     """True when this convolution takes the split-bf16 3x3 kernel in the current math mode."""
-    return (_conv_math["mode"] != "fp32" and d.R == 3 and d.S == 3 and d.stride == 1 and d.pad == 1 and
-            _c3fn("_supported")(d.N, d.H, d.W, d.Ci, d.Co) == 1)
+    mode = _conv_math["mode"]
+    if mode == "fp32" or d.R != 3 or d.S != 3 or d.stride != 1 or d.pad != 1:
+        return False
+    return _memo(("c3ok", mode, d.N, d.H, d.W, d.Ci, d.Co),
+                 lambda: _c3fn("_supported")(d.N, d.H, d.W, d.Ci, d.Co) == 1)
 
 
 _weights_epoch = {"n": 0}
@@ -287,11 +312,14 @@ def _conv3x3_bf16x3(x, w, flip, cin, cout, bias, scale, shift, residual, relu, s
     y = torch.empty((N, H, W, cout), dtype=torch.float32, device=x.device)
     part = counts = info = None
     if stats:
-        ng, rpg = C.c_int(), C.c_int()
-        check(_c3fn("_stats_groups")(N, H, W, cin, cout, C.byref(ng), C.byref(rpg)), "conv3x3 groups")
-        part = torch.empty((ng.value, cout, 2), dtype=torch.float32, device=x.device)
-        counts = torch.empty(ng.value, dtype=torch.int32, device=x.device)
-        info = (ng.value, rpg.value, counts)
+        def groups():
+            ng, rpg = C.c_int(), C.c_int()
+            check(_c3fn("_stats_groups")(N, H, W, cin, cout, C.byref(ng), C.byref(rpg)), "conv3x3 groups")
+            return ng.value, rpg.value
+        ngv, rpgv = _memo(("c3grp", _conv_math["mode"], N, H, W, cin, cout), groups)
+        part = torch.empty((ngv, cout, 2), dtype=torch.float32, device=x.device)
+        counts = torch.empty(ngv, dtype=torch.int32, device=x.device)
+        info = (ngv, rpgv, counts)
     if in_bn is not None:
         mean, invstd, gamma, beta, in_relu = in_bn
         check(lib().buctd_conv3x3_bf16x6_bnin(N, H, W, cin, cout, ptr(x), ptr(wp), ptr(bias), ptr(scale), ptr(shift),
@@ -314,8 +342,9 @@ def bn_in_fusable(x_shape, w):
     if ws[2] != 3 or ws[3] != 3:
         return False
     d = conv_desc(x_shape, ws, 1, 1)
-    return (lib().buctd_conv3x3_bf16x6_supported(d.N, d.H, d.W, d.Ci, d.Co) == 1 and
-            lib().buctd_conv3x3_wgrad_bf16x6_supported(d.N, d.H, d.W, d.Ci, d.Co) == 1)
+    return _memo(("bnin", d.N, d.H, d.W, d.Ci, d.Co),
+                 lambda: (lib().buctd_conv3x3_bf16x6_supported(d.N, d.H, d.W, d.Ci, d.Co) == 1 and
+                          lib().buctd_conv3x3_wgrad_bf16x6_supported(d.N, d.H, d.W, d.Ci, d.Co) == 1))
 
 
 def conv_fwd(x, w, bias=None, stride=1, pad=0, scale=None, shift=None, residual=None, relu=False, stats=False,
@@ -340,8 +369,11 @@ def conv_fwd(x, w, bias=None, stride=1, pad=0, scale=None, shift=None, residual=
         part, info = bn_stats(y)
         return y, part, info
     if stats:
-        ng, rpg = C.c_int(), C.c_int()
-        check(lib().buctd_conv2d_stats_groups(C.byref(d), 0, C.byref(ng), C.byref(rpg)), "conv2d_stats_groups")
+        def groups():
+            ng_, rpg_ = C.c_int(), C.c_int()
+            check(lib().buctd_conv2d_stats_groups(C.byref(d), 0, C.byref(ng_), C.byref(rpg_)), "conv2d_stats_groups")
+            return ng_, rpg_
+        ng, rpg = _memo(("c2grp", 0, d.N, d.H, d.W, d.Ci, d.Co, d.R, d.S, d.stride, d.pad), groups)
         part = torch.empty((ng.value, d.Co, 2), dtype=torch.float32, device=x.device)
         info = (ng.value, rpg.value)
     check(lib().buctd_conv2d_fwd(C.byref(d), ptr(x), ptr(w), ptr(bias), ptr(scale), ptr(shift), ptr(residual),
@@ -357,7 +389,8 @@ def conv_dgrad(dy, w, x_shape, stride=1, pad=0, bias=None, stats=False, residual
     d = conv_desc(x_shape, _wshape(w), stride, pad)
     if tuple(dy.shape) != (d.N, d.Ho, d.Wo, d.Co):
         raise _C.BuctdHipError(f"conv_dgrad: dy shape {tuple(dy.shape)} != {(d.N, d.Ho, d.Wo, d.Co)}")
-    if _bf16x3_ok(d) and _c3fn("_supported")(d.N, d.H, d.W, d.Co, d.Ci) == 1:
+    if _bf16x3_ok(d) and _memo(("c3ok", _conv_math["mode"], d.N, d.H, d.W, d.Co, d.Ci),
+                               lambda: _c3fn("_supported")(d.N, d.H, d.W, d.Co, d.Ci) == 1):
         return _conv3x3_bf16x3(dy, w, 1, d.Co, d.Ci, bias, None, None, residual, False, stats)
     if residual is not None and stats:
         raise _C.BuctdHipError("conv_dgrad: residual and stats do not combine")
@@ -365,8 +398,11 @@ def conv_dgrad(dy, w, x_shape, stride=1, pad=0, bias=None, stats=False, residual
     part = None
     info = None
     if stats:
-        ng, rpg = C.c_int(), C.c_int()
-        check(lib().buctd_conv2d_stats_groups(C.byref(d), 1, C.byref(ng), C.byref(rpg)), "conv2d_stats_groups")
+        def groups():
+            ng_, rpg_ = C.c_int(), C.c_int()
+            check(lib().buctd_conv2d_stats_groups(C.byref(d), 1, C.byref(ng_), C.byref(rpg_)), "conv2d_stats_groups")
+            return ng_, rpg_
+        ng, rpg = _memo(("c2grp", 1, d.N, d.H, d.W, d.Ci, d.Co, d.R, d.S, d.stride, d.pad), groups)
         part = torch.empty((ng.value, d.Ci, 2), dtype=torch.float32, device=dy.device)
         info = (ng.value, rpg.value)
     check(lib().buctd_conv2d_dgrad(C.byref(d), ptr(dy), ptr(w), ptr(bias), ptr(dx), ptr(part), stream_ptr()),
@@ -388,8 +424,11 @@ def conv_wgrad(x, dy, w_like, stride=1, pad=0, out=None, accumulate=0, x_bn=None
     mode = _conv_math["mode"]
     if mode != "fp32" and d.R == 3 and d.S == 3 and d.stride == 1 and d.pad == 1:
         fn = getattr(lib(), "buctd_conv3x3_wgrad_" + mode)
-        if getattr(lib(), "buctd_conv3x3_wgrad_" + mode + "_supported")(d.N, d.H, d.W, d.Ci, d.Co) == 1:
-            need = getattr(lib(), "buctd_conv3x3_wgrad_" + mode + "_workspace")(d.N, d.H, d.W, d.Ci, d.Co)
+        need = _memo(("wg3", mode, d.N, d.H, d.W, d.Ci, d.Co),
+                     lambda: (getattr(lib(), "buctd_conv3x3_wgrad_" + mode + "_workspace")(d.N, d.H, d.W, d.Ci, d.Co)
+                              if getattr(lib(), "buctd_conv3x3_wgrad_" + mode + "_supported")(d.N, d.H, d.W, d.Ci, d.Co) == 1
+                              else -1))
+        if need >= 0:
             ws = workspace(need, x.device)
             if x_bn is not None:
                 if mode != "bf16x6":
