@@ -21,6 +21,22 @@ class ConvDesc(C.Structure):
     _fields_ = [(n, C.c_int) for n in ("N", "H", "W", "Ci", "Co", "R", "S", "stride", "pad", "Ho", "Wo")]
 
 
+class BasicBlockDesc(C.Structure):     # mirrors buctd_basic_block
+    _fields_ = ([(n, C.c_int) for n in ("N", "H", "W", "C")] +
+                [(n, C.c_void_p) for n in ("x", "w1_fwd", "w2_fwd", "w1_bwd", "w2_bwd", "gamma1", "beta1", "gamma2", "beta2",
+                                           "running_mean1", "running_var1", "running_mean2", "running_var2")] +
+                [(n, C.c_float) for n in ("eps1", "momentum1", "eps2", "momentum2")] +
+                [(n, C.c_void_p) for n in ("z1", "z2", "y", "part", "counts")] +
+                [("ngroups", C.c_int), ("rows_per_group", C.c_int), ("stat", C.c_void_p)])
+
+
+class BasicBlockGrads(C.Structure):    # mirrors buctd_basic_block_grads
+    _fields_ = ([(n, C.c_void_p) for n in ("dy", "dz2", "dres", "dy1", "dz1", "dx", "dw1", "dw2", "dgamma1", "dbeta1",
+                                           "dgamma2", "dbeta2")] +
+                [(n, C.c_int) for n in ("acc_w1", "acc_w2", "acc_bn1", "acc_bn2")] +
+                [("bn_ws", C.c_void_p), ("bn_ws_bytes", C.c_size_t), ("wg_ws", C.c_void_p), ("wg_ws_bytes", C.c_size_t)])
+
+
 class MatmulDesc(C.Structure):
     _fields_ = [
         ("batch", C.c_int), ("M", C.c_int), ("N", C.c_int), ("K", C.c_int),
@@ -81,6 +97,8 @@ SIGNATURES = {
     "buctd_bn_bwd_workspace": (_SZ, [_L, _I]),
     "buctd_bn_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _L, _I, _P, _P, _P, _P, _I, _P, _SZ, _P]),
     "buctd_bn_fold": (_I, [_P, _P, _P, _P, _F, _I, _P, _P, _P]),
+    "buctd_basic_block_fwd_train": (_I, [C.POINTER(BasicBlockDesc), _P]),
+    "buctd_basic_block_bwd": (_I, [C.POINTER(BasicBlockDesc), C.POINTER(BasicBlockGrads), _P, _P]),
     "buctd_x6_image_dims": (_I, [_I, _I, _I, _P, _P]),
     "buctd_x6_image_bytes": (C.c_size_t, [_I, _I, _I]),
     "buctd_x6_image": (_I, [_P, _I, _I, _I, _L, _L, _I, _L, _L, _I, _P, _P]),

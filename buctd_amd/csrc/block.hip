@@ -1,0 +1,78 @@
+// Native launch sequences of one residual BasicBlock in train mode (reference lib/models/pose_hrnet.py:28-57, stride 1,
+// no downsample, bf16x6 math):  y = relu(bn2(conv2(relu(bn1(conv1(x))))) + x).
+// Nothing is computed here: these entry points enqueue the kernels that the host mirror used to enqueue one ctypes call
+// at a time (nine calls and a dozen small allocations per block and direction - ~95 us of Python per block forward,
+// which made HRNet-W32 at 256x192 host-bound).  Same kernels, same order, same streams: results are bit-identical.
+#include "common.h"
+#include "../../include/buctd_hip.h"
+
+#define BLK_TRY(call)      \
+  do {                     \
+    const int rc_ = (call); \
+    if (rc_) return rc_;   \
+  } while (0)
+
+extern "C" int buctd_basic_block_fwd_train(const buctd_basic_block* b, void* stream) {
+  BUCTD_CHECK_ARG(b && b->x && b->w1_fwd && b->w2_fwd && b->z1 && b->z2 && b->y && b->part && b->counts && b->stat,
+                  "buctd_basic_block_fwd_train: null pointer");
+  const int N = b->N, H = b->H, W = b->W, C = b->C;
+  const long rows = (long)N * H * W;
+  float* part1 = b->part;
+  float* part2 = b->part + (size_t)b->ngroups * C * 2;
+  int* cnt1 = b->counts;
+  int* cnt2 = b->counts + b->ngroups;
+  float *mean1 = b->stat, *invstd1 = b->stat + C, *mean2 = b->stat + 2 * C, *invstd2 = b->stat + 3 * C;
+  BLK_TRY(buctd_conv3x3_bf16x6(N, H, W, C, C, b->x, b->w1_fwd, nullptr, nullptr, nullptr, nullptr, 0, b->z1, part1, cnt1,
+                               stream));
+  BLK_TRY(buctd_bn_finalize(part1, cnt1, b->ngroups, b->rows_per_group, rows, C, b->eps1, b->momentum1, mean1, invstd1,
+                            b->running_mean1, b->running_var1, stream));
+  // conv2 applies bn1 + ReLU while it stages its input: relu(bn1(z1)) never exists in memory
+  BLK_TRY(buctd_conv3x3_bf16x6_bnin(N, H, W, C, C, b->z1, b->w2_fwd, nullptr, nullptr, nullptr, nullptr, 0, b->z2, part2,
+                                    cnt2, mean1, invstd1, b->gamma1, b->beta1, 1, stream));
+  BLK_TRY(buctd_bn_finalize(part2, cnt2, b->ngroups, b->rows_per_group, rows, C, b->eps2, b->momentum2, mean2, invstd2,
+                            b->running_mean2, b->running_var2, stream));
+  BLK_TRY(buctd_bn_apply(b->z2, mean2, invstd2, b->gamma2, b->beta2, b->x, 1, b->y, rows, C, stream));
+  return BUCTD_OK;
+}
+
+extern "C" int buctd_basic_block_bwd(const buctd_basic_block* b, const buctd_basic_block_grads* g, void* stream,
+                                     void* side_stream) {
+  BUCTD_CHECK_ARG(b && g && b->x && b->w1_bwd && b->w2_bwd && b->z1 && b->z2 && b->y && b->stat && g->dy && g->dz2 && g->dres &&
+                      g->dy1 && g->dz1 && g->dw1 && g->dw2 && g->bn_ws && g->wg_ws,
+                  "buctd_basic_block_bwd: null pointer");
+  const int N = b->N, H = b->H, W = b->W, C = b->C;
+  const long rows = (long)N * H * W;
+  const float *mean1 = b->stat, *invstd1 = b->stat + C, *mean2 = b->stat + 2 * C, *invstd2 = b->stat + 3 * C;
+  hipStream_t main_s = (hipStream_t)stream, side_s = side_stream ? (hipStream_t)side_stream : main_s;
+  // weight gradients run on the side stream behind the kernel that produced their dY operand
+  static thread_local hipEvent_t ev = nullptr;
+  auto fork = [&]() -> int {
+    if (side_s == main_s) return BUCTD_OK;
+    if (!ev && hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) {
+      buctd_set_error("buctd_basic_block_bwd: hipEventCreate failed");
+      return BUCTD_ELAUNCH;
+    }
+    if (hipEventRecord(ev, main_s) != hipSuccess || hipStreamWaitEvent(side_s, ev, 0) != hipSuccess) {
+      buctd_set_error("buctd_basic_block_bwd: stream fork failed");
+      return BUCTD_ELAUNCH;
+    }
+    return BUCTD_OK;
+  };
+  // conv2 / bn2 (+ skip): dres = masked upstream gradient
+  BLK_TRY(buctd_bn_bwd(g->dy, b->y, b->z2, mean2, invstd2, b->gamma2, nullptr, 1, rows, C, g->dz2, g->dres, g->dgamma2,
+                       g->dbeta2, g->acc_bn2, g->bn_ws, g->bn_ws_bytes, stream));
+  BLK_TRY(fork());
+  BLK_TRY(buctd_conv3x3_wgrad_bf16x6_bnin(N, H, W, C, C, b->z1, g->dz2, g->dw2, g->acc_w2, mean1, invstd1, b->gamma1,
+                                          b->beta1, 1, g->wg_ws, g->wg_ws_bytes, side_s));
+  BLK_TRY(buctd_conv3x3_bf16x6(N, H, W, C, C, g->dz2, b->w2_bwd, nullptr, nullptr, nullptr, nullptr, 0, g->dy1, nullptr,
+                               nullptr, stream));
+  // conv1 / bn1: the ReLU mask is rebuilt from z1; the skip gradient joins in the data-gradient epilogue
+  BLK_TRY(buctd_bn_bwd(g->dy1, nullptr, b->z1, mean1, invstd1, b->gamma1, b->beta1, 1, rows, C, g->dz1, nullptr, g->dgamma1,
+                       g->dbeta1, g->acc_bn1, g->bn_ws, g->bn_ws_bytes, stream));
+  BLK_TRY(fork());
+  BLK_TRY(buctd_conv3x3_wgrad_bf16x6(N, H, W, C, C, b->x, g->dz1, g->dw1, g->acc_w1, g->wg_ws, g->wg_ws_bytes, side_s));
+  if (g->dx)
+    BLK_TRY(buctd_conv3x3_bf16x6(N, H, W, C, C, g->dz1, b->w1_bwd, nullptr, nullptr, nullptr, g->dres, 0, g->dx, nullptr,
+                                 nullptr, stream));
+  return BUCTD_OK;
+}

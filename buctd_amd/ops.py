@@ -333,6 +333,9 @@ def _conv3x3_bf16x3(x, w, flip, cin, cout, bias, scale, shift, residual, relu, s
     return (y, part, info) if stats else y
 
 
+_NATIVE_BLOCK = os.environ.get("BUCTD_NATIVE_BLOCK", "1") == "1"
+
+
 def bn_in_fusable(x_shape, w):
     """True when a 3x3/s1/p1 convolution of this shape can apply its producer's BatchNorm(+ReLU) while staging its
     input (bf16x6 kernel): conv_fwd(..., in_bn=...) and conv_wgrad(..., x_bn=...)."""
@@ -1053,6 +1056,8 @@ class BasicBlockFn(torch.autograd.Function):
         # never exists in HBM (one kernel and two tensor passes less per block; conv2's weight gradient rebuilds it the
         # same way).  Bit-identical to the unfused sequence: the staged value is bn_apply's own expression.
         fuse = bn_in_fusable(tuple(x.shape), w2)
+        if fuse and _NATIVE_BLOCK and bn_in_fusable(tuple(x.shape), w1) and bn1.track_running_stats == bn2.track_running_stats:
+            return BasicBlockFn._forward_native(ctx, x, w1, bn1, w2, bn2)
         stats = []
         for w, bn in ((w1, bn1), (w2, bn2)):
             momentum = 0.1 if bn.momentum is None else bn.momentum
@@ -1079,7 +1084,108 @@ class BasicBlockFn(torch.autograd.Function):
         return y
 
     @staticmethod
+    def _forward_native(ctx, x, w1, bn1, w2, bn2):
+        """The same five kernels through ONE library call (block.hip): the nine ctypes calls and dozen small allocations of
+        the step-by-step path cost ~95 us of host time per block - more than HRNet-W32 needs on the GPU."""
+        N, H, W, Cn = x.shape
+        dev = x.device
+        def groups():
+            ng, rpg = C.c_int(), C.c_int()
+            check(lib().buctd_conv3x3_bf16x6_stats_groups(N, H, W, Cn, Cn, C.byref(ng), C.byref(rpg)), "conv3x3 groups")
+            return ng.value, rpg.value
+        ng, rpg = _memo(("c3grp", "bf16x6", N, H, W, Cn, Cn), groups)
+        act = torch.empty((3, N, H, W, Cn), dtype=torch.float32, device=dev)       # z1 | z2 | y
+        part = torch.empty((2, ng, Cn, 2), dtype=torch.float32, device=dev)
+        counts = torch.empty((2, ng), dtype=torch.int32, device=dev)
+        stat = torch.empty((4, Cn), dtype=torch.float32, device=dev)               # mean1 | invstd1 | mean2 | invstd2
+        d = _C.BasicBlockDesc()
+        d.N, d.H, d.W, d.C = N, H, W, Cn
+        d.x = x.data_ptr()
+        d.w1_fwd = _conv3x3_prepared(w1, 0).data_ptr()
+        d.w2_fwd = _conv3x3_prepared(w2, 0).data_ptr()
+        d.gamma1, d.beta1 = bn1.weight.data_ptr(), bn1.bias.data_ptr()
+        d.gamma2, d.beta2 = bn2.weight.data_ptr(), bn2.bias.data_ptr()
+        track = bn1.track_running_stats
+        if track:
+            d.running_mean1, d.running_var1 = bn1.running_mean.data_ptr(), bn1.running_var.data_ptr()
+            d.running_mean2, d.running_var2 = bn2.running_mean.data_ptr(), bn2.running_var.data_ptr()
+        d.eps1, d.momentum1 = bn1.eps, 0.1 if bn1.momentum is None else bn1.momentum
+        d.eps2, d.momentum2 = bn2.eps, 0.1 if bn2.momentum is None else bn2.momentum
+        base, step = act.data_ptr(), 4 * N * H * W * Cn
+        d.z1, d.z2, d.y = base, base + step, base + 2 * step
+        d.part, d.counts, d.ngroups, d.rows_per_group, d.stat = part.data_ptr(), counts.data_ptr(), ng, rpg, stat.data_ptr()
+        check(lib().buctd_basic_block_fwd_train(C.byref(d), stream_ptr()), "basic_block_fwd_train")
+        if track:
+            for bn in (bn1, bn2):
+                bn.count_batch() if hasattr(bn, "count_batch") else bn.num_batches_tracked.add_(1)
+        y = act[2]
+        ctx.meta = (w1, bn1, w2, bn2, "native")
+        ctx.save_for_backward(x, act, stat)
+        return y
+
+    @staticmethod
+    def _backward_native(ctx, dy):
+        w1, bn1, w2, bn2, _ = ctx.meta
+        x, act, stat = ctx.saved_tensors
+        dy = _contig(dy)
+        N, H, W, Cn = x.shape
+        dev = x.device
+        want_dx = ctx.needs_input_grad[0]
+        tmp = torch.empty((5 if want_dx else 4, N, H, W, Cn), dtype=torch.float32, device=dev)   # dz2 | dres | dy1 | dz1 | dx
+        d = _C.BasicBlockDesc()
+        d.N, d.H, d.W, d.C = N, H, W, Cn
+        d.x = x.data_ptr()
+        d.w1_fwd = d.w2_fwd = 0
+        d.w1_bwd = _conv3x3_prepared(w1, 1).data_ptr()
+        d.w2_bwd = _conv3x3_prepared(w2, 1).data_ptr()
+        d.gamma1, d.beta1 = bn1.weight.data_ptr(), bn1.bias.data_ptr()
+        d.gamma2, d.beta2 = bn2.weight.data_ptr(), bn2.bias.data_ptr()
+        base, step = act.data_ptr(), 4 * N * H * W * Cn
+        d.z1, d.z2, d.y = base, base + step, base + 2 * step
+        d.stat = stat.data_ptr()
+        g = _C.BasicBlockGrads()
+        tb = tmp.data_ptr()
+        g.dy, g.dz2, g.dres, g.dy1, g.dz1 = dy.data_ptr(), tb, tb + step, tb + 2 * step, tb + 3 * step
+        g.dx = tb + 4 * step if want_dx else 0
+        dg2, acc_g2 = grad_target(bn2.weight)
+        db2, acc_b2 = grad_target(bn2.bias)
+        dw2, acc_w2 = grad_target(w2)
+        dg1, acc_g1 = grad_target(bn1.weight)
+        db1, acc_b1 = grad_target(bn1.bias)
+        dw1, acc_w1 = grad_target(w1)
+        assert acc_g2 == acc_b2 and acc_g1 == acc_b1
+        weight_rsc(dw1)
+        weight_rsc(dw2)
+        g.dw1, g.dw2 = dw1.data_ptr(), dw2.data_ptr()
+        g.dgamma1, g.dbeta1, g.dgamma2, g.dbeta2 = dg1.data_ptr(), db1.data_ptr(), dg2.data_ptr(), db2.data_ptr()
+        g.acc_w1, g.acc_w2, g.acc_bn1, g.acc_bn2 = int(acc_w1), int(acc_w2), int(acc_g1), int(acc_g2)
+        bn_ws = workspace(lib().buctd_bn_bwd_workspace(N * H * W, Cn), dev)
+        g.bn_ws, g.bn_ws_bytes = bn_ws.data_ptr(), bn_ws.numel()
+        main = torch.cuda.current_stream(dev)
+        use_side = _side["on"]
+        side = _side_stream(dev) if use_side else main
+        need = _memo(("wg3", "bf16x6", N, H, W, Cn, Cn),
+                     lambda: (lib().buctd_conv3x3_wgrad_bf16x6_workspace(N, H, W, Cn, Cn)
+                              if lib().buctd_conv3x3_wgrad_bf16x6_supported(N, H, W, Cn, Cn) == 1 else -1))
+        with torch.cuda.stream(side):
+            wg_ws = workspace(need, dev)           # the side stream's own scratch buffer
+        g.wg_ws, g.wg_ws_bytes = wg_ws.data_ptr(), wg_ws.numel()
+        check(lib().buctd_basic_block_bwd(C.byref(d), C.byref(g), main.cuda_stream, side.cuda_stream if use_side else None),
+              "basic_block_bwd")
+        if use_side:
+            for t in (x, act, stat, tmp):
+                t.record_stream(side)
+            _queue_join()
+        elif _branch["on"]:
+            _queue_join()
+        grad_done(bn2.weight, bn2.bias, w2)
+        grad_done(bn1.weight, bn1.bias, w1)
+        return (tmp[4] if want_dx else None), None, None, None, None
+
+    @staticmethod
     def backward(ctx, dy):
+        if ctx.meta[4] == "native":
+            return BasicBlockFn._backward_native(ctx, dy)
         w1, bn1, w2, bn2, fuse = ctx.meta
         x, z1, mean1, invstd1, y1, z2, mean2, invstd2, y2 = ctx.saved_tensors
         dy = _contig(dy)

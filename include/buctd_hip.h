@@ -276,6 +276,40 @@ int buctd_cond_render(const float* joints, int js, const float* colors, int B, i
 int buctd_flipback_avg(const float* a, const float* b, const int32_t* perm, int N, int K, int H, int W, int shift,
                        float* out, void* stream);
 
+/* ------------------------------------------------------- BasicBlock sequences --- */
+/* The kernel sequence of one residual BasicBlock in train mode (pose_hrnet.py:28-57: stride 1, C -> C, no downsample,
+ * bf16x6 math) behind ONE call per direction: conv1 + statistics, finalize, conv2 with bn1 + ReLU applied in its input
+ * staging + statistics, finalize, bn2 + skip + ReLU - and the mirrored backward with the two weight gradients on
+ * `side_stream` (NULL: same stream).  Pure launch sequences of the entry points above (bit-identical results); they
+ * exist because nine calls per block through a Python binding cost more host time than HRNet-W32 needs GPU time.
+ * part: 2 * ngroups * C * 2 floats, counts: 2 * ngroups ints (buctd_conv3x3_bf16x6_stats_groups), stat: 4 * C floats
+ * receiving mean1, invstd1, mean2, invstd2 (saved for the backward).  running_* may be NULL. */
+typedef struct {
+  int N, H, W, C;
+  const float* x;
+  const void *w1_fwd, *w2_fwd;          /* prepared images, flip = 0 */
+  const void *w1_bwd, *w2_bwd;          /* prepared images, flip = 1 (backward only) */
+  const float *gamma1, *beta1, *gamma2, *beta2;
+  float *running_mean1, *running_var1, *running_mean2, *running_var2;
+  float eps1, momentum1, eps2, momentum2;
+  float *z1, *z2, *y;
+  float* part;
+  int* counts;
+  int ngroups, rows_per_group;
+  float* stat;
+} buctd_basic_block;
+typedef struct {
+  const float* dy;                      /* gradient of the block output */
+  float *dz2, *dres, *dy1, *dz1;        /* scratch tensors of the block's shape */
+  float* dx;                            /* NULL: the block input needs no gradient */
+  float *dw1, *dw2, *dgamma1, *dbeta1, *dgamma2, *dbeta2;
+  int acc_w1, acc_w2, acc_bn1, acc_bn2; /* accumulate into (1) or overwrite (0) the gradient buffers */
+  void* bn_ws; size_t bn_ws_bytes;      /* buctd_bn_bwd_workspace, used on `stream` */
+  void* wg_ws; size_t wg_ws_bytes;      /* buctd_conv3x3_wgrad_bf16x6_workspace, used on `side_stream` */
+} buctd_basic_block_grads;
+int buctd_basic_block_fwd_train(const buctd_basic_block* b, void* stream);
+int buctd_basic_block_bwd(const buctd_basic_block* b, const buctd_basic_block_grads* g, void* stream, void* side_stream);
+
 /* ------------------------------------------------------------ bf16x6 GEMM --- */
 /* C = alpha * A * B (+ bias) in the bf16x6 arithmetic of the 3x3 convolutions (fp32 operands split exactly into three
  * bf16 pieces, six bf16 MFMAs per product, fp32 accumulate) for the large plain GEMMs of the path - fc_o =
