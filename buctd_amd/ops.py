@@ -334,6 +334,9 @@ def _conv3x3_bf16x3(x, w, flip, cin, cout, bias, scale, shift, residual, relu, s
 
 
 _NATIVE_BLOCK = os.environ.get("BUCTD_NATIVE_BLOCK", "1") == "1"
+# optional veto: callable(x_shape) -> True sends a BasicBlock through the step-by-step path (bench.py brackets every launch
+# of its roofline shape with HIP events, which it can only do from the host mirror)
+native_block_veto = {"fn": None}
 
 
 def bn_in_fusable(x_shape, w):
@@ -1056,7 +1059,9 @@ class BasicBlockFn(torch.autograd.Function):
         # never exists in HBM (one kernel and two tensor passes less per block; conv2's weight gradient rebuilds it the
         # same way).  Bit-identical to the unfused sequence: the staged value is bn_apply's own expression.
         fuse = bn_in_fusable(tuple(x.shape), w2)
-        if fuse and _NATIVE_BLOCK and bn_in_fusable(tuple(x.shape), w1) and bn1.track_running_stats == bn2.track_running_stats:
+        veto = native_block_veto["fn"]
+        if (fuse and _NATIVE_BLOCK and bn_in_fusable(tuple(x.shape), w1) and bn1.track_running_stats == bn2.track_running_stats
+                and not (veto is not None and veto(tuple(x.shape)))):
             return BasicBlockFn._forward_native(ctx, x, w1, bn1, w2, bn2)
         stats = []
         for w, bn in ((w1, bn1), (w2, bn2)):
