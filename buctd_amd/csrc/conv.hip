@@ -700,6 +700,57 @@ __global__ __launch_bounds__(256) void conv_dgrad_thin_kernel(ThinDgradArgs p) {
   }
 }
 
+// Data gradient of a stride-2 3x3 convolution with <= 4 INPUT channels (the HRNet stem conv1 behind a preNet, whose
+// 3-channel output needs a gradient: pose_hrnet.py:287 fed by 452-458).  One thread per dx pixel; of the nine taps only
+// those whose output coordinate is an integer contribute (2.25 on average); dy rows come through L1, the filter from LDS.
+struct ThinS2Args {
+  const float* dy;
+  const float* w;      // [Co][3][3][Ci]
+  float* dx;
+  int N, H, W, Ci, Co, Ho, Wo;
+};
+
+__global__ __launch_bounds__(256) void conv_dgrad_thin_s2_kernel(ThinS2Args p) {
+  extern __shared__ __attribute__((aligned(16))) float wsm[];      // [tap][co][4]
+  for (int i = threadIdx.x; i < 9 * p.Co * 4; i += 256) {
+    const int ci = i & 3, co = (i >> 2) % p.Co, tap = i / (4 * p.Co);
+    wsm[i] = ci < p.Ci ? p.w[((long)co * 9 + tap) * p.Ci + ci] : 0.f;
+  }
+  __syncthreads();
+  const long pix = (long)blockIdx.x * 256 + threadIdx.x;
+  if (pix >= (long)p.N * p.H * p.W) return;
+  const int n = (int)(pix / ((long)p.H * p.W));
+  const int rem = (int)(pix - (long)n * p.H * p.W);
+  const int y = rem / p.W, x = rem - y * p.W;
+  f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+  for (int r = 0; r < 3; ++r) {
+    const int ty = y + 1 - r;
+    if (ty < 0 || (ty & 1) || (ty >> 1) >= p.Ho) continue;
+    for (int sx = 0; sx < 3; ++sx) {
+      const int tx = x + 1 - sx;
+      if (tx < 0 || (tx & 1) || (tx >> 1) >= p.Wo) continue;
+      const float* dr = p.dy + (((long)n * p.Ho + (ty >> 1)) * p.Wo + (tx >> 1)) * p.Co;
+      const float* wr = wsm + (r * 3 + sx) * p.Co * 4;
+      for (int co = 0; co < p.Co; co += 4) {
+        const f32x4 dv = *reinterpret_cast<const f32x4*>(dr + co);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const f32x4 wv = *reinterpret_cast<const f32x4*>(wr + (co + j) * 4);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) acc[e] = __builtin_fmaf(dv[j], wv[e], acc[e]);
+        }
+      }
+    }
+  }
+  float* o = p.dx + pix * p.Ci;
+  for (int e = 0; e < p.Ci; ++e) o[e] = acc[e];
+}
+
+static bool dgrad_thin_s2_ok(const buctd_conv_desc* d) {
+  return d->stride == 2 && d->R == 3 && d->S == 3 && d->pad == 1 && d->Ci <= 4 && d->Co % 4 == 0 && d->Co <= 256 &&
+         (long)d->N * d->H * d->W >= 4096;
+}
+
 static bool fwd_thin_ok(const buctd_conv_desc* d) {
 #ifdef BUCTD_TUNING      // experiment builds only: BUCTD_FWD_THIN=0 routes back to the implicit-GEMM kernel
   static const bool off = getenv("BUCTD_FWD_THIN") && atoi(getenv("BUCTD_FWD_THIN")) == 0;
@@ -762,6 +813,16 @@ extern "C" int buctd_conv2d_dgrad(const buctd_conv_desc* d, const float* dy, con
   int rc = check_desc(d, "buctd_conv2d_dgrad");
   if (rc) return rc;
   BUCTD_CHECK_ARG(dy && w && dx, "buctd_conv2d_dgrad: null tensor pointer");
+  if (dgrad_thin_s2_ok(d) && !bias && !stats_partials) {  // stem conv1 behind a preNet: thin dx, stride 2
+    ThinS2Args ta;
+    ta.dy = dy; ta.w = w; ta.dx = dx;
+    ta.N = d->N; ta.H = d->H; ta.W = d->W; ta.Ci = d->Ci; ta.Co = d->Co; ta.Ho = d->Ho; ta.Wo = d->Wo;
+    const long px = (long)d->N * d->H * d->W;
+    hipLaunchKernelGGL(conv_dgrad_thin_s2_kernel, dim3((unsigned)ceil_div(px, 256)), dim3(256), (size_t)9 * d->Co * 4 * sizeof(float),
+                       (hipStream_t)stream, ta);
+    BUCTD_CHECK_LAUNCH("buctd_conv2d_dgrad(thin s2)");
+    return BUCTD_OK;
+  }
   if (fwd_thin_ok(d) && !bias && !stats_partials) {      // the preNet 7x7 with <= 4 output channels: thin dy, wide dx
     ThinDgradArgs ta;
     ta.dy = dy; ta.w = w; ta.dx = dx;

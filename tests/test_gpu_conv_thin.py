@@ -78,3 +78,22 @@ def test_thin_dgrad_vs_fp64(Ci, Co, N, H, W):
     dx = ops.conv_dgrad(dyd, wd, (N, H, W, Ci), 1, 3)
     err = (dx.cpu().double() - ref).abs().max().item() / ref.abs().max().item()
     assert err <= 2e-6, f"thin dgrad {Ci}->{Co}: rel err {err:.2e}"
+
+
+@pytest.mark.parametrize("Ci,Co,N,H,W", [(3, 64, 2, 192, 256), (3, 64, 1, 97, 131), (4, 32, 2, 64, 80), (2, 128, 1, 120, 90)])
+def test_thin_stride2_dgrad_vs_fp64(Ci, Co, N, H, W):
+    """data gradient of a stride-2 3x3 convolution with <= 4 input channels (the stem conv1 behind a preNet), odd sizes too"""
+    from buctd_amd import ops
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(Ci * 3 + Co)
+    Ho, Wo = (H + 2 - 3) // 2 + 1, (W + 2 - 3) // 2 + 1
+    dy = torch.randn(N, Co, Ho, Wo, generator=g, dtype=torch.float64)
+    w = torch.randn(Co, Ci, 3, 3, generator=g, dtype=torch.float64) * (9 * Co) ** -0.5
+    x = torch.zeros(N, Ci, H, W, dtype=torch.float64, requires_grad=True)
+    F.conv2d(x, w, None, 2, 1).backward(dy)
+    ref = x.grad.permute(0, 2, 3, 1)
+    dyd = dy.float().permute(0, 2, 3, 1).contiguous().to(dev)
+    wd = w.float().contiguous(memory_format=torch.channels_last).to(dev)
+    dx = ops.conv_dgrad(dyd, wd, (N, H, W, Ci), 2, 1)
+    err = (dx.cpu().double() - ref).abs().max().item() / ref.abs().max().item()
+    assert err <= 2e-6, f"thin stride-2 dgrad {Ci}->{Co} {H}x{W}: rel err {err:.2e}"
