@@ -137,6 +137,13 @@ def test_train_step_matches_reference(dev, name):
     # A single ReLU whose pre-activation sits within fp32 round-off of zero flips between implementations and shifts
     # every upstream gradient by ~1e-3 (seen on both the HIP and the CPU fp32 side, channel-localised - DESIGN.md);
     # the floors below allow for such flips, a wiring / scaling bug shows up as >= 1e-1.
+    if name == "coam_w16_96x64_channel_only":
+        # a well-conditioned whole-network case (recipe seed chosen for it, oracle/recipes.py:SEEDS): the fp32 CPU oracle is
+        # 2e-5 from fp64, so the bulk of the HIP gradients carries a tight bar.  (The worst tensors do not: a single ReLU of
+        # stage3 branch 0 still flips between summation orders - both HIP math modes, not the CPU - and moves the
+        # gradients of the four blocks in front of it by 5e-3..2e-2, scratch/diag_channel_only.py.)
+        assert med_c <= 1e-4, "the recipe is meant to be well conditioned"
+        assert med_h <= 3e-4, f"{name}: tight bar on the median: {med_h:.2e}"
     assert med_h <= max(3 * med_c, 2e-3), f"{name}: median grad error vs fp64: hip {med_h:.2e}, fp32 CPU {med_c:.2e}"
     assert worst <= max(3 * worst_ref, 5e-2), f"{name}: worst grad error vs fp64: hip {worst:.2e}, fp32 CPU {worst_ref:.2e}"
     print(f"{name}: grad rel err vs fp64 - median hip {med_h:.2e} / cpu32 {med_c:.2e}; max hip {worst:.2e} / cpu32 {worst_ref:.2e}")
