@@ -91,6 +91,14 @@ SIGNATURES = {
     "buctd_conv3x3_wgrad_bf16x6_supported": (_I, [_I, _I, _I, _I, _I]),
     "buctd_conv3x3_wgrad_bf16x6_workspace": (_SZ, [_I, _I, _I, _I, _I]),
     "buctd_conv3x3_wgrad_bf16x6": (_I, [_I, _I, _I, _I, _I, _P, _P, _P, _I, _P, _SZ, _P]),
+    "buctd_x6p_bytes": (_SZ, [_I, _I, _I, _I]),
+    "buctd_x6p_from_nhwc": (_I, [_I, _I, _I, _I, _P, _P, _P, _P, _P, _I, _P, _P]),
+    "buctd_x6p_to_nhwc": (_I, [_I, _I, _I, _I, _P, _P, _P]),
+    "buctd_conv3x3_bf16x6_p_stats_groups": (_I, [_I, _I, _I, _I, _I, _PI, _PI]),
+    "buctd_conv3x3_bf16x6_p": (_I, [_I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P]),
+    "buctd_conv3x3_wgrad_bf16x6_p_supported": (_I, [_I, _I, _I, _I, _I]),
+    "buctd_conv3x3_wgrad_bf16x6_p_workspace": (_SZ, [_I, _I, _I, _I, _I]),
+    "buctd_conv3x3_wgrad_bf16x6_p": (_I, [_I, _I, _I, _I, _I, _P, _P, _P, _I, _P, _SZ, _P]),
     "buctd_bn_stats": (_I, [_P, _L, _I, _P, _PI, _PI, _P]),
     "buctd_bn_stats_groups": (_I, [_L, _I, _PI, _PI]),
     "buctd_bn_apply": (_I, [_P, _P, _P, _P, _P, _P, _I, _P, _L, _I, _P]),

@@ -29,6 +29,7 @@
 //   * epilogue as in conv.hip: bias, Welford BN partials (+ per-group valid-row counts, since pad positions are
 //     skipped), eval-BN scale/shift, residual, ReLU.
 #include "common.h"
+#include "x6p.h"
 #include <stdlib.h>
 #include "../../include/buctd_hip.h"
 
@@ -414,12 +415,15 @@ __device__ unsigned long long c3_trace_wall[4096][2];   // wall clock (100 MHz) 
 #else
 #define C3_TR(k) do {} while (0)
 #endif
-template <int MF, int NF, int WM, int WN, bool DBUF, bool BPF_, int WPS>
+// PL: the input arrives as x6 planes (x6p.h) - already padded and split by its producer.  Staging a chunk is then a plain
+// 16-byte copy (global -> register -> LDS, still one chunk ahead of the MFMAs): no split arithmetic, no zero-selects, no
+// per-row div/mod - the ~2 VALU instructions per MFMA of the fp32-input variant are gone.
+template <int MF, int NF, int WM, int WN, bool DBUF, bool BPF_, int WPS, bool PL = false>
 __global__ __launch_bounds__(256, WPS) void conv3x3_x6_kernel(C3Args p) {
   constexpr int ROWB = Geo<3>::ROWB, PST = Geo<3>::PST, CPR = Geo<3>::CPR;
   constexpr int BM = WM * MF * 16, BN = WN * NF * 16;
   constexpr int RPP = 256 / CPR;                                 // 64 rows staged per pass
-  constexpr int PA = (BM + 2 * MAX_SW + 2 + RPP - 1) / RPP;
+  constexpr int PA = PL ? ((BM + 2 * MAX_SW + 2 + 31) * 6 + 255) / 256 : (BM + 2 * MAX_SW + 2 + RPP - 1) / RPP;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int arows = p.na * 32;
   const size_t abytes = DBUF ? (size_t)arows * ROWB : 0;         // one A buffer; smem = [DBUF ? 2 : 1][arows][ROWB]
@@ -455,28 +459,79 @@ __global__ __launch_bounds__(256, WPS) void conv3x3_x6_kernel(C3Args p) {
   const bool tr_on = t == 0 && by == 0 && bx % tr_stride == 0;
   const int tr_slot = bx / tr_stride;
 #endif
-  int goff[PA];        // global element offset (channel 0) of every staged row of this thread; -1 zero row, -2 beyond
+  int goff[PL ? 1 : PA];   // fp32 input: global element offset (channel 0) of every staged row of this thread; -1 zero row,
+                           // -2 beyond the tile
+  // PL: the LDS image of a chunk tile is its 16-byte pieces in order, piece i = (row i / 6, j = i % 6); this thread moves
+  // pieces t + 256 q.  Their plane offsets are recomputed when used (a handful of integer operations per 16 bytes)
+  // instead of living in PA registers for the whole kernel.
+  const unsigned char* xpl = nullptr;
+  const int npieces = arows * 6;
+  const int rowb = p.Ci * 6;
+  const int pr0 = t / 6, pj0 = t - pr0 * 6;
+  auto piece_off = [&](int q) -> int {     // q is a compile-time constant wherever this is called
+    int i = t + 256 * q;
+    int row = pr0 + 42 * q, j = pj0 + 4 * q;
+    row += j / 6;
+    j -= (j / 6) * 6;
+    if (i >= npieces) { row = arows - 1; j = 5; }   // clamped: the load stays in bounds, the store is skipped
+    return (p0 - halo + row) * rowb + j * 16;
+  };
+  if constexpr (PL) {
+    xpl = reinterpret_cast<const unsigned char*>(p.x) + (size_t)X6P_GB * rowb;
+  } else {
 #pragma unroll
-  for (int q = 0; q < PA; ++q) {
-    const int row = prow + RPP * q;
-    const int pp = p0 - halo + row;
-    int o = row < arows ? -1 : -2;
-    if (row < arows && pp >= 0 && pp < p.P) {
-      const int n = fast_div(pp, p.ib_mul, p.ib_sh);
-      const int rem = pp - n * p.IB;
-      const int yy = fast_div(rem, p.sw_mul, p.sw_sh);
-      const int xx = rem - yy * p.SW;
-      if (n < p.N && yy >= 1 && xx >= 1 && xx <= p.W) o = ((n * p.H + yy - 1) * p.W + xx - 1) * p.Ci;
+    for (int q = 0; q < PA; ++q) {
+      const int row = prow + RPP * q;
+      const int pp = p0 - halo + row;
+      int o = row < arows ? -1 : -2;
+      if (row < arows && pp >= 0 && pp < p.P) {
+        const int n = fast_div(pp, p.ib_mul, p.ib_sh);
+        const int rem = pp - n * p.IB;
+        const int yy = fast_div(rem, p.sw_mul, p.sw_sh);
+        const int xx = rem - yy * p.SW;
+        if (n < p.N && yy >= 1 && xx >= 1 && xx <= p.W) o = ((n * p.H + yy - 1) * p.W + xx - 1) * p.Ci;
+      }
+      goff[q] = o;
     }
-    goff[q] = o;
   }
-  f32x4 areg[PA];
-  auto load_a = [&](int c0) {
+  // PL + DBUF: the tile of chunk ch+1 is copied in NBT = 4 time slices during the steps of chunk ch (slice b loaded in step
+  // b, stored in step b + 1), so that only QB pieces are in registers at any time
+  constexpr int NBT = 4;
+  constexpr int QB = (PA + NBT - 1) / NBT;
+  f32x4 areg[(PL && DBUF) ? QB : PA];
+  auto load_slice = [&](int c0, int b) {
+    const unsigned char* src = xpl + (c0 >> 4) * 96;
 #pragma unroll
-    for (int q = 0; q < PA; ++q)
-      if (RPP * q < arows) areg[q] = *reinterpret_cast<const f32x4*>(p.x + (goff[q] >= 0 ? goff[q] + c0 + c4 : 0));
+    for (int u = 0; u < QB; ++u)
+      if (b * QB + u < PA && 256 * (b * QB + u) < npieces) areg[u] = *reinterpret_cast<const f32x4*>(src + piece_off(b * QB + u));
+  };
+  auto store_slice = [&](unsigned char* At, int b) {
+#pragma unroll
+    for (int u = 0; u < QB; ++u)
+      if (b * QB + u < PA && t + 256 * (b * QB + u) < npieces)
+        *reinterpret_cast<f32x4*>(At + (size_t)(t + 256 * (b * QB + u)) * 16) = areg[u];
+  };
+  auto load_a = [&](int c0) {
+    if constexpr (PL && !DBUF) {
+      const unsigned char* src = xpl + (c0 >> 4) * 96;
+#pragma unroll
+      for (int q = 0; q < PA; ++q)
+        if (256 * q < npieces) areg[q] = *reinterpret_cast<const f32x4*>(src + piece_off(q));
+    } else if constexpr (!PL) {
+#pragma unroll
+      for (int q = 0; q < PA; ++q)
+        if (RPP * q < arows) areg[q] = *reinterpret_cast<const f32x4*>(p.x + (goff[q] >= 0 ? goff[q] + c0 + c4 : 0));
+    }
   };
   auto store_a = [&](unsigned char* At, int c0) {
+    if constexpr (PL) {
+      if constexpr (!DBUF) {
+#pragma unroll
+        for (int q = 0; q < PA; ++q)
+          if (t + 256 * q < npieces) *reinterpret_cast<f32x4*>(At + (size_t)(t + 256 * q) * 16) = areg[q];
+      }
+      return;
+    } else {
     f32x4 mu, sc, be;
     if (p.in_mean) {
       mu = *reinterpret_cast<const f32x4*>(p.in_mean + c0 + c4);
@@ -499,6 +554,7 @@ __global__ __launch_bounds__(256, WPS) void conv3x3_x6_kernel(C3Args p) {
         }
         split_store<3, PST>(At + (size_t)(prow + RPP * q) * ROWB, c4, v);
       }
+    }
   };
 
   // B fragments of this lane: image [step][Co/16][3][64][16 B]
@@ -550,7 +606,7 @@ __global__ __launch_bounds__(256, WPS) void conv3x3_x6_kernel(C3Args p) {
 #pragma unroll
     for (int s = 0; s < 5; ++s) {
       if (ch == 1) C3_TR(50 + s);
-      if (DBUF && s == 2 && ch + 1 < nchunks) {    // next chunk: registers -> pieces -> the other A buffer
+      if (!PL && DBUF && s == 2 && ch + 1 < nchunks) {    // next chunk: registers -> pieces -> the other A buffer
         // done while the fewest registers are live (no B prefetch in flight, no A fragments): the split needs ~60
         if (ch == 1) C3_TR(56);
         store_a(smem + ((ch + 1) & 1) * abytes, (ch + 1) * 16);
@@ -570,7 +626,18 @@ __global__ __launch_bounds__(256, WPS) void conv3x3_x6_kernel(C3Args p) {
       } else {
         load_b(gs, bc);          // 144 MFMAs per step: the fetch latency is small against them, the registers are not
       }
-      if (DBUF && s == 2 && ch + 2 < nchunks) {
+      if constexpr (PL && DBUF) {
+        // planes input: slice s - 1 of the next chunk's tile (loaded a step ago, behind that step's B prefetch) goes to
+        // the other A buffer, then slice s is requested - again behind this step's B prefetch, so that the next step's
+        // wait for its B fragments leaves it in flight
+        if (ch + 1 < nchunks) {
+          __builtin_amdgcn_sched_barrier(0);
+          if (s >= 1) store_slice(smem + ((ch + 1) & 1) * abytes, s - 1);
+          if (s < NBT) load_slice((ch + 1) * 16, s);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+      if (!PL && DBUF && s == 2 && ch + 2 < nchunks) {
         // the global loads of chunk ch+2 go out BEHIND this step's B prefetch: vector loads return in order, so the next
         // step's wait for its B fragments (older) leaves them in flight, and only the wait two steps on needs them -
         // issued in front of the prefetch they put their whole HBM latency into the very next step
@@ -606,11 +673,21 @@ __global__ __launch_bounds__(256, WPS) void conv3x3_x6_kernel(C3Args p) {
   const unsigned tr_lin = blockIdx.y * gridDim.x + blockIdx.x;
   if (t == 0 && tr_lin < 4096) c3_trace_wall[tr_lin][0] = wall_clock64();
 #endif
-  load_a(0);
-  if constexpr (BPF) load_b(0, bn);
-  if constexpr (BPF2) load_b(last_step > 0 ? 1 : 0, bn2);
-  store_a(smem, 0);
-  if (nchunks > 1) load_a(16);
+  if constexpr (PL && DBUF) {
+    if constexpr (BPF) load_b(0, bn);
+    if constexpr (BPF2) load_b(last_step > 0 ? 1 : 0, bn2);
+#pragma unroll
+    for (int b = 0; b < NBT; ++b) {
+      load_slice(0, b);
+      store_slice(smem, b);
+    }
+  } else {
+    load_a(0);
+    if constexpr (BPF) load_b(0, bn);
+    if constexpr (BPF2) load_b(last_step > 0 ? 1 : 0, bn2);
+    store_a(smem, 0);
+    if (nchunks > 1) load_a(16);
+  }
   __syncthreads();
   C3_TR(1);
   for (int ch = 0; ch < nchunks; ++ch) {
@@ -764,7 +841,7 @@ static void magic_u32(unsigned d, unsigned* mul, unsigned* sh) {
 
 static int c3_steps(int Kc, int np) { return np == 3 ? (Kc / 16) * 5 : (Kc / CK) * 9 + ((Kc % CK) ? 5 : 0); }
 
-static bool c3_plan(int np, int N, int H, int W, int Ci, int Co, C3Plan* pl) {
+static bool c3_plan(int np, int N, int H, int W, int Ci, int Co, C3Plan* pl, bool planes_in = false) {
   if (N <= 0 || H <= 0 || W <= 0 || Ci <= 0 || Co <= 0 || Ci % 16 != 0 || Co % 16 != 0 || W + 2 > MAX_SW) return false;
   const int rowb = np == 3 ? Geo<3>::ROWB : Geo<2>::ROWB, blds = np == 3 ? Geo<3>::BLDS : Geo<2>::BLDS;
   const long P = (long)N * (H + 1) * (W + 2) + (W + 2);
@@ -798,7 +875,9 @@ static bool c3_plan(int np, int N, int H, int W, int Ci, int Co, C3Plan* pl) {
     // 512-position tiles in ONE round of workgroups (2 resident per CU = 512 slots) instead of 1.75 rounds of
     // 256-position tiles: the 48-channel branch at N*H*W >= ~115k positions (single A buffer: 64.5 KB at W = 72)
     const long b8 = (P + 511) / 512;
-    if (b8 > 256 && b8 <= 512) { mf = 8; single = true; }
+    // (planes input: the 64 + 4 registers of a single-buffered 512-position tile's prefetch do not fit; the double-buffered
+    // 256-position tile stages in four small time slices instead)
+    if (b8 > 256 && b8 <= 512 && !planes_in) { mf = 8; single = true; }
 #ifdef BUCTD_TUNING      // experiment builds only (scratch/build_trace_lib.sh): 3 lean workgroups per CU instead
     static const int lean_env = getenv("BUCTD_C3_LEAN") ? atoi(getenv("BUCTD_C3_LEAN")) : 0;
     if (lean_env && mf == 8) { mf = 4; pl->lean = 1; }
@@ -829,13 +908,21 @@ static bool c3_plan(int np, int N, int H, int W, int Ci, int Co, C3Plan* pl) {
 static bool c3_np_ok(int np) { return np == 2 || np == 3; }
 
 template <int NP, int MF, int NF, int WM, int WN>
-static int c3_launch(const C3Args& a, const C3Plan& pl, hipStream_t st) {
-  static bool attr_done[3] = {false, false, false};   // idempotent attribute call: a race at first use only repeats it
+static int c3_launch(const C3Args& a, const C3Plan& pl, hipStream_t st, bool planes_in) {
+  static bool attr_done[5] = {false, false, false, false, false};   // idempotent attribute call: a race at first use only repeats it
   void (*fn)(C3Args);
   int variant = 0;
   if constexpr (NP == 3) {
-    if (MF >= 8) fn = conv3x3_x6_kernel<MF, NF, WM, WN, false, false, 2>;
+    if (planes_in) {
+      if constexpr (MF >= 8) {
+        buctd_set_error("conv3x3 (bf16x6, planes input): no 512-position tile variant");
+        return BUCTD_EINVAL;
+      } else { fn = conv3x3_x6_kernel<MF, NF, WM, WN, true, true, 2, true>; variant = 4; }
+    }
+    else if (MF >= 8) fn = conv3x3_x6_kernel<MF, NF, WM, WN, false, false, 2>;
+#ifdef BUCTD_TUNING
     else if (pl.lean) { fn = conv3x3_x6_kernel<MF, NF, WM, WN, false, false, 3>; variant = 1; }
+#endif
     else { fn = conv3x3_x6_kernel<MF, NF, WM, WN, true, true, 2>; variant = 2; }
   }
   else fn = conv3x3_split_kernel<NP, (MF > 4 ? 4 : MF), NF, WM, WN>;
@@ -856,9 +943,9 @@ static int c3_launch(const C3Args& a, const C3Plan& pl, hipStream_t st) {
 }
 
 template <int NP>
-static int c3_dispatch(const C3Args& a, const C3Plan& pl, hipStream_t st) {
+static int c3_dispatch(const C3Args& a, const C3Plan& pl, hipStream_t st, bool planes_in = false) {
 #define C3_CASE(mf, nf, wm, wn) \
-  if (pl.MF == mf && pl.NF == nf && pl.WN == wn) return c3_launch<NP, mf, nf, wm, wn>(a, pl, st);
+  if (pl.MF == mf && pl.NF == nf && pl.WN == wn) return c3_launch<NP, mf, nf, wm, wn>(a, pl, st, planes_in);
 #define C3_MF(nf, wm, wn) C3_CASE(4, nf, wm, wn) C3_CASE(2, nf, wm, wn) C3_CASE(1, nf, wm, wn)
   if constexpr (NP == 3) { C3_CASE(8, 3, 4, 1) C3_CASE(8, 3, 2, 2) }
   C3_MF(1, 4, 1) C3_MF(2, 4, 1) C3_MF(3, 4, 1) C3_MF(3, 2, 2)
@@ -883,9 +970,10 @@ static int c3_supported(int np, int N, int H, int W, int Ci, int Co) {
   return c3_np_ok(np) && c3_plan(np, N, H, W, Ci, Co, &pl) ? 1 : 0;
 }
 
-static int c3_stats_groups(int np, int N, int H, int W, int Ci, int Co, int* ngroups, int* rows_per_group) {
+static int c3_stats_groups(int np, int N, int H, int W, int Ci, int Co, int* ngroups, int* rows_per_group,
+                           bool planes_in = false) {
   C3Plan pl;
-  BUCTD_CHECK_ARG(ngroups && rows_per_group && c3_np_ok(np) && c3_plan(np, N, H, W, Ci, Co, &pl),
+  BUCTD_CHECK_ARG(ngroups && rows_per_group && c3_np_ok(np) && c3_plan(np, N, H, W, Ci, Co, &pl, planes_in),
                   "buctd_conv3x3_*_stats_groups: unsupported shape");
   const long P = (long)N * (H + 1) * (W + 2) + (W + 2);
   *ngroups = ceil_div(P, pl.BM) * pl.WM;
@@ -922,10 +1010,11 @@ struct C3InBn { const float* mean; const float* invstd; const float* gamma; cons
 
 static int c3_run(int np, int N, int H, int W, int Ci, int Co, const float* x, const void* wprep, const float* bias,
                   const float* scale, const float* shift, const float* residual, int relu, float* y,
-                  float* stats_partials, int* stats_counts, void* stream, const C3InBn* in_bn = nullptr) {
+                  float* stats_partials, int* stats_counts, void* stream, const C3InBn* in_bn = nullptr,
+                  bool planes_in = false) {
   C3Plan pl;
   BUCTD_CHECK_ARG(x && wprep && y, "buctd_conv3x3 (split bf16): null tensor pointer");
-  BUCTD_CHECK_ARG(c3_np_ok(np) && c3_plan(np, N, H, W, Ci, Co, &pl),
+  BUCTD_CHECK_ARG(c3_np_ok(np) && c3_plan(np, N, H, W, Ci, Co, &pl, planes_in),
                   "buctd_conv3x3 (split bf16): unsupported shape N%d H%d W%d Ci%d Co%d", N, H, W, Ci, Co);
   BUCTD_CHECK_ARG((scale == nullptr) == (shift == nullptr), "buctd_conv3x3 (split bf16): scale and shift go together");
   BUCTD_CHECK_ARG((stats_partials == nullptr) == (stats_counts == nullptr),
@@ -954,7 +1043,11 @@ static int c3_run(int np, int N, int H, int W, int Ci, int Co, const float* x, c
 #endif
   magic_u32((unsigned)a.IB, &a.ib_mul, &a.ib_sh);
   magic_u32((unsigned)a.SW, &a.sw_mul, &a.sw_sh);
-  return np == 3 ? c3_dispatch<3>(a, pl, (hipStream_t)stream) : c3_dispatch<2>(a, pl, (hipStream_t)stream);
+  if (planes_in) {
+    BUCTD_CHECK_ARG(np == 3 && !a.in_mean, "buctd_conv3x3_bf16x6_p: planes input is a bf16x6 feature without input BatchNorm");
+    BUCTD_CHECK_ARG((P + X6P_GB + X6P_GA) * (long)Ci * 6 < 2147483647L, "buctd_conv3x3_bf16x6_p: tensor too large");
+  }
+  return np == 3 ? c3_dispatch<3>(a, pl, (hipStream_t)stream, planes_in) : c3_dispatch<2>(a, pl, (hipStream_t)stream);
 }
 
 // ---- "bf16x3" (NP = 2) entry points --------------------------------------------------------------------------
@@ -1001,4 +1094,16 @@ extern "C" int buctd_conv3x3_bf16x6_bnin(int N, int H, int W, int Ci, int Co, co
                                          const float* in_gamma, const float* in_beta, int in_relu, void* stream) {
   C3InBn b{in_mean, in_invstd, in_gamma, in_beta, in_relu};
   return c3_run(3, N, H, W, Ci, Co, x, wprep, bias, scale, shift, residual, relu, y, stats_partials, stats_counts, stream, &b);
+}
+
+extern "C" int buctd_conv3x3_bf16x6_p_stats_groups(int N, int H, int W, int Ci, int Co, int* ngroups, int* rows_per_group) {
+  return c3_stats_groups(3, N, H, W, Ci, Co, ngroups, rows_per_group, true);
+}
+/* buctd_conv3x3_bf16x6 with the INPUT given as x6 planes (csrc/x6p.h, buctd_x6p_bytes): the producer already padded and
+ * split it, the kernel stages it with plain 16-byte copies.  Same tiling, same MFMA order: bit-identical results. */
+extern "C" int buctd_conv3x3_bf16x6_p(int N, int H, int W, int Ci, int Co, const void* x_planes, const void* wprep,
+                                      const float* bias, const float* scale, const float* shift, const float* residual,
+                                      int relu, float* y, float* stats_partials, int* stats_counts, void* stream) {
+  return c3_run(3, N, H, W, Ci, Co, (const float*)x_planes, wprep, bias, scale, shift, residual, relu, y, stats_partials,
+                stats_counts, stream, nullptr, true);
 }

@@ -333,6 +333,87 @@ def _conv3x3_bf16x3(x, w, flip, cin, cout, bias, scale, shift, residual, relu, s
     return (y, part, info) if stats else y
 
 
+# ---- x6 planes (csrc/x6p.h): activations stored pre-split + zero-padded for the bf16x6 3x3 kernels ---------------------
+class Planes:
+    """A [N, H, W, C] activation as x6 planes: `buf` is the uint8 allocation (guards + padded rows, 6 bytes / element)."""
+    __slots__ = ("buf", "shape")
+
+    def __init__(self, buf, shape):
+        self.buf, self.shape = buf, tuple(shape)
+
+    def record_stream(self, stream):
+        self.buf.record_stream(stream)
+
+
+def planes_bytes(shape):
+    N, H, W, Cn = shape
+    return _memo(("x6pb", N, H, W, Cn), lambda: int(lib().buctd_x6p_bytes(N, H, W, Cn)))
+
+
+def planes_ok(shape):
+    """True when a [N, H, W, C] activation can be stored as planes (C % 16 == 0, within the kernels' 32-bit offsets)."""
+    return shape[3] % 16 == 0 and planes_bytes(shape) > 0
+
+
+def to_planes(x, bn=None, out=None):
+    """planes of x, or of relu?(bn(x)) for bn = (mean, invstd, gamma, beta, relu) - the value conv_fwd(in_bn=...) stages."""
+    _f32(x, "to_planes input")
+    N, H, W, Cn = x.shape
+    if out is None:
+        out = Planes(torch.empty(planes_bytes(x.shape), dtype=torch.uint8, device=x.device), x.shape)
+    mean = invstd = gamma = beta = None
+    relu = 0
+    if bn is not None:
+        mean, invstd, gamma, beta, relu = bn
+    check(lib().buctd_x6p_from_nhwc(N, H, W, Cn, ptr(x), ptr(mean), ptr(invstd), ptr(gamma), ptr(beta), int(bool(relu)),
+                                    ptr(out.buf), stream_ptr()), "x6p_from_nhwc")
+    return out
+
+
+def from_planes(pl):
+    N, H, W, Cn = pl.shape
+    x = torch.empty(pl.shape, dtype=torch.float32, device=pl.buf.device)
+    check(lib().buctd_x6p_to_nhwc(N, H, W, Cn, ptr(pl.buf), ptr(x), stream_ptr()), "x6p_to_nhwc")
+    return x
+
+
+def conv3x3_planes(xp, w, flip, cout, bias=None, scale=None, shift=None, residual=None, relu=False, stats=False):
+    """3x3 / s1 / p1 convolution (flip = 0) or data gradient (flip = 1) of an input given as planes (bf16x6)."""
+    N, H, W, cin = xp.shape
+    wp = _conv3x3_prepared(w, flip)
+    y = torch.empty((N, H, W, cout), dtype=torch.float32, device=xp.buf.device)
+    part = counts = info = None
+    if stats:
+        def groups():
+            ng, rpg = C.c_int(), C.c_int()
+            check(lib().buctd_conv3x3_bf16x6_p_stats_groups(N, H, W, cin, cout, C.byref(ng), C.byref(rpg)), "conv3x3_p groups")
+            return ng.value, rpg.value
+        ngv, rpgv = _memo(("c3pgrp", N, H, W, cin, cout), groups)
+        part = torch.empty((ngv, cout, 2), dtype=torch.float32, device=y.device)
+        counts = torch.empty(ngv, dtype=torch.int32, device=y.device)
+        info = (ngv, rpgv, counts)
+    check(lib().buctd_conv3x3_bf16x6_p(N, H, W, cin, cout, ptr(xp.buf), ptr(wp), ptr(bias), ptr(scale), ptr(shift),
+                                       ptr(residual), int(bool(relu)), ptr(y), ptr(part), ptr(counts), stream_ptr()),
+          "conv3x3_bf16x6_p")
+    return (y, part, info) if stats else y
+
+
+def wgrad_planes_ok(N, H, W, Ci, Co):
+    return _memo(("wg4ok", N, H, W, Ci, Co), lambda: lib().buctd_conv3x3_wgrad_bf16x6_p_supported(N, H, W, Ci, Co) == 1)
+
+
+def conv_wgrad_planes(xp, dyp, out, accumulate=0):
+    """3x3 weight gradient from both operands as planes; out: channels_last OIHW gradient tensor."""
+    N, H, W, Ci = xp.shape
+    Co = dyp.shape[3]
+    weight_rsc(out)
+    need = _memo(("wg4ws", N, H, W, Ci, Co), lambda: int(lib().buctd_conv3x3_wgrad_bf16x6_p_workspace(N, H, W, Ci, Co)))
+    ws = workspace(need, out.device)
+    check(lib().buctd_conv3x3_wgrad_bf16x6_p(N, H, W, Ci, Co, ptr(xp.buf), ptr(dyp.buf), ptr(out), int(accumulate), ptr(ws),
+                                             ws.numel(), stream_ptr()), "conv3x3_wgrad_bf16x6_p")
+    return out
+
+
 _NATIVE_BLOCK = os.environ.get("BUCTD_NATIVE_BLOCK", "1") == "1"
 # optional veto: callable(x_shape) -> True sends a BasicBlock through the step-by-step path (bench.py brackets every launch
 # of its roofline shape with HIP events, which it can only do from the host mirror)

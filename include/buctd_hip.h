@@ -127,6 +127,30 @@ size_t buctd_conv3x3_wgrad_bf16x3_workspace(int N, int H, int W, int Ci, int Co)
 int buctd_conv3x3_wgrad_bf16x3(int N, int H, int W, int Ci, int Co, const float* x, const float* dy, float* dw,
                                int accumulate, void* workspace, size_t workspace_bytes, void* stream);
 
+/* ------------------------------------------------------------ x6 planes --- */
+/* "x6 planes" (csrc/x6p.h): an activation [N][H][W][C] (C % 16 == 0) stored pre-split for the bf16x6 kernels - one row of
+ * C/16 chunks [16 h | 16 m | 16 l] bf16 (x = h + m + l exactly) per position of the zero-padded flattened pixel space
+ * p = n (H+1)(W+2) + (y+1)(W+2) + (x+1), pad rows and guard rows in front / behind zeroed by the producer.  6 bytes per
+ * element; the consumers stage it with plain copies / LDS-DMA.  Every `planes` pointer below is the allocation base of
+ * buctd_x6p_bytes(N, H, W, C) bytes.  Serves the operands of the BasicBlock convolutions, pose_hrnet.py:28-57. */
+size_t buctd_x6p_bytes(int N, int H, int W, int C);
+/* planes of x, or of relu?((x - mean) * (invstd * gamma) + beta) when mean != NULL (the expression of buctd_bn_apply) */
+int buctd_x6p_from_nhwc(int N, int H, int W, int C, const float* x, const float* mean, const float* invstd,
+                        const float* gamma, const float* beta, int relu, void* planes, void* stream);
+int buctd_x6p_to_nhwc(int N, int H, int W, int C, const void* planes, float* x, void* stream);
+/* buctd_conv3x3_bf16x6 with its input as planes (same tiling and MFMA order: bit-identical results); its statistics
+ * grouping differs from the fp32-input kernel's for the largest maps, hence its own _stats_groups */
+int buctd_conv3x3_bf16x6_p_stats_groups(int N, int H, int W, int Ci, int Co, int* ngroups, int* rows_per_group);
+int buctd_conv3x3_bf16x6_p(int N, int H, int W, int Ci, int Co, const void* x_planes, const void* wprep, const float* bias,
+                           const float* scale, const float* shift, const float* residual, int relu, float* y,
+                           float* stats_partials, int* stats_counts, void* stream);
+/* weight gradient from both operands as planes (Ci, Co multiples of 48): LDS-DMA staging, one 512-thread workgroup per CU,
+ * 256 partial slabs in `workspace` summed in a fixed order (deterministic) */
+int buctd_conv3x3_wgrad_bf16x6_p_supported(int N, int H, int W, int Ci, int Co);
+size_t buctd_conv3x3_wgrad_bf16x6_p_workspace(int N, int H, int W, int Ci, int Co);
+int buctd_conv3x3_wgrad_bf16x6_p(int N, int H, int W, int Ci, int Co, const void* x_planes, const void* dy_planes, float* dw,
+                                 int accumulate, void* workspace, size_t workspace_bytes, void* stream);
+
 /* ---------------------------------------------------------------- matmul --- */
 typedef struct {
   int batch, M, N, K;
