@@ -180,6 +180,46 @@ def gather_validation_shards(all_preds, all_boxes, image_path, filled):
     return preds, boxes, full
 
 
+class _RankBatchSampler:
+    """The batches i = rank, rank + world, ... of a sequential, unshuffled loader: index lists only, so the DataLoader workers
+    of a rank decode, augment and collate its own share of the validation set and nothing else."""
+
+    def __init__(self, num_samples, batch_size, drop_last, rank, world):
+        n = num_samples // batch_size if drop_last else (num_samples + batch_size - 1) // batch_size
+        self.plan = [(i, i * batch_size, min(num_samples, (i + 1) * batch_size)) for i in range(n) if i % world == rank]
+
+    def __iter__(self):
+        for _, a, b in self.plan:
+            yield list(range(a, b))
+
+    def __len__(self):
+        return len(self.plan)
+
+
+def _rank_batches(val_loader, rank, world):
+    """Yields (batch index, first row, batch) for the batches this rank owns.  A torch DataLoader over a sequential sampler
+    is re-created with a per-rank batch sampler (the data path is sharded, not just the model compute); any other iterable
+    of batches is walked in full and foreign batches are skipped (their rows are still counted)."""
+    from torch.utils.data import DataLoader, SequentialSampler
+    if world > 1 and isinstance(val_loader, DataLoader) and isinstance(getattr(val_loader, 'sampler', None), SequentialSampler) \
+            and val_loader.batch_size is not None:
+        bs = _RankBatchSampler(len(val_loader.dataset), val_loader.batch_size, val_loader.drop_last, rank, world)
+        kw = dict(num_workers=val_loader.num_workers, collate_fn=val_loader.collate_fn, pin_memory=val_loader.pin_memory,
+                  worker_init_fn=val_loader.worker_init_fn, timeout=val_loader.timeout)
+        if val_loader.num_workers > 0:
+            kw.update(prefetch_factor=val_loader.prefetch_factor, persistent_workers=False)
+        mine = DataLoader(val_loader.dataset, batch_sampler=bs, **kw)
+        for (i, a, _), batch in zip(bs.plan, mine):
+            yield i, a, batch
+        return
+    cursor = 0
+    for i, batch in enumerate(val_loader):
+        count = batch[0].size(0)
+        if world == 1 or i % world == rank:
+            yield i, cursor, batch
+        cursor += count
+
+
 def _flip_test_forward(config, model, val_dataset, input, meta):
     """Second forward on the mirrored input (reference function.py:213-236); returns the flipped output."""
     if config.MODEL.CONDITIONAL_TOPDOWN:
@@ -203,18 +243,14 @@ def validate(config, val_loader, val_dataset, model, criterion, output_dir, tb_l
     filled = np.zeros(num_samples, dtype=bool)
     image_path = [None] * num_samples if world > 1 else []
     filenames, imgnums = [], []
-    cursor = 0
     last = len(val_loader) - 1
     conditional = bool(config.MODEL.CONDITIONAL_TOPDOWN)
 
     with torch.no_grad():
         tick = time.time()
-        for i, (input, target, target_weight, meta) in enumerate(val_loader):
+        for i, row0, (input, target, target_weight, meta) in _rank_batches(val_loader, rank, world):
             count = input.size(0)
-            rows = slice(cursor, cursor + count)
-            cursor += count
-            if world > 1 and i % world != rank:
-                continue                      # another rank's batch
+            rows = slice(row0, row0 + count)
             input = (input if conditional else input[:, :3]).cuda(non_blocking=True)
             out = model(input)
             output = out[-1] if isinstance(out, list) else out

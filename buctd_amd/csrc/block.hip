@@ -45,7 +45,14 @@ extern "C" int buctd_basic_block_bwd(const buctd_basic_block* b, const buctd_bas
   const float *mean1 = b->stat, *invstd1 = b->stat + C, *mean2 = b->stat + 2 * C, *invstd2 = b->stat + 3 * C;
   hipStream_t main_s = (hipStream_t)stream, side_s = side_stream ? (hipStream_t)side_stream : main_s;
   // weight gradients run on the side stream behind the kernel that produced their dY operand
-  static thread_local hipEvent_t ev = nullptr;
+  // one cached event per host thread AND device (an event belongs to the device it was created on)
+  static thread_local hipEvent_t evs[16] = {nullptr};
+  int devid = 0;
+  if (side_s != main_s && (hipGetDevice(&devid) != hipSuccess || devid < 0 || devid >= 16)) {
+    buctd_set_error("buctd_basic_block_bwd: cannot identify the current device");
+    return BUCTD_ELAUNCH;
+  }
+  hipEvent_t& ev = evs[devid];
   auto fork = [&]() -> int {
     if (side_s == main_s) return BUCTD_OK;
     if (!ev && hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) {

@@ -177,14 +177,18 @@ class DeviceSamplePipeline:
         check(lib().buctd_warp_affine_norm(ptr(table), B, H, W, mean, std, ptr(x), x.stride(0), ptr(crop), stream_ptr()),
               "warp_affine_norm")
         # Gaussian targets: the heat-map centre mu = int(j / stride + 0.5) is evaluated here in float64 exactly like the
-        # reference (JointsDataset.py:417-418); the kernel is handed mu * stride, which it maps back to the same mu
+        # reference (JointsDataset.py:417-418).  The kernel recomputes (int)(v / stride + 0.5f), truncating toward zero as
+        # well, so it is handed a v that maps back to the same mu: mu * stride for mu >= 0 and (mu - 1) * stride for mu < 0
+        # (v / stride + 0.5 = mu - 0.5 truncates to mu; mu * stride would give mu + 0.5 -> mu + 1 for negative centres:
+        # visible joints left of / above the crop would get a shifted Gaussian and a shifted target_weight cut-off)
         stride = self.image_size / self.heatmap_size
         jt = np.zeros((B, K, 3), dtype=np.float32)
         vis = np.zeros((B, K), dtype=np.float32)
         for b, g in enumerate(geos):
             mu_x = (g["joints"][:, 0] / stride[0] + 0.5).astype(int)
             mu_y = (g["joints"][:, 1] / stride[1] + 0.5).astype(int)
-            jt[b, :, 0], jt[b, :, 1] = mu_x * stride[0], mu_y * stride[1]
+            jt[b, :, 0] = np.where(mu_x < 0, mu_x - 1, mu_x) * stride[0]
+            jt[b, :, 1] = np.where(mu_y < 0, mu_y - 1, mu_y) * stride[1]
             vis[b] = g["joints_vis"][:, 0]
         target, weight = ops.gaussian_target(torch.from_numpy(jt).to(dev), torch.from_numpy(vis).to(dev),
                                              self.heatmap_size, self.image_size, self.sigma)

@@ -259,6 +259,7 @@ class DataParallel(torch.nn.Module):
     # -- gradient exchange -----------------------------------------------------------------
     def _start_step(self):
         self._handles = []
+        self._dirty = False
         nb = len(self.buckets.buckets)
         self._ready = [set() for _ in range(nb)]       # parameter ids whose gradient is final, per bucket
         self._streams = [dict() for _ in range(nb)]    # streams that produced gradient work of the bucket
@@ -319,8 +320,16 @@ class DataParallel(torch.nn.Module):
         if not self._pending:
             self._start_step()
         if self._dirty:
+            # buckets already summed over the ranks cannot be summed again: drain what is in flight, reset the step state
+            # (so that the next step starts clean instead of failing for ever) and tell the caller
+            for h in self._handles:
+                h.wait()
+            if self._comm_stream is not None:
+                torch.cuda.current_stream().wait_stream(self._comm_stream)
+            self._handles, self._pending, self._dirty = [], False, False
             raise RuntimeError("engine.DataParallel: a parameter received a second gradient after its bucket was "
-                               "counted (shared weights / gradient accumulation need overlap=False)")
+                               "counted (shared weights / gradient accumulation need overlap=False); this step's "
+                               "gradients are not usable")
         if self.flat.flat.is_cuda:
             ops.wait_side_stream()          # buckets launched here see every gradient kernel enqueued so far
         for i in range(len(self.buckets.buckets)):

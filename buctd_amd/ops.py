@@ -415,6 +415,11 @@ def conv_wgrad_planes(xp, dyp, out, accumulate=0):
 
 
 _NATIVE_BLOCK = os.environ.get("BUCTD_NATIVE_BLOCK", "1") == "1"
+# experiment switches, read ONCE at import (the hot path consults module constants, never the environment)
+_FUSE_BN_IN = os.environ.get("BUCTD_FUSE_BN_IN", "1") == "1"
+_FC_O_X6 = os.environ.get("BUCTD_FC_O_X6", "1") != "0"
+_MHA_X6 = os.environ.get("BUCTD_MHA_X6", "1") != "0"
+_ATTN_X6 = os.environ.get("BUCTD_ATTN_X6", "1") != "0"
 # optional veto: callable(x_shape) -> True sends a BasicBlock through the step-by-step path (bench.py brackets every launch
 # of its roofline shape with HIP events, which it can only do from the host mirror)
 native_block_veto = {"fn": None}
@@ -423,7 +428,7 @@ native_block_veto = {"fn": None}
 def bn_in_fusable(x_shape, w):
     """True when a 3x3/s1/p1 convolution of this shape can apply its producer's BatchNorm(+ReLU) while staging its
     input (bf16x6 kernel): conv_fwd(..., in_bn=...) and conv_wgrad(..., x_bn=...)."""
-    if _conv_math["mode"] != "bf16x6" or os.environ.get("BUCTD_FUSE_BN_IN", "1") != "1":
+    if _conv_math["mode"] != "bf16x6" or not _FUSE_BN_IN:
         return False
     ws = _wshape(w)
     if ws[2] != 3 or ws[3] != 3:
@@ -448,7 +453,8 @@ def conv_fwd(x, w, bias=None, stride=1, pad=0, scale=None, shift=None, residual=
     y = torch.empty((d.N, d.Ho, d.Wo, d.Co), dtype=torch.float32, device=x.device)
     part = None
     info = None
-    if stats and scale is None and residual is None and not relu and lib().buctd_conv2d_fwd_thin(C.byref(d)) == 1:
+    if stats and scale is None and residual is None and not relu and \
+            _memo(("thin", d.N, d.H, d.W, d.Ci, d.Co, d.R, d.S, d.stride, d.pad), lambda: lib().buctd_conv2d_fwd_thin(C.byref(d)) == 1):
         # <= 4 output channels at full resolution (preNet 7x7): the thin kernel has no fused epilogue; the BatchNorm
         # partials of its 3-channel result are one cheap extra pass
         check(lib().buctd_conv2d_fwd(C.byref(d), ptr(x), ptr(w), ptr(bias), None, None, None, 0, ptr(y), None, stream_ptr()),
@@ -739,7 +745,7 @@ def _x6_weight_image(w, V, K, transposed):
 
 def fc_o_x6_ok(T, rows):
     """the bf16x6 GEMM pays once the product is large (its images are padded to 128 x 192 x 128 tiles)"""
-    return _conv_math["mode"] == "bf16x6" and T >= 512 and rows >= 192 and os.environ.get("BUCTD_FC_O_X6", "1") != "0"
+    return _conv_math["mode"] == "bf16x6" and T >= 512 and rows >= 192 and _FC_O_X6
 
 
 def bn_finalize(part, info, rows, Cn, eps, momentum, running_mean, running_var):
@@ -1464,7 +1470,7 @@ def mha_fwd(qk, v, scale=None):
     out = torch.empty((B, T, d), dtype=torch.float32, device=qk.device)
     kptr = C.c_void_p(qk.data_ptr() + 4 * d)
     # default math mode: both products in bf16x6 (fp32 class on the bf16 matrix cores); fp32 mode: exact fp32 MFMA
-    fn = lib().buctd_mha_fwd_bf16x6 if (_conv_math["mode"] == "bf16x6" and os.environ.get("BUCTD_MHA_X6", "1") != "0") \
+    fn = lib().buctd_mha_fwd_bf16x6 if (_conv_math["mode"] == "bf16x6" and _MHA_X6) \
         else lib().buctd_mha_fwd
     check(fn(B, T, d, ptr(qk), kptr, ptr(v), two_d, v.shape[2],
              (1.0 / math.sqrt(d)) if scale is None else float(scale), ptr(out), None, stream_ptr()), "mha_fwd")
@@ -1515,7 +1521,7 @@ class SmallQKAttention(torch.autograd.Function):
         # contractions over T and C on the bf16 matrix cores: two pieces per operand in the bf16x3 mode, three (fp32
         # class) in the default bf16x6 mode, the exact fp32 MFMA kernels in the fp32 mode
         b3 = {"bf16x3": 1, "bf16x6": 2}.get(_conv_math["mode"], 0)
-        if os.environ.get("BUCTD_ATTN_X6", "1") == "0" and b3 == 2:
+        if not _ATTN_X6 and b3 == 2:
             b3 = 0
         check(lib().buctd_attn_smallqk_fwd(B, T, R4, Cn, ptr(qp), ptr(kp), ptr(v), scale, p_eff, seed, b3, ptr(out), ptr(m),
                                            ptr(linv), stream_ptr()), "attn_smallqk_fwd")

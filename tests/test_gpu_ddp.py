@@ -118,3 +118,20 @@ def test_validate_is_sharded_over_ranks(tmp_path):
     assert list(a["paths"]) == list(b["paths"])
     perfs = [float(l.split()[2]) for l in log.splitlines() if l.startswith("PERF")]
     assert len(perfs) == 2 and perfs[0] == perfs[1], "perf_indicator is broadcast to every rank"
+
+
+def test_bench_launches_its_own_ranks(tmp_path):
+    """`python bench.py --gpus 2` (how the driver calls it) starts its two ranks itself and prints ONE JSON line from rank 0
+    with n_gpus = 2, the max-over-ranks step time and the exposed gradient-exchange time.  On a 1-GPU box both ranks sit on
+    GPU 0 over gloo (BUCTD_SINGLE_DEVICE / BUCTD_DIST_BACKEND are test hooks of engine.init_distributed)."""
+    import json
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                        "--workload", "train_c2", "--batch", "4", "--no-kernel-timer"],
+                       env=_env(BUCTD_DIST_BACKEND="gloo", BUCTD_SINGLE_DEVICE="1"), capture_output=True, text=True,
+                       timeout=900)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-2500:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 2 and out["scaling"] == "weak" and out["value"] > 0
+    assert out["config"]["global_batch"] == 8 and out["allreduce_exposed_ms_per_step"] >= 0

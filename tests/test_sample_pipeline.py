@@ -143,6 +143,38 @@ def test_device_pipeline_matches_oracle(dev, colored):
 
 
 @pytest.mark.gpu
+def test_targets_of_visible_joints_outside_the_crop(dev):
+    """Visible joints that land left of / above the crop (negative heat-map centres, JointsDataset.py:417-430): the Gaussian
+    and the target_weight cut-off (br < 0) must sit where generate_target puts them - int() truncates toward zero, so
+    mu = -1 comes from j / stride + 0.5 in (-2, -1]."""
+    from oracle import core as oc, sample as S
+    from buctd_amd.dataset.pipeline import DeviceSamplePipeline
+    cfg = _cfg(True)
+    pipe = DeviceSamplePipeline(cfg, oc.CROWDPOSE_FLIP_PAIRS, range(8), oc.CROWDPOSE_KPT_COLORS, MEAN, STD, is_train=True)
+    recs = _records(3, 23)
+    for r in recs:
+        # push joints outside the box the crop is taken from: crop x in about [-40, -1] and y likewise
+        c, s = r["center"], r["scale"] * 200.0
+        x0, y0 = c[0] - s[0] / 2, c[1] - s[1] / 2
+        for k, (fx, fy) in enumerate([(-0.02, 0.3), (-0.09, 0.5), (-0.16, 0.7), (-0.25, 0.2), (-0.40, 0.5), (0.4, -0.03),
+                                      (0.6, -0.11), (0.5, -0.19), (-0.05, -0.05), (-0.21, -0.3)]):
+            r["joints_3d"][k, 0], r["joints_3d"][k, 1] = x0 + fx * s[0], y0 + fy * s[1]
+            r["joints_3d_vis"][k, :2] = 1
+    augs = [(r["center"], r["scale"], 0.0, False) for r in recs]
+    dev_recs = [dict(r, image=torch.from_numpy(r["image_np"]).to(dev)) for r in recs]
+    x, target, weight, meta = pipe(dev_recs, augs)
+    neg = 0
+    for i, (r, a) in enumerate(zip(recs, augs)):
+        xo, to, wo, jo, cjo, cropo = S.make_sample(r["image_np"], r["joints_3d"], r["joints_3d_vis"], r["cond_joints"],
+                                                   r["cond_joints_vis"], a[0], a[1], a[2], a[3], [64, 96], [16, 24], 2,
+                                                   oc.CROWDPOSE_FLIP_PAIRS, MEAN, STD, oc.CROWDPOSE_KPT_COLORS[:14], mono=False)
+        neg += int(((jo[:10, 0] / 4 + 0.5).astype(int) < 0).sum() + ((jo[:10, 1] / 4 + 0.5).astype(int) < 0).sum())
+        assert np.array_equal(weight[i].cpu().numpy(), wo), f"sample {i}: target_weight differs"
+        assert np.abs(target[i].cpu().numpy() - to).max() <= 2e-7, f"sample {i}: target differs"
+    assert neg >= 8, "the fixture is meant to produce negative heat-map centres"
+
+
+@pytest.mark.gpu
 def test_iterative_refinement_matches_oracle_loop(dev):
     """3 chained passes of a conditional model: prediction -> box / condition -> new crop -> prediction (f3)."""
     from oracle import core as oc, recipes, sample as S
