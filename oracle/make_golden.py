@@ -315,6 +315,115 @@ def pose_synthesis_case(runs=1500):
     np.savez_compressed(os.path.join(OUT, "pose_synthesis.npz"), **rec)
 
 
+def entry_batches(cfg, n_batches, batch, k=14, seed0=500, cond_channels=3):
+    """The in-memory loader of the entry-point goldens: (input, target, target_weight, meta) batches, fully seeded -
+    tests/test_gpu_entry.py rebuilds the same batches from the same seeds."""
+    from oracle import recipes
+    out = []
+    for i in range(n_batches):
+        x, joints = recipes.make_inputs(cfg, batch, seed0 + i, cond_channels)
+        tgt, wt = recipes.make_targets(cfg, joints, seed0 + 100 + i)
+        g = torch.Generator().manual_seed(seed0 + 200 + i)
+        meta = {"center": torch.rand(batch, 2, generator=g) * 100 + 50, "scale": torch.rand(batch, 2, generator=g) + 0.5,
+                "score": torch.rand(batch, generator=g), "annotation_id": torch.arange(batch) + i * batch,
+                "image": [f"img_{i}_{j}.jpg" for j in range(batch)],
+                "cond_joints": torch.cat([joints, torch.zeros(batch, k, 1)], 2),
+                "cond_joints_vis": torch.ones(batch, k, 3)}
+        out.append((x, tgt, wt, meta))
+    return out
+
+
+def entry_case():
+    """The reference's OWN entry points, lib/core/function.py:train (102-175) and validate (178-336), imported and run on
+    the CPU (stubs: torchvision / cv2 / .cuda(); utils.vis - visualisation, out of scope - replaced by a no-op module;
+    the fake dataset's get_condition_image_colored is the oracle's restatement of the cv2 blur).  Their
+    outputs - per-iteration losses and accuracies, parameter / buffer checksums after three Adam steps, all_preds,
+    all_boxes, image paths, the validation meters - become tests/golden/entry.npz."""
+    vis = types.ModuleType("utils.vis")
+    vis.save_debug_images = lambda *a, **k: None
+    sys.modules["utils.vis"] = vis
+    import core.function as rf          # the reference module
+    from core.loss import JointsMSELoss as RefLoss
+    from oracle import recipes, core as oc
+    from oracle.cfg import Cfg
+
+    class Writer:
+        def __init__(self):
+            self.scalars = []
+
+        def add_scalar(self, k, v, s):
+            self.scalars.append((k, float(v), s))
+
+        def add_scalars(self, k, d, s):
+            self.scalars.append((k, dict(d), s))
+
+    class Dataset:
+        def __init__(self, n, image_size):
+            self.n, self.image_size = n, np.array(image_size)
+            self.flip_pairs, self.kpt_colors = oc.CROWDPOSE_FLIP_PAIRS, oc.CROWDPOSE_KPT_COLORS
+            self.captured = None
+
+        def __len__(self):
+            return self.n
+
+        def get_condition_image_colored(self, kpts, size, colors):
+            return oc.get_condition_image_colored(kpts, size, colors)
+
+        def evaluate(self, cfg, preds, output_dir, all_boxes, img_path, *a, **k):
+            self.captured = (preds.copy(), all_boxes.copy(), list(img_path))
+            return {"AP": 0.5, "AP .5": 0.75}, 0.5
+
+    rec = {}
+    # ---- train(): 3 iterations, Adam lr 1e-3, dropout 0 --------------------------------------------------------------
+    cfg, omodel, _, _ = recipes.build("coam_w16_96x64_colored")
+    cfg.PRINT_FREQ = 1
+    rmodel = ref_model_for("coam", cfg)
+    rmodel.load_state_dict(omodel.state_dict(), strict=True)
+    recipes.set_dropout(rmodel, 0.0)
+    loader = entry_batches(cfg, 3, 2)
+    opt = torch.optim.Adam(rmodel.parameters(), lr=1e-3)
+    wd = {"writer": Writer(), "train_global_steps": 0}
+    rf.train(cfg, loader, rmodel, RefLoss(True), opt, 1, "/tmp", "/tmp", wd)
+    assert wd["train_global_steps"] == 3
+    rec["train_loss"] = np.array([v for k, v, _ in wd["writer"].scalars if k == "train_loss"])
+    rec["train_acc"] = np.array([v for k, v, _ in wd["writer"].scalars if k == "train_acc"])
+    sd = rmodel.state_dict()
+    names = [k for k, _ in rmodel.named_parameters()]
+    rec["param_names"] = np.array(names)
+    rec["param_sums"] = np.array([sd[k].double().sum().item() for k in names])
+    rec["param_norms"] = np.array([sd[k].double().norm().item() for k in names])
+    for k in ("final_layer.weight", "conv1.weight"):
+        rec["param::" + k] = sd[k].numpy()
+    bnames = sorted(k for k in sd if k.endswith("running_mean") or k.endswith("running_var"))
+    rec["buf_names"] = np.array(bnames)
+    rec["buf_norms"] = np.array([sd[k].double().norm().item() for k in bnames])
+    rec["num_batches_tracked"] = np.int64(int(sd["bn1.num_batches_tracked"]))
+    rec["state_sha_before"] = np.array(state_digest(omodel))
+    print(f"  entry: reference train() 3 iterations, losses {rec['train_loss']}, acc {rec['train_acc']}")
+    # ---- validate(): flip test off / on, colored and mono condition -----------------------------------------------------
+    for tag, recipe, flip in (("val_colored", "coam_w16_96x64_colored", False), ("val_colored_flip", "coam_w16_96x64_colored", True),
+                              ("val_mono_flip", "coam_w16_96x64_mono_default_att", True)):
+        cfg, omodel, _, _ = recipes.build(recipe)
+        cfg.PRINT_FREQ = 1
+        cfg.TEST = Cfg({"FLIP_TEST": flip, "POST_PROCESS": True, "SHIFT_HEATMAP": True})
+        rmodel = ref_model_for("coam", cfg)
+        rmodel.load_state_dict(omodel.state_dict(), strict=True)
+        # mono: the ONE blurred, int-truncated channel replicated x3 (JointsDataset.py:500-516); under FLIP_TEST the
+        # reference re-renders it COLORED (transforms.py:38-47, heatmap.shape[1] == 3) - the goldens pin that behaviour
+        loader = entry_batches(cfg, 2, 2, seed0=700, cond_channels=1 if "mono" in recipe else 3)
+        ds = Dataset(4, [64, 96])
+        wd = {"writer": Writer(), "valid_global_steps": 0}
+        perf = rf.validate(cfg, loader, ds, rmodel, RefLoss(True), "/tmp", "/tmp", wd)
+        assert perf == 0.5 and wd["valid_global_steps"] == 1
+        preds, boxes, paths = ds.captured
+        rec[tag + "_preds"], rec[tag + "_boxes"], rec[tag + "_paths"] = preds, boxes, np.array(paths)
+        rec[tag + "_loss"] = np.float64([v for k, v, _ in wd["writer"].scalars if k == "valid_loss"][0])
+        rec[tag + "_acc"] = np.float64([v for k, v, _ in wd["writer"].scalars if k == "valid_acc"][0])
+        rec[tag + "_x_sha"] = np.array(sha(torch.cat([b[0] for b in loader])))
+        print(f"  entry: reference validate() [{tag}] loss {rec[tag + '_loss']:.6f} acc {rec[tag + '_acc']:.3f}")
+    np.savez_compressed(os.path.join(OUT, "entry.npz"), **rec)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--fast", action="store_true")
@@ -333,6 +442,10 @@ def main():
         target_case()
         nms_case()
         pose_synthesis_case()
+        entry_case()
+    elif args.only == "entry":
+        entry_case()
+        return
     small = ["prenet_w16_96x64", "coam_w16_96x64_colored", "coam_w16_96x64_mono_default_att",
              "coam_w16_96x64_stacked_2heads", "coam_w16_96x64_channel_only", "transpose_w16_96x64", "resnet18_96x64"]
     full = ["coam_w48_384x288", "prenet_w32_256x192", "resnet50_256x192", "prenet_w48_384x288", "transpose_a6_256x192"]

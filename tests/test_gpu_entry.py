@@ -162,3 +162,93 @@ def test_validate_entry_point_matches_oracle_loop(dev, flip):
         assert np.allclose(boxes[idx:idx + n, 4], np.prod(meta["scale"].numpy() * 200, 1))
         assert np.allclose(boxes[idx:idx + n, 6], meta["annotation_id"].numpy())
         idx += n
+
+
+# ---- against the REFERENCE's own entry points (tests/golden/entry.npz, written by oracle/make_golden.py:entry_case, which
+# ---- imports and runs lib/core/function.py:train / validate of the reference on the same seeded batches) -----------------
+def _golden_entry():
+    import os
+    return np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "entry.npz"))
+
+
+def test_train_entry_point_matches_reference_train(dev):
+    from oracle import recipes
+    from oracle.make_golden import entry_batches, state_digest
+    from buctd_amd import models, engine
+    from buctd_amd.core.function import train
+    from buctd_amd.core.loss import JointsMSELoss
+    gold = _golden_entry()
+    cfg = _cfg_for(True, False)
+    ocfg, omodel, _, _ = recipes.build("coam_w16_96x64_colored")
+    assert state_digest(omodel) == str(gold["state_sha_before"]), "the golden was made from another initial state"
+    net = models.pose_hrnet_coam.get_pose_net(cfg, is_train=False)
+    net.load_state_dict(omodel.state_dict(), strict=True)
+    model = engine.DataParallel(net).cuda()
+    optimizer = engine.get_optimizer(cfg, model)
+    recipes.set_dropout(model, 0.0)
+    loader = entry_batches(ocfg, 3, 2)
+    wd = {"writer": Writer(), "train_global_steps": 0}
+    train(cfg, loader, model, JointsMSELoss(True).cuda(), optimizer, 1, "/tmp", "/tmp", wd)
+    losses = np.array([v for k, v, _ in wd["writer"].scalars if k == "train_loss"])
+    accs = np.array([v for k, v, _ in wd["writer"].scalars if k == "train_acc"])
+    ref = gold["train_loss"]
+    assert abs(losses[0] - ref[0]) <= 1e-4 * abs(ref[0]), (losses, ref)
+    # Adam's first updates are sign-like (m / sqrt(v) ~ +-1): round-off level gradient noise moves weights by lr, so the
+    # trajectories agree to a few percent after the first step, not to round-off (same bar as the oracle-loop test)
+    assert np.all(np.abs(losses[1:] - ref[1:]) <= 5e-2 * np.abs(ref[1:])), (losses, ref)
+    assert np.array_equal(accs, gold["train_acc"])
+    sd = model.module.state_dict()
+    assert int(sd["bn1.num_batches_tracked"]) == int(gold["num_batches_tracked"]) == 3
+    assert [k for k, _ in model.module.named_parameters()] == list(gold["param_names"])
+    for k in ("final_layer.weight", "conv1.weight"):
+        assert float((sd[k].cpu() - torch.from_numpy(gold["param::" + k])).abs().max()) <= 6.5e-3, k
+    norms = np.array([float(sd[k].double().norm()) for k in gold["param_names"]])
+    # every weight moves by at most ~lr per step: ||w - w_ref|| <= 6 lr sqrt(numel)
+    numel = np.array([sd[k].numel() for k in gold["param_names"]])
+    assert np.all(np.abs(norms - gold["param_norms"]) <= 6.5e-3 * np.sqrt(numel) + 1e-6)
+    bn = np.array([float(sd[k].double().norm()) for k in gold["buf_names"]])
+    assert np.all(np.abs(bn - gold["buf_norms"]) <= 0.1 * np.maximum(1.0, gold["buf_norms"]))
+
+
+@pytest.mark.parametrize("tag", ["val_colored", "val_colored_flip", "val_mono_flip"])
+def test_validate_entry_point_matches_reference_validate(dev, tag):
+    """all_preds / all_boxes / image paths / meters of the reference's validate(): flip test off and on, colored condition
+    and the mono condition (whose flipped twin the reference re-renders COLORED, transforms.py:38-47)."""
+    from oracle import recipes, core as oc
+    from oracle.make_golden import entry_batches, sha
+    from buctd_amd import models
+    from buctd_amd.core.function import validate
+    from buctd_amd.core.loss import JointsMSELoss
+    gold = _golden_entry()
+    mono = "mono" in tag
+    recipe = "coam_w16_96x64_mono_default_att" if mono else "coam_w16_96x64_colored"
+    ocfg, omodel, _, _ = recipes.build(recipe)
+    cfg = _cfg_for(False, tag.endswith("flip"))
+    if mono:
+        from buctd_amd.config import hrnet_extra
+        cfg.defrost()
+        cfg.MODEL.ATT_MODULES = [False, False, True, True]
+        cfg.MODEL.EXTRA = hrnet_extra(16, use_attention=True, modules=(1, 1, 1))
+        cfg.DATASET.COLORED = False
+        cfg.freeze()
+    net = models.pose_hrnet_coam.get_pose_net(cfg, is_train=False)
+    net.load_state_dict(omodel.state_dict(), strict=True)
+    net = net.cuda()
+    loader = entry_batches(ocfg, 2, 2, seed0=700, cond_channels=1 if mono else 3)
+    assert sha(torch.cat([b[0] for b in loader])) == str(gold[tag + "_x_sha"]), "the golden was made from other inputs"
+    ds = FakeDataset(4, [64, 96], oc.CROWDPOSE_FLIP_PAIRS, oc.CROWDPOSE_KPT_COLORS)
+    wd = {"writer": Writer(), "valid_global_steps": 0}
+    perf = validate(cfg, loader, ds, net, JointsMSELoss(True).cuda(), "/tmp", "/tmp", wd)
+    assert perf == 0.5 and wd["valid_global_steps"] == 1
+    preds, boxes, paths = ds.captured
+    assert paths == list(gold[tag + "_paths"])
+    assert np.allclose(boxes, gold[tag + "_boxes"], rtol=1e-6, atol=1e-6)
+    rp = gold[tag + "_preds"]
+    # final coordinates are image pixels (~ 200 * scale / 16 per heat-map pixel): identical arg-max, quarter-pixel
+    # refinement decided by heat-map differences that are far from zero
+    assert np.abs(preds[:, :, :2] - rp[:, :, :2]).max() <= 1e-2, "final preds differ from the reference's"
+    assert np.abs(preds[:, :, 2] - rp[:, :, 2]).max() <= 1e-3 * max(1.0, np.abs(rp[:, :, 2]).max())
+    vl = [v for k, v, _ in wd["writer"].scalars if k == "valid_loss"][0]
+    va = [v for k, v, _ in wd["writer"].scalars if k == "valid_acc"][0]
+    assert abs(vl - float(gold[tag + "_loss"])) <= 1e-4 * float(gold[tag + "_loss"])
+    assert va == float(gold[tag + "_acc"])
