@@ -22,13 +22,23 @@ extern "C" int buctd_basic_block_fwd_train(const buctd_basic_block* b, void* str
   int* cnt1 = b->counts;
   int* cnt2 = b->counts + b->ngroups;
   float *mean1 = b->stat, *invstd1 = b->stat + C, *mean2 = b->stat + 2 * C, *invstd2 = b->stat + 3 * C;
-  BLK_TRY(buctd_conv3x3_bf16x6(N, H, W, C, C, b->x, b->w1_fwd, nullptr, nullptr, nullptr, nullptr, 0, b->z1, part1, cnt1,
-                               stream));
+  const bool planes = b->xp && b->y1p;
+  BUCTD_CHECK_ARG((b->xp == nullptr) == (b->y1p == nullptr), "buctd_basic_block_fwd_train: xp and y1p go together");
+  if (planes)     // conv1 also writes the split x it staged: the X operand of its weight gradient
+    BLK_TRY(buctd_conv3x3_bf16x6_emit(N, H, W, C, C, b->x, b->w1_fwd, b->z1, part1, cnt1, nullptr, nullptr, nullptr, nullptr, 0,
+                                      b->xp, stream));
+  else
+    BLK_TRY(buctd_conv3x3_bf16x6(N, H, W, C, C, b->x, b->w1_fwd, nullptr, nullptr, nullptr, nullptr, 0, b->z1, part1, cnt1,
+                                 stream));
   BLK_TRY(buctd_bn_finalize(part1, cnt1, b->ngroups, b->rows_per_group, rows, C, b->eps1, b->momentum1, mean1, invstd1,
                             b->running_mean1, b->running_var1, stream));
   // conv2 applies bn1 + ReLU while it stages its input: relu(bn1(z1)) never exists in memory
-  BLK_TRY(buctd_conv3x3_bf16x6_bnin(N, H, W, C, C, b->z1, b->w2_fwd, nullptr, nullptr, nullptr, nullptr, 0, b->z2, part2,
-                                    cnt2, mean1, invstd1, b->gamma1, b->beta1, 1, stream));
+  if (planes)     // ... and here y1 = relu(bn1(z1)) reaches memory after all - as planes, for conv2's weight gradient
+    BLK_TRY(buctd_conv3x3_bf16x6_emit(N, H, W, C, C, b->z1, b->w2_fwd, b->z2, part2, cnt2, mean1, invstd1, b->gamma1, b->beta1, 1,
+                                      b->y1p, stream));
+  else
+    BLK_TRY(buctd_conv3x3_bf16x6_bnin(N, H, W, C, C, b->z1, b->w2_fwd, nullptr, nullptr, nullptr, nullptr, 0, b->z2, part2,
+                                      cnt2, mean1, invstd1, b->gamma1, b->beta1, 1, stream));
   BLK_TRY(buctd_bn_finalize(part2, cnt2, b->ngroups, b->rows_per_group, rows, C, b->eps2, b->momentum2, mean2, invstd2,
                             b->running_mean2, b->running_var2, stream));
   BLK_TRY(buctd_bn_apply(b->z2, mean2, invstd2, b->gamma2, b->beta2, b->x, 1, b->y, rows, C, stream));
@@ -37,9 +47,11 @@ extern "C" int buctd_basic_block_fwd_train(const buctd_basic_block* b, void* str
 
 extern "C" int buctd_basic_block_bwd(const buctd_basic_block* b, const buctd_basic_block_grads* g, void* stream,
                                      void* side_stream) {
-  BUCTD_CHECK_ARG(b && g && b->x && b->w1_bwd && b->w2_bwd && b->z1 && b->z2 && b->y && b->stat && g->dy && g->dz2 && g->dres &&
-                      g->dy1 && g->dz1 && g->dw1 && g->dw2 && g->bn_ws && g->wg_ws,
+  BUCTD_CHECK_ARG(b && g && b->x && b->w1_bwd && b->w2_bwd && b->z1 && b->z2 && b->y && b->stat && g->dy && g->dres &&
+                      g->dy1 && g->dw1 && g->dw2 && g->bn_ws && g->wg_ws,
                   "buctd_basic_block_bwd: null pointer");
+  const bool planes = b->xp && b->y1p && g->dz2p && g->dz1p;
+  BUCTD_CHECK_ARG(planes || (g->dz2 && g->dz1), "buctd_basic_block_bwd: dz2 / dz1 scratch missing");
   const int N = b->N, H = b->H, W = b->W, C = b->C;
   const long rows = (long)N * H * W;
   const float *mean1 = b->stat, *invstd1 = b->stat + C, *mean2 = b->stat + 2 * C, *invstd2 = b->stat + 3 * C;
@@ -65,6 +77,24 @@ extern "C" int buctd_basic_block_bwd(const buctd_basic_block* b, const buctd_bas
     }
     return BUCTD_OK;
   };
+  if (planes) {
+    // planes mode: the BatchNorm backward writes dz pre-split (its only consumers are the two bf16x6 kernels), the weight
+    // gradients stage both operands by LDS-DMA, the data gradients with plain copies
+    BLK_TRY(buctd_bn_bwd_p(g->dy, b->y, b->z2, mean2, invstd2, b->gamma2, nullptr, 1, N, H, W, C, g->dz2p, g->dres, g->dgamma2,
+                           g->dbeta2, g->acc_bn2, g->bn_ws, g->bn_ws_bytes, stream));
+    BLK_TRY(fork());
+    BLK_TRY(buctd_conv3x3_wgrad_bf16x6_p(N, H, W, C, C, b->y1p, g->dz2p, g->dw2, g->acc_w2, g->wg_ws, g->wg_ws_bytes, side_s));
+    BLK_TRY(buctd_conv3x3_bf16x6_p(N, H, W, C, C, g->dz2p, b->w2_bwd, nullptr, nullptr, nullptr, nullptr, 0, g->dy1, nullptr,
+                                   nullptr, stream));
+    BLK_TRY(buctd_bn_bwd_p(g->dy1, nullptr, b->z1, mean1, invstd1, b->gamma1, b->beta1, 1, N, H, W, C, g->dz1p, nullptr,
+                           g->dgamma1, g->dbeta1, g->acc_bn1, g->bn_ws, g->bn_ws_bytes, stream));
+    BLK_TRY(fork());
+    BLK_TRY(buctd_conv3x3_wgrad_bf16x6_p(N, H, W, C, C, b->xp, g->dz1p, g->dw1, g->acc_w1, g->wg_ws, g->wg_ws_bytes, side_s));
+    if (g->dx)
+      BLK_TRY(buctd_conv3x3_bf16x6_p(N, H, W, C, C, g->dz1p, b->w1_bwd, nullptr, nullptr, nullptr, g->dres, 0, g->dx, nullptr,
+                                     nullptr, stream));
+    return BUCTD_OK;
+  }
   // conv2 / bn2 (+ skip): dres = masked upstream gradient
   BLK_TRY(buctd_bn_bwd(g->dy, b->y, b->z2, mean2, invstd2, b->gamma2, nullptr, 1, rows, C, g->dz2, g->dres, g->dgamma2,
                        g->dbeta2, g->acc_bn2, g->bn_ws, g->bn_ws_bytes, stream));

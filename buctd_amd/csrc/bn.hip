@@ -431,6 +431,12 @@ extern "C" int buctd_bn_apply(const float* z, const float* mean, const float* in
   return BUCTD_OK;
 }
 
+__global__ void bn_bwd_reduce2_kernel(const float* __restrict__ dy, const float* __restrict__ y, const float* __restrict__ z,
+                                      const float* __restrict__ mean, const float* __restrict__ invstd,
+                                      const float* __restrict__ gamma, const float* __restrict__ beta, int relu, long rows,
+                                      int C, long rows_per_block, float* __restrict__ part);
+static long bwd2_blocks(long rows, long* rows_per_block);
+
 extern "C" size_t buctd_bn_bwd_workspace(long rows, int C) {
   const long nchunks = (rows + BWD_ROWS - 1) / BWD_ROWS;
   return (size_t)(nchunks * 2 * C + 2 * C) * sizeof(float);
@@ -448,13 +454,17 @@ extern "C" int buctd_bn_bwd(const float* dy, const float* y, const float* z, con
     return BUCTD_EWORKSPACE;
   }
   hipStream_t st = (hipStream_t)stream;
-  const int nchunks = ceil_div(rows, BWD_ROWS);
+  int nchunks = ceil_div(rows, BWD_ROWS);
   float* part = (float*)workspace;
   float* s = part + (long)nchunks * 2 * C;
-  if (C % 4 == 0 && C / 4 <= 256)
-    hipLaunchKernelGGL(bn_bwd_reduce_vec_kernel, dim3(nchunks), dim3(256), 0, st, dy, y, z, mean, invstd, gamma, beta, relu,
-                       rows, C, part);
-  else
+  if (C % 4 == 0 && C / 4 <= 256) {
+    // the fixed-grid reduction (see bn_bwd_reduce2_kernel below): at most 1024 partials, never more than rows / 64
+    long rpb;
+    const long nb = bwd2_blocks(rows, &rpb);
+    hipLaunchKernelGGL(bn_bwd_reduce2_kernel, dim3((unsigned)nb), dim3(256), 0, st, dy, y, z, mean, invstd, gamma, beta, relu,
+                       rows, C, rpb, part);
+    nchunks = (int)nb;
+  } else
     hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(nchunks), dim3(256), 0, st, dy, y, z, mean, invstd, gamma, beta, relu, rows,
                        C, part);
   BUCTD_CHECK_LAUNCH("buctd_bn_bwd(reduce)");
@@ -480,5 +490,222 @@ extern "C" int buctd_bn_fold(const float* gamma, const float* beta, const float*
   hipLaunchKernelGGL(bn_fold_kernel, dim3(ceil_div(C, 256)), dim3(256), 0, (hipStream_t)stream, gamma, beta,
                      running_mean, running_var, eps, C, scale, shift);
   BUCTD_CHECK_LAUNCH("buctd_bn_fold");
+  return BUCTD_OK;
+}
+
+// =====================================================================================================================
+// BatchNorm backward, second generation (used by the BasicBlock sequences of block.hip):
+//   * bn_bwd_reduce2_kernel: a FIXED grid of <= 1024 workgroups, each walking a contiguous range of rows with four
+//     independent 16-byte loads per tensor in flight (the first generation launched one workgroup per 64 rows - 3456 tiny
+//     workgroups for the 96x72 maps, three dependent-latency round trips each: 1.4-2.2 TB/s); the finalize then folds
+//     <= 1024 partials per channel instead of rows / 64;
+//   * bn_bwd_apply_p_kernel: writes dz as x6 PLANES (x6p.h) - the only consumers of dz are the bf16x6 data-gradient and
+//     weight-gradient kernels, which then stage it without splitting it again (6 B/elem written instead of 4).  Only
+//     pixel rows are written: the pad and guard rows of the destination are zero and stay zero (the caller hands a
+//     buffer whose non-pixel rows are zero, e.g. from ops.PlanesPool).
+// Arithmetic of every element is the expression of the first-generation kernels, in the same order.
+#include "x6p.h"
+
+#define BWD2_MAX_BLOCKS 1024
+
+__global__ __launch_bounds__(256) void bn_bwd_reduce2_kernel(const float* __restrict__ dy, const float* __restrict__ y,
+                                                             const float* __restrict__ z, const float* __restrict__ mean,
+                                                             const float* __restrict__ invstd,
+                                                             const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                             int relu, long rows, int C, long rows_per_block,
+                                                             float* __restrict__ part) {
+  __shared__ f32x4 sm[2][256];
+  const int c4n = C >> 2;                 // C % 4 == 0, C / 4 <= 256
+  const int rl = 256 / c4n;
+  const int tc = threadIdx.x % c4n, tr = threadIdx.x / c4n;
+  const long r0 = (long)blockIdx.x * rows_per_block;
+  long r1 = r0 + rows_per_block;
+  if (r1 > rows) r1 = rows;
+  f32x4 s1 = (f32x4){0.f, 0.f, 0.f, 0.f}, s2 = s1;
+  if (tr < rl) {
+    const f32x4 mu = reinterpret_cast<const f32x4*>(mean)[tc];
+    const f32x4 is = reinterpret_cast<const f32x4*>(invstd)[tc];
+    f32x4 sc = is, be = is;
+    const bool rebuild = relu && !y;      // mask recomputed exactly as bn_apply formed its output
+    if (rebuild) {
+      sc = is * reinterpret_cast<const f32x4*>(gamma)[tc];
+      be = reinterpret_cast<const f32x4*>(beta)[tc];
+    }
+    auto body = [&](f32x4 g, f32x4 zz, f32x4 yy) {
+      if (relu) {
+        if (rebuild) yy = (zz - mu) * sc + be;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (!(yy[j] > 0.f)) g[j] = 0.f;
+      }
+      s1 += g;
+      s2 += g * (zz - mu) * is;
+    };
+    long r = r0 + tr;
+    const long step = rl;
+    for (; r + 3 * step < r1; r += 4 * step) {
+      f32x4 g[4], zz[4], yy[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const long o = (r + u * step) * c4n + tc;
+        g[u] = reinterpret_cast<const f32x4*>(dy)[o];
+        zz[u] = reinterpret_cast<const f32x4*>(z)[o];
+        yy[u] = (relu && y) ? reinterpret_cast<const f32x4*>(y)[o] : zz[u];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) body(g[u], zz[u], yy[u]);
+    }
+    for (; r < r1; r += step) {
+      const long o = r * c4n + tc;
+      const f32x4 zz = reinterpret_cast<const f32x4*>(z)[o];
+      body(reinterpret_cast<const f32x4*>(dy)[o], zz, (relu && y) ? reinterpret_cast<const f32x4*>(y)[o] : zz);
+    }
+  }
+  sm[0][threadIdx.x] = s1;
+  sm[1][threadIdx.x] = s2;
+  __syncthreads();
+  if (tr == 0) {
+    for (int k = 1; k < rl; ++k) {
+      s1 += sm[0][k * c4n + tc];
+      s2 += sm[1][k * c4n + tc];
+    }
+    reinterpret_cast<f32x4*>(part + ((long)blockIdx.x * 2 + 0) * C)[tc] = s1;
+    reinterpret_cast<f32x4*>(part + ((long)blockIdx.x * 2 + 1) * C)[tc] = s2;
+  }
+}
+
+struct BnPlanesGeo {
+  int H, W, SW, IB;
+  unsigned w_mul, w_sh, h_mul, h_sh;
+};
+static void bn_magic(unsigned d, unsigned* mul, unsigned* sh) {
+  if (d == 1) { *mul = 0xFFFFFFFFu; *sh = 0; return; }
+  unsigned l = 0;
+  while ((1ull << l) < d) ++l;
+  *mul = (unsigned)(((1ull << (31 + l)) + d - 1) / d);
+  *sh = l - 1;
+}
+
+// thread = (pixel, 8 channels): dz of eight channels -> three 16-byte pieces of the pixel's planes row; dres = masked dy
+__global__ __launch_bounds__(256) void bn_bwd_apply_p_kernel(const float* __restrict__ dy, const float* __restrict__ y,
+                                                             const float* __restrict__ z, const float* __restrict__ mean,
+                                                             const float* __restrict__ invstd,
+                                                             const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                             const float* __restrict__ s, int relu, long rows, int C,
+                                                             float inv_rows, BnPlanesGeo geo,
+                                                             unsigned char* __restrict__ dz_planes,
+                                                             float* __restrict__ dres) {
+  const int c8n = C >> 3;
+  const long items = rows * c8n;
+  const long step = (long)gridDim.x * 256;
+  const int dc = (int)(step % c8n);
+  const long dr = step / c8n;
+  long i = (long)blockIdx.x * 256 + threadIdx.x;
+  long row = i / c8n;
+  int c8 = (int)(i - row * c8n);
+  unsigned char* prow0 = dz_planes + (size_t)X6P_GB * (size_t)(C * 6);
+  for (; i < items; i += step) {
+    const long o = row * C + c8 * 8;
+    float g[8], zz[8];
+    {
+      const f32x4 a = *reinterpret_cast<const f32x4*>(dy + o), b = *reinterpret_cast<const f32x4*>(dy + o + 4);
+      const f32x4 c = *reinterpret_cast<const f32x4*>(z + o), d = *reinterpret_cast<const f32x4*>(z + o + 4);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { g[j] = a[j]; g[4 + j] = b[j]; zz[j] = c[j]; zz[4 + j] = d[j]; }
+    }
+    if (relu) {
+      float yy[8];
+      if (y) {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(y + o), b = *reinterpret_cast<const f32x4*>(y + o + 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { yy[j] = a[j]; yy[4 + j] = b[j]; }
+      } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int c = c8 * 8 + j;
+          const float sc = invstd[c] * gamma[c];
+          yy[j] = (zz[j] - mean[c]) * sc + beta[c];
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        if (!(yy[j] > 0.f)) g[j] = 0.f;
+    }
+    float ov[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int c = c8 * 8 + j;
+      const float is = invstd[c];
+      const float zh = (zz[j] - mean[c]) * is;
+      ov[j] = gamma[c] * is * (g[j] - s[c] * inv_rows - zh * s[C + c] * inv_rows);
+    }
+    // pixel row -> padded position p = n*IB + (y+1)*SW + (x+1)
+    const int q = (int)(__umulhi((unsigned)row, geo.w_mul) >> geo.w_sh);      // row / W = n*H + y
+    const int xx = (int)row - q * geo.W;
+    const int n = (int)(__umulhi((unsigned)q, geo.h_mul) >> geo.h_sh);          // / H
+    const int yy_ = q - n * geo.H;
+    const long pp = (long)n * geo.IB + (long)(yy_ + 1) * geo.SW + xx + 1;
+    x6p_u16x8 h, m, l;
+    x6p_split8(ov, h, m, l);
+    x6p_store8(prow0 + (size_t)pp * (size_t)(C * 6), c8, h, m, l);
+    if (dres) {
+      *reinterpret_cast<f32x4*>(dres + o) = (f32x4){g[0], g[1], g[2], g[3]};
+      *reinterpret_cast<f32x4*>(dres + o + 4) = (f32x4){g[4], g[5], g[6], g[7]};
+    }
+    c8 += dc;
+    row += dr;
+    if (c8 >= c8n) { c8 -= c8n; ++row; }
+  }
+}
+
+static long bwd2_blocks(long rows, long* rows_per_block) {
+  long rpb = (rows + BWD2_MAX_BLOCKS - 1) / BWD2_MAX_BLOCKS;
+  if (rpb < 64) rpb = 64;      // never more partials than the first generation's rows / 64 (its workspace size)
+  *rows_per_block = rpb;
+  return (rows + rpb - 1) / rpb;
+}
+
+extern "C" size_t buctd_bn_bwd_p_workspace(long rows, int C) {
+  return (size_t)(BWD2_MAX_BLOCKS * 2 * (long)C + 2 * C) * sizeof(float);
+}
+
+/* BatchNorm (+ReLU) backward of an NHWC tensor [N][H][W][C] (C % 16 == 0, C <= 1024) with dz written as x6 planes
+ * (allocation base; its non-pixel rows must already be zero) and the masked upstream gradient as fp32 `dres` (optional).
+ * dgamma / dbeta and the semantics of y / beta / relu as buctd_bn_bwd. */
+extern "C" int buctd_bn_bwd_p(const float* dy, const float* y, const float* z, const float* mean, const float* invstd,
+                              const float* gamma, const float* beta, int relu, int N, int H, int W, int C,
+                              void* dz_planes, float* dres, float* dgamma, float* dbeta, int accumulate, void* workspace,
+                              size_t workspace_bytes, void* stream) {
+  BUCTD_CHECK_ARG(dy && z && mean && invstd && gamma && dz_planes && N > 0 && H > 0 && W > 0 && C > 0 && C % 16 == 0 && C <= 1024,
+                  "buctd_bn_bwd_p: bad argument");
+  BUCTD_CHECK_ARG(!relu || y || beta, "buctd_bn_bwd_p: relu backward needs the forward output, or beta to rebuild its sign");
+  const long rows = (long)N * H * W;
+  BUCTD_CHECK_ARG(rows < 2147483647L, "buctd_bn_bwd_p: tensor too large");
+  const size_t need = buctd_bn_bwd_p_workspace(rows, C);
+  if (!workspace || workspace_bytes < need) {
+    buctd_set_error("buctd_bn_bwd_p: workspace %zu bytes < required %zu", workspace_bytes, need);
+    return BUCTD_EWORKSPACE;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  long rpb;
+  const long nb = bwd2_blocks(rows, &rpb);
+  float* part = (float*)workspace;
+  float* s = part + (long)BWD2_MAX_BLOCKS * 2 * C;
+  hipLaunchKernelGGL(bn_bwd_reduce2_kernel, dim3((unsigned)nb), dim3(256), 0, st, dy, y, z, mean, invstd, gamma, beta, relu,
+                     rows, C, rpb, part);
+  BUCTD_CHECK_LAUNCH("buctd_bn_bwd_p(reduce)");
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(256), 0, st, (const float*)part, (int)nb, C, s, dgamma, dbeta,
+                     accumulate);
+  BUCTD_CHECK_LAUNCH("buctd_bn_bwd_p(finalize)");
+  BnPlanesGeo geo;
+  geo.H = H; geo.W = W; geo.SW = W + 2; geo.IB = (H + 1) * (W + 2);
+  bn_magic((unsigned)W, &geo.w_mul, &geo.w_sh);
+  bn_magic((unsigned)H, &geo.h_mul, &geo.h_sh);
+  const long items = rows * (C / 8);
+  long blocks = (items + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(bn_bwd_apply_p_kernel, dim3((unsigned)blocks), dim3(256), 0, st, dy, y, z, mean, invstd, gamma, beta,
+                     (const float*)s, relu, rows, C, 1.0f / (float)rows, geo, (unsigned char*)dz_planes, dres);
+  BUCTD_CHECK_LAUNCH("buctd_bn_bwd_p(apply)");
   return BUCTD_OK;
 }

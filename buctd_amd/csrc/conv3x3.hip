@@ -77,6 +77,10 @@ struct C3Args {
   const float* in_beta;
   int in_relu;
   int col_major;       // bf16x6 kernel: consecutive workgroups of an XCD share the COLUMN tile (see the kernel)
+  // bf16x6, fp32 input: optional by-product - the staged (normalised, split, zero-padded) input written out as x6 planes
+  // (allocation base; rows of positions [0, ceil(P / BM) * BM) are written, pads as zeros).  The weight gradient of the
+  // same convolution stages it by LDS-DMA in the backward pass instead of splitting the tensor a second time.
+  unsigned char* planes_out;
   unsigned ib_mul, ib_sh, sw_mul, sw_sh;   // n / d == mulhi(n, mul) >> sh for 0 <= n < 2^31 (Granlund-Montgomery)
 };
 
@@ -418,7 +422,9 @@ __device__ unsigned long long c3_trace_wall[4096][2];   // wall clock (100 MHz) 
 // PL: the input arrives as x6 planes (x6p.h) - already padded and split by its producer.  Staging a chunk is then a plain
 // 16-byte copy (global -> register -> LDS, still one chunk ahead of the MFMAs): no split arithmetic, no zero-selects, no
 // per-row div/mod - the ~2 VALU instructions per MFMA of the fp32-input variant are gone.
-template <int MF, int NF, int WM, int WN, bool DBUF, bool BPF_, int WPS, bool PL = false>
+// EMIT (fp32 input only): also write the staged tiles out as x6 planes (C3Args::planes_out) - a separate instantiation, so
+// that the plain kernels keep their register allocation.
+template <int MF, int NF, int WM, int WN, bool DBUF, bool BPF_, int WPS, bool PL = false, bool EMIT = false>
 __global__ __launch_bounds__(256, WPS) void conv3x3_x6_kernel(C3Args p) {
   constexpr int ROWB = Geo<3>::ROWB, PST = Geo<3>::PST, CPR = Geo<3>::CPR;
   constexpr int BM = WM * MF * 16, BN = WN * NF * 16;
@@ -601,6 +607,26 @@ __global__ __launch_bounds__(256, WPS) void conv3x3_x6_kernel(C3Args p) {
   };
   auto run_chunk = [&](int ch) {
     const unsigned char* abase = smem + (ch & 1) * abytes + aoff;
+    if constexpr (EMIT && !PL) {
+      if (by == 0) {
+        // the tile of this chunk is complete in LDS: rows [halo, halo + BM) are the planes rows of this workgroup's
+        // positions, chunk ch - 16-byte pieces straight from LDS to the planes (no arithmetic); a rolled loop, four
+        // pieces in flight: the registers of the MFMA loop are all taken
+        const int orowb = p.Ci * 6;
+        const unsigned char* src = smem + (ch & 1) * abytes + (size_t)halo * ROWB;
+        unsigned char* dst = p.planes_out + ((size_t)X6P_GB + p0) * orowb + ch * 96;
+        constexpr int NQ = (BM * 6 + 255) / 256;
+#pragma unroll 3
+        for (int q = 0; q < NQ; ++q) {
+          const int i = t + 256 * q;
+          if (BM * 6 % 256 == 0 || i < BM * 6) {
+            const int row = (i * 43691) >> 18, j = i - row * 6;        // i / 6 for i < 8192
+            *reinterpret_cast<f32x4*>(dst + (size_t)row * orowb + j * 16) = *reinterpret_cast<const f32x4*>(src + (size_t)i * 16);
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
 #pragma unroll
     for (int i = 0; i < AD; ++i) read_a(abase, i, a[i]);
 #pragma unroll
@@ -909,7 +935,7 @@ static bool c3_np_ok(int np) { return np == 2 || np == 3; }
 
 template <int NP, int MF, int NF, int WM, int WN>
 static int c3_launch(const C3Args& a, const C3Plan& pl, hipStream_t st, bool planes_in) {
-  static bool attr_done[5] = {false, false, false, false, false};   // idempotent attribute call: a race at first use only repeats it
+  static bool attr_done[7] = {false, false, false, false, false, false, false};   // idempotent attribute call: a race at first use only repeats it
   void (*fn)(C3Args);
   int variant = 0;
   if constexpr (NP == 3) {
@@ -918,6 +944,10 @@ static int c3_launch(const C3Args& a, const C3Plan& pl, hipStream_t st, bool pla
         buctd_set_error("conv3x3 (bf16x6, planes input): no 512-position tile variant");
         return BUCTD_EINVAL;
       } else { fn = conv3x3_x6_kernel<MF, NF, WM, WN, true, true, 2, true>; variant = 4; }
+    }
+    else if (a.planes_out) {
+      if (MF >= 8) { fn = conv3x3_x6_kernel<MF, NF, WM, WN, false, false, 2, false, true>; variant = 5; }
+      else { fn = conv3x3_x6_kernel<MF, NF, WM, WN, true, true, 2, false, true>; variant = 6; }
     }
     else if (MF >= 8) fn = conv3x3_x6_kernel<MF, NF, WM, WN, false, false, 2>;
 #ifdef BUCTD_TUNING
@@ -1011,7 +1041,7 @@ struct C3InBn { const float* mean; const float* invstd; const float* gamma; cons
 static int c3_run(int np, int N, int H, int W, int Ci, int Co, const float* x, const void* wprep, const float* bias,
                   const float* scale, const float* shift, const float* residual, int relu, float* y,
                   float* stats_partials, int* stats_counts, void* stream, const C3InBn* in_bn = nullptr,
-                  bool planes_in = false) {
+                  bool planes_in = false, void* planes_out = nullptr) {
   C3Plan pl;
   BUCTD_CHECK_ARG(x && wprep && y, "buctd_conv3x3 (split bf16): null tensor pointer");
   BUCTD_CHECK_ARG(c3_np_ok(np) && c3_plan(np, N, H, W, Ci, Co, &pl, planes_in),
@@ -1029,6 +1059,9 @@ static int c3_run(int np, int N, int H, int W, int Ci, int Co, const float* x, c
                   "buctd_conv3x3 (split bf16): tensor too large");
   a.P = (int)P;
   a.relu = relu; a.na = pl.na;
+  a.planes_out = (unsigned char*)planes_out;
+  BUCTD_CHECK_ARG(!planes_out || (np == 3 && !planes_in), "buctd_conv3x3: the planes by-product is a feature of the fp32-input bf16x6 kernel");
+  BUCTD_CHECK_ARG(!planes_out || (P + X6P_GB + X6P_GA) * (long)Ci * 6 < 2147483647L, "buctd_conv3x3: tensor too large for planes");
   a.in_mean = a.in_invstd = a.in_gamma = a.in_beta = nullptr;
   a.in_relu = 0;
   if (in_bn && in_bn->mean) {
@@ -1106,4 +1139,18 @@ extern "C" int buctd_conv3x3_bf16x6_p(int N, int H, int W, int Ci, int Co, const
                                       int relu, float* y, float* stats_partials, int* stats_counts, void* stream) {
   return c3_run(3, N, H, W, Ci, Co, (const float*)x_planes, wprep, bias, scale, shift, residual, relu, y, stats_partials,
                 stats_counts, stream, nullptr, true);
+}
+
+/* buctd_conv3x3_bf16x6(_bnin) (no bias / eval scale / residual / ReLU: the BasicBlock use) that also writes what it staged -
+ * x, or relu?((x - mean) * (invstd * gamma) + beta) when in_mean != NULL - as x6 planes into x_planes_out (allocation
+ * base of buctd_x6p_bytes(N, H, W, Ci) bytes whose non-pixel rows are zero or will be overwritten with zeros): the operand
+ * of this convolution's weight gradient (buctd_conv3x3_wgrad_bf16x6_p), produced by the pass that splits it anyway. */
+extern "C" int buctd_conv3x3_bf16x6_emit(int N, int H, int W, int Ci, int Co, const float* x, const void* wprep, float* y,
+                                         float* stats_partials, int* stats_counts, const float* in_mean,
+                                         const float* in_invstd, const float* in_gamma, const float* in_beta, int in_relu,
+                                         void* x_planes_out, void* stream) {
+  C3InBn b{in_mean, in_invstd, in_gamma, in_beta, in_relu};
+  BUCTD_CHECK_ARG(x_planes_out, "buctd_conv3x3_bf16x6_emit: null planes pointer");
+  return c3_run(3, N, H, W, Ci, Co, x, wprep, nullptr, nullptr, nullptr, nullptr, 0, y, stats_partials, stats_counts, stream,
+                in_mean ? &b : nullptr, false, x_planes_out);
 }

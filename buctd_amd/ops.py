@@ -414,6 +414,61 @@ def conv_wgrad_planes(xp, dyp, out, accumulate=0):
     return out
 
 
+class _PlanesPool:
+    """Planes buffers whose NON-PIXEL rows (pads, guards) are zero and stay zero: they are created with torch.zeros and every
+    kernel that writes them writes pixel rows only, or pad rows as zeros (csrc/x6p.h).  Keeping them in a pool instead of
+    returning them to the caching allocator is what preserves that invariant without a memset per use.
+    Stream safety: buffers saved from a forward pass for its backward (acquire / release) are reused by the NEXT forward
+    pass at the earliest - after the end-of-backward join of the weight-gradient stream; scratch sets used inside a
+    backward pass (scratch / scratch_done) rotate through a ring and carry the event of their last reader."""
+
+    def __init__(self, ring=3):
+        self.free = {}
+        self.rings = {}
+        self.ring = ring
+
+    def acquire(self, shape, device):
+        key = (device.index, tuple(shape))
+        lst = self.free.get(key)
+        if lst:
+            return Planes(lst.pop(), shape)
+        return Planes(torch.zeros(planes_bytes(shape), dtype=torch.uint8, device=device), shape)
+
+    def release(self, pl):
+        self.free.setdefault((pl.buf.device.index, pl.shape), []).append(pl.buf)
+
+    def scratch(self, shape, device, n):
+        """n planes buffers for the current stream to write; waits (on the current stream) for the last reader of the set."""
+        key = (device.index, tuple(shape), n)
+        r = self.rings.get(key)
+        if r is None:
+            r = {"sets": [], "i": 0}
+            self.rings[key] = r
+        if len(r["sets"]) < self.ring:
+            r["sets"].append([[Planes(torch.zeros(planes_bytes(shape), dtype=torch.uint8, device=device), shape)
+                               for _ in range(n)], None])
+            st = r["sets"][-1]
+        else:
+            st = r["sets"][r["i"]]
+            r["i"] = (r["i"] + 1) % self.ring
+            if st[1] is not None:
+                torch.cuda.current_stream(device).wait_event(st[1])
+        return st
+
+    def clear(self):
+        self.free.clear()
+        self.rings.clear()
+
+
+planes_pool = _PlanesPool()
+# BasicBlocks of 48-channel-multiple widths CAN run their backward pass on x6 planes (csrc/x6p.h; read once).  Off by default:
+# measured inside the CoAM-W48 train step (profiles/r03_planes_in_step.txt) the LDS-DMA weight gradient is 10 % faster
+# (118 vs 130 us with its slab reduction) but the forward convolutions that emit the planes lose 10 us each and the
+# planes-input data gradients 5 us (6 B/elem instead of 4 through a memory system that three concurrent streams already
+# load): 406 img/s against 431.  Solo, every planes kernel is the faster one (DESIGN.md 3.9).
+_PLANES_BLOCKS = os.environ.get("BUCTD_PLANES", "0") == "1"
+
+
 _NATIVE_BLOCK = os.environ.get("BUCTD_NATIVE_BLOCK", "1") == "1"
 # experiment switches, read ONCE at import (the hot path consults module constants, never the environment)
 _FUSE_BN_IN = os.environ.get("BUCTD_FUSE_BN_IN", "1") == "1"
@@ -1206,7 +1261,14 @@ class BasicBlockFn(torch.autograd.Function):
         base, step = act.data_ptr(), 4 * N * H * W * Cn
         d.z1, d.z2, d.y = base, base + step, base + 2 * step
         d.part, d.counts, d.ngroups, d.rows_per_group, d.stat = part.data_ptr(), counts.data_ptr(), ng, rpg, stat.data_ptr()
+        planes = None
+        if _PLANES_BLOCKS and wgrad_planes_ok(N, H, W, Cn, Cn) and planes_ok((N, H, W, Cn)):
+            # the forward convolutions also write what they staged (x and y1 = relu(bn1(z1)), split and zero-padded) as
+            # planes: the X operands of the two weight gradients, which then stage them by LDS-DMA
+            planes = (planes_pool.acquire((N, H, W, Cn), dev), planes_pool.acquire((N, H, W, Cn), dev))
+            d.xp, d.y1p = planes[0].buf.data_ptr(), planes[1].buf.data_ptr()
         check(lib().buctd_basic_block_fwd_train(C.byref(d), stream_ptr()), "basic_block_fwd_train")
+        ctx.planes = planes
         if track:
             for bn in (bn1, bn2):
                 bn.count_batch() if hasattr(bn, "count_batch") else bn.num_batches_tracked.add_(1)
@@ -1223,6 +1285,9 @@ class BasicBlockFn(torch.autograd.Function):
         N, H, W, Cn = x.shape
         dev = x.device
         want_dx = ctx.needs_input_grad[0]
+        planes = getattr(ctx, "planes", None)
+        if planes is not None:
+            return BasicBlockFn._backward_planes(ctx, dy, planes)
         tmp = torch.empty((5 if want_dx else 4, N, H, W, Cn), dtype=torch.float32, device=dev)   # dz2 | dres | dy1 | dz1 | dx
         d = _C.BasicBlockDesc()
         d.N, d.H, d.W, d.C = N, H, W, Cn
@@ -1273,6 +1338,77 @@ class BasicBlockFn(torch.autograd.Function):
         grad_done(bn2.weight, bn2.bias, w2)
         grad_done(bn1.weight, bn1.bias, w1)
         return (tmp[4] if want_dx else None), None, None, None, None
+
+    @staticmethod
+    def _backward_planes(ctx, dy, planes):
+        """The native backward with dz2 / dz1 as x6 planes: BatchNorm backward (fixed-grid reduction) writes them pre-split,
+        the weight gradients (LDS-DMA kernel) read them and the planes saved by the forward, the data gradients stage them
+        with plain copies."""
+        w1, bn1, w2, bn2, _ = ctx.meta
+        x, act, stat = ctx.saved_tensors
+        N, H, W, Cn = x.shape
+        dev = x.device
+        want_dx = ctx.needs_input_grad[0]
+        tmp = torch.empty((3 if want_dx else 2, N, H, W, Cn), dtype=torch.float32, device=dev)   # dres | dy1 | dx
+        d = _C.BasicBlockDesc()
+        d.N, d.H, d.W, d.C = N, H, W, Cn
+        d.x = x.data_ptr()
+        d.w1_fwd = d.w2_fwd = 0
+        d.w1_bwd = _conv3x3_prepared(w1, 1).data_ptr()
+        d.w2_bwd = _conv3x3_prepared(w2, 1).data_ptr()
+        d.gamma1, d.beta1 = bn1.weight.data_ptr(), bn1.bias.data_ptr()
+        d.gamma2, d.beta2 = bn2.weight.data_ptr(), bn2.bias.data_ptr()
+        base, step = act.data_ptr(), 4 * N * H * W * Cn
+        d.z1, d.z2, d.y = base, base + step, base + 2 * step
+        d.stat = stat.data_ptr()
+        d.xp, d.y1p = planes[0].buf.data_ptr(), planes[1].buf.data_ptr()
+        g = _C.BasicBlockGrads()
+        tb = tmp.data_ptr()
+        g.dy, g.dres, g.dy1 = dy.data_ptr(), tb, tb + step
+        g.dz2 = g.dz1 = 0
+        g.dx = tb + 2 * step if want_dx else 0
+        scratch = planes_pool.scratch((N, H, W, Cn), dev, 2)      # waits for the last reader of this set on this stream
+        g.dz2p, g.dz1p = scratch[0][0].buf.data_ptr(), scratch[0][1].buf.data_ptr()
+        dg2, acc_g2 = grad_target(bn2.weight)
+        db2, acc_b2 = grad_target(bn2.bias)
+        dw2, acc_w2 = grad_target(w2)
+        dg1, acc_g1 = grad_target(bn1.weight)
+        db1, acc_b1 = grad_target(bn1.bias)
+        dw1, acc_w1 = grad_target(w1)
+        assert acc_g2 == acc_b2 and acc_g1 == acc_b1
+        weight_rsc(dw1)
+        weight_rsc(dw2)
+        g.dw1, g.dw2 = dw1.data_ptr(), dw2.data_ptr()
+        g.dgamma1, g.dbeta1, g.dgamma2, g.dbeta2 = dg1.data_ptr(), db1.data_ptr(), dg2.data_ptr(), db2.data_ptr()
+        g.acc_w1, g.acc_w2, g.acc_bn1, g.acc_bn2 = int(acc_w1), int(acc_w2), int(acc_g1), int(acc_g2)
+        bn_ws = workspace(_memo(("bnpws", N * H * W, Cn), lambda: int(lib().buctd_bn_bwd_p_workspace(N * H * W, Cn))), dev)
+        g.bn_ws, g.bn_ws_bytes = bn_ws.data_ptr(), bn_ws.numel()
+        main = torch.cuda.current_stream(dev)
+        use_side = _side["on"]
+        side = _side_stream(dev) if use_side else main
+        need = _memo(("wg4ws", N, H, W, Cn, Cn), lambda: int(lib().buctd_conv3x3_wgrad_bf16x6_p_workspace(N, H, W, Cn, Cn)))
+        with torch.cuda.stream(side):
+            wg_ws = workspace(need, dev)           # the side stream's own scratch buffer
+        g.wg_ws, g.wg_ws_bytes = wg_ws.data_ptr(), wg_ws.numel()
+        check(lib().buctd_basic_block_bwd(C.byref(d), C.byref(g), main.cuda_stream, side.cuda_stream if use_side else None),
+              "basic_block_bwd")
+        if use_side:
+            for t in (x, act, stat, tmp):
+                t.record_stream(side)
+            ev = torch.cuda.Event()
+            ev.record(side)                         # the last reader of the scratch planes is the second weight gradient
+            scratch[1] = ev
+            _queue_join()
+        else:
+            scratch[1] = None
+            if _branch["on"]:
+                _queue_join()
+        planes_pool.release(planes[0])
+        planes_pool.release(planes[1])
+        ctx.planes = None
+        grad_done(bn2.weight, bn2.bias, w2)
+        grad_done(bn1.weight, bn1.bias, w1)
+        return (tmp[2] if want_dx else None), None, None, None, None
 
     @staticmethod
     def backward(ctx, dy):

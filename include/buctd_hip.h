@@ -144,6 +144,19 @@ int buctd_conv3x3_bf16x6_p_stats_groups(int N, int H, int W, int Ci, int Co, int
 int buctd_conv3x3_bf16x6_p(int N, int H, int W, int Ci, int Co, const void* x_planes, const void* wprep, const float* bias,
                            const float* scale, const float* shift, const float* residual, int relu, float* y,
                            float* stats_partials, int* stats_counts, void* stream);
+/* buctd_conv3x3_bf16x6(_bnin) without epilogue options (the BasicBlock use) that ALSO writes what it staged - x, or
+ * relu?((x - mean)(invstd gamma) + beta) when in_mean != NULL - as planes into x_planes_out: the X operand of this
+ * convolution's weight gradient, produced by the pass that splits it anyway (rows of all positions are written, pads as
+ * zeros; guard rows must be zero already). */
+int buctd_conv3x3_bf16x6_emit(int N, int H, int W, int Ci, int Co, const float* x, const void* wprep, float* y,
+                              float* stats_partials, int* stats_counts, const float* in_mean, const float* in_invstd,
+                              const float* in_gamma, const float* in_beta, int in_relu, void* x_planes_out, void* stream);
+/* BatchNorm(+ReLU) backward (as buctd_bn_bwd) of an NHWC tensor with dz written as planes (only pixel rows are written: the
+ * buffer's pad / guard rows must be zero) and the masked upstream gradient as fp32 dres (optional); fixed-grid reduction */
+size_t buctd_bn_bwd_p_workspace(long rows, int C);
+int buctd_bn_bwd_p(const float* dy, const float* y, const float* z, const float* mean, const float* invstd,
+                   const float* gamma, const float* beta, int relu, int N, int H, int W, int C, void* dz_planes, float* dres,
+                   float* dgamma, float* dbeta, int accumulate, void* workspace, size_t workspace_bytes, void* stream);
 /* weight gradient from both operands as planes (Ci, Co multiples of 48): LDS-DMA staging, one 512-thread workgroup per CU,
  * 256 partial slabs in `workspace` summed in a fixed order (deterministic) */
 int buctd_conv3x3_wgrad_bf16x6_p_supported(int N, int H, int W, int Ci, int Co);
@@ -321,6 +334,10 @@ typedef struct {
   int* counts;
   int ngroups, rows_per_group;
   float* stat;
+  /* planes mode (both non-NULL, C % 48 == 0): the forward convolutions also write their staged inputs - x and
+   * y1 = relu(bn1(z1)) - as x6 planes (allocation bases, non-pixel rows zero); the backward's weight gradients then stage
+   * them by LDS-DMA (buctd_conv3x3_wgrad_bf16x6_p).  NULL: fp32 operands everywhere, as before. */
+  void *xp, *y1p;
 } buctd_basic_block;
 typedef struct {
   const float* dy;                      /* gradient of the block output */
@@ -329,7 +346,10 @@ typedef struct {
   float *dw1, *dw2, *dgamma1, *dbeta1, *dgamma2, *dbeta2;
   int acc_w1, acc_w2, acc_bn1, acc_bn2; /* accumulate into (1) or overwrite (0) the gradient buffers */
   void* bn_ws; size_t bn_ws_bytes;      /* buctd_bn_bwd_workspace, used on `stream` */
-  void* wg_ws; size_t wg_ws_bytes;      /* buctd_conv3x3_wgrad_bf16x6_workspace, used on `side_stream` */
+  void* wg_ws; size_t wg_ws_bytes;      /* buctd_conv3x3_wgrad_bf16x6(_p)_workspace, used on `side_stream` */
+  /* planes mode: dz2 / dz1 exist only as planes (scratch allocations whose non-pixel rows are zero); the fp32 dz2 / dz1
+   * above are then unused (may be NULL) and bn_ws must hold buctd_bn_bwd_p_workspace bytes */
+  void *dz2p, *dz1p;
 } buctd_basic_block_grads;
 int buctd_basic_block_fwd_train(const buctd_basic_block* b, void* stream);
 int buctd_basic_block_bwd(const buctd_basic_block* b, const buctd_basic_block_grads* g, void* stream, void* side_stream);

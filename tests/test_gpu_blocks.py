@@ -102,8 +102,9 @@ def test_basic_block_input_bn_fusion_is_bit_identical(dev, shape, monkeypatch):
     w2 = tnn.Parameter((torch.randn(Cn, Cn, 3, 3, generator=g) * 0.08).contiguous(memory_format=torch.channels_last).to(dev))
     dy = torch.randn(N, H, W, Cn, generator=g).to(dev)
     res = {}
+    monkeypatch.setattr(ops, "_PLANES_BLOCKS", False)    # the planes backward (other reduction orders) has its own test below
     for flag in ("1", "0"):
-        monkeypatch.setenv("BUCTD_FUSE_BN_IN", flag)
+        monkeypatch.setattr(ops, "_FUSE_BN_IN", flag == "1")
         assert ops.bn_in_fusable((N, H, W, Cn), w2) == (flag == "1")
         bns = []
         for s in (1, 2):
@@ -122,6 +123,48 @@ def test_basic_block_input_bn_fusion_is_bit_identical(dev, shape, monkeypatch):
                      bns[0].bias.grad.clone(), bns[1].weight.grad.clone(), bns[1].running_var.clone()]
     for a, b in zip(res["1"], res["0"]):
         assert torch.equal(a, b), f"fused vs unfused differ by {(a - b).abs().max().item():.3e}"
+
+
+@pytest.mark.parametrize("shape", [(2, 24, 18, 48), (3, 12, 9, 96), (4, 6, 5, 192), (20, 96, 72, 48)])
+def test_basic_block_planes_backward_matches_fp32_operand_backward(dev, shape, monkeypatch):
+    """BasicBlocks of 48-channel-multiple widths run their backward on x6 planes (forward convs emit the split x / y1, the
+    BatchNorm backward writes dz pre-split, LDS-DMA weight gradient).  Forward: same kernels, same bits.  Backward: the
+    same arithmetic per element with other (fixed) summation orders in the BatchNorm reductions and the weight-gradient
+    split - agreement to fp32 round-off of the respective sums, and run-to-run bit-reproducible."""
+    import torch.nn as tnn
+    from buctd_amd import ops
+    N, H, W, Cn = shape
+    g = torch.Generator().manual_seed(H + Cn + 1)
+    x = torch.randn(N, H, W, Cn, generator=g).to(dev)
+    w1 = tnn.Parameter((torch.randn(Cn, Cn, 3, 3, generator=g) * 0.08).contiguous(memory_format=torch.channels_last).to(dev))
+    w2 = tnn.Parameter((torch.randn(Cn, Cn, 3, 3, generator=g) * 0.08).contiguous(memory_format=torch.channels_last).to(dev))
+    dy = torch.randn(N, H, W, Cn, generator=g).to(dev)
+    res = {}
+    for mode in ("planes", "fp32", "planes2"):
+        monkeypatch.setattr(ops, "_PLANES_BLOCKS", mode != "fp32")
+        bns = []
+        for s in (1, 2):
+            bn = tnn.BatchNorm2d(Cn).to(dev).train()
+            with torch.no_grad():
+                bn.weight.copy_(torch.rand(Cn, generator=torch.Generator().manual_seed(s)) + 0.5)
+                bn.bias.copy_(torch.randn(Cn, generator=torch.Generator().manual_seed(10 + s)) * 0.2)
+            bns.append(bn)
+        for p in (w1, w2):
+            p.grad = None
+        xi = x.clone().requires_grad_(True)
+        y = ops.BasicBlockFn.apply(xi, w1, bns[0], w2, bns[1])
+        y.backward(dy)
+        torch.cuda.synchronize()
+        res[mode] = [y.detach().clone(), xi.grad.clone(), w1.grad.clone(), w2.grad.clone(), bns[0].weight.grad.clone(),
+                     bns[0].bias.grad.clone(), bns[1].weight.grad.clone(), bns[1].bias.grad.clone()]
+    assert torch.equal(res["planes"][0], res["fp32"][0]), "forward must not change"
+    for a, b in zip(res["planes"], res["planes2"]):
+        assert torch.equal(a, b), "planes backward is not run-to-run reproducible"
+    names = ["y", "dx", "dw1", "dw2", "dgamma1", "dbeta1", "dgamma2", "dbeta2"]
+    for n, a, b in zip(names, res["planes"], res["fp32"]):
+        sc = b.abs().max().item()
+        err = (a - b).abs().max().item()
+        assert err <= 2e-5 * sc, f"{n}: planes vs fp32-operand backward differ by {err:.3e} (scale {sc:.3e})"
 
 
 def test_eval_bn_fold_cache_follows_training_updates(dev):
