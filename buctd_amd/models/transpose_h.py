@@ -36,8 +36,12 @@ class MultiheadAttention(nn.Module):
         if p_eff == 0.0 and not needs_grad and ops.mha_fused_ok(qk.shape[1], self.embed_dim, self.num_heads):
             # inference (BASELINE config C5): flash-style fused attention, no T x T matrix in HBM
             out = ops.mha_fwd(qk, v)
+        elif ops.mha_train_ok(qk.shape[1], self.embed_dim, self.num_heads):
+            # training: fused in both directions - forward with in-kernel attention dropout, flash-style backward
+            out = ops.FusedMHA.apply(qk, v, float(self.dropout), self.training)
         else:
-            # training: materialised soft-max with the counter-hash attention dropout and its backward
+            # shapes the fused kernels do not take (T not a multiple of 128, several heads): materialised soft-max with
+            # the same counter-hash dropout
             out = ops.PositionAttention.apply(qk, None, v, self.num_heads, float(self.dropout), self.training)
         return self.out_proj(out)
 

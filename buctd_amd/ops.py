@@ -1613,6 +1613,51 @@ def mha_fwd(qk, v, scale=None):
     return out
 
 
+def mha_train_ok(T, d, h=1):
+    """True when the fused training attention (attn_mha_train.hip: forward with dropout + lse, flash-style backward) covers
+    this shape."""
+    return h == 1 and _memo(("mhatr", int(T), int(d)), lambda: lib().buctd_mha_train_supported(int(T), int(d)) == 1)
+
+
+class FusedMHA(torch.autograd.Function):
+    """softmax(q k^T / sqrt(d)) -> dropout -> . v for ONE head without the T x T matrix, forward and backward (reference
+    nn.MultiheadAttention inside transpose_h.py:192-197, training).  qk [B, T, 2d] = q | k side by side (the packed input
+    projection), v [B, T, d] -> [B, T, d]; the backward returns the packed gradient d(q | k) and dv."""
+
+    @staticmethod
+    def forward(ctx, qk, v, p_drop, training):
+        qk, v = _contig(qk), _contig(v)
+        _f32(qk, "mha qk")
+        _f32(v, "mha v")
+        B, T, two_d = qk.shape
+        d = two_d // 2
+        scale = 1.0 / math.sqrt(d)
+        p_eff = float(p_drop) if training else 0.0
+        seed = next_seed()
+        out = torch.empty((B, T, d), dtype=torch.float32, device=qk.device)
+        lse = torch.empty((B, T), dtype=torch.float32, device=qk.device)
+        check(lib().buctd_mha_fwd_train(B, T, d, ptr(qk), C.c_void_p(qk.data_ptr() + 4 * d), ptr(v), two_d, v.shape[2], scale,
+                                        p_eff, seed, ptr(out), ptr(lse), stream_ptr()), "mha_fwd_train")
+        ctx.meta = (scale, p_eff, seed)
+        ctx.save_for_backward(qk, v, out, lse)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        scale, p_eff, seed = ctx.meta
+        qk, v, out, lse = ctx.saved_tensors
+        dout = _contig(dout)
+        B, T, two_d = qk.shape
+        d = two_d // 2
+        dqk = torch.empty_like(qk)
+        dv = torch.empty_like(v)
+        ws = workspace(lib().buctd_mha_bwd_workspace(B, T), qk.device)
+        check(lib().buctd_mha_bwd(B, T, d, ptr(qk), C.c_void_p(qk.data_ptr() + 4 * d), ptr(v), two_d, v.shape[2], ptr(out),
+                                  ptr(dout), ptr(lse), scale, p_eff, seed, ptr(dqk), C.c_void_p(dqk.data_ptr() + 4 * d), two_d,
+                                  ptr(dv), dv.shape[2], ptr(ws), ws.numel(), stream_ptr()), "mha_bwd")
+        return dqk, dv, None, None
+
+
 def attn_smallqk_ok(T, d_in, C, h=1):
     """True when the fused narrow-contraction attention (attn_smallqk.hip) covers this shape."""
     if h != 1 or d_in + 1 > 20:

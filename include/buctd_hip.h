@@ -388,6 +388,17 @@ int buctd_mha_fwd(int B, int T, int d, const float* q, const float* k, const flo
  * accumulate: fp32 class on the bf16 matrix cores); probabilities stay in registers (S^T formulation). */
 int buctd_mha_fwd_bf16x6(int B, int T, int d, const float* q, const float* k, const float* v, int ldqk, int ldv,
                          float scale, float* out, float* lse, void* stream);
+/* The same attention for TRAINING (transpose_h.py:168-213, autograd of softmax -> dropout -> . v), fused in both
+ * directions - nothing T x T in HBM: forward with in-kernel attention dropout (counter hash keyed by (seed, (b T + q) T + key),
+ * the function of buctd_softmax_dropout_fwd) and the row statistic lse [B][T]; flash-style backward (one kernel template in
+ * two roles: dK/dV with the keys owned, dQ with the queries owned).  Exact fp32 MFMA.  T % 128 == 0, d % 16 == 0, d <= 128. */
+int buctd_mha_train_supported(int T, int d);
+int buctd_mha_fwd_train(int B, int T, int d, const float* q, const float* k, const float* v, int ldqk, int ldv, float scale,
+                        float p_drop, uint64_t seed, float* out, float* lse, void* stream);
+size_t buctd_mha_bwd_workspace(int B, int T);
+int buctd_mha_bwd(int B, int T, int d, const float* q, const float* k, const float* v, int ldqk, int ldv, const float* out,
+                  const float* dout, const float* lse, float scale, float p_drop, uint64_t seed, float* dq, float* dk,
+                  int lddqk, float* dv, int lddv, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------- sample pipeline --- */
 /* Person crop of the per-sample pipeline (dataset/JointsDataset.py:287-294): cv2.warpAffine(img_u8, M, (w, h),

@@ -96,3 +96,55 @@ def test_fused_mha_forward_vs_fp64(dev, B, T, d, mode):
     mat = ops.PositionAttention.apply(qk.to(dev), None, v.to(dev), 1, 0.0, False)
     assert (mat - out).abs().max().item() <= 2e-5 * ref.abs().max().item()
     assert not ops.mha_fused_ok(100, d) and not ops.mha_fused_ok(T, 20)
+
+
+@pytest.mark.parametrize("B,T,d", [(2, 384, 48), (1, 3072, 112), (3, 128, 16), (2, 256, 128)])
+def test_fused_mha_training_forward_backward_vs_fp64(dev, B, T, d):
+    """attn_mha_train.hip (TransPose encoder self-attention, training; reference transpose_h.py:168-213): fused forward +
+    flash-style backward against torch autograd in fp64, no dropout.  Nothing T x T is allocated."""
+    from buctd_amd import ops
+    g = torch.Generator().manual_seed(B * T + d + 1)
+    qk = (torch.randn(B, T, 2 * d, generator=g) * 1.2).double().requires_grad_(True)
+    v = torch.randn(B, T, d, generator=g).double().requires_grad_(True)
+    with torch.no_grad():
+        qk[:, ::7, :d] *= 3.0
+    q64, k64 = qk[..., :d], qk[..., d:]
+    ref = torch.softmax(q64 @ k64.transpose(1, 2) / math.sqrt(d), dim=-1) @ v
+    dout = torch.randn(ref.shape, generator=g).double()
+    ref.backward(dout)
+    assert ops.mha_train_ok(T, d)
+    qkd = qk.detach().float().to(dev).requires_grad_(True)
+    vd = v.detach().float().to(dev).requires_grad_(True)
+    torch.cuda.reset_peak_memory_stats()
+    base = torch.cuda.memory_allocated()
+    out = ops.FusedMHA.apply(qkd, vd, 0.1, False)
+    out.backward(dout.float().to(dev))
+    peak = torch.cuda.max_memory_allocated() - base
+    if T >= 2048:          # (small T: the grow-only 1 MB workspace and the outputs themselves exceed T x T)
+        assert peak < 4 * B * T * T // 2, "the fused path must not allocate anything T x T"
+    for name, a, b in (("out", out.detach(), ref.detach()), ("dqk", qkd.grad, qk.grad), ("dv", vd.grad, v.grad)):
+        err = _e(a, b)
+        assert err <= 2e-5, f"fused MHA training {name} (B{B} T{T} d{d}): rel err {err:.2e}"
+
+
+def test_fused_mha_training_dropout_matches_materialised_path(dev, monkeypatch):
+    """With attention dropout the fused kernels draw the SAME mask as the materialised path for the same seed (counter hash
+    keyed by (seed, (b T + q) T + key)): outputs and gradients agree to round-off."""
+    from buctd_amd import ops
+    B, T, d = 2, 256, 48
+    g = torch.Generator().manual_seed(11)
+    qk = torch.randn(B, T, 2 * d, generator=g)
+    v = torch.randn(B, T, d, generator=g)
+    dout = torch.randn(B, T, d, generator=g).to(dev)
+    monkeypatch.setattr(ops, "next_seed", lambda: 0x1234567890ABCDEF)
+    res = []
+    for fused in (True, False):
+        qkd, vd = qk.to(dev).requires_grad_(True), v.to(dev).requires_grad_(True)
+        out = ops.FusedMHA.apply(qkd, vd, 0.3, True) if fused else ops.PositionAttention.apply(qkd, None, vd, 1, 0.3, True)
+        out.backward(dout)
+        res.append((out.detach(), qkd.grad, vd.grad))
+    nodrop = ops.FusedMHA.apply(qk.to(dev), v.to(dev), 0.3, False)
+    assert (res[0][0] - nodrop).abs().max().item() > 1e-2, "dropout must change the output"
+    for name, a, b in zip(("out", "dqk", "dv"), res[0], res[1]):
+        err = ((a - b).norm() / b.norm()).item()
+        assert err <= 2e-5, f"fused vs materialised with dropout: {name} rel err {err:.2e}"
