@@ -112,6 +112,8 @@ SIGNATURES = {
     "buctd_bn_fold": (_I, [_P, _P, _P, _P, _F, _I, _P, _P, _P]),
     "buctd_basic_block_fwd_train": (_I, [C.POINTER(BasicBlockDesc), _P]),
     "buctd_basic_block_bwd": (_I, [C.POINTER(BasicBlockDesc), C.POINTER(BasicBlockGrads), _P, _P]),
+    "buctd_basic_chain_fwd_train": (_I, [_I, C.POINTER(BasicBlockDesc), _P]),
+    "buctd_basic_chain_bwd": (_I, [_I, C.POINTER(BasicBlockDesc), C.POINTER(BasicBlockGrads), _P, _P]),
     "buctd_x6_image_dims": (_I, [_I, _I, _I, _P, _P]),
     "buctd_x6_image_bytes": (C.c_size_t, [_I, _I, _I]),
     "buctd_x6_image": (_I, [_P, _I, _I, _I, _L, _L, _I, _L, _L, _I, _P, _P]),

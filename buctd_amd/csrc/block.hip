@@ -113,3 +113,19 @@ extern "C" int buctd_basic_block_bwd(const buctd_basic_block* b, const buctd_bas
                                  nullptr, stream));
   return BUCTD_OK;
 }
+
+// A residual CHAIN (the four BasicBlocks of an HRNet branch, pose_hrnet.py:165-185 _make_one_branch): the blocks' launch
+// sequences behind ONE call per direction.  Block k's input is block k-1's output; in the backward block k's upstream
+// gradient is block k+1's input gradient.  Same kernels, same order, same streams as n single calls (bit-identical); what
+// it saves is host time - the HRNet-W32 step is bound by it, and the W48 step starves the GPU wherever the maps are small.
+extern "C" int buctd_basic_chain_fwd_train(int n, const buctd_basic_block* blocks, void* stream) {
+  BUCTD_CHECK_ARG(n > 0 && blocks, "buctd_basic_chain_fwd_train: bad argument");
+  for (int k = 0; k < n; ++k) BLK_TRY(buctd_basic_block_fwd_train(blocks + k, stream));
+  return BUCTD_OK;
+}
+extern "C" int buctd_basic_chain_bwd(int n, const buctd_basic_block* blocks, const buctd_basic_block_grads* grads, void* stream,
+                                     void* side_stream) {
+  BUCTD_CHECK_ARG(n > 0 && blocks && grads, "buctd_basic_chain_bwd: bad argument");
+  for (int k = n - 1; k >= 0; --k) BLK_TRY(buctd_basic_block_bwd(blocks + k, grads + k, stream, side_stream));
+  return BUCTD_OK;
+}

@@ -67,6 +67,25 @@ class Bottleneck(nn.Module):
         return nn.conv_bn_act(out, self.conv3, self.bn3, relu=True, residual=residual)
 
 
+class BlockChain(nn.Chain):
+    """nn.Sequential of residual blocks (same child names as the reference's: '0', '1', ...).  A chain of plain BasicBlocks
+    in a training forward runs as ONE autograd node / one library call per direction (ops.BasicChainFn)."""
+
+    def forward(self, x):
+        if (len(self) > 1 and self.training and x.is_cuda and torch.is_grad_enabled() and ops.native_chain_ok(tuple(x.shape))
+                and all(type(m) is BasicBlock and m.downsample is None and m.stride == 1 and m.conv1.bias is None
+                        and m.conv2.bias is None and m.bn1.track_running_stats == m.bn2.track_running_stats
+                        == self[0].bn1.track_running_stats for m in self)
+                and ops.bn_in_fusable(tuple(x.shape), self[0].conv1.weight)):
+            blocks = []
+            for m in self:
+                nn._as_channels_last_(m.conv1.weight)
+                nn._as_channels_last_(m.conv2.weight)
+                blocks.append((m.conv1.weight, m.bn1, m.conv2.weight, m.bn2))
+            return ops.BasicChainFn.apply(x, self[0].conv1.weight, blocks)
+        return super().forward(x)
+
+
 blocks_dict = {"BASIC": BasicBlock, "BOTTLENECK": Bottleneck}
 
 
@@ -81,7 +100,7 @@ def make_residual_layer(block, inplanes, planes, blocks, stride=1):
     inplanes = planes * block.expansion
     for _ in range(1, blocks):
         layers.append(block(inplanes, planes))
-    return nn.Chain(*layers), inplanes
+    return BlockChain(*layers), inplanes
 
 
 class HighResolutionModule(nn.Module):

@@ -37,6 +37,18 @@ def workspace(nbytes, device):
     return buf
 
 
+def workspace_on(stream, nbytes, device):
+    """The scratch buffer of `stream` (a torch.cuda.Stream) without making it current: entering a stream context costs
+    ~15 us of host time, per BasicBlock backward.  The buffer is never returned to the allocator, so which stream it
+    was allocated under does not matter."""
+    key = (device.index, stream.cuda_stream)
+    buf = _workspaces.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
+        _workspaces[key] = buf
+    return buf
+
+
 _seed_state = {"seed": None, "counter": 0}
 
 
@@ -478,6 +490,11 @@ _ATTN_X6 = os.environ.get("BUCTD_ATTN_X6", "1") != "0"
 # optional veto: callable(x_shape) -> True sends a BasicBlock through the step-by-step path (bench.py brackets every launch
 # of its roofline shape with HIP events, which it can only do from the host mirror)
 native_block_veto = {"fn": None}
+
+
+def native_chain_ok(x_shape):
+    """True when a chain of BasicBlocks on this activation shape may take the one-call-per-direction path."""
+    return (_NATIVE_BLOCK and not _PLANES_BLOCKS and _conv_math["mode"] == "bf16x6" and native_block_veto["fn"] is None)
 
 
 def bn_in_fusable(x_shape, w):
@@ -1324,8 +1341,7 @@ class BasicBlockFn(torch.autograd.Function):
         need = _memo(("wg3", "bf16x6", N, H, W, Cn, Cn),
                      lambda: (lib().buctd_conv3x3_wgrad_bf16x6_workspace(N, H, W, Cn, Cn)
                               if lib().buctd_conv3x3_wgrad_bf16x6_supported(N, H, W, Cn, Cn) == 1 else -1))
-        with torch.cuda.stream(side):
-            wg_ws = workspace(need, dev)           # the side stream's own scratch buffer
+        wg_ws = workspace_on(side, need, dev)      # the side stream's own scratch buffer
         g.wg_ws, g.wg_ws_bytes = wg_ws.data_ptr(), wg_ws.numel()
         check(lib().buctd_basic_block_bwd(C.byref(d), C.byref(g), main.cuda_stream, side.cuda_stream if use_side else None),
               "basic_block_bwd")
@@ -1387,8 +1403,7 @@ class BasicBlockFn(torch.autograd.Function):
         use_side = _side["on"]
         side = _side_stream(dev) if use_side else main
         need = _memo(("wg4ws", N, H, W, Cn, Cn), lambda: int(lib().buctd_conv3x3_wgrad_bf16x6_p_workspace(N, H, W, Cn, Cn)))
-        with torch.cuda.stream(side):
-            wg_ws = workspace(need, dev)           # the side stream's own scratch buffer
+        wg_ws = workspace_on(side, need, dev)      # the side stream's own scratch buffer
         g.wg_ws, g.wg_ws_bytes = wg_ws.data_ptr(), wg_ws.numel()
         check(lib().buctd_basic_block_bwd(C.byref(d), C.byref(g), main.cuda_stream, side.cuda_stream if use_side else None),
               "basic_block_bwd")
@@ -1439,6 +1454,121 @@ class BasicBlockFn(torch.autograd.Function):
         conv_wgrad_async(x, dz1, w1, 1, 1, dw, acc_w)
         grad_done(bn1.weight, bn1.bias, w1)
         return dx, None, None, None, None
+
+
+class BasicChainFn(torch.autograd.Function):
+    """A chain of residual BasicBlocks (an HRNet branch: pose_hrnet.py:165-185) as ONE autograd node and one library call
+    per direction (block.hip: buctd_basic_chain_*): the launches of BasicBlockFn's native path, a quarter of its host work
+    per block.  blocks: [(w1, bn1, w2, bn2), ...]; w_first only makes autograd build the node when x needs no gradient."""
+
+    @staticmethod
+    def forward(ctx, x, w_first, blocks):
+        n = len(blocks)
+        N, H, W, Cn = x.shape
+        dev = x.device
+        def groups():
+            ng, rpg = C.c_int(), C.c_int()
+            check(lib().buctd_conv3x3_bf16x6_stats_groups(N, H, W, Cn, Cn, C.byref(ng), C.byref(rpg)), "conv3x3 groups")
+            return ng.value, rpg.value
+        ng, rpg = _memo(("c3grp", "bf16x6", N, H, W, Cn, Cn), groups)
+        act = torch.empty((n, 3, N, H, W, Cn), dtype=torch.float32, device=dev)        # per block: z1 | z2 | y
+        part = torch.empty((n, 2, ng, Cn, 2), dtype=torch.float32, device=dev)
+        counts = torch.empty((n, 2, ng), dtype=torch.int32, device=dev)
+        stat = torch.empty((n, 4, Cn), dtype=torch.float32, device=dev)
+        descs = (_C.BasicBlockDesc * n)()
+        step = 4 * N * H * W * Cn
+        abase, pbase, cbase, sbase = act.data_ptr(), part.data_ptr(), counts.data_ptr(), stat.data_ptr()
+        xin = x.data_ptr()
+        for k, (w1, bn1, w2, bn2) in enumerate(blocks):
+            d = descs[k]
+            d.N, d.H, d.W, d.C = N, H, W, Cn
+            d.x = xin
+            d.w1_fwd = _conv3x3_prepared(w1, 0).data_ptr()
+            d.w2_fwd = _conv3x3_prepared(w2, 0).data_ptr()
+            d.gamma1, d.beta1 = bn1.weight.data_ptr(), bn1.bias.data_ptr()
+            d.gamma2, d.beta2 = bn2.weight.data_ptr(), bn2.bias.data_ptr()
+            if bn1.track_running_stats:
+                d.running_mean1, d.running_var1 = bn1.running_mean.data_ptr(), bn1.running_var.data_ptr()
+                d.running_mean2, d.running_var2 = bn2.running_mean.data_ptr(), bn2.running_var.data_ptr()
+                bn1.count_batch() if hasattr(bn1, "count_batch") else bn1.num_batches_tracked.add_(1)
+                bn2.count_batch() if hasattr(bn2, "count_batch") else bn2.num_batches_tracked.add_(1)
+            d.eps1, d.momentum1 = bn1.eps, 0.1 if bn1.momentum is None else bn1.momentum
+            d.eps2, d.momentum2 = bn2.eps, 0.1 if bn2.momentum is None else bn2.momentum
+            b0 = abase + 3 * step * k
+            d.z1, d.z2, d.y = b0, b0 + step, b0 + 2 * step
+            d.part, d.counts = pbase + k * 2 * ng * Cn * 8, cbase + k * 2 * ng * 4
+            d.ngroups, d.rows_per_group, d.stat = ng, rpg, sbase + k * 4 * Cn * 4
+            xin = d.y
+        check(lib().buctd_basic_chain_fwd_train(n, descs, stream_ptr()), "basic_chain_fwd_train")
+        ctx.blocks = blocks
+        ctx.save_for_backward(x, act, stat)
+        return act[n - 1, 2]
+
+    @staticmethod
+    def backward(ctx, dy):
+        blocks = ctx.blocks
+        n = len(blocks)
+        x, act, stat = ctx.saved_tensors
+        dy = _contig(dy)
+        N, H, W, Cn = x.shape
+        dev = x.device
+        want_dx = ctx.needs_input_grad[0]
+        tmp = torch.empty((n, 5, N, H, W, Cn), dtype=torch.float32, device=dev)     # per block: dz2 | dres | dy1 | dz1 | dx
+        step = 4 * N * H * W * Cn
+        abase, sbase, tb = act.data_ptr(), stat.data_ptr(), tmp.data_ptr()
+        descs = (_C.BasicBlockDesc * n)()
+        grads = (_C.BasicBlockGrads * n)()
+        bn_ws = workspace(lib().buctd_bn_bwd_workspace(N * H * W, Cn), dev)
+        main = torch.cuda.current_stream(dev)
+        use_side = _side["on"]
+        side = _side_stream(dev) if use_side else main
+        need = _memo(("wg3", "bf16x6", N, H, W, Cn, Cn),
+                     lambda: (lib().buctd_conv3x3_wgrad_bf16x6_workspace(N, H, W, Cn, Cn)
+                              if lib().buctd_conv3x3_wgrad_bf16x6_supported(N, H, W, Cn, Cn) == 1 else -1))
+        wg_ws = workspace_on(side, need, dev)
+        xin = x.data_ptr()
+        for k, (w1, bn1, w2, bn2) in enumerate(blocks):
+            d, g = descs[k], grads[k]
+            d.N, d.H, d.W, d.C = N, H, W, Cn
+            d.x = xin
+            d.w1_bwd = _conv3x3_prepared(w1, 1).data_ptr()
+            d.w2_bwd = _conv3x3_prepared(w2, 1).data_ptr()
+            d.gamma1, d.beta1 = bn1.weight.data_ptr(), bn1.bias.data_ptr()
+            d.gamma2, d.beta2 = bn2.weight.data_ptr(), bn2.bias.data_ptr()
+            b0 = abase + 3 * step * k
+            d.z1, d.z2, d.y = b0, b0 + step, b0 + 2 * step
+            d.stat = sbase + k * 4 * Cn * 4
+            xin = d.y
+            t0 = tb + 5 * step * k
+            g.dy = dy.data_ptr() if k == n - 1 else tb + 5 * step * (k + 1) + 4 * step      # the next block's dx
+            g.dz2, g.dres, g.dy1, g.dz1 = t0, t0 + step, t0 + 2 * step, t0 + 3 * step
+            g.dx = t0 + 4 * step if (k > 0 or want_dx) else 0
+            dg2, acc_g2 = grad_target(bn2.weight)
+            db2, acc_b2 = grad_target(bn2.bias)
+            dw2, acc_w2 = grad_target(w2)
+            dg1, acc_g1 = grad_target(bn1.weight)
+            db1, acc_b1 = grad_target(bn1.bias)
+            dw1, acc_w1 = grad_target(w1)
+            assert acc_g2 == acc_b2 and acc_g1 == acc_b1
+            weight_rsc(dw1)
+            weight_rsc(dw2)
+            g.dw1, g.dw2 = dw1.data_ptr(), dw2.data_ptr()
+            g.dgamma1, g.dbeta1, g.dgamma2, g.dbeta2 = dg1.data_ptr(), db1.data_ptr(), dg2.data_ptr(), db2.data_ptr()
+            g.acc_w1, g.acc_w2, g.acc_bn1, g.acc_bn2 = int(acc_w1), int(acc_w2), int(acc_g1), int(acc_g2)
+            g.bn_ws, g.bn_ws_bytes = bn_ws.data_ptr(), bn_ws.numel()
+            g.wg_ws, g.wg_ws_bytes = wg_ws.data_ptr(), wg_ws.numel()
+        check(lib().buctd_basic_chain_bwd(n, descs, grads, main.cuda_stream, side.cuda_stream if use_side else None),
+              "basic_chain_bwd")
+        if use_side:
+            for t in (x, act, stat, tmp, dy):
+                t.record_stream(side)
+            _queue_join()
+        elif _branch["on"]:
+            _queue_join()
+        for (w1, bn1, w2, bn2) in reversed(blocks):
+            grad_done(bn2.weight, bn2.bias, w2)
+            grad_done(bn1.weight, bn1.bias, w1)
+        return (tmp[0, 4] if want_dx else None), None, None
 
 
 class Conv(torch.autograd.Function):

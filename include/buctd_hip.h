@@ -353,6 +353,11 @@ typedef struct {
 } buctd_basic_block_grads;
 int buctd_basic_block_fwd_train(const buctd_basic_block* b, void* stream);
 int buctd_basic_block_bwd(const buctd_basic_block* b, const buctd_basic_block_grads* g, void* stream, void* side_stream);
+/* n chained blocks (an HRNet branch, pose_hrnet.py:165-185) behind one call per direction: blocks[k].x = blocks[k-1].y,
+ * grads[k].dy = grads[k+1].dx; the caller wires the pointers.  Same launches as n single calls. */
+int buctd_basic_chain_fwd_train(int n, const buctd_basic_block* blocks, void* stream);
+int buctd_basic_chain_bwd(int n, const buctd_basic_block* blocks, const buctd_basic_block_grads* grads, void* stream,
+                          void* side_stream);
 
 /* ------------------------------------------------------------ bf16x6 GEMM --- */
 /* C = alpha * A * B (+ bias) in the bf16x6 arithmetic of the 3x3 convolutions (fp32 operands split exactly into three

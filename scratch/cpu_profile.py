@@ -6,8 +6,10 @@ from buctd_amd import engine, models, ops
 from buctd_amd.core.loss import JointsMSELoss
 ops.set_conv_math("bf16x6")
 dev = torch.device("cuda:0")
-cfg = bench.coam_w48_cfg(2)
-net = models.pose_hrnet_coam.get_pose_net(cfg, is_train=True).to(dev).train()
+WL = sys.argv[1] if len(sys.argv) > 1 else "train_c4"
+mk, module = bench.TRAIN_WORKLOADS[WL][0], bench.TRAIN_WORKLOADS[WL][1]
+cfg = mk(2)
+net = getattr(models, module).get_pose_net(cfg, is_train=True).to(dev).train()
 model = engine.DataParallel(net)
 opt = engine.get_optimizer(cfg, model)
 x, tgt, wt = bench.synthetic_batch(cfg, 2, dev, 1)
