@@ -7,6 +7,13 @@
 // candidates" is done in two passes over a counter-based generator: count the survivors (64 candidates per step,
 // ballot + popcount), draw (source, rank), regenerate that source's candidates and take the survivor of that rank.
 // float64 throughout, like the reference.  oracle/pose_synthesis.py is the CPU twin (same generator, same scheme).
+//
+// Known deviation (documented, shared by the twin): the reference updates synth_joints[j] IN PLACE inside its joint loop, so
+// for the SECOND joint of a symmetric pair its inversion source synth_joints[pair] (pose_synthesis.py:271) - and the
+// distance guards against it - is the first joint AFTER its own perturbation (or (0, 0) if that joint was dropped).  The
+// joints here are synthesized in parallel, each from the UNPERTURBED pose.  The per-joint class frequencies measured
+// against the imported reference (oracle/make_golden.py:pose_synthesis_case, 1500 runs, max gap 0.03) include that effect;
+// sample-level equality is claimed against the twin only.
 #include "common.h"
 #include "../../include/buctd_hip.h"
 

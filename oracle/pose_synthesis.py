@@ -77,6 +77,10 @@ def synthesize_pose(dataset, joints, estimated, near, area, num_overlap, seed, p
         if joints[j, 2] == 0:
             synth[j] = estimated[j]
     nv = int(np.sum(joints[:, 2] > 0))
+    # Known deviation from the reference (shared with the HIP kernel, synth.hip): every joint is synthesized from the
+    # UNPERTURBED pose `synth`; the reference's in-place update makes the second joint of a symmetric pair see the first
+    # one's perturbed position as its inversion source (pose_synthesis.py:271).  Parity with the reference is therefore
+    # distributional (make_golden.py:pose_synthesis_case), sample-exact only between this twin and the kernel.
     pair_of = {}
     for q, w in T["symmetry"]:
         pair_of[q], pair_of[w] = w, q
