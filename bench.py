@@ -32,7 +32,7 @@ MFMAS_PER_PRODUCT = {"bf16x6": 6, "bf16x3": 3}
 # quoted only for the math mode and batch it was collected at.
 PMC_TRAFFIC_BYTES_N32 = {"bf16x6": {"fwd": 102.8e6,      # 2 x 30.33 MB fetched + 42.17 MB written (x6 kernel, 512-position tiles)
                                     "wgrad": 181.1e6}}   # kernel 2 x 48.65 + 42.17 (slabs), reduce 2 x 20.76 + 0.08
-# (profiles/r02_pmc_conv3x3_bf16x6.txt)
+# (profiles/r02_pmc_conv3x3_bf16x6.txt; re-measured unchanged in round 3: profiles/r03_pmc_conv3x3_default_path.txt)
 
 
 def coam_w48_cfg(batch):

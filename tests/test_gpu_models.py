@@ -179,14 +179,16 @@ def test_full_size_baseline_configs_forward(dev, name):
     assert np.array_equal(y.reshape(y.shape[0], y.shape[1], -1).argmax(2), gold["argmax"])
 
 
-def test_full_size_c4_train_step_vs_oracle(dev):
-    """BASELINE config C4 at full size (CoAM-W48 384x288, the bench workload) in TRAIN mode: the kernels only this size
-    reaches - 512-position conv tiles, fc_o on the bf16x6 GEMM at T = 6912, the position attention at T = 6912 - inside
-    one forward + loss + backward, against the fp32 and fp64 CPU oracle evaluated here.  Batch 2 (the recipe's image
-    and a scaled copy) so that the batch statistics are not degenerate."""
+@pytest.mark.parametrize("name,tag", [("coam_w48_384x288", "C4"), ("prenet_w48_384x288", "C3"), ("prenet_w32_256x192", "C2")])
+def test_full_size_train_step_vs_oracle(dev, name, tag):
+    """BASELINE configs C4 (CoAM-W48 384x288, the bench workload), C3 (preNet W48 384x288) and C2 (preNet W32 256x192) at
+    full size in TRAIN mode: the kernels only these sizes reach - 512-position conv tiles, the full-resolution preNet 7x7
+    convolutions, fc_o on the bf16x6 GEMM and the position attention at T = 6912, the 32 / 64 / 128 / 256-channel tile plans of
+    W32 - inside one forward + loss + backward, against the fp32 and fp64 CPU oracle evaluated here.  Batch 2 (the recipe's
+    image and a scaled mirror image) so that the batch statistics are not degenerate."""
     from oracle import recipes
     from buctd_amd.core.loss import JointsMSELoss
-    cfg, omodel, x, joints = recipes.build("coam_w48_384x288")
+    cfg, omodel, x, joints = recipes.build(name)
     x = torch.cat([x, x.flip(3) * 0.9], 0)
     joints = torch.cat([joints, joints], 0)
     tgt, wt = recipes.make_targets(cfg, joints, 77)
@@ -206,18 +208,23 @@ def test_full_size_c4_train_step_vs_oracle(dev):
     g32 = {k: p.grad.detach() for k, p in o32.named_parameters() if p.grad is not None}
     top = float(y32.detach().abs().max())
     err = float((y.detach().cpu() - y32.detach()).abs().max())
-    print(f"C4 full size train: max|y| {top:.3f}, |hip - oracle| {err:.3e}, loss hip {loss.item():.6f} oracle {l32.item():.6f}")
+    print(f"{tag} full size train: max|y| {top:.3f}, |hip - oracle| {err:.3e}, loss hip {loss.item():.6f} oracle {l32.item():.6f}")
     assert err <= BAR * max(1.0, top)
     assert rel(loss.item(), l32.item()) <= 1e-4
     params = dict(m.named_parameters())
     gmax = max(v.norm().item() for v in g64.values())
-    e_hip, e_cpu = [], []
+    e_hip, e_cpu, keys = [], [], []
     for k, g in g64.items():
         den = g.norm().item()
         if den <= 1e-6 * gmax:
             continue
         e_hip.append((params[k].grad.detach().cpu().double() - g).norm().item() / den)
         e_cpu.append((g32[k].double() - g).norm().item() / den)
+        keys.append(k)
     med_h, med_c, worst, worst_ref = float(np.median(e_hip)), float(np.median(e_cpu)), max(e_hip), max(e_cpu)
-    print(f"C4 full size: grad rel err vs fp64 - median hip {med_h:.2e} / cpu32 {med_c:.2e}; max hip {worst:.2e} / cpu32 {worst_ref:.2e}")
-    assert med_h <= max(3 * med_c, 2e-3) and worst <= max(3 * worst_ref, 5e-2)
+    order = np.argsort(e_hip)[::-1][:4]
+    print(f"{tag} full size: grad rel err vs fp64 - median hip {med_h:.2e} / cpu32 {med_c:.2e}; max hip {worst:.2e} / cpu32 "
+          f"{worst_ref:.2e}; worst tensors: " + ", ".join(f"{keys[i]} {e_hip[i]:.1e} (cpu32 {e_cpu[i]:.1e})" for i in order))
+    # the HIP path must be as close to the fp64 truth as the fp32 CPU path is (3x), with floors for a flipped ReLU
+    # (DESIGN.md 4): 2e-3 on the median, 2e-2 on the worst tensor - a wiring or scaling error of 2 % in one tensor shows
+    assert med_h <= max(3 * med_c, 2e-3) and worst <= max(3 * worst_ref, 2e-2)
