@@ -447,7 +447,8 @@ def main():
         entry_case()
         return
     small = ["prenet_w16_96x64", "coam_w16_96x64_colored", "coam_w16_96x64_mono_default_att",
-             "coam_w16_96x64_stacked_2heads", "coam_w16_96x64_channel_only", "transpose_w16_96x64", "resnet18_96x64"]
+             "coam_w16_96x64_stacked_2heads", "coam_w16_96x64_channel_only", "coam_w16_96x64_selfatt", "transpose_w16_96x64",
+             "resnet18_96x64"]
     full = ["coam_w48_384x288", "prenet_w32_256x192", "resnet50_256x192", "prenet_w48_384x288", "transpose_a6_256x192"]
     for name in small + ([] if args.fast else full):
         if args.only and args.only != name:

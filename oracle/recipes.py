@@ -138,6 +138,17 @@ def _coam_channel_only():
     return c, 2, 3
 
 
+@case("coam_w16_96x64_selfatt")
+def _coam_selfatt():
+    # MODEL.SELFATT_MODULES [F,T,F,F] with ATT_MODULES all off (the constructor asserts they never coincide,
+    # pose_hrnet_coam.py:461-462): SelfAttentionModule / SelfDAModule are CONSTRUCTED (their parameters are part of the
+    # state_dict) but the reference's forward only ever calls stageN_att under att_config[N] (pose_hrnet_coam.py:521-562), so
+    # the variant is a plain HRNet on the RGB channels carrying unused parameters - which is what this case pins
+    c = ocfg.hrnet_cfg(16, 14, (64, 96), "pose_hrnet_coam", use_attention=True, att_modules=(False, False, False, False),
+                       selfatt=(False, True, False, False), stage_modules=(1, 1, 1))
+    return c, 2, 3
+
+
 @case("transpose_w16_96x64")
 def _transpose_small():
     c = ocfg.hrnet_cfg(16, 17, (64, 96), "transpose_h", use_attention=True, stage_modules=(1, 2, 2))
@@ -192,7 +203,7 @@ def _transpose_full():
 # input: a power of two, so the scaling itself is exact and the recipe stays a pure function of its seed.
 FINAL_SCALE_LOG2 = {
     "prenet_w16_96x64": 6, "coam_w16_96x64_colored": 6, "coam_w16_96x64_mono_default_att": 7,
-    "coam_w16_96x64_stacked_2heads": 5, "coam_w16_96x64_channel_only": 9, "transpose_w16_96x64": 2, "resnet18_96x64": 3, "coam_w48_384x288": 6,
+    "coam_w16_96x64_stacked_2heads": 5, "coam_w16_96x64_channel_only": 9, "coam_w16_96x64_selfatt": 5, "transpose_w16_96x64": 2, "resnet18_96x64": 3, "coam_w48_384x288": 6,
     "prenet_w32_256x192": 7, "resnet50_256x192": 3, "prenet_w48_384x288": 7, "transpose_a6_256x192": 3,
 }
 

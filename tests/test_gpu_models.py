@@ -18,7 +18,8 @@ pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 SMALL = ["prenet_w16_96x64", "coam_w16_96x64_colored", "coam_w16_96x64_mono_default_att",
-         "coam_w16_96x64_stacked_2heads", "coam_w16_96x64_channel_only", "transpose_w16_96x64", "resnet18_96x64"]
+         "coam_w16_96x64_stacked_2heads", "coam_w16_96x64_channel_only", "coam_w16_96x64_selfatt", "transpose_w16_96x64",
+         "resnet18_96x64"]
 # BASELINE.json configs at full size: C4, C2, C1, C3, C5
 FULL = ["coam_w48_384x288", "prenet_w32_256x192", "resnet50_256x192", "prenet_w48_384x288", "transpose_a6_256x192"]
 BAR = 1e-3     # north_star: heat-maps within 1e-3 (fp32) of the reference forward - absolute, on unit-scale heat-maps

@@ -55,7 +55,7 @@ def test_config_node_matches_reference_yaml_workflow(tmp_path):
     assert isinstance(c.clone(), CfgNode)
 
 
-@pytest.mark.parametrize("name", ["prenet_w16_96x64", "coam_w16_96x64_colored", "coam_w16_96x64_stacked_2heads",
+@pytest.mark.parametrize("name", ["prenet_w16_96x64", "coam_w16_96x64_colored", "coam_w16_96x64_stacked_2heads", "coam_w16_96x64_selfatt",
                                   "transpose_w16_96x64", "resnet18_96x64"])
 def test_state_dict_contract_equals_oracle(name):
     from oracle import recipes

@@ -59,7 +59,8 @@ def test_condition_render_hand_derived():
 
 
 @pytest.mark.parametrize("name", ["prenet_w16_96x64", "coam_w16_96x64_colored", "coam_w16_96x64_mono_default_att",
-                                  "coam_w16_96x64_stacked_2heads", "coam_w16_96x64_channel_only", "transpose_w16_96x64", "resnet18_96x64"])
+                                  "coam_w16_96x64_stacked_2heads", "coam_w16_96x64_channel_only", "coam_w16_96x64_selfatt", "transpose_w16_96x64",
+                                  "resnet18_96x64"])
 def test_oracle_models_reproduce_reference_outputs(name):
     from oracle import recipes
     torch.set_num_threads(max(1, (os.cpu_count() or 2) // 2))
