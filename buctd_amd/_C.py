@@ -162,6 +162,7 @@ SIGNATURES = {
     "buctd_cond_render_workspace": (_SZ, [_I, _I, _I, _I]),
     "buctd_cond_render": (_I, [_P, _I, _P, _I, _I, _I, _I, _I, _I, _P, _P, _SZ, _P]),
     "buctd_flipback_avg": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P, _P]),
+    "buctd_sgd_step": (_I, [_P, _P, _P, _L, _F, _F, _F, _I, _I, _F, _P]),
     "buctd_adam_step": (_I, [_P, _P, _P, _P, _L, _F, _F, _F, _F, _I, _F, _P]),
 }
 

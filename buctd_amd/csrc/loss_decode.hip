@@ -385,3 +385,32 @@ extern "C" int buctd_adam_step(float* p, const float* g, float* m, float* v, lon
   BUCTD_CHECK_LAUNCH("buctd_adam_step");
   return BUCTD_OK;
 }
+
+// ---------------------------------------------------------------------- sgd ----
+// torch.optim.SGD(lr, momentum, dampening = 0, weight_decay, nesterov) on the flat arena - the 'sgd' branch of the
+// reference's get_optimizer (lib/utils/utils.py:260-267):
+//   g += wd p ;  buf = g (first step) | mu buf + g ;  g = nesterov ? g + mu buf : buf ;  p -= lr g        (mu = 0: no buffer)
+__global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ buf,
+                                                  long n, float lr, float mu, float wd, int nesterov, int first, float gscale) {
+  const long step = (long)gridDim.x * 256;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += step) {
+    float pp = p[i];
+    float gg = g[i] * gscale + wd * pp;
+    if (mu != 0.f) {
+      const float b = first ? gg : mu * buf[i] + gg;
+      buf[i] = b;
+      gg = nesterov ? gg + mu * b : b;
+    }
+    p[i] = pp - lr * gg;
+  }
+}
+extern "C" int buctd_sgd_step(float* p, const float* g, float* momentum_buf, long n, float lr, float momentum,
+                              float weight_decay, int nesterov, int first_step, float gscale, void* stream) {
+  BUCTD_CHECK_ARG(p && g && n > 0 && (momentum == 0.f || momentum_buf), "buctd_sgd_step: bad argument");
+  long blocks = (n + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(sgd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p, g, momentum_buf, n, lr,
+                     momentum, weight_decay, nesterov, first_step, gscale);
+  BUCTD_CHECK_LAUNCH("buctd_sgd_step");
+  return BUCTD_OK;
+}

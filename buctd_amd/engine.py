@@ -171,6 +171,78 @@ class FusedAdam(torch.optim.Optimizer):
                 g[k] = v
 
 
+class FusedSGD(torch.optim.Optimizer):
+    """torch.optim.SGD(lr, momentum, weight_decay, nesterov) semantics on the flat arena (one kernel per step) - the 'sgd'
+    branch of the reference's get_optimizer (lib/utils/utils.py:260-267).  Reads and writes torch.optim.SGD state_dicts."""
+
+    def __init__(self, flat, lr=1e-3, momentum=0.0, weight_decay=0.0, nesterov=False, grad_sync=None):
+        if not isinstance(flat, FlatParams):
+            raise TypeError("FusedSGD works on an engine.FlatParams arena")
+        if nesterov and momentum <= 0:
+            raise ValueError("Nesterov momentum requires a momentum and zero dampening")
+        super().__init__(flat.params, dict(lr=lr, momentum=momentum, dampening=0, weight_decay=weight_decay,
+                                           nesterov=nesterov))
+        self.flat = flat
+        self.buf = torch.zeros_like(flat.flat) if momentum else None
+        self.step_count = 0
+        self.grad_sync = grad_sync
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        if closure is not None:
+            raise NotImplementedError("closures are not used on the BUCTD path")
+        self.flat.collect()
+        gscale = self.grad_sync() if self.grad_sync is not None else 1.0
+        g = self.param_groups[0]
+        ops.sgd_step(self.flat.flat, self.flat.grad, self.buf, g["lr"], g["momentum"], g["weight_decay"], g["nesterov"],
+                     self.step_count == 0, gscale)
+        self.step_count += 1
+        ops.weights_updated()
+        ops.refresh_prepared(self.flat.flat.device)
+
+    def zero_grad(self, set_to_none=True):
+        for p in self.flat.params:
+            p.grad = None
+
+    def state_dict(self):
+        state = {}
+        if self.buf is not None and self.step_count > 0:
+            for i, p in enumerate(self.flat.params):
+                o, _ = self.flat.span(p)
+                state[i] = {"momentum_buffer": torch.as_strided(self.buf, p.shape, p.stride(), o).clone()}
+        groups = []
+        for g in self.param_groups:
+            d = {k: v for k, v in g.items() if k != "params"}
+            for k, v in (("maximize", False), ("foreach", None), ("differentiable", False), ("fused", None)):
+                d.setdefault(k, v)
+            d["params"] = list(range(len(self.flat.params)))
+            groups.append(d)
+        return {"state": state, "param_groups": groups}
+
+    def load_state_dict(self, sd):
+        state = sd.get("state", {})
+        loaded = 0
+        for i, p in enumerate(self.flat.params):
+            st = state.get(i, state.get(str(i)))
+            if st is None or st.get("momentum_buffer") is None:
+                continue
+            if self.buf is None:
+                raise ValueError("FusedSGD was built without momentum but the state_dict carries momentum buffers")
+            o, _ = self.flat.span(p)
+            torch.as_strided(self.buf, p.shape, p.stride(), o).copy_(st["momentum_buffer"])
+            loaded += 1
+        self.step_count = 1 if loaded else 0
+        for g, src in zip(self.param_groups, sd["param_groups"]):
+            for k, v in src.items():
+                if k == "params":
+                    continue
+                if k == "dampening" and v not in (0, 0.0):
+                    raise ValueError("FusedSGD implements dampening = 0 (the reference's recipe)")
+                if k == "maximize" and v:
+                    raise ValueError("FusedSGD does not implement maximize")
+                g[k] = v
+
+
 class GradBuckets:
     """Contiguous slices of the gradient arena, cut so that a bucket closes when the backward pass (which
     produces gradients roughly in reverse registration order) has written all of its tensors."""
@@ -348,14 +420,18 @@ class DataParallel(torch.nn.Module):
 
 
 def get_optimizer(cfg, model):
-    """reference lib/utils/utils.py:258-274: Adam(lr) for 'adam' (no weight decay), SGD otherwise - here the
-    fused flat-arena Adam, wired to the data-parallel gradient exchange when `model` is an engine.DataParallel."""
-    if cfg.TRAIN.OPTIMIZER != "adam":
-        raise NotImplementedError("every BUCTD recipe trains with Adam (get_optimizer: 'we only use adam')")
+    """reference lib/utils/utils.py:258-274: SGD(lr, MOMENTUM, WD, NESTEROV) for 'sgd', Adam(lr) for 'adam' - here the fused
+    flat-arena optimizers, wired to the data-parallel gradient exchange when `model` is an engine.DataParallel."""
     if isinstance(model, DataParallel):
-        flat = model.flatten()
-        return FusedAdam(flat, lr=cfg.TRAIN.LR, grad_sync=model.sync_gradients)
-    return FusedAdam(FlatParams(model), lr=cfg.TRAIN.LR)
+        flat, sync = model.flatten(), model.sync_gradients
+    else:
+        flat, sync = FlatParams(model), None
+    if cfg.TRAIN.OPTIMIZER == "sgd":
+        return FusedSGD(flat, lr=cfg.TRAIN.LR, momentum=cfg.TRAIN.MOMENTUM, weight_decay=cfg.TRAIN.WD,
+                        nesterov=cfg.TRAIN.NESTEROV, grad_sync=sync)
+    if cfg.TRAIN.OPTIMIZER == "adam":
+        return FusedAdam(flat, lr=cfg.TRAIN.LR, grad_sync=sync)
+    return None       # the reference returns None for any other name (utils.py:259, 274)
 
 
 def init_distributed():

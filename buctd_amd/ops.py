@@ -1077,6 +1077,11 @@ def adam_step(p, g, m, v, lr, beta1, beta2, eps, step, gscale=1.0):
                                 stream_ptr()), "adam_step")
 
 
+def sgd_step(p, g, buf, lr, momentum, weight_decay, nesterov, first, gscale=1.0):
+    check(lib().buctd_sgd_step(ptr(p), ptr(g), ptr(buf), p.numel(), lr, momentum, weight_decay, int(bool(nesterov)),
+                               int(bool(first)), gscale, stream_ptr()), "sgd_step")
+
+
 def layernorm_fwd(x, gamma, beta, eps):
     Cn = x.shape[-1]
     rows = x.numel() // Cn

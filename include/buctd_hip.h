@@ -380,6 +380,10 @@ int buctd_x6_gemm(int M, int N, int K, const void* a_image, const void* b_image,
  * on flat fp32 buffers; gscale multiplies the gradient first (1/world for averaged all-reduce). */
 int buctd_adam_step(float* p, const float* g, float* m, float* v, long n, float lr, float beta1, float beta2,
                     float eps, int step, float gscale, void* stream);
+/* torch.optim.SGD(lr, momentum, dampening 0, weight_decay, nesterov) on a flat arena - the 'sgd' branch of get_optimizer
+ * (lib/utils/utils.py:260-267).  first_step != 0: the momentum buffer is initialised with the gradient. */
+int buctd_sgd_step(float* p, const float* g, float* momentum_buf, long n, float lr, float momentum, float weight_decay,
+                   int nesterov, int first_step, float gscale, void* stream);
 
 /* Fused single-head self-attention forward (flash style, exact fp32) - nn.MultiheadAttention of the TransPose encoder
  * layer, transpose_h.py:192-197, in eval mode / without attention dropout: out[b][i] = softmax_j(scale * q_i . k_j) v_j.

@@ -421,3 +421,35 @@ def test_target_and_condition_render_vs_oracle(dev):
         ref = oc.get_condition_image(cj[b].numpy(), (H, W))[0:1].astype(np.float64)
         d = np.abs(mono[b] - ref)
         assert d.max() <= 1.0 and (d > 0).mean() < 1e-3, "mono condition: only integer-boundary flips allowed"
+
+
+@pytest.mark.parametrize("momentum,nesterov,wd", [(0.9, False, 1e-4), (0.9, True, 0.0), (0.0, False, 1e-2)])
+def test_fused_sgd_matches_torch_sgd(dev, momentum, nesterov, wd):
+    """engine.FusedSGD (the 'sgd' branch of the reference's get_optimizer, lib/utils/utils.py:260-267) against
+    torch.optim.SGD on the CPU: three steps, parameters and momentum buffers."""
+    import copy
+    from buctd_amd import engine
+    torch.manual_seed(3)
+    net = torch.nn.Sequential(torch.nn.Conv2d(3, 8, 3), torch.nn.BatchNorm2d(8), torch.nn.Conv2d(8, 4, 1))
+    twin = copy.deepcopy(net).to(dev)
+    ref = torch.optim.SGD(net.parameters(), lr=0.05, momentum=momentum, weight_decay=wd, nesterov=nesterov)
+    fused = engine.FusedSGD(engine.FlatParams(twin), lr=0.05, momentum=momentum, weight_decay=wd, nesterov=nesterov)
+    for it in range(3):
+        grads = [torch.randn_like(p) for p in net.parameters()]
+        for p, q, g in zip(net.parameters(), twin.parameters(), grads):
+            p.grad = g.clone()
+            q.grad = g.to(dev)
+        ref.step()
+        fused.step()
+    for p, q in zip(net.parameters(), twin.parameters()):
+        assert (p.detach() - q.detach().cpu()).abs().max().item() <= 1e-6 * max(1.0, p.abs().max().item())
+    sd = fused.state_dict()
+    if momentum:
+        back = torch.optim.SGD(copy.deepcopy(net).parameters(), lr=1.0, momentum=momentum)
+        back.load_state_dict(sd)        # torch accepts what FusedSGD writes
+        rs = ref.state_dict()["state"]
+        for i in rs:
+            assert (rs[i]["momentum_buffer"] - sd["state"][i]["momentum_buffer"].cpu()).abs().max().item() <= 1e-6
+        again = engine.FusedSGD(engine.FlatParams(copy.deepcopy(twin)), lr=0.01, momentum=momentum)
+        again.load_state_dict(ref.state_dict())
+        assert again.param_groups[0]["lr"] == 0.05 and again.step_count == 1

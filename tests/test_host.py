@@ -229,3 +229,22 @@ def test_fused_adam_checkpoint_is_torch_adam_format():
     bad["param_groups"][0]["weight_decay"] = 0.1
     with pytest.raises(ValueError):
         fused.load_state_dict(bad)
+
+
+def test_get_optimizer_branches_like_the_reference():
+    """lib/utils/utils.py:258-274: 'sgd' -> SGD(LR, MOMENTUM, WD, NESTEROV), 'adam' -> Adam(LR), anything else -> None."""
+    from buctd_amd import engine
+    from buctd_amd.config import cfg
+    net = torch.nn.Sequential(torch.nn.Conv2d(3, 4, 3), torch.nn.BatchNorm2d(4))
+    c = cfg.clone()
+    c.defrost()
+    c.TRAIN.OPTIMIZER, c.TRAIN.LR = "sgd", 0.01
+    opt = engine.get_optimizer(c, net)
+    g = opt.param_groups[0]
+    assert isinstance(opt, engine.FusedSGD) and (g["lr"], g["momentum"], g["weight_decay"], g["nesterov"]) == (0.01, 0.9, 1e-4, False)
+    sd = opt.state_dict()
+    assert sd["state"] == {} and sd["param_groups"][0]["dampening"] == 0
+    c.TRAIN.OPTIMIZER = "adam"
+    assert isinstance(engine.get_optimizer(c, torch.nn.Sequential(torch.nn.Conv2d(3, 4, 3))), engine.FusedAdam)
+    c.TRAIN.OPTIMIZER = "rmsprop"
+    assert engine.get_optimizer(c, torch.nn.Sequential(torch.nn.Conv2d(3, 4, 3))) is None
