@@ -15,6 +15,8 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libbuctd_hip.so")
+if os.environ.get("BUCTD_LIB_TRACE") == "1":      # scratch experiments only: the -DBUCTD_TUNING build (scratch/build_trace_lib.sh)
+    LIB_PATH = os.path.join(os.path.dirname(_HERE), "scratch", "libbuctd_hip_trace.so")
 
 
 class ConvDesc(C.Structure):
@@ -119,6 +121,7 @@ SIGNATURES = {
     "buctd_x6_image": (_I, [_P, _I, _I, _I, _L, _L, _I, _L, _L, _I, _P, _P]),
     "buctd_x6_gemm": (_I, [_I, _I, _I, _P, _P, _P, _I, _F, _P, _L, _I, _L, _P]),
     "buctd_add": (_I, [_P, _P, _P, _L, _I, _P]),
+    "buctd_add_n": (_I, [C.POINTER(_P), _I, _P, _L, _P]),
     "buctd_mul": (_I, [_P, _P, _P, _L, _P]),
     "buctd_scale": (_I, [_P, _P, _F, _P, _L, _P]),
     "buctd_copy_channels": (_I, [_P, _L, _I, _I, _P, _I, _I, _I, _P]),

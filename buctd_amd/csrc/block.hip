@@ -6,6 +6,20 @@
 #include "common.h"
 #include "../../include/buctd_hip.h"
 
+// Experiment builds only (scratch/build_trace_lib.sh, -DBUCTD_TUNING): BUCTD_SKIP = bit mask of launches to leave out of the
+// backward sequence - 1: weight gradients, 2: BatchNorm backward, 4: data gradients - for "what if this were free"
+// timings of the train step (results are garbage).  The product build reads no environment.
+#ifdef BUCTD_TUNING
+#include <stdlib.h>
+static int blk_skip() {
+  static const int v = getenv("BUCTD_SKIP") ? atoi(getenv("BUCTD_SKIP")) : 0;
+  return v;
+}
+#define BLK_SKIP(bit) (blk_skip() & (bit))
+#else
+#define BLK_SKIP(bit) 0
+#endif
+
 #define BLK_TRY(call)      \
   do {                     \
     const int rc_ = (call); \
@@ -24,23 +38,27 @@ extern "C" int buctd_basic_block_fwd_train(const buctd_basic_block* b, void* str
   float *mean1 = b->stat, *invstd1 = b->stat + C, *mean2 = b->stat + 2 * C, *invstd2 = b->stat + 3 * C;
   const bool planes = b->xp && b->y1p;
   BUCTD_CHECK_ARG((b->xp == nullptr) == (b->y1p == nullptr), "buctd_basic_block_fwd_train: xp and y1p go together");
+  // (what-if bits of the forward, tuning builds: 8 convolutions, 16 finalizes, 32 the output bn_apply)
   if (planes)     // conv1 also writes the split x it staged: the X operand of its weight gradient
     BLK_TRY(buctd_conv3x3_bf16x6_emit(N, H, W, C, C, b->x, b->w1_fwd, b->z1, part1, cnt1, nullptr, nullptr, nullptr, nullptr, 0,
                                       b->xp, stream));
-  else
+  else if (!BLK_SKIP(8))
     BLK_TRY(buctd_conv3x3_bf16x6(N, H, W, C, C, b->x, b->w1_fwd, nullptr, nullptr, nullptr, nullptr, 0, b->z1, part1, cnt1,
                                  stream));
-  BLK_TRY(buctd_bn_finalize(part1, cnt1, b->ngroups, b->rows_per_group, rows, C, b->eps1, b->momentum1, mean1, invstd1,
-                            b->running_mean1, b->running_var1, stream));
+  if (!BLK_SKIP(16))
+    BLK_TRY(buctd_bn_finalize(part1, cnt1, b->ngroups, b->rows_per_group, rows, C, b->eps1, b->momentum1, mean1, invstd1,
+                              b->running_mean1, b->running_var1, stream));
   // conv2 applies bn1 + ReLU while it stages its input: relu(bn1(z1)) never exists in memory
   if (planes)     // ... and here y1 = relu(bn1(z1)) reaches memory after all - as planes, for conv2's weight gradient
     BLK_TRY(buctd_conv3x3_bf16x6_emit(N, H, W, C, C, b->z1, b->w2_fwd, b->z2, part2, cnt2, mean1, invstd1, b->gamma1, b->beta1, 1,
                                       b->y1p, stream));
-  else
+  else if (!BLK_SKIP(8))
     BLK_TRY(buctd_conv3x3_bf16x6_bnin(N, H, W, C, C, b->z1, b->w2_fwd, nullptr, nullptr, nullptr, nullptr, 0, b->z2, part2,
                                       cnt2, mean1, invstd1, b->gamma1, b->beta1, 1, stream));
-  BLK_TRY(buctd_bn_finalize(part2, cnt2, b->ngroups, b->rows_per_group, rows, C, b->eps2, b->momentum2, mean2, invstd2,
-                            b->running_mean2, b->running_var2, stream));
+  if (!BLK_SKIP(16))
+    BLK_TRY(buctd_bn_finalize(part2, cnt2, b->ngroups, b->rows_per_group, rows, C, b->eps2, b->momentum2, mean2, invstd2,
+                              b->running_mean2, b->running_var2, stream));
+  if (BLK_SKIP(32)) return BUCTD_OK;
   BLK_TRY(buctd_bn_apply(b->z2, mean2, invstd2, b->gamma2, b->beta2, b->x, 1, b->y, rows, C, stream));
   return BUCTD_OK;
 }
@@ -96,19 +114,24 @@ extern "C" int buctd_basic_block_bwd(const buctd_basic_block* b, const buctd_bas
     return BUCTD_OK;
   }
   // conv2 / bn2 (+ skip): dres = masked upstream gradient
-  BLK_TRY(buctd_bn_bwd(g->dy, b->y, b->z2, mean2, invstd2, b->gamma2, nullptr, 1, rows, C, g->dz2, g->dres, g->dgamma2,
-                       g->dbeta2, g->acc_bn2, g->bn_ws, g->bn_ws_bytes, stream));
+  if (!BLK_SKIP(2))
+    BLK_TRY(buctd_bn_bwd(g->dy, b->y, b->z2, mean2, invstd2, b->gamma2, nullptr, 1, rows, C, g->dz2, g->dres, g->dgamma2,
+                         g->dbeta2, g->acc_bn2, g->bn_ws, g->bn_ws_bytes, stream));
   BLK_TRY(fork());
-  BLK_TRY(buctd_conv3x3_wgrad_bf16x6_bnin(N, H, W, C, C, b->z1, g->dz2, g->dw2, g->acc_w2, mean1, invstd1, b->gamma1,
-                                          b->beta1, 1, g->wg_ws, g->wg_ws_bytes, side_s));
-  BLK_TRY(buctd_conv3x3_bf16x6(N, H, W, C, C, g->dz2, b->w2_bwd, nullptr, nullptr, nullptr, nullptr, 0, g->dy1, nullptr,
-                               nullptr, stream));
+  if (!BLK_SKIP(1))
+    BLK_TRY(buctd_conv3x3_wgrad_bf16x6_bnin(N, H, W, C, C, b->z1, g->dz2, g->dw2, g->acc_w2, mean1, invstd1, b->gamma1,
+                                            b->beta1, 1, g->wg_ws, g->wg_ws_bytes, side_s));
+  if (!BLK_SKIP(4))
+    BLK_TRY(buctd_conv3x3_bf16x6(N, H, W, C, C, g->dz2, b->w2_bwd, nullptr, nullptr, nullptr, nullptr, 0, g->dy1, nullptr,
+                                 nullptr, stream));
   // conv1 / bn1: the ReLU mask is rebuilt from z1; the skip gradient joins in the data-gradient epilogue
-  BLK_TRY(buctd_bn_bwd(g->dy1, nullptr, b->z1, mean1, invstd1, b->gamma1, b->beta1, 1, rows, C, g->dz1, nullptr, g->dgamma1,
-                       g->dbeta1, g->acc_bn1, g->bn_ws, g->bn_ws_bytes, stream));
+  if (!BLK_SKIP(2))
+    BLK_TRY(buctd_bn_bwd(g->dy1, nullptr, b->z1, mean1, invstd1, b->gamma1, b->beta1, 1, rows, C, g->dz1, nullptr, g->dgamma1,
+                         g->dbeta1, g->acc_bn1, g->bn_ws, g->bn_ws_bytes, stream));
   BLK_TRY(fork());
-  BLK_TRY(buctd_conv3x3_wgrad_bf16x6(N, H, W, C, C, b->x, g->dz1, g->dw1, g->acc_w1, g->wg_ws, g->wg_ws_bytes, side_s));
-  if (g->dx)
+  if (!BLK_SKIP(1))
+    BLK_TRY(buctd_conv3x3_wgrad_bf16x6(N, H, W, C, C, b->x, g->dz1, g->dw1, g->acc_w1, g->wg_ws, g->wg_ws_bytes, side_s));
+  if (g->dx && !BLK_SKIP(4))
     BLK_TRY(buctd_conv3x3_bf16x6(N, H, W, C, C, g->dz1, b->w1_bwd, nullptr, nullptr, nullptr, g->dres, 0, g->dx, nullptr,
                                  nullptr, stream));
   return BUCTD_OK;

@@ -458,3 +458,33 @@ extern "C" int buctd_maxpool3x3s2_bwd(const float* dy, const int32_t* idx, int N
   BUCTD_CHECK_LAUNCH("buctd_maxpool3x3s2_bwd");
   return BUCTD_OK;
 }
+
+// out = a0 + a1 (+ a2 (+ a3)) : the gradient fan-in of a tensor with several consumers (an HRNet branch output feeds up to
+// four fuse rows, pose_hrnet.py:257-265) in ONE pass instead of autograd's chain of two-operand adds.  Summation order
+// a0 + a1 + a2 + a3, left to right (what the chain computes).
+struct AddNArgs { const float* a[4]; };
+__global__ __launch_bounds__(256) void add_n_kernel(AddNArgs p, int n, float* __restrict__ out, long count) {
+  const long n4 = count >> 2;
+  const long step = (long)gridDim.x * 256;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += step) {
+    f32x4 s = reinterpret_cast<const f32x4*>(p.a[0])[i] + reinterpret_cast<const f32x4*>(p.a[1])[i];
+    if (n > 2) s += reinterpret_cast<const f32x4*>(p.a[2])[i];
+    if (n > 3) s += reinterpret_cast<const f32x4*>(p.a[3])[i];
+    reinterpret_cast<f32x4*>(out)[i] = s;
+  }
+  for (long i = n4 * 4 + (long)blockIdx.x * 256 + threadIdx.x; i < count; i += step) {
+    float s = p.a[0][i] + p.a[1][i];
+    if (n > 2) s += p.a[2][i];
+    if (n > 3) s += p.a[3][i];
+    out[i] = s;
+  }
+}
+extern "C" int buctd_add_n(const float* const* terms, int n, float* out, long count, void* stream) {
+  BUCTD_CHECK_ARG(terms && n >= 2 && n <= 4 && out && count > 0, "buctd_add_n: 2..4 terms");
+  AddNArgs a;
+  for (int k = 0; k < 4; ++k) a.a[k] = k < n ? terms[k] : nullptr;
+  for (int k = 0; k < n; ++k) BUCTD_CHECK_ARG(a.a[k], "buctd_add_n: null term");
+  hipLaunchKernelGGL(add_n_kernel, dim3(stream_grid((count + 3) / 4)), dim3(256), 0, (hipStream_t)stream, a, n, out, count);
+  BUCTD_CHECK_LAUNCH("buctd_add_n");
+  return BUCTD_OK;
+}

@@ -164,22 +164,27 @@ class HighResolutionModule(nn.Module):
             return [self.branches[0](x[0])]
         xs = ops.fork_join([lambda i=i: self.branches[i](x[i]) for i in range(self.num_branches)],
                            [x[i] for i in range(self.num_branches)])
+        rows = list(enumerate(self.fuse_layers))
+        # every branch output feeds every fuse row: with gradients wanted, hand out aliases whose gradients are summed by one
+        # n-ary add (ops.FanOut) instead of autograd's chain of two-operand adds
+        fan = len(rows) > 1 and torch.is_grad_enabled() and any(t.requires_grad for t in xs)
+        xr = [ops.FanOut.apply(xs[j], len(rows)) if fan and xs[j].is_cuda else [xs[j]] * len(rows)
+              for j in range(self.num_branches)]
 
         def fuse_row(i, row):
             terms, shifts = [], []
             for j in range(self.num_branches):
                 if j == i:
-                    terms.append(xs[j])
+                    terms.append(xr[j][i])
                     shifts.append(0)
                 elif j > i:
-                    terms.append(row[j](xs[j]))   # 1x1 conv + BN at the low resolution
-                    shifts.append(j - i)          # nearest up-sampling happens inside the fuse kernel
+                    terms.append(row[j](xr[j][i]))   # 1x1 conv + BN at the low resolution
+                    shifts.append(j - i)             # nearest up-sampling happens inside the fuse kernel
                 else:
-                    terms.append(row[j](xs[j]))
+                    terms.append(row[j](xr[j][i]))
                     shifts.append(0)
             return ops.FuseSum.apply(tuple(shifts), True, *terms)
 
-        rows = list(enumerate(self.fuse_layers))
         return ops.fork_join([lambda i=i, row=row: fuse_row(i, row) for i, row in rows], [xs for _ in rows], tag=1)
 
 

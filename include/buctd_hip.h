@@ -212,6 +212,9 @@ int buctd_bn_fold(const float* gamma, const float* beta, const float* running_me
 /* ----------------------------------------------------------- elementwise --- */
 /* out[i] = a[i] + b[i] (b may be NULL -> copy); relu optional */
 int buctd_add(const float* a, const float* b, float* out, long n, int relu, void* stream);
+/* out = terms[0] + ... + terms[n-1] (2 <= n <= 4, host array of device pointers), summed left to right: the gradient
+ * fan-in of a tensor with several consumers (HRNet fuse rows, pose_hrnet.py:257-265) in one pass */
+int buctd_add_n(const float* const* terms, int n, float* out, long count, void* stream);
 /* out[i] = a[i] * b[i]: DAModule with MODEL.ATT_CHANNEL_ONLY, `input * c_out` (pose_hrnet_coam.py:716-717) */
 int buctd_mul(const float* a, const float* b, float* out, long n, void* stream);
 /* out[i] = x[i] * alpha * (*dev_scalar) ; dev_scalar is a device pointer or NULL (chain rule through
