@@ -435,14 +435,18 @@ def bench_infer_c5(args, rank, world, device):
         tf = flops / us / 1e6
         x6 = args.conv_math == "bf16x6" and os.environ.get("BUCTD_MHA_X6", "1") != "0"
         peak = PEAK_BF16_MFMA_TFLOPS / 6 if x6 else PEAK_FP32_MFMA_TFLOPS
-        out["roofline"] = {"kernel": f"{'mha_fwd_x6_kernel' if x6 else 'mha_fwd_kernel'}<7>: fused self-attention forward, "
+        pre = x6 and os.environ.get("BUCTD_MHA_PRESPLIT", "1") != "0"
+        kname = ("mha_kv_split_kernel + mha_fwd_x6q_kernel" if pre else "mha_fwd_x6_kernel") if x6 else "mha_fwd_kernel"
+        out["roofline"] = {"kernel": f"{kname}<7>: fused self-attention forward, "
                                      f"T={T} d={d} N={args.batch} (TransPose encoder layer)", "bound": "mfma",
                            "achieved": round(tf, 2), "peak": round(peak, 1), "unit": "TFLOP/s", "frac": round(tf / peak, 4),
                            "traffic": None, "algorithmic_flops": flops, "algorithmic_bytes": bytes_,
                            "avg_launch_us": round(us, 1), "launches_timed": len(mha["pairs"]),
                            "hbm_frac": round(bytes_ / us / 1e3 / PEAK_HBM_GBPS, 4),
-                           "timing": "HIP events on the launching stream around every launch in the timed steps "
-                                     "(single stream: no co-runners)",
+                           "timing": "HIP events on the launching stream around every call in the timed steps "
+                                     "(single stream: no co-runners)" +
+                                     ("; a call = the K/V pre-split launch (6 B/element image, ~45 us) + the attention launch"
+                                      if pre else ""),
                            "note": ("bf16x6: dense bf16 MFMA peak 2500 TFLOP/s / 6 MFMAs per fp32 product = 416.7 TFLOP/s-"
                                     "equivalent" if x6 else "exact fp32 MFMA (v_mfma_f32_16x16x4_f32, 157.3 TFLOP/s peak)") +
                                    " binds: 4 T^2 d FLOP against 4 T d floats of HBM traffic per image"}

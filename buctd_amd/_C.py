@@ -153,6 +153,8 @@ SIGNATURES = {
     "buctd_mha_fwd_supported": (_I, [_I, _I]),
     "buctd_mha_fwd": (_I, [_I, _I, _I, _P, _P, _P, _I, _I, _F, _P, _P, _P]),
     "buctd_mha_fwd_bf16x6": (_I, [_I, _I, _I, _P, _P, _P, _I, _I, _F, _P, _P, _P]),
+    "buctd_mha_fwd_bf16x6_workspace": (_SZ, [_I, _I, _I]),
+    "buctd_mha_fwd_bf16x6_ws": (_I, [_I, _I, _I, _P, _P, _P, _I, _I, _F, _P, _P, _P, _SZ, _P]),
     "buctd_mha_train_supported": (_I, [_I, _I]),
     "buctd_mha_fwd_train": (_I, [_I, _I, _I, _P, _P, _P, _I, _I, _F, _F, _U64, _P, _P, _P]),
     "buctd_mha_bwd_workspace": (_SZ, [_I, _I]),

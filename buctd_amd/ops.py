@@ -486,6 +486,7 @@ _NATIVE_BLOCK = os.environ.get("BUCTD_NATIVE_BLOCK", "1") == "1"
 _FUSE_BN_IN = os.environ.get("BUCTD_FUSE_BN_IN", "1") == "1"
 _FC_O_X6 = os.environ.get("BUCTD_FC_O_X6", "1") != "0"
 _MHA_X6 = os.environ.get("BUCTD_MHA_X6", "1") != "0"
+_MHA_PRESPLIT = os.environ.get("BUCTD_MHA_PRESPLIT", "1") != "0"
 _ATTN_X6 = os.environ.get("BUCTD_ATTN_X6", "1") != "0"
 # optional veto: callable(x_shape) -> True sends a BasicBlock through the step-by-step path (bench.py brackets every launch
 # of its roofline shape with HIP events, which it can only do from the host mirror)
@@ -1771,10 +1772,18 @@ def mha_fwd(qk, v, scale=None):
     out = torch.empty((B, T, d), dtype=torch.float32, device=qk.device)
     kptr = C.c_void_p(qk.data_ptr() + 4 * d)
     # default math mode: both products in bf16x6 (fp32 class on the bf16 matrix cores); fp32 mode: exact fp32 MFMA
-    fn = lib().buctd_mha_fwd_bf16x6 if (_conv_math["mode"] == "bf16x6" and _MHA_X6) \
-        else lib().buctd_mha_fwd
-    check(fn(B, T, d, ptr(qk), kptr, ptr(v), two_d, v.shape[2],
-             (1.0 / math.sqrt(d)) if scale is None else float(scale), ptr(out), None, stream_ptr()), "mha_fwd")
+    sc = (1.0 / math.sqrt(d)) if scale is None else float(scale)
+    if _conv_math["mode"] == "bf16x6" and _MHA_X6:
+        if _MHA_PRESPLIT:       # keys / values split once into the workspace, streamed by DMA (same bits, faster)
+            nb = _memo(("mhaws", B, T, d), lambda: lib().buctd_mha_fwd_bf16x6_workspace(B, T, d))
+            ws = workspace(nb, qk.device)
+            check(lib().buctd_mha_fwd_bf16x6_ws(B, T, d, ptr(qk), kptr, ptr(v), two_d, v.shape[2], sc, ptr(out), None,
+                                                ptr(ws), ws.numel(), stream_ptr()), "mha_fwd")
+            return out
+        fn = lib().buctd_mha_fwd_bf16x6
+    else:
+        fn = lib().buctd_mha_fwd
+    check(fn(B, T, d, ptr(qk), kptr, ptr(v), two_d, v.shape[2], sc, ptr(out), None, stream_ptr()), "mha_fwd")
     return out
 
 

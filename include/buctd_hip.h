@@ -400,6 +400,12 @@ int buctd_mha_fwd(int B, int T, int d, const float* q, const float* k, const flo
  * accumulate: fp32 class on the bf16 matrix cores); probabilities stay in registers (S^T formulation). */
 int buctd_mha_fwd_bf16x6(int B, int T, int d, const float* q, const float* k, const float* v, int ldqk, int ldv,
                          float scale, float* out, float* lse, void* stream);
+/* bf16x6 attention over keys / values split ONCE per call into the workspace (6 B per element, the kernel's LDS tile layout)
+ * and streamed into LDS by DMA - same results bit for bit as buctd_mha_fwd_bf16x6 (same pieces, same MFMA order), faster:
+ * no per-workgroup re-split, K/V copies overlap the products, one image per XCD L2. */
+size_t buctd_mha_fwd_bf16x6_workspace(int B, int T, int d);
+int buctd_mha_fwd_bf16x6_ws(int B, int T, int d, const float* q, const float* k, const float* v, int ldqk, int ldv,
+                            float scale, float* out, float* lse, void* workspace, size_t workspace_bytes, void* stream);
 /* The same attention for TRAINING (transpose_h.py:168-213, autograd of softmax -> dropout -> . v), fused in both
  * directions - nothing T x T in HBM: forward with in-kernel attention dropout (counter hash keyed by (seed, (b T + q) T + key),
  * the function of buctd_softmax_dropout_fwd) and the row statistic lse [B][T]; flash-style backward (one kernel template in

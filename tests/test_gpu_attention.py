@@ -98,6 +98,42 @@ def test_fused_mha_forward_vs_fp64(dev, B, T, d, mode):
     assert not ops.mha_fused_ok(100, d) and not ops.mha_fused_ok(T, 20)
 
 
+@pytest.mark.parametrize("B,T,d", [(8, 384, 112), (16, 128, 48), (3, 256, 16), (1, 3072, 112), (2, 256, 128)])
+def test_fused_mha_presplit_matches_the_in_kernel_split(dev, B, T, d, monkeypatch):
+    """buctd_mha_fwd_bf16x6_ws (keys / values split once into the workspace, DMA-staged tiles, 32 queries per wavefront,
+    the key range split over the two wave quartets and merged, one image per XCD - B a multiple of 8 takes the XCD-aware
+    workgroup map, other B the plain one) against buctd_mha_fwd_bf16x6: the same exact pieces and products, a different
+    association of the online soft-max (32-key tiles, two halves merged) -> equal to fp32 round-off, and as close to fp64.
+    The workspace is dirtied first: pad bytes of the image rows are never read."""
+    from buctd_amd import ops
+    g = torch.Generator().manual_seed(B * T + d + 5)
+    qk = (torch.randn(B, T, 2 * d, generator=g) * 1.5)
+    qk[:, ::5, :d] *= 4.0
+    v = torch.randn(B, T, d, generator=g)
+    ref64 = torch.softmax(qk[..., :d].double() @ qk[..., d:].double().transpose(1, 2) / math.sqrt(d), dim=-1) @ v.double()
+    qk, v = qk.to(dev), v.to(dev)
+    monkeypatch.setattr(ops, "_MHA_PRESPLIT", False)
+    ref = ops.mha_fwd(qk, v)
+    monkeypatch.setattr(ops, "_MHA_PRESPLIT", True)
+    ops.workspace(ops.lib().buctd_mha_fwd_bf16x6_workspace(B, T, d), dev).fill_(0xFF)
+    out = ops.mha_fwd(qk, v)
+    scale = ref64.abs().max().item()
+    assert (out - ref).abs().max().item() <= 4e-6 * scale
+    e_new = (out.cpu().double() - ref64).abs().max().item() / scale
+    e_old = (ref.cpu().double() - ref64).abs().max().item() / scale
+    assert e_new <= max(2e-6, 2 * e_old), f"rel err {e_new:.2e} (in-kernel split: {e_old:.2e})"
+    # the optional log-sum-exp output (merged over the two key halves)
+    lse = torch.empty(B, T, device=dev)
+    ws = ops.workspace(ops.lib().buctd_mha_fwd_bf16x6_workspace(B, T, d), dev)
+    out2 = torch.empty_like(out)
+    ops.check(ops.lib().buctd_mha_fwd_bf16x6_ws(B, T, d, ops.ptr(qk), qk.data_ptr() + 4 * d, ops.ptr(v), 2 * d, d,
+                                                1.0 / math.sqrt(d), ops.ptr(out2), ops.ptr(lse), ops.ptr(ws), ws.numel(),
+                                                ops.stream_ptr()), "mha_fwd_ws")
+    l64 = torch.logsumexp(qk[..., :d].double() @ qk[..., d:].double().transpose(1, 2) / math.sqrt(d), dim=-1)
+    assert torch.equal(out2, out) and (lse.double() - l64).abs().max().item() <= 1e-4
+    assert ops.lib().buctd_mha_fwd_bf16x6_workspace(B, 100, d) == 0
+
+
 @pytest.mark.parametrize("B,T,d", [(2, 384, 48), (1, 3072, 112), (3, 128, 16), (2, 256, 128)])
 def test_fused_mha_training_forward_backward_vs_fp64(dev, B, T, d):
     """attn_mha_train.hip (TransPose encoder self-attention, training; reference transpose_h.py:168-213): fused forward +
