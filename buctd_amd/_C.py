@@ -17,6 +17,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libbuctd_hip.so")
 if os.environ.get("BUCTD_LIB_TRACE") == "1":      # scratch experiments only: the -DBUCTD_TUNING build (scratch/build_trace_lib.sh)
     LIB_PATH = os.path.join(os.path.dirname(_HERE), "scratch", "libbuctd_hip_trace.so")
+elif os.environ.get("BUCTD_LIB_ALT"):               # scratch experiments only: another build of the same sources
+    LIB_PATH = os.path.join(os.path.dirname(_HERE), "scratch", os.environ["BUCTD_LIB_ALT"])
 
 
 class ConvDesc(C.Structure):
@@ -153,6 +155,12 @@ SIGNATURES = {
     "buctd_mha_fwd_supported": (_I, [_I, _I]),
     "buctd_mha_fwd": (_I, [_I, _I, _I, _P, _P, _P, _I, _I, _F, _P, _P, _P]),
     "buctd_mha_fwd_bf16x6": (_I, [_I, _I, _I, _P, _P, _P, _I, _I, _F, _P, _P, _P]),
+    "buctd_gconv_x6_supported": (_I, [_I] * 7),
+    "buctd_gconv_x6_prep_bytes": (_SZ, [_I, _I, _I, _I]),
+    "buctd_gconv_x6_prep": (_I, [_I, _I, _I, _P, _I, _P, _P]),
+    "buctd_gconv_x6_stats_groups": (_I, [_I] * 6 + [_PI, _PI]),
+    "buctd_gconv_x6_fwd": (_I, [_I] * 6 + [_P] * 6 + [_I, _P, _P, _P, _P]),
+    "buctd_gconv_x6_dgrad": (_I, [_I] * 6 + [_P] * 4 + [_P]),
     "buctd_mha_fwd_bf16x6_workspace": (_SZ, [_I, _I, _I]),
     "buctd_mha_fwd_bf16x6_ws": (_I, [_I, _I, _I, _P, _P, _P, _I, _I, _F, _P, _P, _P, _SZ, _P]),
     "buctd_mha_train_supported": (_I, [_I, _I]),

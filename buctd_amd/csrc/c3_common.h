@@ -1,0 +1,213 @@
+// Shared pieces of the bf16-split convolution kernels (conv3x3.hip: 3x3 stride 1 over an LDS-resident tile;
+// conv_gather_x6.hip: stride-2 3x3 / 1x1 / data gradients as a gathered implicit GEMM): piece geometry, the argument block,
+// the fp32 -> bf16-piece split, and the epilogue (bias, Welford BatchNorm partials, eval-BN, residual, ReLU, store).
+#pragma once
+#include "common.h"
+#include "x6p.h"
+#include <stdlib.h>
+#include "../../include/buctd_hip.h"
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned short u16x4 __attribute__((ext_vector_type(4)));
+
+#define CK 32              // NP = 2: channels per full chunk
+
+// per-mode geometry
+template <int NP> struct Geo;
+template <> struct Geo<2> {
+  static constexpr int ROWB = 160;   // LDS bytes per A row: 32 hi | 32 lo | 32 B pad
+  static constexpr int PST = 64;     // byte stride between the pieces of an A row
+  static constexpr int CPR = 8;      // float4 per staged row (32 channels)
+  static constexpr int BROW = 128;   // global bytes per (step, co) row of the prepared image
+  static constexpr int BLDS = 160;   // LDS stride of a B row
+};
+template <> struct Geo<3> {
+  static constexpr int ROWB = 96;    // 16 h | 16 m | 16 l
+  static constexpr int PST = 32;
+  static constexpr int CPR = 4;      // 16 channels
+  static constexpr int BROW = 192;   // 32 h | 32 m | 32 l k-slots
+  static constexpr int BLDS = 224;   // + 32 B pad: 224 = 32 mod 64
+};
+
+struct C3Args {
+  const float* x;
+  const unsigned char* wp;   // prepared weight image: [steps][Co][NP pieces x 32 bf16 k-slots]
+  float* out;
+  const float* bias;
+  const float* scale;
+  const float* shift;
+  const float* res;
+  float* stats;
+  int* counts;
+  int N, H, W, Ci, Co;
+  int SW, IB, P;       // padded row width, padded image block, total padded positions
+  int relu, na;        // na: 32-row groups of the staged tile = ceil((BM + 2*SW + 2) / 32)
+  // optional BatchNorm(+ReLU) of the PRODUCER applied to the input while it is staged (bf16x6 kernel only): the input
+  // tensor is the producer's raw convolution output z and the kernel consumes relu((z - mean) * (invstd * gamma) + beta),
+  // the exact expression of bn_apply_kernel - the normalised tensor never exists in HBM
+  const float* in_mean;
+  const float* in_invstd;
+  const float* in_gamma;
+  const float* in_beta;
+  int in_relu;
+  int col_major;       // bf16x6 kernel: consecutive workgroups of an XCD share the COLUMN tile (see the kernel)
+  // bf16x6, fp32 input: optional by-product - the staged (normalised, split, zero-padded) input written out as x6 planes
+  // (allocation base; rows of positions [0, ceil(P / BM) * BM) are written, pads as zeros).  The weight gradient of the
+  // same convolution stages it by LDS-DMA in the backward pass instead of splitting the tensor a second time.
+  unsigned char* planes_out;
+  unsigned ib_mul, ib_sh, sw_mul, sw_sh;   // n / d == mulhi(n, mul) >> sh for 0 <= n < 2^31 (Granlund-Montgomery)
+  // output map of the gathered kernels (conv_gather_x6.hip; omap = 0: the H x W grid itself): grid pixel (y, x) is written
+  // to pixel (y * ost + oy0, x * ost + ox0) of an oH x oW tensor - the parity classes of a stride-2 data gradient
+  int omap, oH, oW, ost, oy0, ox0;
+};
+
+__device__ __forceinline__ int fast_div(int n, unsigned mul, unsigned sh) {
+  return (int)(__umulhi((unsigned)n, mul) >> sh);
+}
+
+// channels c..c+3 of one row -> NP bf16 pieces, piece q at byte q*PST + 2c.  The residual subtractions are exact.
+template <int NP, int PST>
+__device__ __forceinline__ void split_store(unsigned char* row, int c, f32x4 v) {
+#pragma unroll
+  for (int q = 0; q < NP; ++q) {
+    u16x4 pc;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const __bf16 h = (__bf16)v[j];
+      pc[j] = __builtin_bit_cast(unsigned short, h);
+      v[j] -= (float)h;
+    }
+    *reinterpret_cast<u16x4*>(row + q * PST + 2 * c) = pc;
+  }
+}
+
+#define MAX_SW 75          // W <= 73: the staged tile is at most BM + 152 rows
+
+template <int V>
+struct IC { static constexpr int value = V; };
+
+// ---- epilogue (shared by both kernels) -----------------------------------------------------------------------
+// accumulator (mf, nf, reg): row = wave_m*MR + mf*16 + (lane>>4)*4 + reg, col = wave_n*NF*16 + nf*16 + (lane&15).
+// Called after a barrier that ends every read of the staged tiles: the tile area of `smem` is reused for staging.
+template <int MF, int NF, int WM, int WN>
+__device__ __forceinline__ void c3_epilogue(const C3Args& p, f32x4 (&acc)[MF][NF], unsigned char* smem, int bx, int by,
+                                            int p0, int n0) {
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int i16 = lane & 15, g = lane >> 4;
+  const int wave_m = wave % WM, wave_n = wave / WM;
+  // The tile goes through LDS (the A tile is dead by now) so that every output row leaves as 16-byte pieces of one
+  // contiguous run instead of 64-byte column slivers of four rows.
+  constexpr int MR = MF * 16;              // rows of this wave's tile (<= 128)
+  constexpr int RH = (MR + 63) / 64;       // 64-row halves: lane r owns rows r and r + 64
+  constexpr int LD = NF * 16 + 4;          // staging row stride in floats: 4*LD = 16 mod 64 keeps the writes conflict-free
+  constexpr int EP = MF >= 2 ? 2 : 1;      // 16-row fragments staged per pass
+  static_assert(MR <= 128, "c3_epilogue: at most 128 rows per wave");
+  float* stg = reinterpret_cast<float*>(smem) + wave * (EP * 16 * LD);
+  int* rowoff = reinterpret_cast<int*>(smem) + 4 * EP * 16 * LD + wave * 128;
+  // element offset of output row r of this wave (-1: pad position)
+  unsigned long long vmask[RH];
+  int cnt = 0;
+#pragma unroll
+  for (int h = 0; h < RH; ++h) {
+    int myoff = -1;
+    const int r = lane + 64 * h;
+    if (r < MR) {
+      const int pp = p0 + wave_m * MR + r;
+      if (pp < p.P) {
+        const int n = fast_div(pp, p.ib_mul, p.ib_sh);
+        const int rem = pp - n * p.IB;
+        const int yy = fast_div(rem, p.sw_mul, p.sw_sh), xx = rem - yy * p.SW;
+        if (n < p.N && yy >= 1 && xx >= 1 && xx <= p.W)
+          myoff = p.omap ? ((n * p.oH + (yy - 1) * p.ost + p.oy0) * p.oW + (xx - 1) * p.ost + p.ox0) * p.Co
+                         : ((n * p.H + yy - 1) * p.W + xx - 1) * p.Co;
+      }
+    }
+    vmask[h] = __ballot(myoff >= 0);
+    cnt += __popcll(vmask[h]);
+    rowoff[r] = myoff;
+  }
+  auto valid = [&](int row) -> bool { return (vmask[row >> 6] >> (row & 63)) & 1ull; };
+  const int grp = bx * WM + wave_m;
+  if (p.stats && p.counts && by == 0 && wave_n == 0 && lane == 0) p.counts[grp] = cnt;
+  const int ncol0 = n0 + wave_n * NF * 16;
+  float bv[NF];
+#pragma unroll
+  for (int nf = 0; nf < NF; ++nf) bv[nf] = p.bias ? p.bias[ncol0 + nf * 16 + i16] : 0.f;
+  if (p.stats) {
+    const float inv_cnt = cnt > 0 ? 1.f / (float)cnt : 0.f;
+#pragma unroll
+    for (int nf = 0; nf < NF; ++nf) {
+      float s1 = 0.f;
+#pragma unroll
+      for (int mf = 0; mf < MF; ++mf)
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) s1 += valid(mf * 16 + g * 4 + rg) ? acc[mf][nf][rg] + bv[nf] : 0.f;
+      s1 += __shfl_xor(s1, 16, 64);
+      s1 += __shfl_xor(s1, 32, 64);
+      const float mean = s1 * inv_cnt;
+      float s2 = 0.f;
+#pragma unroll
+      for (int mf = 0; mf < MF; ++mf)
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) {
+          const float d = acc[mf][nf][rg] + bv[nf] - mean;
+          s2 += valid(mf * 16 + g * 4 + rg) ? d * d : 0.f;
+        }
+      s2 += __shfl_xor(s2, 16, 64);
+      s2 += __shfl_xor(s2, 32, 64);
+      if (g == 0) {
+        const int n = ncol0 + nf * 16 + i16;
+        *reinterpret_cast<float2*>(p.stats + ((long)grp * p.Co + n) * 2) = make_float2(mean, s2);
+      }
+    }
+  }
+#pragma unroll
+  for (int ps = 0; ps < MF / EP; ++ps) {
+    if (ps) __syncthreads();
+#pragma unroll
+    for (int e = 0; e < EP; ++e)
+#pragma unroll
+      for (int nf = 0; nf < NF; ++nf)
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg)
+          stg[(e * 16 + g * 4 + rg) * LD + nf * 16 + i16] = acc[ps * EP + e][nf][rg] + bv[nf];
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < EP * NF; ++k) {
+      const int item = lane + 64 * k;
+      const int row = item / (NF * 4), c4 = item - row * (NF * 4);
+      f32x4 v = *reinterpret_cast<const f32x4*>(stg + row * LD + c4 * 4);
+      const int off = rowoff[ps * EP * 16 + row];
+      const int n = ncol0 + c4 * 4;
+      if (off >= 0) {
+        if (p.scale) {
+          const f32x4 sc = *reinterpret_cast<const f32x4*>(p.scale + n);
+          const f32x4 sh = *reinterpret_cast<const f32x4*>(p.shift + n);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) v[j] = v[j] * sc[j] + sh[j];
+        }
+        if (p.res) {
+          const f32x4 r = *reinterpret_cast<const f32x4*>(p.res + off + n);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) v[j] += r[j];
+        }
+        if (p.relu) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
+        }
+        *reinterpret_cast<f32x4*>(p.out + off + n) = v;
+      }
+    }
+  }
+}
+
+
+static inline void magic_u32(unsigned d, unsigned* mul, unsigned* sh) {
+  if (d == 1) { *mul = 0xFFFFFFFFu; *sh = 0; return; }   // never taken: IB and SW are >= 3
+  unsigned l = 0;
+  while ((1ull << l) < d) ++l;                  // l = ceil(log2 d)
+  // n < 2^31: m = ceil(2^(31+l) / d) fits in 32 bits and q = (n*m) >> (31+l) is exact
+  const unsigned long long m = ((1ull << (31 + l)) + d - 1) / d;
+  *mul = (unsigned)m;
+  *sh = l - 1;                                  // mulhi already shifts by 32: total shift 31 + l
+}

@@ -1,0 +1,379 @@
+// The convolutions around the BasicBlocks in the bf16x6 arithmetic of conv3x3.hip (fp32 operands split exactly into three
+// bf16 pieces, six v_mfma_f32_16x16x32_bf16 per product, fp32 accumulate): the stride-2 3x3 convolutions of the HRNet
+// transitions and fuse layers (reference lib/models/pose_hrnet.py:187-245, 338-372), the 1x1 convolutions of the fuse
+// layers and of the layer1 Bottlenecks (pose_hrnet.py:60-108), forward and data gradient.  Until round 3 these ran on the
+// exact-fp32 MFMA (conv.hip, 157 TFLOP/s peak, 25-45 % of it on these shapes).
+//
+// A stride-2 window is not a shifted window of a dense tile, so this is a GATHERED implicit GEMM, one kernel for all of them:
+//   * the OUTPUT pixels of a launch form a grid Hg x Wg per image, addressed in the zero-padded flattened position space of
+//     conv3x3.hip (so that the epilogue - bias, Welford BatchNorm partials + valid-row counts, eval-BN, residual, ReLU,
+//     coalesced stores - is literally c3_epilogue);
+//   * the contraction runs over (tap, 16-channel chunk) "half-steps", two per K = 32 MFMA step (lanes 0-31 / 32-63 of the A
+//     operand); tap t of grid pixel (y, x) reads source pixel (y * ss + tdy[t], x * ss + tdx[t]), zero outside the source:
+//       forward, stride 2 : grid = Ho x Wo, ss = 2, nine taps (r - 1, s - 1);
+//       1x1               : grid = H x W, ss = 1, one tap (0, 0);
+//       data gradient of a stride-2 conv: FOUR parity classes in blockIdx.z - class (a, b) owns the input pixels
+//         (2u + a, 2v + b), grid = H/2 x W/2, source = dy, ss = 1, and only the taps that reach that parity (1, 2, 2 or 4 of
+//         the nine: rows a = 0 -> r = 1 at dy row u; a = 1 -> r = 0 at u + 1 and r = 2 at u), written through the epilogue's
+//         output map (pixel (y, x) of the class grid -> (2y + a, 2x + b));
+//   * a workgroup = 256 threads owns BM consecutive positions x BN output channels; per step every thread gathers its 16-byte
+//     pieces of the two half-step tiles into registers one step ahead, splits them into LDS rows [16 h | 16 m | 16 l]
+//     (the A-row format of conv3x3.hip) and the four waves multiply; the weight fragments come straight from the prepared
+//     image in L2 ([step][output channel][32 h | 32 m | 32 l k-slots], built once per weight update by buctd_gconv_x6_prep),
+//     also one step ahead.
+// VALU per MFMA: 16 gathered floats per thread and step x ~4 instructions against 72 MFMAs per wave (BN = 96) - under one.
+#include "c3_common.h"
+
+#define GC_MAXT 9
+
+struct GcClass {
+  int ntaps, nhs, nsteps;            // taps, half-steps = ntaps * (SC / 16), steps = ceil(nhs / 2)
+  int oy0, ox0;                      // output map offsets of the class
+  long wp_off;                       // byte offset of the class's weight image
+  int tdy[GC_MAXT], tdx[GC_MAXT];
+};
+
+struct GcArgs {
+  C3Args e;                          // epilogue view: grid geometry (N, H = Hg, W = Wg, SW, IB, P), Co = output channels ...
+  const float* src;                  // [N][SH][SWd][SC]
+  const unsigned char* wp;
+  int SH, SWd, SC, ss, cpt;          // cpt = SC / 16 chunks per tap
+  int ncls;
+  GcClass cls[4];
+};
+
+template <int MF, int NF, int WM, int WN>
+__global__ __launch_bounds__(256, 2) void gconv_x6_kernel(GcArgs p) {
+  constexpr int BM = WM * MF * 16, BN = WN * NF * 16, ROWB = 96, PST = 32, BROW = 192;
+  constexpr int QA = BM / 64;                           // rows per thread and half-step (thread = row t >> 2 + 64 q, float4 t & 3)
+  static_assert(WM * WN == 4 && BM % 64 == 0, "four waves, BM a multiple of 64");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];     // A: [2 half-steps][BM][96 B]; then the epilogue's
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int i16 = lane & 15, g = lane >> 4;
+  const int wave_m = wave % WM, wave_n = wave / WM;
+  const int bx = blockIdx.x, by = blockIdx.y;
+  const GcClass& c = p.cls[blockIdx.z];
+  C3Args e = p.e;
+  e.oy0 = c.oy0; e.ox0 = c.ox0;
+  const int p0 = bx * BM, n0 = by * BN;
+
+  // rows this thread gathers: grid pixel -> source pixel of tap (0, 0)
+  int simg[QA], sy0[QA], sx0[QA];
+  const int arow = t >> 2, c4 = t & 3;
+#pragma unroll
+  for (int q = 0; q < QA; ++q) {
+    const int pp = p0 + arow + 64 * q;
+    simg[q] = -1; sy0[q] = 0; sx0[q] = 0;
+    if (pp < e.P) {
+      const int n = fast_div(pp, e.ib_mul, e.ib_sh);
+      const int rem = pp - n * e.IB;
+      const int yy = fast_div(rem, e.sw_mul, e.sw_sh), xx = rem - yy * e.SW;
+      if (n < e.N && yy >= 1 && xx >= 1 && xx <= e.W) {
+        simg[q] = n * p.SH;
+        sy0[q] = (yy - 1) * p.ss;
+        sx0[q] = (xx - 1) * p.ss;
+      }
+    }
+  }
+  const unsigned char* wbase = p.wp + c.wp_off + (size_t)(n0 + wave_n * NF * 16 + i16) * BROW + g * 16;
+  const size_t wstep = (size_t)e.Co * BROW;
+
+  f32x4 areg[2][QA];
+  bf16x8 bnx[3][NF];
+  int tap = 0, chunk = 0;                   // (tap, chunk) of the next half-step to load
+  auto load_step = [&](int st) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const bool live = 2 * st + h < c.nhs;
+      const int dy = c.tdy[live ? tap : 0], dx = c.tdx[live ? tap : 0];
+#pragma unroll
+      for (int q = 0; q < QA; ++q) {
+        const int sy = sy0[q] + dy, sx = sx0[q] + dx;
+        const bool ok = live && simg[q] >= 0 && (unsigned)sy < (unsigned)p.SH && (unsigned)sx < (unsigned)p.SWd;
+        areg[h][q] = ok ? *reinterpret_cast<const f32x4*>(p.src + ((long)(simg[q] + sy) * p.SWd + sx) * p.SC + chunk * 16 + c4 * 4)
+                        : (f32x4){0.f, 0.f, 0.f, 0.f};
+      }
+      if (live) {
+        if (++chunk == p.cpt) { chunk = 0; ++tap; }
+      }
+    }
+    const unsigned char* wp = wbase + (size_t)st * wstep;
+#pragma unroll
+    for (int q = 0; q < 3; ++q)
+#pragma unroll
+      for (int nf = 0; nf < NF; ++nf) bnx[q][nf] = *reinterpret_cast<const bf16x8*>(wp + (size_t)nf * 16 * BROW + q * 64);
+  };
+  auto store_step = [&]() {
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int q = 0; q < QA; ++q)
+        split_store<3, PST>(smem + ((size_t)h * BM + arow + 64 * q) * ROWB, c4 * 4, areg[h][q]);
+  };
+
+  f32x4 acc[MF][NF];
+#pragma unroll
+  for (int mf = 0; mf < MF; ++mf)
+#pragma unroll
+    for (int nf = 0; nf < NF; ++nf) acc[mf][nf] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  // this lane's A fragment bytes: half-step g >> 1, channels 8 (g & 1) .. + 7 of row wave_m * MF * 16 + mf * 16 + i16
+  const unsigned char* abase = smem + ((size_t)(g >> 1) * BM + wave_m * MF * 16 + i16) * ROWB + (g & 1) * 16;
+
+  load_step(0);
+  for (int st = 0; st < c.nsteps; ++st) {
+    __syncthreads();                       // the previous step's fragments are read
+    store_step();
+    bf16x8 bc[3][NF];
+#pragma unroll
+    for (int q = 0; q < 3; ++q)
+#pragma unroll
+      for (int nf = 0; nf < NF; ++nf) bc[q][nf] = bnx[q][nf];
+    __syncthreads();
+    if (st + 1 < c.nsteps) load_step(st + 1);
+    bf16x8 a[2][3];
+#pragma unroll
+    for (int q = 0; q < 3; ++q) a[0][q] = *reinterpret_cast<const bf16x8*>(abase + q * PST);
+#pragma unroll
+    for (int mf = 0; mf < MF; ++mf) {
+      if (mf + 1 < MF) {
+#pragma unroll
+        for (int q = 0; q < 3; ++q)
+          a[(mf + 1) & 1][q] = *reinterpret_cast<const bf16x8*>(abase + (size_t)(mf + 1) * 16 * ROWB + q * PST);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      bf16x8 (&ac)[3] = a[mf & 1];
+#define GC_MMA(qa, qb) acc[mf][nf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ac[qa], bc[qb][nf], acc[mf][nf], 0, 0, 0);
+#pragma unroll
+      for (int nf = 0; nf < NF; ++nf) { GC_MMA(2, 0) GC_MMA(0, 2) GC_MMA(1, 1) GC_MMA(1, 0) GC_MMA(0, 1) GC_MMA(0, 0) }
+#undef GC_MMA
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  __syncthreads();
+  c3_epilogue<MF, NF, WM, WN>(e, acc, smem, bx, by, p0, n0);
+}
+
+// ---- prepared weight images --------------------------------------------------------------------------------------------
+// w is [Co][R][S][Ci] (the engine's filter layout).  dir 0 (forward): rows = Co, contraction = (tap, ci);
+// dir 1 (data gradient): rows = Ci, contraction = (tap, co).
+struct GcPrep {
+  const float* w;
+  unsigned char* out;
+  int Co, Ci, R, S, dir;
+  int ncls;
+  int ntaps[4], nsteps[4];
+  long off[4];                       // byte offsets of the class images; off[ncls] is not needed
+  int tr[4][GC_MAXT], ts[4][GC_MAXT];
+  long items[4];                     // cumulative (step, row, k-slot) counts
+};
+
+__global__ __launch_bounds__(256) void gconv_x6_prep_kernel(GcPrep p) {
+  const int nrows = p.dir ? p.Ci : p.Co, kc = p.dir ? p.Co : p.Ci, cpt = kc / 16;
+  const long total = p.items[p.ncls - 1];
+  for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+    int cl = 0;
+    while (idx >= p.items[cl]) ++cl;
+    const long li = idx - (cl ? p.items[cl - 1] : 0);
+    const int ks = (int)(li & 31);
+    const long sr = li >> 5;
+    const int row = (int)(sr % nrows), st = (int)(sr / nrows);
+    const int hs = 2 * st + (ks >> 4);
+    float v = 0.f;
+    if (hs < p.ntaps[cl] * cpt) {
+      const int tp = hs / cpt, k = (hs - tp * cpt) * 16 + (ks & 15);
+      const int r = p.tr[cl][tp], s = p.ts[cl][tp];
+      const int co = p.dir ? k : row, ci = p.dir ? row : k;
+      v = p.w[(((long)co * p.R + r) * p.S + s) * p.Ci + ci];
+    }
+    unsigned char* o = p.out + p.off[cl] + ((size_t)st * nrows + row) * 192 + ks * 2;
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+      const __bf16 h = (__bf16)v;
+      *reinterpret_cast<unsigned short*>(o + q * 64) = __builtin_bit_cast(unsigned short, h);
+      v -= (float)h;
+    }
+  }
+}
+
+// kind 1: 1x1 stride 1 pad 0; kind 2: 3x3 stride 2 pad 1
+static bool gc_kind_ok(int kind) { return kind == 1 || kind == 2; }
+
+// tap lists of one (kind, dir, class): (r, s) of the filter and the source offset (dy, dx)
+static int gc_taps(int kind, int dir, int cls, int* tr, int* ts, int* tdy, int* tdx) {
+  if (kind == 1) { tr[0] = ts[0] = 0; tdy[0] = tdx[0] = 0; return 1; }
+  if (!dir) {
+    for (int r = 0; r < 3; ++r)
+      for (int s = 0; s < 3; ++s) { tr[r * 3 + s] = r; ts[r * 3 + s] = s; tdy[r * 3 + s] = r - 1; tdx[r * 3 + s] = s - 1; }
+    return 9;
+  }
+  const int a = cls >> 1, b = cls & 1;
+  // parity a = 0: filter row 1 at dy row u; a = 1: filter row 0 at u + 1, filter row 2 at u
+  const int rl[2][2] = {{1, -1}, {0, 2}}, dl[2][2] = {{0, 0}, {1, 0}}, nl[2] = {1, 2};
+  int n = 0;
+  for (int i = 0; i < nl[a]; ++i)
+    for (int j = 0; j < nl[b]; ++j) {
+      tr[n] = rl[a][i]; ts[n] = rl[b][j]; tdy[n] = dl[a][i]; tdx[n] = dl[b][j];
+      ++n;
+    }
+  return n;
+}
+
+static int gc_ncls(int kind, int dir) { return (kind == 2 && dir) ? 4 : 1; }
+
+static size_t gc_class_bytes(int ntaps, int kc, int nrows) {
+  const int nhs = ntaps * (kc / 16);
+  return (size_t)((nhs + 1) / 2) * nrows * 192;
+}
+
+extern "C" size_t buctd_gconv_x6_prep_bytes(int kind, int Ci, int Co, int dir) {
+  if (!gc_kind_ok(kind) || Ci <= 0 || Co <= 0 || Ci % 16 || Co % 16) return 0;
+  const int kc = dir ? Co : Ci, nrows = dir ? Ci : Co;
+  size_t total = 0;
+  int tr[GC_MAXT], ts[GC_MAXT], ty[GC_MAXT], tx[GC_MAXT];
+  for (int c = 0; c < gc_ncls(kind, dir); ++c) total += gc_class_bytes(gc_taps(kind, dir, c, tr, ts, ty, tx), kc, nrows);
+  return total;
+}
+
+extern "C" int buctd_gconv_x6_prep(int kind, int Ci, int Co, const float* w, int dir, void* wprep, void* stream) {
+  BUCTD_CHECK_ARG(w && wprep, "buctd_gconv_x6_prep: null pointer");
+  BUCTD_CHECK_ARG(buctd_gconv_x6_prep_bytes(kind, Ci, Co, dir) > 0, "buctd_gconv_x6_prep: unsupported kind %d Ci%d Co%d", kind, Ci,
+                  Co);
+  GcPrep p;
+  p.w = w; p.out = (unsigned char*)wprep; p.Co = Co; p.Ci = Ci; p.R = p.S = kind == 1 ? 1 : 3; p.dir = dir;
+  p.ncls = gc_ncls(kind, dir);
+  const int kc = dir ? Co : Ci, nrows = dir ? Ci : Co;
+  long off = 0, items = 0;
+  int ty[GC_MAXT], tx[GC_MAXT];
+  for (int c = 0; c < 4; ++c) { p.ntaps[c] = 0; p.nsteps[c] = 0; p.off[c] = 0; p.items[c] = 0; }
+  for (int c = 0; c < p.ncls; ++c) {
+    p.ntaps[c] = gc_taps(kind, dir, c, p.tr[c], p.ts[c], ty, tx);
+    p.nsteps[c] = (p.ntaps[c] * (kc / 16) + 1) / 2;
+    p.off[c] = off;
+    off += (long)gc_class_bytes(p.ntaps[c], kc, nrows);
+    items += (long)p.nsteps[c] * nrows * 32;
+    p.items[c] = items;
+  }
+  long blocks = (items + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(gconv_x6_prep_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p);
+  BUCTD_CHECK_LAUNCH("buctd_gconv_x6_prep");
+  return BUCTD_OK;
+}
+
+// ---- launch ----------------------------------------------------------------------------------------------------------------
+struct GcPlan { int MF, NF, WM, WN, BM, BN; };
+
+static bool gc_plan(int nout, GcPlan* pl) {
+  if (nout % 96 == 0) *pl = {4, 3, 2, 2, 128, 96};
+  else if (nout % 64 == 0) *pl = {4, 4, 4, 1, 256, 64};
+  else if (nout % 48 == 0) *pl = {4, 3, 4, 1, 256, 48};
+  else return false;
+  return true;
+}
+
+// geometry of a launch: grid Hg x Wg, source SH x SWd, channels
+static bool gc_geo(int kind, int dir, int N, int H, int W, int Ci, int Co, int* Hg, int* Wg, int* SH, int* SWd, int* SC, int* nout) {
+  if (!gc_kind_ok(kind) || N <= 0 || H <= 0 || W <= 0 || Ci <= 0 || Co <= 0 || Ci % 16 || Co % 16) return false;
+  if (kind == 1) { *Hg = H; *Wg = W; *SH = H; *SWd = W; }
+  else {
+    if ((H & 1) || (W & 1)) return false;
+    *Hg = H / 2; *Wg = W / 2;
+    if (!dir) { *SH = H; *SWd = W; } else { *SH = H / 2; *SWd = W / 2; }
+  }
+  *SC = dir ? Co : Ci;
+  *nout = dir ? Ci : Co;
+  const long P = (long)N * (*Hg + 1) * (*Wg + 2) + *Wg + 2;
+  const long big = (long)N * H * W * (Ci > Co ? Ci : Co);
+  GcPlan pl;
+  return gc_plan(*nout, &pl) && P < 2147483647L && big < 2147483647L;
+}
+
+extern "C" int buctd_gconv_x6_supported(int kind, int N, int H, int W, int Ci, int Co, int dir) {
+  int a, b, c, d, e, f;
+  return gc_geo(kind, dir, N, H, W, Ci, Co, &a, &b, &c, &d, &e, &f) ? 1 : 0;
+}
+
+extern "C" int buctd_gconv_x6_stats_groups(int kind, int N, int H, int W, int Ci, int Co, int* ngroups, int* rows_per_group) {
+  int Hg, Wg, SH, SWd, SC, nout;
+  BUCTD_CHECK_ARG(ngroups && rows_per_group && gc_geo(kind, 0, N, H, W, Ci, Co, &Hg, &Wg, &SH, &SWd, &SC, &nout),
+                  "buctd_gconv_x6_stats_groups: unsupported shape");
+  GcPlan pl;
+  gc_plan(nout, &pl);
+  const long P = (long)N * (Hg + 1) * (Wg + 2) + Wg + 2;
+  *ngroups = (int)((P + pl.BM - 1) / pl.BM) * pl.WM;
+  *rows_per_group = pl.MF * 16;
+  return BUCTD_OK;
+}
+
+template <int MF, int NF, int WM, int WN>
+static int gc_launch(const GcArgs& a, int tiles, int ncol, hipStream_t st) {
+  constexpr int BM = WM * MF * 16, LD = NF * 16 + 4, EP = MF >= 2 ? 2 : 1;
+  constexpr size_t tile = (size_t)2 * BM * 96, epi = (size_t)4 * EP * 16 * LD * 4 + 4 * 128 * 4;
+  constexpr size_t lds = tile > epi ? tile : epi;
+  static_assert(lds <= 64 * 1024, "gconv_x6: static LDS budget");
+  hipLaunchKernelGGL((gconv_x6_kernel<MF, NF, WM, WN>), dim3(tiles, ncol, a.ncls), dim3(256), lds, st, a);
+  return BUCTD_OK;
+}
+
+static int gc_run(int kind, int dir, int N, int H, int W, int Ci, int Co, const float* src, const void* wprep, const float* bias,
+                  const float* scale, const float* shift, const float* residual, int relu, float* out, float* stats_partials,
+                  int* stats_counts, void* stream, const char* who) {
+  int Hg, Wg, SH, SWd, SC, nout;
+  BUCTD_CHECK_ARG(src && wprep && out, "%s: null tensor pointer", who);
+  BUCTD_CHECK_ARG(gc_geo(kind, dir, N, H, W, Ci, Co, &Hg, &Wg, &SH, &SWd, &SC, &nout),
+                  "%s: unsupported shape kind %d N%d H%d W%d Ci%d Co%d", who, kind, N, H, W, Ci, Co);
+  BUCTD_CHECK_ARG((scale == nullptr) == (shift == nullptr), "%s: scale and shift go together", who);
+  BUCTD_CHECK_ARG((stats_partials == nullptr) == (stats_counts == nullptr), "%s: stats partials and counts go together", who);
+  BUCTD_CHECK_ARG(!(dir && stats_partials), "%s: no statistics on the data gradient", who);
+  GcPlan pl;
+  gc_plan(nout, &pl);
+  GcArgs a;
+  C3Args& e = a.e;
+  e.x = nullptr; e.wp = nullptr; e.out = out; e.bias = bias; e.scale = scale; e.shift = shift; e.res = residual;
+  e.stats = stats_partials; e.counts = stats_counts;
+  e.N = N; e.H = Hg; e.W = Wg; e.Ci = SC; e.Co = nout;
+  e.SW = Wg + 2; e.IB = (Hg + 1) * (Wg + 2);
+  e.P = (int)((long)N * e.IB + e.SW);
+  e.relu = relu; e.na = 0;
+  e.in_mean = e.in_invstd = e.in_gamma = e.in_beta = nullptr; e.in_relu = 0; e.col_major = 0; e.planes_out = nullptr;
+  magic_u32((unsigned)e.IB, &e.ib_mul, &e.ib_sh);
+  magic_u32((unsigned)e.SW, &e.sw_mul, &e.sw_sh);
+  const bool par = kind == 2 && dir;
+  e.omap = par ? 1 : 0; e.oH = H; e.oW = W; e.ost = par ? 2 : 1; e.oy0 = e.ox0 = 0;
+  a.src = src; a.wp = (const unsigned char*)wprep;
+  a.SH = SH; a.SWd = SWd; a.SC = SC; a.ss = (kind == 2 && !dir) ? 2 : 1; a.cpt = SC / 16;
+  a.ncls = gc_ncls(kind, dir);
+  long off = 0;
+  int tr[GC_MAXT], ts[GC_MAXT];
+  for (int c = 0; c < 4; ++c) {
+    GcClass& k = a.cls[c];
+    k.ntaps = k.nhs = k.nsteps = 0; k.oy0 = k.ox0 = 0; k.wp_off = 0;
+    if (c >= a.ncls) continue;
+    k.ntaps = gc_taps(kind, dir, c, tr, ts, k.tdy, k.tdx);
+    k.nhs = k.ntaps * a.cpt;
+    k.nsteps = (k.nhs + 1) / 2;
+    k.oy0 = par ? (c >> 1) : 0; k.ox0 = par ? (c & 1) : 0;
+    k.wp_off = off;
+    off += (long)gc_class_bytes(k.ntaps, SC, nout);
+  }
+  const int tiles = (e.P + pl.BM - 1) / pl.BM, ncol = nout / pl.BN;
+  hipStream_t st = (hipStream_t)stream;
+  if (pl.NF == 3 && pl.WM == 2) gc_launch<4, 3, 2, 2>(a, tiles, ncol, st);
+  else if (pl.NF == 4) gc_launch<4, 4, 4, 1>(a, tiles, ncol, st);
+  else gc_launch<4, 3, 4, 1>(a, tiles, ncol, st);
+  BUCTD_CHECK_LAUNCH(who);
+  return BUCTD_OK;
+}
+
+extern "C" int buctd_gconv_x6_fwd(int kind, int N, int H, int W, int Ci, int Co, const float* x, const void* wprep,
+                                  const float* bias, const float* scale, const float* shift, const float* residual, int relu,
+                                  float* y, float* stats_partials, int* stats_counts, void* stream) {
+  return gc_run(kind, 0, N, H, W, Ci, Co, x, wprep, bias, scale, shift, residual, relu, y, stats_partials, stats_counts, stream,
+                "buctd_gconv_x6_fwd");
+}
+
+extern "C" int buctd_gconv_x6_dgrad(int kind, int N, int H, int W, int Ci, int Co, const float* dy, const void* wprep,
+                                    const float* residual, float* dx, void* stream) {
+  return gc_run(kind, 1, N, H, W, Ci, Co, dy, wprep, nullptr, nullptr, nullptr, residual, 0, dx, nullptr, nullptr, stream,
+                "buctd_gconv_x6_dgrad");
+}

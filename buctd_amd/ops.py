@@ -345,6 +345,66 @@ def _conv3x3_bf16x3(x, w, flip, cin, cout, bias, scale, shift, residual, relu, s
     return (y, part, info) if stats else y
 
 
+# ---- gathered bf16x6 convolutions (csrc/conv_gather_x6.hip): 1x1 and stride-2 3x3, forward + data gradient ----------------
+_GCONV_X6 = os.environ.get("BUCTD_GCONV_X6", "1") != "0"
+
+
+def _gconv_kind(d):
+    """1: 1x1 / stride 1 / pad 0; 2: 3x3 / stride 2 / pad 1; 0: neither."""
+    if d.R == 1 and d.S == 1 and d.stride == 1 and d.pad == 0:
+        return 1
+    if d.R == 3 and d.S == 3 and d.stride == 2 and d.pad == 1:
+        return 2
+    return 0
+
+
+def _gconv_ok(d, direction):
+    """True when this convolution (direction 0 forward, 1 data gradient) takes the gathered bf16x6 kernel."""
+    if _conv_math["mode"] != "bf16x6" or not _GCONV_X6:
+        return False
+    kind = _gconv_kind(d)
+    return kind != 0 and _memo(("gcok", kind, d.N, d.H, d.W, d.Ci, d.Co, direction),
+                               lambda: lib().buctd_gconv_x6_supported(kind, d.N, d.H, d.W, d.Ci, d.Co, direction) == 1)
+
+
+def _gconv_prepared(w, kind, direction):
+    """weight image of the gathered kernels, cached on the weight tensor until it changes (optimizer epoch / version)."""
+    Co, Ci = _wshape(w)[0], _wshape(w)[1]
+    key = (w.data_ptr(), w._version, _weights_epoch["n"])
+    cache = getattr(w, "_buctd_gprep", None)
+    if cache is None or cache[0] != key:
+        cache = [key, None, None]
+        try:
+            w._buctd_gprep = cache
+        except (AttributeError, RuntimeError, TypeError):
+            pass
+    if cache[1 + direction] is None:
+        nbytes = _memo(("gcpb", kind, Ci, Co, direction), lambda: int(lib().buctd_gconv_x6_prep_bytes(kind, Ci, Co, direction)))
+        img = torch.empty(nbytes, dtype=torch.uint8, device=w.device)
+        check(lib().buctd_gconv_x6_prep(kind, Ci, Co, ptr(w), direction, ptr(img), stream_ptr()), "gconv_x6_prep")
+        cache[1 + direction] = img
+    return cache[1 + direction]
+
+
+def _gconv_fwd(x, w, d, bias, scale, shift, residual, relu, stats):
+    kind = _gconv_kind(d)
+    wp = _gconv_prepared(w, kind, 0)
+    y = torch.empty((d.N, d.Ho, d.Wo, d.Co), dtype=torch.float32, device=x.device)
+    part = counts = info = None
+    if stats:
+        def groups():
+            ng, rpg = C.c_int(), C.c_int()
+            check(lib().buctd_gconv_x6_stats_groups(kind, d.N, d.H, d.W, d.Ci, d.Co, C.byref(ng), C.byref(rpg)), "gconv groups")
+            return ng.value, rpg.value
+        ngv, rpgv = _memo(("gcgrp", kind, d.N, d.H, d.W, d.Ci, d.Co), groups)
+        part = torch.empty((ngv, d.Co, 2), dtype=torch.float32, device=x.device)
+        counts = torch.empty(ngv, dtype=torch.int32, device=x.device)
+        info = (ngv, rpgv, counts)
+    check(lib().buctd_gconv_x6_fwd(kind, d.N, d.H, d.W, d.Ci, d.Co, ptr(x), ptr(wp), ptr(bias), ptr(scale), ptr(shift),
+                                   ptr(residual), int(bool(relu)), ptr(y), ptr(part), ptr(counts), stream_ptr()), "gconv_x6_fwd")
+    return (y, part, info) if stats else y
+
+
 # ---- x6 planes (csrc/x6p.h): activations stored pre-split + zero-padded for the bf16x6 3x3 kernels ---------------------
 class Planes:
     """A [N, H, W, C] activation as x6 planes: `buf` is the uint8 allocation (guards + padded rows, 6 bytes / element)."""
@@ -523,6 +583,8 @@ def conv_fwd(x, w, bias=None, stride=1, pad=0, scale=None, shift=None, residual=
         raise _C.BuctdHipError("conv_fwd: in_bn needs the bf16x6 3x3 kernel (check bn_in_fusable first)")
     if _bf16x3_ok(d):
         return _conv3x3_bf16x3(x, w, 0, d.Ci, d.Co, bias, scale, shift, residual, relu, stats, in_bn)
+    if _gconv_ok(d, 0):
+        return _gconv_fwd(x, w, d, bias, scale, shift, residual, relu, stats)
     y = torch.empty((d.N, d.Ho, d.Wo, d.Co), dtype=torch.float32, device=x.device)
     part = None
     info = None
@@ -560,6 +622,12 @@ def conv_dgrad(dy, w, x_shape, stride=1, pad=0, bias=None, stats=False, residual
         return _conv3x3_bf16x3(dy, w, 1, d.Co, d.Ci, bias, None, None, residual, False, stats)
     if residual is not None and stats:
         raise _C.BuctdHipError("conv_dgrad: residual and stats do not combine")
+    if bias is None and not stats and _gconv_ok(d, 1):
+        dx = torch.empty(tuple(x_shape), dtype=torch.float32, device=dy.device)
+        kind = _gconv_kind(d)
+        check(lib().buctd_gconv_x6_dgrad(kind, d.N, d.H, d.W, d.Ci, d.Co, ptr(dy), ptr(_gconv_prepared(w, kind, 1)),
+                                         ptr(residual), ptr(dx), stream_ptr()), "gconv_x6_dgrad")
+        return dx
     dx = torch.empty(tuple(x_shape), dtype=torch.float32, device=dy.device)
     part = None
     info = None

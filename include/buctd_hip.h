@@ -316,6 +316,25 @@ int buctd_cond_render(const float* joints, int js, const float* colors, int B, i
 int buctd_flipback_avg(const float* a, const float* b, const int32_t* perm, int N, int K, int H, int W, int shift,
                        float* out, void* stream);
 
+/* ------------------------------------------- gathered bf16x6 convolutions --- */
+/* The convolutions around the BasicBlocks in the bf16x6 arithmetic (csrc/conv_gather_x6.hip): kind 1 = 1x1 / stride 1 /
+ * pad 0 (fuse layers pose_hrnet.py:187-245, Bottlenecks :60-108), kind 2 = 3x3 / stride 2 / pad 1 (transitions :338-372,
+ * fuse-layer downsampling), forward (dir 0) and data gradient (dir 1; a stride-2 data gradient runs its four output
+ * parities as one launch).  (H, W) are the INPUT dims of the convolution, NHWC fp32 tensors, w is [Co][R][S][Ci];
+ * Ci % 16 == 0, Co % 16 == 0, output channels of the launch a multiple of 48 or 64, H and W even for kind 2.
+ * prep builds the weight image the kernels consume - once per weight update, per direction.  The forward takes the
+ * epilogue options and Welford BatchNorm partials + counts of buctd_conv3x3_bf16x6 (groups from _stats_groups); the data
+ * gradient adds `residual` (NULL ok) to dx.  Replace what cuDNN does for F.conv2d / its backward on those layers. */
+int buctd_gconv_x6_supported(int kind, int N, int H, int W, int Ci, int Co, int dir);
+size_t buctd_gconv_x6_prep_bytes(int kind, int Ci, int Co, int dir);
+int buctd_gconv_x6_prep(int kind, int Ci, int Co, const float* w, int dir, void* wprep, void* stream);
+int buctd_gconv_x6_stats_groups(int kind, int N, int H, int W, int Ci, int Co, int* ngroups, int* rows_per_group);
+int buctd_gconv_x6_fwd(int kind, int N, int H, int W, int Ci, int Co, const float* x, const void* wprep, const float* bias,
+                       const float* scale, const float* shift, const float* residual, int relu, float* y,
+                       float* stats_partials, int* stats_counts, void* stream);
+int buctd_gconv_x6_dgrad(int kind, int N, int H, int W, int Ci, int Co, const float* dy, const void* wprep,
+                         const float* residual, float* dx, void* stream);
+
 /* ------------------------------------------------------- BasicBlock sequences --- */
 /* The kernel sequence of one residual BasicBlock in train mode (pose_hrnet.py:28-57: stride 1, C -> C, no downsample,
  * bf16x6 math) behind ONE call per direction: conv1 + statistics, finalize, conv2 with bn1 + ReLU applied in its input

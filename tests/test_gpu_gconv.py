@@ -1,0 +1,112 @@
+"""The gathered bf16x6 convolutions (buctd_amd/csrc/conv_gather_x6.hip): 1x1 and stride-2 3x3, forward (with the fused
+epilogue and BatchNorm statistics) and data gradient (four output parities of a stride-2 convolution in one launch),
+against fp64 evaluations of torch's conv2d - the 2e-6 bar of the 3x3 stride-1 bf16x6 kernel - and against the exact-fp32
+kernels they replace (reference layers: lib/models/pose_hrnet.py:60-108, 187-245, 338-372)."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+TOL = 2e-6
+
+
+def nhwc(t):
+    return t.permute(0, 2, 3, 1).contiguous()
+
+
+def nchw(t):
+    return t.permute(0, 3, 1, 2).contiguous()
+
+
+# (N, H, W, Ci, Co, k, stride, pad)
+SHAPES = [(2, 24, 18, 48, 96, 3, 2, 1), (2, 12, 10, 96, 192, 3, 2, 1), (3, 8, 6, 192, 384, 3, 2, 1), (2, 16, 12, 48, 48, 3, 2, 1),
+          (2, 20, 14, 64, 64, 3, 2, 1), (1, 6, 4, 256, 96, 3, 2, 1), (2, 2, 2, 48, 192, 3, 2, 1), (4, 96, 72, 48, 96, 3, 2, 1),
+          (2, 24, 18, 64, 256, 1, 1, 0), (2, 24, 18, 256, 64, 1, 1, 0), (3, 12, 9, 96, 48, 1, 1, 0), (2, 7, 5, 192, 96, 1, 1, 0),
+          (2, 6, 5, 384, 192, 1, 1, 0), (1, 1, 1, 48, 48, 1, 1, 0), (2, 48, 36, 96, 48, 1, 1, 0)]
+
+
+@pytest.mark.parametrize("shape", SHAPES)
+def test_gconv_fwd_dgrad_vs_fp64(dev, shape):
+    from buctd_amd import ops
+    N, H, W, Ci, Co, k, st, pad = shape
+    assert ops.get_conv_math() == "bf16x6"
+    g = torch.Generator().manual_seed(sum(shape))
+    x = torch.randn(N, Ci, H, W, generator=g).double().requires_grad_(True)
+    w = (torch.randn(Co, Ci, k, k, generator=g) / math.sqrt(Ci * k * k)).double().requires_grad_(True)
+    b = torch.randn(Co, generator=g).double()
+    y_ref = F.conv2d(x, w, b, st, pad)
+    dy = torch.randn(y_ref.shape, generator=g).double()
+    y_ref.backward(dy)
+    d = ops.conv_desc((N, H, W, Ci), (Co, Ci, k, k), st, pad)
+    assert ops._gconv_ok(d, 0) and ops._gconv_ok(d, 1), "shape should take the gathered bf16x6 kernel"
+    xd = nhwc(x.detach().float()).to(dev)
+    wd = w.detach().float().contiguous(memory_format=torch.channels_last).to(dev)
+    y = ops.conv_fwd(xd, wd, b.float().to(dev), st, pad)
+    sc = y_ref.abs().max().item()
+    err = (nchw(y).cpu().double() - y_ref).abs().max().item()
+    assert err <= TOL * sc, f"fwd {shape}: {err:.3e} vs scale {sc:.2f}"
+    dyd = nhwc(dy.float()).to(dev)
+    dx = ops.conv_dgrad(dyd, wd, tuple(xd.shape), st, pad)
+    sc = x.grad.abs().max().item()
+    err = (nchw(dx).cpu().double() - x.grad).abs().max().item()
+    assert err <= TOL * sc, f"dgrad {shape}: {err:.3e} vs scale {sc:.2f}"
+    res = torch.randn(xd.shape, generator=g).to(dev)
+    dx2 = ops.conv_dgrad(dyd, wd, tuple(xd.shape), st, pad, residual=res)
+    assert (dx2 - dx - res).abs().max().item() <= 1e-6 * max(1.0, sc)
+    # against the exact-fp32 kernels these replace
+    ops.set_conv_math("fp32")
+    try:
+        y32 = ops.conv_fwd(xd, wd, b.float().to(dev), st, pad)
+        dx32 = ops.conv_dgrad(dyd, wd, tuple(xd.shape), st, pad)
+    finally:
+        ops.set_conv_math("bf16x6")
+    assert (y32 - y).abs().max().item() <= 1e-5 * y_ref.abs().max().item()
+    assert (dx32 - dx).abs().max().item() <= 1e-5 * sc
+
+
+@pytest.mark.parametrize("shape", [(2, 24, 18, 48, 96, 3, 2, 1), (3, 12, 10, 192, 48, 1, 1, 0), (2, 10, 8, 64, 256, 1, 1, 0)])
+def test_gconv_epilogue_and_statistics(dev, shape):
+    """eval-BN scale/shift + residual + ReLU in the epilogue, and the train-mode BatchNorm statistics (Welford partials +
+    valid-row counts of the padded position tiles) finalised by buctd_bn_finalize."""
+    from buctd_amd import ops
+    N, H, W, Ci, Co, k, st, pad = shape
+    g = torch.Generator().manual_seed(sum(shape) + 1)
+    x = torch.randn(N, H, W, Ci, generator=g).to(dev)
+    w = (torch.randn(Co, Ci, k, k, generator=g) / math.sqrt(Ci * k * k)).contiguous(memory_format=torch.channels_last).to(dev)
+    y0 = ops.conv_fwd(x, w, None, st, pad)
+    scale = (torch.rand(Co, generator=g) + 0.5).to(dev)
+    shift = torch.randn(Co, generator=g).to(dev)
+    res = torch.randn(y0.shape, generator=g).to(dev)
+    y1 = ops.conv_fwd(x, w, None, st, pad, scale=scale, shift=shift, residual=res, relu=True)
+    assert (y1 - torch.relu(y0 * scale + shift + res)).abs().max().item() <= 2e-6 * max(1.0, y0.abs().max().item())
+    y2, part, info = ops.conv_fwd(x, w, None, st, pad, stats=True)
+    assert torch.equal(y2, y0) and len(info) == 3
+    rows = y0.numel() // Co
+    assert int(info[2].sum().item()) == rows
+    rm, rv = torch.zeros(Co, device=dev), torch.ones(Co, device=dev)
+    mean, invstd = ops.bn_finalize(part, info, rows, Co, 1e-5, 0.1, rm, rv)
+    z = y0.reshape(rows, Co).double()
+    assert (mean.double() - z.mean(0)).abs().max().item() <= 1e-6
+    assert (invstd.double() - 1.0 / torch.sqrt(z.var(0, unbiased=False) + 1e-5)).abs().max().item() <= 1e-5
+
+
+def test_gconv_dispatch_boundaries(dev):
+    """odd input sizes of a stride-2 convolution, thin channels and the fp32 math mode stay on the exact-fp32 kernels"""
+    from buctd_amd import ops
+    assert not ops._gconv_ok(ops.conv_desc((2, 9, 7, 48), (96, 48, 3, 3), 2, 1), 0)
+    assert not ops._gconv_ok(ops.conv_desc((2, 384, 288, 3), (64, 3, 3, 3), 2, 1), 0)
+    assert not ops._gconv_ok(ops.conv_desc((2, 8, 8, 48), (32, 48, 1, 1), 1, 0), 0)       # 32 output channels
+    assert ops._gconv_ok(ops.conv_desc((2, 8, 8, 32), (48, 32, 1, 1), 1, 0), 0)
+    ops.set_conv_math("fp32")
+    try:
+        assert not ops._gconv_ok(ops.conv_desc((2, 8, 8, 48), (96, 48, 3, 3), 2, 1), 0)
+    finally:
+        ops.set_conv_math("bf16x6")
+    # data-gradient image of a stride-2 filter: four parity classes of 1 + 2 + 2 + 4 taps = the nine taps once
+    lib = ops.lib()
+    per_tap = 96 // 16 * 48 * 192 // 2           # (Co / 16 half-steps) x Ci rows x 192 B / 2 half-steps per step
+    assert lib.buctd_gconv_x6_prep_bytes(2, 48, 96, 1) == 9 * per_tap
+    assert lib.buctd_gconv_x6_prep_bytes(2, 48, 96, 0) == (9 * 3 + 1) // 2 * 96 * 192
+    assert lib.buctd_gconv_x6_prep_bytes(3, 48, 96, 0) == 0 and lib.buctd_gconv_x6_prep_bytes(1, 40, 96, 0) == 0
