@@ -158,6 +158,9 @@ SIGNATURES = {
     "buctd_gconv_x6_supported": (_I, [_I] * 7),
     "buctd_gconv_x6_prep_bytes": (_SZ, [_I, _I, _I, _I]),
     "buctd_gconv_x6_prep": (_I, [_I, _I, _I, _P, _I, _P, _P]),
+    "buctd_gconv_x6_prep_item_bytes": (_SZ, []),
+    "buctd_gconv_x6_prep_item": (_I, [_I, _I, _I, _P, _I, _P, _P]),
+    "buctd_gconv_x6_prep_batched": (_I, [_P, _I, _P]),
     "buctd_gconv_x6_stats_groups": (_I, [_I] * 6 + [_PI, _PI]),
     "buctd_gconv_x6_fwd": (_I, [_I] * 6 + [_P] * 6 + [_I, _P, _P, _P, _P]),
     "buctd_gconv_x6_dgrad": (_I, [_I] * 6 + [_P] * 4 + [_P]),

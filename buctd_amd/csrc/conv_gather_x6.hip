@@ -167,7 +167,7 @@ struct GcPrep {
   long items[4];                     // cumulative (step, row, k-slot) counts
 };
 
-__global__ __launch_bounds__(256) void gconv_x6_prep_kernel(GcPrep p) {
+__device__ __forceinline__ void gc_prep_body(const GcPrep& p) {
   const int nrows = p.dir ? p.Ci : p.Co, kc = p.dir ? p.Co : p.Ci, cpt = kc / 16;
   const long total = p.items[p.ncls - 1];
   for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
@@ -193,6 +193,13 @@ __global__ __launch_bounds__(256) void gconv_x6_prep_kernel(GcPrep p) {
       v -= (float)h;
     }
   }
+}
+
+__global__ __launch_bounds__(256) void gconv_x6_prep_kernel(GcPrep p) { gc_prep_body(p); }
+
+// every image of a model in one launch (after the optimizer step): blockIdx.y = item of a device table of GcPrep
+__global__ __launch_bounds__(256) void gconv_x6_prep_batched_kernel(const GcPrep* __restrict__ items) {
+  gc_prep_body(items[blockIdx.y]);
 }
 
 // kind 1: 1x1 stride 1 pad 0; kind 2: 3x3 stride 2 pad 1
@@ -234,29 +241,53 @@ extern "C" size_t buctd_gconv_x6_prep_bytes(int kind, int Ci, int Co, int dir) {
   return total;
 }
 
-extern "C" int buctd_gconv_x6_prep(int kind, int Ci, int Co, const float* w, int dir, void* wprep, void* stream) {
+static int gc_prep_fill(int kind, int Ci, int Co, const float* w, int dir, void* wprep, GcPrep* p, long* items_out) {
   BUCTD_CHECK_ARG(w && wprep, "buctd_gconv_x6_prep: null pointer");
   BUCTD_CHECK_ARG(buctd_gconv_x6_prep_bytes(kind, Ci, Co, dir) > 0, "buctd_gconv_x6_prep: unsupported kind %d Ci%d Co%d", kind, Ci,
                   Co);
-  GcPrep p;
-  p.w = w; p.out = (unsigned char*)wprep; p.Co = Co; p.Ci = Ci; p.R = p.S = kind == 1 ? 1 : 3; p.dir = dir;
-  p.ncls = gc_ncls(kind, dir);
+  memset(p, 0, sizeof(GcPrep));
+  p->w = w; p->out = (unsigned char*)wprep; p->Co = Co; p->Ci = Ci; p->R = p->S = kind == 1 ? 1 : 3; p->dir = dir;
+  p->ncls = gc_ncls(kind, dir);
   const int kc = dir ? Co : Ci, nrows = dir ? Ci : Co;
   long off = 0, items = 0;
   int ty[GC_MAXT], tx[GC_MAXT];
-  for (int c = 0; c < 4; ++c) { p.ntaps[c] = 0; p.nsteps[c] = 0; p.off[c] = 0; p.items[c] = 0; }
-  for (int c = 0; c < p.ncls; ++c) {
-    p.ntaps[c] = gc_taps(kind, dir, c, p.tr[c], p.ts[c], ty, tx);
-    p.nsteps[c] = (p.ntaps[c] * (kc / 16) + 1) / 2;
-    p.off[c] = off;
-    off += (long)gc_class_bytes(p.ntaps[c], kc, nrows);
-    items += (long)p.nsteps[c] * nrows * 32;
-    p.items[c] = items;
+  for (int c = 0; c < p->ncls; ++c) {
+    p->ntaps[c] = gc_taps(kind, dir, c, p->tr[c], p->ts[c], ty, tx);
+    p->nsteps[c] = (p->ntaps[c] * (kc / 16) + 1) / 2;
+    p->off[c] = off;
+    off += (long)gc_class_bytes(p->ntaps[c], kc, nrows);
+    items += (long)p->nsteps[c] * nrows * 32;
+    p->items[c] = items;
   }
+  *items_out = items;
+  return BUCTD_OK;
+}
+
+extern "C" int buctd_gconv_x6_prep(int kind, int Ci, int Co, const float* w, int dir, void* wprep, void* stream) {
+  GcPrep p;
+  long items;
+  const int rc = gc_prep_fill(kind, Ci, Co, w, dir, wprep, &p, &items);
+  if (rc) return rc;
   long blocks = (items + 255) / 256;
   if (blocks > 4096) blocks = 4096;
   hipLaunchKernelGGL(gconv_x6_prep_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p);
   BUCTD_CHECK_LAUNCH("buctd_gconv_x6_prep");
+  return BUCTD_OK;
+}
+
+extern "C" size_t buctd_gconv_x6_prep_item_bytes(void) { return sizeof(GcPrep); }
+
+extern "C" int buctd_gconv_x6_prep_item(int kind, int Ci, int Co, const float* w, int dir, void* wprep, void* item_host) {
+  BUCTD_CHECK_ARG(item_host, "buctd_gconv_x6_prep_item: null pointer");
+  long items;
+  return gc_prep_fill(kind, Ci, Co, w, dir, wprep, (GcPrep*)item_host, &items);
+}
+
+extern "C" int buctd_gconv_x6_prep_batched(const void* items_device, int n, void* stream) {
+  BUCTD_CHECK_ARG(items_device && n > 0 && n <= 65535, "buctd_gconv_x6_prep_batched: bad argument");
+  hipLaunchKernelGGL(gconv_x6_prep_batched_kernel, dim3(48, (unsigned)n), dim3(256), 0, (hipStream_t)stream,
+                     (const GcPrep*)items_device);
+  BUCTD_CHECK_LAUNCH("buctd_gconv_x6_prep_batched");
   return BUCTD_OK;
 }
 

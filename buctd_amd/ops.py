@@ -272,20 +272,75 @@ def _prep_all(device):
             total += img.numel() // unit
         cache[0] = (w.data_ptr(), w._version, epoch, mode)
     _prep_registry["weights"] = live
-    if not items:
+    launched = False
+    if items:
+        key = tuple(items)
+        if _prep_registry["table_key"] != key:
+            arr = (_PrepItem * len(items))(*[_PrepItem(*it) for it in items])
+            host = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8)
+            _prep_registry["table"] = host.to(device)
+            _prep_registry["table_key"] = key
+        check(lib().buctd_conv3x3_bf16x3_prep_batched(ptr(_prep_registry["table"]), len(items), total, stream_ptr()),
+              "conv3x3 prep_batched")
+        launched = True
+    launched = _gprep_all(device, epoch) or launched
+    if not launched:
         return
-    key = tuple(items)
-    if _prep_registry["table_key"] != key:
-        arr = (_PrepItem * len(items))(*[_PrepItem(*it) for it in items])
-        host = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8)
-        _prep_registry["table"] = host.to(device)
-        _prep_registry["table_key"] = key
-    check(lib().buctd_conv3x3_bf16x3_prep_batched(ptr(_prep_registry["table"]), len(items), total, stream_ptr()),
-          "conv3x3 prep_batched")
     ev = torch.cuda.Event()
     ev.record()
     _prep_registry["event"], _prep_registry["stream"] = ev, torch.cuda.current_stream(device).cuda_stream
     _prep_registry["waited"] = set()
+
+
+def _prep_wait(device):
+    """A batched refresh ran on the optimizer's stream: other streams order themselves behind it once."""
+    ev = _prep_registry["event"]
+    if ev is not None:
+        cur = torch.cuda.current_stream(device).cuda_stream
+        if cur != _prep_registry["stream"] and cur not in _prep_registry["waited"]:
+            torch.cuda.current_stream(device).wait_event(ev)
+            _prep_registry["waited"].add(cur)
+
+
+_gprep_registry = {"weights": [], "table": None, "table_key": None}
+
+
+def _gprep_all(device, epoch):
+    """The gathered-convolution images (csrc/conv_gather_x6.hip) of every registered filter in ONE launch; True if launched."""
+    if _conv_math["mode"] != "bf16x6":
+        return False
+    items, live = [], []
+    for ref in _gprep_registry["weights"]:
+        w = ref()
+        if w is None or not w.is_cuda or w.device != device:
+            continue
+        cache = getattr(w, "_buctd_gprep", None)
+        if cache is None or cache[0][0] != w.data_ptr():
+            continue
+        live.append(ref)
+        if cache[0] == (w.data_ptr(), w._version, epoch):
+            continue
+        Co, Ci = _wshape(w)[0], _wshape(w)[1]
+        for direction in (0, 1):
+            img = cache[2 + direction]
+            if img is not None:
+                items.append((cache[1], Ci, Co, w.data_ptr(), direction, img.data_ptr()))
+        cache[0] = (w.data_ptr(), w._version, epoch)
+    _gprep_registry["weights"] = live
+    if not items:
+        return False
+    key = tuple(items)
+    if _gprep_registry["table_key"] != key:
+        isz = int(lib().buctd_gconv_x6_prep_item_bytes())
+        buf = C.create_string_buffer(isz * len(items))
+        base = C.addressof(buf)
+        for i, (kind, Ci, Co, wptr, direction, iptr) in enumerate(items):
+            check(lib().buctd_gconv_x6_prep_item(kind, Ci, Co, C.c_void_p(wptr), direction, C.c_void_p(iptr),
+                                                 C.c_void_p(base + i * isz)), "gconv_x6_prep_item")
+        _gprep_registry["table"] = torch.frombuffer(bytearray(buf.raw), dtype=torch.uint8).to(device)
+        _gprep_registry["table_key"] = key
+    check(lib().buctd_gconv_x6_prep_batched(ptr(_gprep_registry["table"]), len(items), stream_ptr()), "gconv_x6_prep_batched")
+    return True
 
 
 def _conv3x3_prepared(w, flip):
@@ -309,12 +364,7 @@ def _conv3x3_prepared(w, flip):
         img = torch.empty(nbytes, dtype=torch.uint8, device=w.device)
         check(_c3fn("_prep")(Ci, Co, ptr(w), flip, ptr(img), stream_ptr()), "conv3x3 prep")
         cache[1 + flip] = img
-    ev = _prep_registry["event"]
-    if ev is not None:
-        cur = torch.cuda.current_stream(w.device).cuda_stream
-        if cur != _prep_registry["stream"] and cur not in _prep_registry["waited"]:
-            torch.cuda.current_stream(w.device).wait_event(ev)   # batched refresh ran on another stream
-            _prep_registry["waited"].add(cur)
+    _prep_wait(w.device)
     return cache[1 + flip]
 
 
@@ -368,22 +418,28 @@ def _gconv_ok(d, direction):
 
 
 def _gconv_prepared(w, kind, direction):
-    """weight image of the gathered kernels, cached on the weight tensor until it changes (optimizer epoch / version)."""
+    """weight image of the gathered kernels, cached on the weight tensor until it changes; filters rewritten in place by
+    the optimizer kernel are refreshed together by _prep_all (one launch per step)."""
+    import weakref
     Co, Ci = _wshape(w)[0], _wshape(w)[1]
     key = (w.data_ptr(), w._version, _weights_epoch["n"])
     cache = getattr(w, "_buctd_gprep", None)
-    if cache is None or cache[0] != key:
-        cache = [key, None, None]
+    if cache is not None and cache[0] != key and cache[0][:2] == key[:2] and _PREP_BATCH:
+        _prep_all(w.device)           # same storage, new optimizer epoch: batch-refresh every registered image
+    if cache is None or cache[0] != key or cache[1] != kind:
+        cache = [key, kind, None, None]
         try:
             w._buctd_gprep = cache
+            _gprep_registry["weights"].append(weakref.ref(w))
         except (AttributeError, RuntimeError, TypeError):
             pass
-    if cache[1 + direction] is None:
+    if cache[2 + direction] is None:
         nbytes = _memo(("gcpb", kind, Ci, Co, direction), lambda: int(lib().buctd_gconv_x6_prep_bytes(kind, Ci, Co, direction)))
         img = torch.empty(nbytes, dtype=torch.uint8, device=w.device)
         check(lib().buctd_gconv_x6_prep(kind, Ci, Co, ptr(w), direction, ptr(img), stream_ptr()), "gconv_x6_prep")
-        cache[1 + direction] = img
-    return cache[1 + direction]
+        cache[2 + direction] = img
+    _prep_wait(w.device)
+    return cache[2 + direction]
 
 
 def _gconv_fwd(x, w, d, bias, scale, shift, residual, relu, stats):

@@ -328,6 +328,12 @@ int buctd_flipback_avg(const float* a, const float* b, const int32_t* perm, int 
 int buctd_gconv_x6_supported(int kind, int N, int H, int W, int Ci, int Co, int dir);
 size_t buctd_gconv_x6_prep_bytes(int kind, int Ci, int Co, int dir);
 int buctd_gconv_x6_prep(int kind, int Ci, int Co, const float* w, int dir, void* wprep, void* stream);
+/* all images of a model with ONE launch (after an optimizer step rewrote the filters in place): the caller fills one table
+ * entry per (filter, direction) on the host with _prep_item (entry size _prep_item_bytes), uploads the table once, and
+ * launches _prep_batched on it whenever the filters change. */
+size_t buctd_gconv_x6_prep_item_bytes(void);
+int buctd_gconv_x6_prep_item(int kind, int Ci, int Co, const float* w, int dir, void* wprep, void* item_host);
+int buctd_gconv_x6_prep_batched(const void* items_device, int n, void* stream);
 int buctd_gconv_x6_stats_groups(int kind, int N, int H, int W, int Ci, int Co, int* ngroups, int* rows_per_group);
 int buctd_gconv_x6_fwd(int kind, int N, int H, int W, int Ci, int Co, const float* x, const void* wprep, const float* bias,
                        const float* scale, const float* shift, const float* residual, int relu, float* y,

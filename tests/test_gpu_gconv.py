@@ -110,3 +110,40 @@ def test_gconv_dispatch_boundaries(dev):
     assert lib.buctd_gconv_x6_prep_bytes(2, 48, 96, 1) == 9 * per_tap
     assert lib.buctd_gconv_x6_prep_bytes(2, 48, 96, 0) == (9 * 3 + 1) // 2 * 96 * 192
     assert lib.buctd_gconv_x6_prep_bytes(3, 48, 96, 0) == 0 and lib.buctd_gconv_x6_prep_bytes(1, 40, 96, 0) == 0
+
+
+def test_prepared_images_follow_in_place_weight_updates(dev):
+    """An optimizer kernel rewrites filters through raw pointers (no autograd version bump): weights_updated() +
+    refresh_prepared() rebuild every registered image - the gathered kernels' and the 3x3 stride-1 kernels' - with one launch
+    each, and the next convolutions see the new filters (forward and data gradient)."""
+    from buctd_amd import ops
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(2, 12, 8, 48, generator=g).to(dev)
+    ws = [(torch.randn(96, 48, 3, 3, generator=g) / 20).contiguous(memory_format=torch.channels_last).to(dev),
+          (torch.randn(48, 48, 1, 1, generator=g) / 7).contiguous(memory_format=torch.channels_last).to(dev),
+          (torch.randn(48, 48, 3, 3, generator=g) / 20).contiguous(memory_format=torch.channels_last).to(dev)]
+    cfgs = [(2, 1), (1, 0), (1, 1)]
+
+    def run():
+        outs = []
+        for w, (st, pad) in zip(ws, cfgs):
+            y = ops.conv_fwd(x, w, None, st, pad)
+            outs += [y, ops.conv_dgrad(torch.ones_like(y), w, tuple(x.shape), st, pad)]
+        return outs
+    before = run()
+    for w in ws:
+        ptr_before, ver = w.data_ptr(), w._version
+        w.data.mul_(1.5).add_(0.01)      # in place, like the fused optimizer kernel (through .data: no version bump)
+        assert w.data_ptr() == ptr_before and w._version == ver
+    stale = run()
+    assert all(torch.equal(a, b) for a, b in zip(before, stale))          # images are cached on (pointer, version, epoch)
+    ops.weights_updated()
+    ops.refresh_prepared(dev)
+    fresh = run()
+    ref = []
+    for w, (st, pad) in zip(ws, cfgs):
+        w2 = w.detach().clone().contiguous(memory_format=torch.channels_last)
+        y = ops.conv_fwd(x, w2, None, st, pad)
+        ref += [y, ops.conv_dgrad(torch.ones_like(y), w2, tuple(x.shape), st, pad)]
+    assert all(torch.equal(a, b) for a, b in zip(fresh, ref))
+    assert not torch.equal(fresh[0], before[0])
