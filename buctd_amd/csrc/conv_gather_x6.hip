@@ -9,7 +9,7 @@
 //     conv3x3.hip (so that the epilogue - bias, Welford BatchNorm partials + valid-row counts, eval-BN, residual, ReLU,
 //     coalesced stores - is literally c3_epilogue);
 //   * the contraction runs over (tap, 16-channel chunk) "half-steps", two per K = 32 MFMA step (lanes 0-31 / 32-63 of the A
-//     operand); tap t of grid pixel (y, x) reads source pixel (y * ss + tdy[t], x * ss + tdx[t]), zero outside the source:
+//     operand); tap t of grid pixel (y, x) reads source pixel (y * ss + dy_t, x * ss + dx_t), zero outside the source:
 //       forward, stride 2 : grid = Ho x Wo, ss = 2, nine taps (r - 1, s - 1);
 //       1x1               : grid = H x W, ss = 1, one tap (0, 0);
 //       data gradient of a stride-2 conv: FOUR parity classes in blockIdx.z - class (a, b) owns the input pixels
@@ -17,20 +17,24 @@
 //         the nine: rows a = 0 -> r = 1 at dy row u; a = 1 -> r = 0 at u + 1 and r = 2 at u), written through the epilogue's
 //         output map (pixel (y, x) of the class grid -> (2y + a, 2x + b));
 //   * a workgroup = 256 threads owns BM consecutive positions x BN output channels; per step every thread gathers its 16-byte
-//     pieces of the two half-step tiles into registers one step ahead, splits them into LDS rows [16 h | 16 m | 16 l]
+//     pieces of the two half-step tiles into registers TWO steps ahead, splits them into LDS rows [16 h | 16 m | 16 l]
 //     (the A-row format of conv3x3.hip) and the four waves multiply; the weight fragments come straight from the prepared
 //     image in L2 ([step][output channel][32 h | 32 m | 32 l k-slots], built once per weight update by buctd_gconv_x6_prep),
-//     also one step ahead.
+//     one step ahead.
 // VALU per MFMA: 16 gathered floats per thread and step x ~4 instructions against 72 MFMAs per wave (BN = 96) - under one.
 #include "c3_common.h"
 
 #define GC_MAXT 9
+#ifndef GC_ABL
+#define GC_ABL 0      // what-if switches (scratch/gc_abl.sh): 1 no weight loads, 2 no gathers, 4 no LDS stores, 8 no barriers, 16 no MFMAs
+#endif
 
 struct GcClass {
   int ntaps, nhs, nsteps;            // taps, half-steps = ntaps * (SC / 16), steps = ceil(nhs / 2)
   int oy0, ox0;                      // output map offsets of the class
   long wp_off;                       // byte offset of the class's weight image
-  int tdy[GC_MAXT], tdx[GC_MAXT];
+  unsigned pdy, pdx;                 // source offsets of the taps, 2 bits each: (offset + 1) << (2 * tap) - scalar arithmetic in
+                                     // the kernel (an indexed kernarg array became a vector load + vmcnt(0) in the step loop)
 };
 
 struct GcArgs {
@@ -78,37 +82,54 @@ __global__ __launch_bounds__(256, 2) void gconv_x6_kernel(GcArgs p) {
   const unsigned char* wbase = p.wp + c.wp_off + (size_t)(n0 + wave_n * NF * 16 + i16) * BROW + g * 16;
   const size_t wstep = (size_t)e.Co * BROW;
 
-  f32x4 areg[2][QA];
+  // the gathered A pieces travel TWO steps ahead of their MFMAs through two register sets (a step's 72 MFMAs per wave cover
+  // ~0.5 us, a gathered L2 / HBM round trip under load takes 1-2 us), the weight fragments (hot in L2) one step ahead
+  f32x4 areg[2][2][QA];                     // [set][half-step][row]
+  unsigned aok[2] = {0u, 0u};               // bit h * QA + q: that piece is a real source pixel (else zero)
   bf16x8 bnx[3][NF];
   int tap = 0, chunk = 0;                   // (tap, chunk) of the next half-step to load
-  auto load_step = [&](int st) {
+  int cur_dy = (int)(c.pdy & 3u) - 1, cur_dx = (int)(c.pdx & 3u) - 1;
+  // Every load is unconditional - a piece outside the source reads the tensor's first pixel and is zeroed when it is stored
+  // (a predicated load merged with zeros made the compiler wait for the data right behind the load: no prefetch at all).
+  auto load_a = [&](int st, f32x4 (&dst)[2][QA], unsigned& okm) {
+    okm = 0u;
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
       const bool live = 2 * st + h < c.nhs;
-      const int dy = c.tdy[live ? tap : 0], dx = c.tdx[live ? tap : 0];
 #pragma unroll
       for (int q = 0; q < QA; ++q) {
-        const int sy = sy0[q] + dy, sx = sx0[q] + dx;
+        const int sy = sy0[q] + cur_dy, sx = sx0[q] + cur_dx;
         const bool ok = live && simg[q] >= 0 && (unsigned)sy < (unsigned)p.SH && (unsigned)sx < (unsigned)p.SWd;
-        areg[h][q] = ok ? *reinterpret_cast<const f32x4*>(p.src + ((long)(simg[q] + sy) * p.SWd + sx) * p.SC + chunk * 16 + c4 * 4)
-                        : (f32x4){0.f, 0.f, 0.f, 0.f};
+        const long off = ok ? ((long)(simg[q] + sy) * p.SWd + sx) * p.SC + chunk * 16 : 0L;
+        if (!(GC_ABL & 2) || st < 2) dst[h][q] = *reinterpret_cast<const f32x4*>(p.src + off + c4 * 4);
+        okm |= (ok ? 1u : 0u) << (h * QA + q);
       }
-      if (live) {
-        if (++chunk == p.cpt) { chunk = 0; ++tap; }
+      if (live && ++chunk == p.cpt) {
+        chunk = 0;
+        ++tap;
+        cur_dy = (int)((c.pdy >> (2 * tap)) & 3u) - 1;
+        cur_dx = (int)((c.pdx >> (2 * tap)) & 3u) - 1;
       }
     }
+  };
+  auto load_b = [&](int st) {
+    if ((GC_ABL & 1) && st > 0) return;
     const unsigned char* wp = wbase + (size_t)st * wstep;
 #pragma unroll
     for (int q = 0; q < 3; ++q)
 #pragma unroll
       for (int nf = 0; nf < NF; ++nf) bnx[q][nf] = *reinterpret_cast<const bf16x8*>(wp + (size_t)nf * 16 * BROW + q * 64);
   };
-  auto store_step = [&]() {
+  auto store_a = [&](const f32x4 (&src)[2][QA], unsigned okm) {
 #pragma unroll
     for (int h = 0; h < 2; ++h)
 #pragma unroll
-      for (int q = 0; q < QA; ++q)
-        split_store<3, PST>(smem + ((size_t)h * BM + arow + 64 * q) * ROWB, c4 * 4, areg[h][q]);
+      for (int q = 0; q < QA; ++q) {
+        const bool ok = (okm >> (h * QA + q)) & 1u;
+        const f32x4 v = src[h][q];
+        split_store<3, PST>(smem + ((size_t)h * BM + arow + 64 * q) * ROWB, c4 * 4,
+                            (f32x4){ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f});
+      }
   };
 
   f32x4 acc[MF][NF];
@@ -119,17 +140,23 @@ __global__ __launch_bounds__(256, 2) void gconv_x6_kernel(GcArgs p) {
   // this lane's A fragment bytes: half-step g >> 1, channels 8 (g & 1) .. + 7 of row wave_m * MF * 16 + mf * 16 + i16
   const unsigned char* abase = smem + ((size_t)(g >> 1) * BM + wave_m * MF * 16 + i16) * ROWB + (g & 1) * 16;
 
-  load_step(0);
-  for (int st = 0; st < c.nsteps; ++st) {
-    __syncthreads();                       // the previous step's fragments are read
-    store_step();
+  auto step = [&](int st, auto set) {
+    constexpr int SET = decltype(set)::value;
+    if (!(GC_ABL & 8)) __syncthreads();    // the previous step's fragments are read
+    if (!(GC_ABL & 4) || st < 2) store_a(areg[SET], aok[SET]);
     bf16x8 bc[3][NF];
 #pragma unroll
     for (int q = 0; q < 3; ++q)
 #pragma unroll
       for (int nf = 0; nf < NF; ++nf) bc[q][nf] = bnx[q][nf];
-    __syncthreads();
-    if (st + 1 < c.nsteps) load_step(st + 1);
+    // the take-over of the weight fragments (and its wait) stays in front of the new loads: behind them the in-order load
+    // counter would make it wait for the gathers just issued
+    __builtin_amdgcn_sched_barrier(0);
+    if (!(GC_ABL & 8)) __syncthreads();
+    // unconditional on purpose (past the end: dummy pieces, the last weight step again): a skipped load is a merge of old
+    // and new register contents, which the compiler resolves with copies that wait for the loads just issued
+    load_a(st + 2, areg[SET], aok[SET]);
+    load_b(st + 1 < c.nsteps ? st + 1 : st);
     bf16x8 a[2][3];
 #pragma unroll
     for (int q = 0; q < 3; ++q) a[0][q] = *reinterpret_cast<const bf16x8*>(abase + q * PST);
@@ -144,10 +171,21 @@ __global__ __launch_bounds__(256, 2) void gconv_x6_kernel(GcArgs p) {
       bf16x8 (&ac)[3] = a[mf & 1];
 #define GC_MMA(qa, qb) acc[mf][nf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ac[qa], bc[qb][nf], acc[mf][nf], 0, 0, 0);
 #pragma unroll
-      for (int nf = 0; nf < NF; ++nf) { GC_MMA(2, 0) GC_MMA(0, 2) GC_MMA(1, 1) GC_MMA(1, 0) GC_MMA(0, 1) GC_MMA(0, 0) }
+      for (int nf = 0; nf < NF; ++nf) {
+        if (GC_ABL & 16) { acc[mf][nf][0] += (float)ac[0][0] + (float)ac[1][1] + (float)ac[2][2] + (float)bc[0][nf][0] + (float)bc[1][nf][1] + (float)bc[2][nf][2]; continue; }
+        GC_MMA(2, 0) GC_MMA(0, 2) GC_MMA(1, 1) GC_MMA(1, 0) GC_MMA(0, 1) GC_MMA(0, 0)
+      }
 #undef GC_MMA
       __builtin_amdgcn_sched_barrier(0);
     }
+  };
+
+  load_a(0, areg[0], aok[0]);
+  load_b(0);
+  load_a(1, areg[1], aok[1]);
+  for (int st = 0; st < c.nsteps; st += 2) {
+    step(st, IC<0>{});
+    if (st + 1 < c.nsteps) step(st + 1, IC<1>{});
   }
   __syncthreads();
   c3_epilogue<MF, NF, WM, WN>(e, acc, smem, bx, by, p0, n0);
@@ -296,7 +334,7 @@ struct GcPlan { int MF, NF, WM, WN, BM, BN; };
 
 static bool gc_plan(int nout, GcPlan* pl) {
   if (nout % 96 == 0) *pl = {4, 3, 2, 2, 128, 96};
-  else if (nout % 64 == 0) *pl = {4, 4, 4, 1, 256, 64};
+  else if (nout % 64 == 0) *pl = {2, 4, 4, 1, 128, 64};
   else if (nout % 48 == 0) *pl = {4, 3, 4, 1, 256, 48};
   else return false;
   return true;
@@ -378,9 +416,15 @@ static int gc_run(int kind, int dir, int N, int H, int W, int Ci, int Co, const 
   int tr[GC_MAXT], ts[GC_MAXT];
   for (int c = 0; c < 4; ++c) {
     GcClass& k = a.cls[c];
-    k.ntaps = k.nhs = k.nsteps = 0; k.oy0 = k.ox0 = 0; k.wp_off = 0;
+    k.ntaps = k.nhs = k.nsteps = 0; k.oy0 = k.ox0 = 0; k.wp_off = 0; k.pdy = k.pdx = 0u;
     if (c >= a.ncls) continue;
-    k.ntaps = gc_taps(kind, dir, c, tr, ts, k.tdy, k.tdx);
+    int tdy[GC_MAXT], tdx[GC_MAXT];
+    k.ntaps = gc_taps(kind, dir, c, tr, ts, tdy, tdx);
+    k.pdy = k.pdx = 0u;
+    for (int t = 0; t < k.ntaps; ++t) {
+      k.pdy |= (unsigned)(tdy[t] + 1) << (2 * t);
+      k.pdx |= (unsigned)(tdx[t] + 1) << (2 * t);
+    }
     k.nhs = k.ntaps * a.cpt;
     k.nsteps = (k.nhs + 1) / 2;
     k.oy0 = par ? (c >> 1) : 0; k.ox0 = par ? (c & 1) : 0;
@@ -390,7 +434,7 @@ static int gc_run(int kind, int dir, int N, int H, int W, int Ci, int Co, const 
   const int tiles = (e.P + pl.BM - 1) / pl.BM, ncol = nout / pl.BN;
   hipStream_t st = (hipStream_t)stream;
   if (pl.NF == 3 && pl.WM == 2) gc_launch<4, 3, 2, 2>(a, tiles, ncol, st);
-  else if (pl.NF == 4) gc_launch<4, 4, 4, 1>(a, tiles, ncol, st);
+  else if (pl.NF == 4) gc_launch<2, 4, 4, 1>(a, tiles, ncol, st);
   else gc_launch<4, 3, 4, 1>(a, tiles, ncol, st);
   BUCTD_CHECK_LAUNCH(who);
   return BUCTD_OK;
