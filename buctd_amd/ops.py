@@ -611,7 +611,7 @@ native_block_veto = {"fn": None}
 
 def native_chain_ok(x_shape):
     """True when a chain of BasicBlocks on this activation shape may take the one-call-per-direction path."""
-    return (_NATIVE_BLOCK and not _PLANES_BLOCKS and _conv_math["mode"] == "bf16x6" and native_block_veto["fn"] is None)
+    return (_NATIVE_BLOCK and _conv_math["mode"] == "bf16x6" and native_block_veto["fn"] is None)
 
 
 def bn_in_fusable(x_shape, w):
@@ -1629,8 +1629,15 @@ class BasicChainFn(torch.autograd.Function):
             d.part, d.counts = pbase + k * 2 * ng * Cn * 8, cbase + k * 2 * ng * 4
             d.ngroups, d.rows_per_group, d.stat = ng, rpg, sbase + k * 4 * Cn * 4
             xin = d.y
+        planes = None
+        if _PLANES_BLOCKS and wgrad_planes_ok(N, H, W, Cn, Cn) and planes_ok((N, H, W, Cn)):
+            # planes mode (BasicBlockFn): every block's forward convolutions also write x and y1 as x6 planes
+            planes = [planes_pool.acquire((N, H, W, Cn), dev) for _ in range(2 * n)]
+            for k in range(n):
+                descs[k].xp, descs[k].y1p = planes[2 * k].buf.data_ptr(), planes[2 * k + 1].buf.data_ptr()
         check(lib().buctd_basic_chain_fwd_train(n, descs, stream_ptr()), "basic_chain_fwd_train")
         ctx.blocks = blocks
+        ctx.planes = planes
         ctx.save_for_backward(x, act, stat)
         return act[n - 1, 2]
 
@@ -1648,17 +1655,29 @@ class BasicChainFn(torch.autograd.Function):
         abase, sbase, tb = act.data_ptr(), stat.data_ptr(), tmp.data_ptr()
         descs = (_C.BasicBlockDesc * n)()
         grads = (_C.BasicBlockGrads * n)()
-        bn_ws = workspace(lib().buctd_bn_bwd_workspace(N * H * W, Cn), dev)
+        planes = getattr(ctx, "planes", None)
         main = torch.cuda.current_stream(dev)
         use_side = _side["on"]
         side = _side_stream(dev) if use_side else main
-        need = _memo(("wg3", "bf16x6", N, H, W, Cn, Cn),
-                     lambda: (lib().buctd_conv3x3_wgrad_bf16x6_workspace(N, H, W, Cn, Cn)
-                              if lib().buctd_conv3x3_wgrad_bf16x6_supported(N, H, W, Cn, Cn) == 1 else -1))
+        scratch = None
+        if planes is not None:
+            # dz2 / dz1 of every block exist only as planes: one scratch set of 2 n buffers per call (a ring of such sets per
+            # shape; taking one waits, on this stream, for the weight gradients that read it last)
+            bn_ws = workspace(_memo(("bnpws", N * H * W, Cn), lambda: int(lib().buctd_bn_bwd_p_workspace(N * H * W, Cn))), dev)
+            need = _memo(("wg4ws", N, H, W, Cn, Cn), lambda: int(lib().buctd_conv3x3_wgrad_bf16x6_p_workspace(N, H, W, Cn, Cn)))
+            scratch = planes_pool.scratch((N, H, W, Cn), dev, 2 * n)
+        else:
+            bn_ws = workspace(lib().buctd_bn_bwd_workspace(N * H * W, Cn), dev)
+            need = _memo(("wg3", "bf16x6", N, H, W, Cn, Cn),
+                         lambda: (lib().buctd_conv3x3_wgrad_bf16x6_workspace(N, H, W, Cn, Cn)
+                                  if lib().buctd_conv3x3_wgrad_bf16x6_supported(N, H, W, Cn, Cn) == 1 else -1))
         wg_ws = workspace_on(side, need, dev)
         xin = x.data_ptr()
         for k, (w1, bn1, w2, bn2) in enumerate(blocks):
             d, g = descs[k], grads[k]
+            if planes is not None:
+                d.xp, d.y1p = planes[2 * k].buf.data_ptr(), planes[2 * k + 1].buf.data_ptr()
+                g.dz2p, g.dz1p = scratch[0][2 * k].buf.data_ptr(), scratch[0][2 * k + 1].buf.data_ptr()
             d.N, d.H, d.W, d.C = N, H, W, Cn
             d.x = xin
             d.w1_bwd = _conv3x3_prepared(w1, 1).data_ptr()
@@ -1692,9 +1711,20 @@ class BasicChainFn(torch.autograd.Function):
         if use_side:
             for t in (x, act, stat, tmp, dy):
                 t.record_stream(side)
+            if scratch is not None:
+                ev = torch.cuda.Event()
+                ev.record(side)                     # the last readers of the scratch planes are the weight gradients
+                scratch[1] = ev
             _queue_join()
-        elif _branch["on"]:
-            _queue_join()
+        else:
+            if scratch is not None:
+                scratch[1] = None
+            if _branch["on"]:
+                _queue_join()
+        if planes is not None:
+            for pl in planes:
+                planes_pool.release(pl)
+            ctx.planes = None
         for (w1, bn1, w2, bn2) in reversed(blocks):
             grad_done(bn2.weight, bn2.bias, w2)
             grad_done(bn1.weight, bn1.bias, w1)

@@ -167,6 +167,54 @@ def test_basic_block_planes_backward_matches_fp32_operand_backward(dev, shape, m
         assert err <= 2e-5 * sc, f"{n}: planes vs fp32-operand backward differ by {err:.3e} (scale {sc:.3e})"
 
 
+@pytest.mark.parametrize("planes", [False, True])
+def test_block_chain_equals_single_blocks(dev, planes, monkeypatch):
+    """BasicChainFn (one library call per direction for a whole branch) runs the launches of n BasicBlockFn calls: same bits
+    for the output, the input gradient and every parameter gradient - with fp32 operands and in planes mode (per-block planes
+    from the pool, one scratch set of 2 n dz planes per call)."""
+    import torch.nn as tnn
+    from buctd_amd import ops
+    monkeypatch.setattr(ops, "_PLANES_BLOCKS", planes)
+    N, H, W, Cn, n = 3, 12, 10, 48, 3
+    g = torch.Generator().manual_seed(77)
+    x = torch.randn(N, H, W, Cn, generator=g).to(dev)
+    dy = torch.randn(N, H, W, Cn, generator=g).to(dev)
+    blocks = []
+    for k in range(n):
+        ws = [tnn.Parameter((torch.randn(Cn, Cn, 3, 3, generator=g) * 0.08).contiguous(memory_format=torch.channels_last).to(dev))
+              for _ in range(2)]
+        bns = []
+        for s in (1, 2):
+            bn = tnn.BatchNorm2d(Cn).to(dev).train()
+            with torch.no_grad():
+                bn.weight.copy_(torch.rand(Cn, generator=g) + 0.5)
+                bn.bias.copy_(torch.randn(Cn, generator=g) * 0.2)
+            bns.append(bn)
+        blocks.append((ws[0], bns[0], ws[1], bns[1]))
+    params = [q for b in blocks for q in (b[0], b[2], b[1].weight, b[1].bias, b[3].weight, b[3].bias)]
+    res = {}
+    for mode in ("chain", "single", "chain2"):
+        for q in params:
+            q.grad = None
+        for b in blocks:
+            for bn in (b[1], b[3]):
+                bn.running_mean.zero_(); bn.running_var.fill_(1.0)
+        xi = x.clone().requires_grad_(True)
+        if mode == "single":
+            y = xi
+            for b in blocks:
+                y = ops.BasicBlockFn.apply(y, *b)
+        else:
+            assert ops.native_chain_ok(tuple(xi.shape))
+            y = ops.BasicChainFn.apply(xi, blocks[0][0], blocks)
+        y.backward(dy)
+        torch.cuda.synchronize()
+        res[mode] = [y.detach().clone(), xi.grad.clone()] + [q.grad.clone() for q in params] + \
+            [blocks[-1][3].running_var.clone()]
+    for a, b, c in zip(res["chain"], res["single"], res["chain2"]):
+        assert torch.equal(a, b) and torch.equal(a, c)
+
+
 def test_eval_bn_fold_cache_follows_training_updates(dev):
     """eval-mode scale / shift are folded once per BatchNorm and cached; a train-mode forward (running statistics updated
     through raw pointers) or a parameter update must invalidate them."""
