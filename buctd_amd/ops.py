@@ -397,6 +397,7 @@ def _conv3x3_bf16x3(x, w, flip, cin, cout, bias, scale, shift, residual, relu, s
 
 # ---- gathered bf16x6 convolutions (csrc/conv_gather_x6.hip): 1x1 and stride-2 3x3, forward + data gradient ----------------
 _GCONV_X6 = os.environ.get("BUCTD_GCONV_X6", "1") != "0"
+_GCONV_MASK = int(os.environ.get("BUCTD_GCONV_MASK", "15"))     # experiments: bit 0/1 = 1x1 forward / data gradient, 2/3 = stride-2 3x3
 
 
 def _gconv_kind(d):
@@ -413,6 +414,8 @@ def _gconv_ok(d, direction):
     if _conv_math["mode"] != "bf16x6" or not _GCONV_X6:
         return False
     kind = _gconv_kind(d)
+    if kind and not (_GCONV_MASK >> (2 * (kind - 1) + direction)) & 1:
+        return False
     return kind != 0 and _memo(("gcok", kind, d.N, d.H, d.W, d.Ci, d.Co, direction),
                                lambda: lib().buctd_gconv_x6_supported(kind, d.N, d.H, d.W, d.Ci, d.Co, direction) == 1)
 

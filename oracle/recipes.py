@@ -210,7 +210,14 @@ FINAL_SCALE_LOG2 = {
 
 # recipe seeds other than the default: the channel-only net at seed 1234 has a ReLU pre-activation within fp32 round-off
 # of zero in its train step (the fp32 CPU oracle itself sits 4e-3 from its fp64 evaluation there, against 2e-5 at seed 1)
-SEEDS = {"coam_w16_96x64_channel_only": 1}
+# (round 3) the mono / default-attention net at seed 1234 has one BasicBlock pre-activation of its 3x2-pixel stage-4 branch
+# within round-off of zero: which side of the ReLU it lands on depends on the summation order of the convolutions in front
+# of it, and with 12 samples per BatchNorm channel there one flipped unit moves most gradients by 5-10 % (scratch/
+# diag_chain_internal.py, scratch/seed_scan.py: at seed 1 the fp32 CPU oracle and every HIP math variant sit 2-3e-5 from fp64)
+# The TransPose trunk is the worst conditioned of the small nets: per seed, one of {fp32 CPU oracle, HIP with / without the
+# gathered bf16x6 convolutions} sits 1e-3..2e-2 from fp64 (seed: cpu32 median / HIP median - 1234: 1e-5 / 5e-3, 1: 4e-3 / 4e-5,
+# 2: 2e-5 / 2e-3, 4: 2e-5 / 3e-3); seed 5 has no pre-activation near zero for any of them (2e-5 / 1e-4).
+SEEDS = {"coam_w16_96x64_channel_only": 1, "coam_w16_96x64_mono_default_att": 1, "transpose_w16_96x64": 5}
 
 
 def build(name, seed=None, final_scale_log2=None):
