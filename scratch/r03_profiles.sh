@@ -11,7 +11,7 @@ cd /tmp && export TMPDIR=/tmp
 timeout 400 rocprofv3 --kernel-trace --output-format csv -d /tmp/tr3 -o t -- python $GRAFT_REPO_ROOT/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-kernel-timer > /tmp/tr3.log 2>&1
 cd $GRAFT_REPO_ROOT
 f=$(find /tmp/tr3 -name "*kernel_trace.csv" | head -1)
-[ -n "$f" ] && python scratch/trace_csv_stats.py $f > $O/kernel_trace_stats.txt 2>&1 && python scratch/timeline_gaps.py $f > $O/timeline.txt 2>&1
+[ -n "$f" ] && python scratch/trace_csv_stats.py $f > $O/kernel_trace_stats.txt 2>&1 && python scratch/timeline_gaps.py $f > $O/timeline.txt 2>&1 && python scratch/critical_path.py $f 1 > $O/critical_path.txt 2>&1
 bash scratch/pmc_run.sh r3fwd bf16x6 fwd > /dev/null 2>&1; python scratch/pmc_summary.py gpurun_out/pmc_r3fwd conv3x3 > $O/pmc_fwd.txt 2>&1
 bash scratch/pmc_run.sh r3wg bf16x6 wgrad > /dev/null 2>&1; python scratch/pmc_summary.py gpurun_out/pmc_r3wg "" > $O/pmc_wgrad.txt 2>&1
 bash scratch/pmc_run.sh r3dg bf16x6 dgrad > /dev/null 2>&1; python scratch/pmc_summary.py gpurun_out/pmc_r3dg conv3x3 > $O/pmc_dgrad.txt 2>&1
