@@ -51,7 +51,7 @@ __global__ __launch_bounds__(256, 2) void gconv_x6_kernel(GcArgs p) {
   constexpr int BM = WM * MF * 16, BN = WN * NF * 16, ROWB = 96, PST = 32, BROW = 192;
   constexpr int QA = BM / 64;                           // rows per thread and half-step (thread = row t >> 2 + 64 q, float4 t & 3)
   static_assert(WM * WN == 4 && BM % 64 == 0, "four waves, BM a multiple of 64");
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];     // A: [2 half-steps][BM][96 B]; then the epilogue's
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];     // A: [2 stages][2 half-steps][BM][96 B]; then the epilogue's
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int i16 = lane & 15, g = lane >> 4;
   const int wave_m = wave % WM, wave_n = wave / WM;
@@ -120,14 +120,15 @@ __global__ __launch_bounds__(256, 2) void gconv_x6_kernel(GcArgs p) {
 #pragma unroll
       for (int nf = 0; nf < NF; ++nf) bnx[q][nf] = *reinterpret_cast<const bf16x8*>(wp + (size_t)nf * 16 * BROW + q * 64);
   };
-  auto store_a = [&](const f32x4 (&src)[2][QA], unsigned okm) {
+  constexpr int ABUF = 2 * BM * ROWB;       // one A stage: two half-step tiles
+  auto store_a = [&](const f32x4 (&src)[2][QA], unsigned okm, int buf) {
 #pragma unroll
     for (int h = 0; h < 2; ++h)
 #pragma unroll
       for (int q = 0; q < QA; ++q) {
         const bool ok = (okm >> (h * QA + q)) & 1u;
         const f32x4 v = src[h][q];
-        split_store<3, PST>(smem + ((size_t)h * BM + arow + 64 * q) * ROWB, c4 * 4,
+        split_store<3, PST>(smem + (size_t)buf * ABUF + ((size_t)h * BM + arow + 64 * q) * ROWB, c4 * 4,
                             (f32x4){ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f});
       }
   };
@@ -140,10 +141,11 @@ __global__ __launch_bounds__(256, 2) void gconv_x6_kernel(GcArgs p) {
   // this lane's A fragment bytes: half-step g >> 1, channels 8 (g & 1) .. + 7 of row wave_m * MF * 16 + mf * 16 + i16
   const unsigned char* abase = smem + ((size_t)(g >> 1) * BM + wave_m * MF * 16 + i16) * ROWB + (g & 1) * 16;
 
+  // LDS holds two A stages: while the four waves multiply stage st out of buffer st & 1, they split and store stage st + 1
+  // (in registers since the previous step) into the other one - ONE barrier per step, and the store phase (VALU + ds_write)
+  // has MFMAs beside it (with a single buffer and two barriers it took 40 % of the step, scratch/gc_abl.sh).
   auto step = [&](int st, auto set) {
     constexpr int SET = decltype(set)::value;
-    if (!(GC_ABL & 8)) __syncthreads();    // the previous step's fragments are read
-    if (!(GC_ABL & 4) || st < 2) store_a(areg[SET], aok[SET]);
     bf16x8 bc[3][NF];
 #pragma unroll
     for (int q = 0; q < 3; ++q)
@@ -152,20 +154,20 @@ __global__ __launch_bounds__(256, 2) void gconv_x6_kernel(GcArgs p) {
     // the take-over of the weight fragments (and its wait) stays in front of the new loads: behind them the in-order load
     // counter would make it wait for the gathers just issued
     __builtin_amdgcn_sched_barrier(0);
-    if (!(GC_ABL & 8)) __syncthreads();
     // unconditional on purpose (past the end: dummy pieces, the last weight step again): a skipped load is a merge of old
     // and new register contents, which the compiler resolves with copies that wait for the loads just issued
-    load_a(st + 2, areg[SET], aok[SET]);
+    load_a(st + 2, areg[SET], aok[SET]);        // this set's stage st went to LDS during the previous step
     load_b(st + 1 < c.nsteps ? st + 1 : st);
+    const unsigned char* ab = abase + SET * ABUF;
     bf16x8 a[2][3];
 #pragma unroll
-    for (int q = 0; q < 3; ++q) a[0][q] = *reinterpret_cast<const bf16x8*>(abase + q * PST);
+    for (int q = 0; q < 3; ++q) a[0][q] = *reinterpret_cast<const bf16x8*>(ab + q * PST);
 #pragma unroll
     for (int mf = 0; mf < MF; ++mf) {
       if (mf + 1 < MF) {
 #pragma unroll
         for (int q = 0; q < 3; ++q)
-          a[(mf + 1) & 1][q] = *reinterpret_cast<const bf16x8*>(abase + (size_t)(mf + 1) * 16 * ROWB + q * PST);
+          a[(mf + 1) & 1][q] = *reinterpret_cast<const bf16x8*>(ab + (size_t)(mf + 1) * 16 * ROWB + q * PST);
       }
       __builtin_amdgcn_sched_barrier(0);
       bf16x8 (&ac)[3] = a[mf & 1];
@@ -176,13 +178,36 @@ __global__ __launch_bounds__(256, 2) void gconv_x6_kernel(GcArgs p) {
         GC_MMA(2, 0) GC_MMA(0, 2) GC_MMA(1, 1) GC_MMA(1, 0) GC_MMA(0, 1) GC_MMA(0, 0)
       }
 #undef GC_MMA
+      // a quarter of the next stage's split + store behind each fragment's MFMAs
+      if (!(GC_ABL & 4) || st < 1) {
+        if (mf < 2 * QA && mf < MF) {
+          const int h = mf / QA, q = mf % QA;
+          const bool ok = (aok[1 - SET] >> (h * QA + q)) & 1u;
+          const f32x4 v = areg[1 - SET][h][q];
+          split_store<3, PST>(smem + (size_t)(1 - SET) * ABUF + ((size_t)h * BM + arow + 64 * q) * ROWB, c4 * 4,
+                              (f32x4){ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f});
+        }
+      }
       __builtin_amdgcn_sched_barrier(0);
     }
+    if (2 * QA > MF) {          // pieces that found no fragment slot
+#pragma unroll
+      for (int i = MF; i < 2 * QA; ++i) {
+        const int h = i / QA, q = i % QA;
+        const bool ok = (aok[1 - SET] >> (h * QA + q)) & 1u;
+        const f32x4 v = areg[1 - SET][h][q];
+        split_store<3, PST>(smem + (size_t)(1 - SET) * ABUF + ((size_t)h * BM + arow + 64 * q) * ROWB, c4 * 4,
+                            (f32x4){ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f});
+      }
+    }
+    if (!(GC_ABL & 8)) __syncthreads();        // stage st + 1 is complete, stage st is read
   };
 
   load_a(0, areg[0], aok[0]);
   load_b(0);
   load_a(1, areg[1], aok[1]);
+  store_a(areg[0], aok[0], 0);
+  __syncthreads();
   for (int st = 0; st < c.nsteps; st += 2) {
     step(st, IC<0>{});
     if (st + 1 < c.nsteps) step(st + 1, IC<1>{});
@@ -335,7 +360,7 @@ struct GcPlan { int MF, NF, WM, WN, BM, BN; };
 static bool gc_plan(int nout, GcPlan* pl) {
   if (nout % 96 == 0) *pl = {4, 3, 2, 2, 128, 96};
   else if (nout % 64 == 0) *pl = {2, 4, 4, 1, 128, 64};
-  else if (nout % 48 == 0) *pl = {4, 3, 4, 1, 256, 48};
+  else if (nout % 48 == 0) *pl = {2, 3, 4, 1, 128, 48};
   else return false;
   return true;
 }
@@ -377,7 +402,7 @@ extern "C" int buctd_gconv_x6_stats_groups(int kind, int N, int H, int W, int Ci
 template <int MF, int NF, int WM, int WN>
 static int gc_launch(const GcArgs& a, int tiles, int ncol, hipStream_t st) {
   constexpr int BM = WM * MF * 16, LD = NF * 16 + 4, EP = MF >= 2 ? 2 : 1;
-  constexpr size_t tile = (size_t)2 * BM * 96, epi = (size_t)4 * EP * 16 * LD * 4 + 4 * 128 * 4;
+  constexpr size_t tile = (size_t)2 * 2 * BM * 96, epi = (size_t)4 * EP * 16 * LD * 4 + 4 * 128 * 4;
   constexpr size_t lds = tile > epi ? tile : epi;
   static_assert(lds <= 64 * 1024, "gconv_x6: static LDS budget");
   hipLaunchKernelGGL((gconv_x6_kernel<MF, NF, WM, WN>), dim3(tiles, ncol, a.ncls), dim3(256), lds, st, a);
@@ -435,7 +460,7 @@ static int gc_run(int kind, int dir, int N, int H, int W, int Ci, int Co, const 
   hipStream_t st = (hipStream_t)stream;
   if (pl.NF == 3 && pl.WM == 2) gc_launch<4, 3, 2, 2>(a, tiles, ncol, st);
   else if (pl.NF == 4) gc_launch<2, 4, 4, 1>(a, tiles, ncol, st);
-  else gc_launch<4, 3, 4, 1>(a, tiles, ncol, st);
+  else gc_launch<2, 3, 4, 1>(a, tiles, ncol, st);
   BUCTD_CHECK_LAUNCH(who);
   return BUCTD_OK;
 }
