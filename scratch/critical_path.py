@@ -42,3 +42,16 @@ for name, v in chain_time.most_common(32):
 print("largest gaps on the chain (us: kernel <- predecessor):")
 for gp, nm, pn in sorted(gaps, reverse=True)[:12]:
     print(f"  {gp/1e3:7.1f}  {nm}  <-  {pn}")
+
+# per-queue activity: when does each HIP queue finish its part of the step, and who is busy during the last 10 ms?
+print("per queue: first start / last end (ms from step start), busy ms, busy in the last 10 ms before the step's last kernel ends:")
+qs = collections.defaultdict(list)
+for k in st: qs[k[3]].append(k)
+t0 = st[0][0]
+for q, lst in sorted(qs.items()):
+    lastwin = sum(max(0, min(k[1], t_end) - max(k[0], t_end - 10_000_000)) for k in lst if k[1] > t_end - 10_000_000)
+    names = collections.Counter()
+    for k in lst:
+        if k[1] > t_end - 10_000_000: names[k[2][:40]] += max(0, min(k[1], t_end) - max(k[0], t_end - 10_000_000))
+    top = ", ".join(f"{n} {v/1e6:.1f}" for n, v in names.most_common(3))
+    print(f"  queue {q}: {(lst[0][0]-t0)/1e6:6.2f} .. {(max(k[1] for k in lst)-t0)/1e6:6.2f}  busy {sum(k[1]-k[0] for k in lst)/1e6:6.2f}  last-10ms busy {lastwin/1e6:5.2f}  [{top}]")
