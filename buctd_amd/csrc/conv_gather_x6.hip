@@ -61,21 +61,28 @@ __global__ __launch_bounds__(256, 2) void gconv_x6_kernel(GcArgs p) {
   e.oy0 = c.oy0; e.ox0 = c.ox0;
   const int p0 = bx * BM, n0 = by * BN;
 
-  // rows this thread gathers: grid pixel -> source pixel of tap (0, 0)
-  int simg[QA], sy0[QA], sx0[QA];
+  // rows this thread gathers: grid pixel -> element offset of the source pixel of tap offset (0, 0), and ONE bit per tap:
+  // that tap's source pixel exists.  The step loop then needs an add and a bit test per 16-byte piece (counters of the first
+  // version: 6.3 VALU instructions per MFMA, most of them this address and bounds arithmetic redone for every piece).
+  long rowbase[QA];
+  unsigned tapok[QA];
   const int arow = t >> 2, c4 = t & 3;
 #pragma unroll
   for (int q = 0; q < QA; ++q) {
     const int pp = p0 + arow + 64 * q;
-    simg[q] = -1; sy0[q] = 0; sx0[q] = 0;
+    rowbase[q] = 0;
+    tapok[q] = 0u;
     if (pp < e.P) {
       const int n = fast_div(pp, e.ib_mul, e.ib_sh);
       const int rem = pp - n * e.IB;
       const int yy = fast_div(rem, e.sw_mul, e.sw_sh), xx = rem - yy * e.SW;
       if (n < e.N && yy >= 1 && xx >= 1 && xx <= e.W) {
-        simg[q] = n * p.SH;
-        sy0[q] = (yy - 1) * p.ss;
-        sx0[q] = (xx - 1) * p.ss;
+        const int sy0 = (yy - 1) * p.ss, sx0 = (xx - 1) * p.ss;
+        rowbase[q] = ((long)(n * p.SH + sy0) * p.SWd + sx0) * p.SC + c4 * 4;
+        for (int tp = 0; tp < c.ntaps; ++tp) {
+          const int sy = sy0 + (int)((c.pdy >> (2 * tp)) & 3u) - 1, sx = sx0 + (int)((c.pdx >> (2 * tp)) & 3u) - 1;
+          if ((unsigned)sy < (unsigned)p.SH && (unsigned)sx < (unsigned)p.SWd) tapok[q] |= 1u << tp;
+        }
       }
     }
   }
@@ -86,9 +93,14 @@ __global__ __launch_bounds__(256, 2) void gconv_x6_kernel(GcArgs p) {
   // ~0.5 us, a gathered L2 / HBM round trip under load takes 1-2 us), the weight fragments (hot in L2) one step ahead
   f32x4 areg[2][2][QA];                     // [set][half-step][row]
   unsigned aok[2] = {0u, 0u};               // bit h * QA + q: that piece is a real source pixel (else zero)
-  bf16x8 bnx[3][NF];
+  bf16x8 bnx[2][3][NF];                     // weight fragments: set st & 1 is multiplied, the other one travels
   int tap = 0, chunk = 0;                   // (tap, chunk) of the next half-step to load
-  int cur_dy = (int)(c.pdy & 3u) - 1, cur_dx = (int)(c.pdx & 3u) - 1;
+  // element offset of the current tap relative to tap offset (0, 0) - scalar
+  auto tap_delta = [&](int tp) -> long {
+    const int dy = (int)((c.pdy >> (2 * tp)) & 3u) - 1, dx = (int)((c.pdx >> (2 * tp)) & 3u) - 1;
+    return ((long)dy * p.SWd + dx) * p.SC;
+  };
+  long cur_delta = tap_delta(0);
   // Every load is unconditional - a piece outside the source reads the tensor's first pixel and is zeroed when it is stored
   // (a predicated load merged with zeros made the compiler wait for the data right behind the load: no prefetch at all).
   auto load_a = [&](int st, f32x4 (&dst)[2][QA], unsigned& okm) {
@@ -96,29 +108,29 @@ __global__ __launch_bounds__(256, 2) void gconv_x6_kernel(GcArgs p) {
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
       const bool live = 2 * st + h < c.nhs;
+      const long d = cur_delta + chunk * 16;
+      const unsigned tbit = live ? (1u << tap) : 0u;
 #pragma unroll
       for (int q = 0; q < QA; ++q) {
-        const int sy = sy0[q] + cur_dy, sx = sx0[q] + cur_dx;
-        const bool ok = live && simg[q] >= 0 && (unsigned)sy < (unsigned)p.SH && (unsigned)sx < (unsigned)p.SWd;
-        const long off = ok ? ((long)(simg[q] + sy) * p.SWd + sx) * p.SC + chunk * 16 : 0L;
-        if (!(GC_ABL & 2) || st < 2) dst[h][q] = *reinterpret_cast<const f32x4*>(p.src + off + c4 * 4);
+        const bool ok = (tapok[q] & tbit) != 0u;
+        const long off = ok ? rowbase[q] + d : (long)(c4 * 4);
+        dst[h][q] = *reinterpret_cast<const f32x4*>(p.src + off);
         okm |= (ok ? 1u : 0u) << (h * QA + q);
       }
       if (live && ++chunk == p.cpt) {
         chunk = 0;
         ++tap;
-        cur_dy = (int)((c.pdy >> (2 * tap)) & 3u) - 1;
-        cur_dx = (int)((c.pdx >> (2 * tap)) & 3u) - 1;
+        cur_delta = tap_delta(tap);
       }
     }
   };
-  auto load_b = [&](int st) {
-    if ((GC_ABL & 1) && st > 0) return;
+  auto load_b = [&](int st, bf16x8 (&dst)[3][NF]) {
+    if ((GC_ABL & 1) && st > 1) return;
     const unsigned char* wp = wbase + (size_t)st * wstep;
 #pragma unroll
     for (int q = 0; q < 3; ++q)
 #pragma unroll
-      for (int nf = 0; nf < NF; ++nf) bnx[q][nf] = *reinterpret_cast<const bf16x8*>(wp + (size_t)nf * 16 * BROW + q * 64);
+      for (int nf = 0; nf < NF; ++nf) dst[q][nf] = *reinterpret_cast<const bf16x8*>(wp + (size_t)nf * 16 * BROW + q * 64);
   };
   constexpr int ABUF = 2 * BM * ROWB;       // one A stage: two half-step tiles
   auto store_a = [&](const f32x4 (&src)[2][QA], unsigned okm, int buf) {
@@ -128,7 +140,7 @@ __global__ __launch_bounds__(256, 2) void gconv_x6_kernel(GcArgs p) {
       for (int q = 0; q < QA; ++q) {
         const bool ok = (okm >> (h * QA + q)) & 1u;
         const f32x4 v = src[h][q];
-        split_store<3, PST>(smem + (size_t)buf * ABUF + ((size_t)h * BM + arow + 64 * q) * ROWB, c4 * 4,
+        split_store_pk<3, PST>(smem + (size_t)buf * ABUF + ((size_t)h * BM + arow + 64 * q) * ROWB, c4 * 4,
                             (f32x4){ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f});
       }
   };
@@ -146,18 +158,11 @@ __global__ __launch_bounds__(256, 2) void gconv_x6_kernel(GcArgs p) {
   // has MFMAs beside it (with a single buffer and two barriers it took 40 % of the step, scratch/gc_abl.sh).
   auto step = [&](int st, auto set) {
     constexpr int SET = decltype(set)::value;
-    bf16x8 bc[3][NF];
-#pragma unroll
-    for (int q = 0; q < 3; ++q)
-#pragma unroll
-      for (int nf = 0; nf < NF; ++nf) bc[q][nf] = bnx[q][nf];
-    // the take-over of the weight fragments (and its wait) stays in front of the new loads: behind them the in-order load
-    // counter would make it wait for the gathers just issued
-    __builtin_amdgcn_sched_barrier(0);
+    bf16x8 (&bc)[3][NF] = bnx[SET];
     // unconditional on purpose (past the end: dummy pieces, the last weight step again): a skipped load is a merge of old
     // and new register contents, which the compiler resolves with copies that wait for the loads just issued
     load_a(st + 2, areg[SET], aok[SET]);        // this set's stage st went to LDS during the previous step
-    load_b(st + 1 < c.nsteps ? st + 1 : st);
+    load_b(st + 1 < c.nsteps ? st + 1 : st, bnx[1 - SET]);
     const unsigned char* ab = abase + SET * ABUF;
     bf16x8 a[2][3];
 #pragma unroll
@@ -184,7 +189,7 @@ __global__ __launch_bounds__(256, 2) void gconv_x6_kernel(GcArgs p) {
           const int h = mf / QA, q = mf % QA;
           const bool ok = (aok[1 - SET] >> (h * QA + q)) & 1u;
           const f32x4 v = areg[1 - SET][h][q];
-          split_store<3, PST>(smem + (size_t)(1 - SET) * ABUF + ((size_t)h * BM + arow + 64 * q) * ROWB, c4 * 4,
+          split_store_pk<3, PST>(smem + (size_t)(1 - SET) * ABUF + ((size_t)h * BM + arow + 64 * q) * ROWB, c4 * 4,
                               (f32x4){ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f});
         }
       }
@@ -196,7 +201,7 @@ __global__ __launch_bounds__(256, 2) void gconv_x6_kernel(GcArgs p) {
         const int h = i / QA, q = i % QA;
         const bool ok = (aok[1 - SET] >> (h * QA + q)) & 1u;
         const f32x4 v = areg[1 - SET][h][q];
-        split_store<3, PST>(smem + (size_t)(1 - SET) * ABUF + ((size_t)h * BM + arow + 64 * q) * ROWB, c4 * 4,
+        split_store_pk<3, PST>(smem + (size_t)(1 - SET) * ABUF + ((size_t)h * BM + arow + 64 * q) * ROWB, c4 * 4,
                             (f32x4){ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f});
       }
     }
@@ -204,7 +209,7 @@ __global__ __launch_bounds__(256, 2) void gconv_x6_kernel(GcArgs p) {
   };
 
   load_a(0, areg[0], aok[0]);
-  load_b(0);
+  load_b(0, bnx[0]);
   load_a(1, areg[1], aok[1]);
   store_a(areg[0], aok[0], 0);
   __syncthreads();

@@ -1,0 +1,7 @@
+# sweep of one environment variable on the default bench: bash scratch/sweep_env2.sh VAR v1 v2 ...
+cd $GRAFT_REPO_ROOT
+var=$1; shift
+for v in "$@"; do
+  r=$(env $var=$v timeout 200 python bench.py --steps 20 --warmup 5 --no-cpu-baseline 2>/dev/null | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'])")
+  echo "$var=$v: $r"
+done

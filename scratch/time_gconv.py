@@ -10,12 +10,13 @@ w = (torch.randn(Co, Ci, k, k, device=dev) / math.sqrt(Ci * k * k)).contiguous(m
 y = ops.conv_fwd(x, w, None, st, pad)
 dy = torch.randn_like(y)
 fn = (lambda: ops.conv_dgrad(dy, w, tuple(x.shape), st, pad)) if dg else (lambda: ops.conv_fwd(x, w, None, st, pad, stats=True))
-for _ in range(200): fn()
+NW, NT = (3, 6) if os.environ.get('PMC_SHORT') else (200, 300)
+for _ in range(NW): fn()
 torch.cuda.synchronize()
 a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 a.record()
-for _ in range(300): fn()
+for _ in range(NT): fn()
 b.record(); b.synchronize()
-us = a.elapsed_time(b) / 300 * 1e3
+us = a.elapsed_time(b) / NT * 1e3
 fl = 2.0 * y.numel() * Ci * k * k
 print(f"{os.environ.get('BUCTD_LIB_ALT', 'product')}: {'dgrad' if dg else 'fwd'} {sys.argv[1:9]}: {us:.1f} us, {fl / us / 1e6:.1f} TFLOP/s-eq")
