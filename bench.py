@@ -251,8 +251,8 @@ def roofline_entry(math, batch, kind, in_step, solo, traffic, shape=(48, 96, 72)
             "roof_times_us": {"mfma": round(mfma_us, 2), "hbm": round(hbm_us, 2)},
             "timing": "HIP events on the launching stream around each launch. avg_launch_us: every launch of this "
                       "shape inside the timed steps (the step keeps 4 streams busy, so a launch shares the GPU with "
-                      "its co-runners); avg_launch_us_solo: 30 launches of the same kernel alone on the GPU right "
-                      "after the timed steps",
+                      "its co-runners); avg_launch_us_solo: 60 launches of the same kernel alone on the GPU right "
+                      "after the timed steps and 150 warm-up rounds (settled clock)",
             "note": f"binding roof = {bound}: {unit_note}; HBM roof 8 TB/s on {bytes_ / 1e6:.1f} MB/launch"}
 
 
@@ -584,15 +584,15 @@ def main():
         comm_ms = round(1e3 * float(t.item()), 3)
     solo = {k: (None, 0) for k in in_step}
     if not args.no_kernel_timer and rank == 0:
-        # the same kernels alone on the GPU: 30 launches each on a stage-4-branch-0 sized activation with one of the
+        # the same kernels alone on the GPU: 60 launches each (after 150 warm-up rounds) on a stage-4-branch-0 sized activation with one of the
         # model's own 48 -> 48 filters (forward with the BN-statistics epilogue, as in the step)
         timer.reset()
         wsel = next(p for p in net.parameters() if tuple(p.shape) == (rshape[0], rshape[0], 3, 3))
         xs = torch.randn(args.batch, rshape[1], rshape[2], rshape[0], device=device)
         dys = torch.randn(args.batch, rshape[1], rshape[2], rshape[0], device=device)
         gw = torch.empty_like(wsel)
-        for it in range(35):
-            timer.enabled = it >= 5
+        for it in range(210):                 # 150 untimed rounds first: the chip ramps its clock over ~20-30 ms of load
+            timer.enabled = it >= 150
             ops.conv_fwd(xs, wsel, None, 1, 1, stats=True)
             ops.conv_dgrad(dys, wsel, tuple(xs.shape), 1, 1)
             ops.conv_wgrad(xs, dys, wsel, 1, 1, out=gw, accumulate=0)
