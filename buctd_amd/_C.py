@@ -145,6 +145,7 @@ SIGNATURES = {
     "buctd_attn_smallqk_fwd": (_I, [_I, _I, _I, _I, _P, _P, _P, _F, _F, _U64, _I, _P, _P, _P, _P]),
     "buctd_attn_smallqk_bwd": (_I, [_I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _F, _F, _U64, _I, _P, _P, _P, _P, _P]),
     "buctd_layernorm_fwd": (_I, [_P, _P, _P, _L, _I, _F, _P, _P, _P, _P]),
+    "buctd_add_layernorm_fwd": (_I, [_P, _P, _P, _P, _L, _I, _F, _P, _P, _P, _P, _P]),
     "buctd_layernorm_bwd_workspace": (_SZ, [_L, _I]),
     "buctd_layernorm_bwd": (_I, [_P, _P, _P, _P, _P, _L, _I, _P, _P, _P, _I, _P, _SZ, _P]),
     "buctd_joints_mse": (_I, [_P, _P, _P, _I, _I, _I, _P, _P, _F, _P, _SZ, _P]),

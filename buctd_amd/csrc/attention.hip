@@ -193,10 +193,12 @@ extern "C" int buctd_dropout(const float* x, float* y, long n, float p_drop, uin
 
 // ----------------------------------------------------------------- layernorm ----
 #define LN_NPT 8  // one wave per row, C <= 512
-__global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restrict__ x,
+// x2 (NULL ok): the normalised value is x + x2 - the post-norm residual of the encoder layer, transpose_h.py:204-209, without
+// a separate addition pass; sum_out (NULL ok) receives x + x2 (what the backward pass normalises again)
+__global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restrict__ x, const float* __restrict__ x2,
                                                             const float* __restrict__ gamma,
                                                             const float* __restrict__ beta, long rows, int C,
-                                                            float eps, float* __restrict__ y,
+                                                            float eps, float* __restrict__ sum_out, float* __restrict__ y,
                                                             float* __restrict__ mean, float* __restrict__ invstd) {
   const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
@@ -207,6 +209,10 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
   for (int j = 0; j < LN_NPT; ++j) {
     const int c = lane + 64 * j;
     v[j] = c < C ? x[row * C + c] : 0.f;
+    if (x2 && c < C) {
+      v[j] += x2[row * C + c];
+      if (sum_out) sum_out[row * C + c] = v[j];
+    }
     s += v[j];
   }
   const float mu = wave_sum(s) / (float)C;
@@ -299,9 +305,18 @@ extern "C" int buctd_layernorm_fwd(const float* x, const float* gamma, const flo
                                    float* y, float* mean, float* invstd, void* stream) {
   BUCTD_CHECK_ARG(x && gamma && beta && y && mean && invstd && rows > 0 && C > 0, "buctd_layernorm_fwd: bad argument");
   BUCTD_CHECK_ARG(C <= 64 * LN_NPT, "buctd_layernorm_fwd: C %d > %d unsupported", C, 64 * LN_NPT);
-  hipLaunchKernelGGL(layernorm_fwd_kernel, dim3(ceil_div(rows, 4)), dim3(256), 0, (hipStream_t)stream, x, gamma, beta,
-                     rows, C, eps, y, mean, invstd);
+  hipLaunchKernelGGL(layernorm_fwd_kernel, dim3(ceil_div(rows, 4)), dim3(256), 0, (hipStream_t)stream, x,
+                     (const float*)nullptr, gamma, beta, rows, C, eps, (float*)nullptr, y, mean, invstd);
   BUCTD_CHECK_LAUNCH("buctd_layernorm_fwd");
+  return BUCTD_OK;
+}
+extern "C" int buctd_add_layernorm_fwd(const float* a, const float* b, const float* gamma, const float* beta, long rows, int C,
+                                       float eps, float* sum_out, float* y, float* mean, float* invstd, void* stream) {
+  BUCTD_CHECK_ARG(a && b && gamma && beta && y && mean && invstd && rows > 0 && C > 0, "buctd_add_layernorm_fwd: bad argument");
+  BUCTD_CHECK_ARG(C <= 64 * LN_NPT, "buctd_add_layernorm_fwd: C %d > %d unsupported", C, 64 * LN_NPT);
+  hipLaunchKernelGGL(layernorm_fwd_kernel, dim3(ceil_div(rows, 4)), dim3(256), 0, (hipStream_t)stream, a, b, gamma, beta,
+                     rows, C, eps, sum_out, y, mean, invstd);
+  BUCTD_CHECK_LAUNCH("buctd_add_layernorm_fwd");
   return BUCTD_OK;
 }
 extern "C" size_t buctd_layernorm_bwd_workspace(long rows, int C) {

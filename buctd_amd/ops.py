@@ -1221,6 +1221,19 @@ def layernorm_fwd(x, gamma, beta, eps):
     return y, mean, invstd
 
 
+def add_layernorm_fwd(a, b, gamma, beta, eps, keep_sum=True):
+    """LayerNorm(a + b) in one pass; -> y, mean, invstd, a + b (None unless keep_sum: the backward pass needs it)."""
+    Cn = a.shape[-1]
+    rows = a.numel() // Cn
+    y = torch.empty_like(a)
+    s = torch.empty_like(a) if keep_sum else None
+    mean = torch.empty(rows, dtype=torch.float32, device=a.device)
+    invstd = torch.empty(rows, dtype=torch.float32, device=a.device)
+    check(lib().buctd_add_layernorm_fwd(ptr(a), ptr(b), ptr(gamma), ptr(beta), rows, Cn, eps, ptr(s), ptr(y), ptr(mean),
+                                        ptr(invstd), stream_ptr()), "add_layernorm_fwd")
+    return y, mean, invstd, s
+
+
 def layernorm_bwd(dy, x, mean, invstd, gamma, dgamma, dbeta, accumulate):
     Cn = x.shape[-1]
     rows = x.numel() // Cn

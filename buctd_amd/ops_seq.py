@@ -84,10 +84,11 @@ class AddLayerNorm(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, a, b, ln):
-        s = ops.add(a, b)
-        y, mean, invstd = ops.layernorm_fwd(s, ln.weight, ln.bias, ln.eps)
+        keep = bool(ctx.needs_input_grad[0] or ctx.needs_input_grad[1])     # backward() runs only then (it also owns ln's gradients)
+        y, mean, invstd, s = ops.add_layernorm_fwd(a.contiguous(), b.contiguous(), ln.weight, ln.bias, ln.eps, keep_sum=keep)
         ctx.ln = ln
-        ctx.save_for_backward(s, mean, invstd)
+        if keep:
+            ctx.save_for_backward(s, mean, invstd)
         return y
 
     @staticmethod

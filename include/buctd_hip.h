@@ -283,6 +283,10 @@ int buctd_dropout(const float* x, float* y, long n, float p_drop, uint64_t seed,
 /* LayerNorm over the last dim (transpose_h.py:178-179) */
 int buctd_layernorm_fwd(const float* x, const float* gamma, const float* beta, long rows, int C, float eps, float* y,
                         float* mean, float* invstd, void* stream);
+/* LayerNorm(a + b) in one pass (the post-norm residual of the encoder layer, transpose_h.py:204-209); sum_out (NULL ok)
+ * receives a + b - the tensor buctd_layernorm_bwd takes as x. */
+int buctd_add_layernorm_fwd(const float* a, const float* b, const float* gamma, const float* beta, long rows, int C, float eps,
+                            float* sum_out, float* y, float* mean, float* invstd, void* stream);
 size_t buctd_layernorm_bwd_workspace(long rows, int C);
 int buctd_layernorm_bwd(const float* dy, const float* x, const float* mean, const float* invstd, const float* gamma,
                         long rows, int C, float* dx, float* dgamma, float* dbeta, int accumulate, void* workspace,

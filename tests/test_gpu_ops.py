@@ -318,6 +318,24 @@ def test_layernorm_dropout(dev):
     close(dx, x.grad, 2e-5, "ln dx")
     close(dg, gamma.grad, 2e-5, "ln dgamma")
     close(db, beta.grad, 2e-5, "ln dbeta")
+    # LayerNorm(a + b) in one pass == add, then LayerNorm: same bits; the sum is returned only when the backward needs it
+    a, b = x.detach().to(dev), torch.randn(300, 112, generator=g).to(dev)
+    y2, m2, i2, s2 = ops.add_layernorm_fwd(a, b, gamma.detach().to(dev), beta.detach().to(dev), 1e-5, keep_sum=True)
+    y3, m3, i3 = ops.layernorm_fwd(a + b, gamma.detach().to(dev), beta.detach().to(dev), 1e-5)
+    assert torch.equal(s2, a + b) and torch.equal(y2, y3) and torch.equal(m2, m3) and torch.equal(i2, i3)
+    y4, _, _, s4 = ops.add_layernorm_fwd(a, b, gamma.detach().to(dev), beta.detach().to(dev), 1e-5, keep_sum=False)
+    assert s4 is None and torch.equal(y4, y3)
+    from buctd_amd import ops_seq
+    ln = torch.nn.LayerNorm(112).to(dev)
+    ar, br = a.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    out = ops_seq.AddLayerNorm.apply(ar, br, ln)
+    out.backward(dy.to(dev))
+    a64, b64 = a.cpu().double().requires_grad_(True), b.cpu().double().requires_grad_(True)
+    F.layer_norm(a64 + b64, (112,), ln.weight.detach().cpu().double(), ln.bias.detach().cpu().double(), 1e-5).backward(dy.double())
+    close(ar.grad, a64.grad.float(), 2e-5, "add+ln da")
+    close(br.grad, b64.grad.float(), 2e-5, "add+ln db")
+    with torch.no_grad():
+        assert torch.equal(ops_seq.AddLayerNorm.apply(a, b, ln), out.detach())
     z = torch.ones(100000, device=dev)
     d1 = ops.dropout(z, 0.1, 42)
     assert abs((d1 != 0).float().mean().item() - 0.9) < 0.01
