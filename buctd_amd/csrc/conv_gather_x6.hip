@@ -64,12 +64,18 @@ __global__ __launch_bounds__(256, 2) void gconv_x6_kernel(GcArgs p) {
   // rows this thread gathers: grid pixel -> element offset of the source pixel of tap offset (0, 0), and ONE bit per tap:
   // that tap's source pixel exists.  The step loop then needs an add and a bit test per 16-byte piece (counters of the first
   // version: 6.3 VALU instructions per MFMA, most of them this address and bounds arithmetic redone for every piece).
+  // WN == 1 (48- / 64-wide outputs): a wave multiplies ITS MF * 16 rows by all BN columns, so it stages exactly those rows
+  // itself (16 per pass) and the step loop needs no workgroup barrier at all - LDS operations of one wave execute in order.
+  // WN == 2: the two waves of a row share the rows; the workgroup stages them together (64 per pass) behind a barrier.
+  constexpr bool PRIV = WN == 1;
+  constexpr int RSTEP = PRIV ? 16 : 64;
+  static_assert(!PRIV || MF * 16 / 16 == QA, "wave-private staging: MF passes of 16 rows == BM / 64");
   long rowbase[QA];
   unsigned tapok[QA];
-  const int arow = t >> 2, c4 = t & 3;
+  const int arow = PRIV ? wave * (MF * 16) + (lane >> 2) : (t >> 2), c4 = t & 3;
 #pragma unroll
   for (int q = 0; q < QA; ++q) {
-    const int pp = p0 + arow + 64 * q;
+    const int pp = p0 + arow + RSTEP * q;
     rowbase[q] = 0;
     tapok[q] = 0u;
     if (pp < e.P) {
@@ -140,7 +146,7 @@ __global__ __launch_bounds__(256, 2) void gconv_x6_kernel(GcArgs p) {
       for (int q = 0; q < QA; ++q) {
         const bool ok = (okm >> (h * QA + q)) & 1u;
         const f32x4 v = src[h][q];
-        split_store_pk<3, PST>(smem + (size_t)buf * ABUF + ((size_t)h * BM + arow + 64 * q) * ROWB, c4 * 4,
+        split_store_pk<3, PST>(smem + (size_t)buf * ABUF + ((size_t)h * BM + arow + RSTEP * q) * ROWB, c4 * 4,
                             (f32x4){ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f});
       }
   };
@@ -189,7 +195,7 @@ __global__ __launch_bounds__(256, 2) void gconv_x6_kernel(GcArgs p) {
           const int h = mf / QA, q = mf % QA;
           const bool ok = (aok[1 - SET] >> (h * QA + q)) & 1u;
           const f32x4 v = areg[1 - SET][h][q];
-          split_store_pk<3, PST>(smem + (size_t)(1 - SET) * ABUF + ((size_t)h * BM + arow + 64 * q) * ROWB, c4 * 4,
+          split_store_pk<3, PST>(smem + (size_t)(1 - SET) * ABUF + ((size_t)h * BM + arow + RSTEP * q) * ROWB, c4 * 4,
                               (f32x4){ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f});
         }
       }
@@ -201,18 +207,18 @@ __global__ __launch_bounds__(256, 2) void gconv_x6_kernel(GcArgs p) {
         const int h = i / QA, q = i % QA;
         const bool ok = (aok[1 - SET] >> (h * QA + q)) & 1u;
         const f32x4 v = areg[1 - SET][h][q];
-        split_store_pk<3, PST>(smem + (size_t)(1 - SET) * ABUF + ((size_t)h * BM + arow + 64 * q) * ROWB, c4 * 4,
+        split_store_pk<3, PST>(smem + (size_t)(1 - SET) * ABUF + ((size_t)h * BM + arow + RSTEP * q) * ROWB, c4 * 4,
                             (f32x4){ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f});
       }
     }
-    if (!(GC_ABL & 8)) __syncthreads();        // stage st + 1 is complete, stage st is read
+    if (!PRIV && !(GC_ABL & 8)) __syncthreads();        // stage st + 1 is complete, stage st is read
   };
 
   load_a(0, areg[0], aok[0]);
   load_b(0, bnx[0]);
   load_a(1, areg[1], aok[1]);
   store_a(areg[0], aok[0], 0);
-  __syncthreads();
+  if (!PRIV) __syncthreads();
   for (int st = 0; st < c.nsteps; st += 2) {
     step(st, IC<0>{});
     if (st + 1 < c.nsteps) step(st + 1, IC<1>{});
@@ -363,6 +369,8 @@ extern "C" int buctd_gconv_x6_prep_batched(const void* items_device, int n, void
 struct GcPlan { int MF, NF, WM, WN, BM, BN; };
 
 static bool gc_plan(int nout, GcPlan* pl) {
+  // 96-wide tiles gather every source piece once per 96 outputs; the barrier-free 48-wide ones would win only where the
+  // contraction is long and the source tiny (192 -> 384 at 24 x 18: 79 -> 55 us) and lose elsewhere (48 -> 96 at 96 x 72: 43 -> 57)
   if (nout % 96 == 0) *pl = {4, 3, 2, 2, 128, 96};
   else if (nout % 64 == 0) *pl = {2, 4, 4, 1, 128, 64};
   else if (nout % 48 == 0) *pl = {2, 3, 4, 1, 128, 48};
