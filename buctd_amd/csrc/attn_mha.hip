@@ -929,7 +929,11 @@ template <int DF>
 static int mha_launch_p(int B, int T, const float* q, const unsigned char* k6, const unsigned char* v6, int ldq, float scale,
                         float* out, float* lse, hipStream_t st) {
   static bool attr_set[2] = {false, false};      // idempotent attribute call: a race at first use only repeats it
+#ifdef BUCTD_TUNING      // experiment builds only: BUCTD_MHA_Q16=1 runs the 16-query kernel for comparison
   static const bool wide = []() { const char* e = getenv("BUCTD_MHA_Q16"); return !(e && e[0] == '1'); }();
+#else
+  constexpr bool wide = true;
+#endif
   // wide (default): 32 queries per wavefront, keys split over the two wave quartets, 32-key tiles; BUCTD_MHA_Q16=1 keeps the
   // 16-query kernel (bit-identical to buctd_mha_fwd_bf16x6) for comparison
   void (*fn)(const float*, const unsigned char*, const unsigned char*, int, int, int, float, float*, float*) =
