@@ -15,10 +15,8 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libbuctd_hip.so")
-if os.environ.get("BUCTD_LIB_TRACE") == "1":      # scratch experiments only: the -DBUCTD_TUNING build (scratch/build_trace_lib.sh)
-    LIB_PATH = os.path.join(os.path.dirname(_HERE), "scratch", "libbuctd_hip_trace.so")
-elif os.environ.get("BUCTD_LIB_ALT"):               # scratch experiments only: another build of the same sources
-    LIB_PATH = os.path.join(os.path.dirname(_HERE), "scratch", os.environ["BUCTD_LIB_ALT"])
+# The product loader reads no environment.  Experiments that need another build of the same sources go through
+# scratch/run_alt.py, which sets LIB_PATH before the first lib() call.
 
 
 class ConvDesc(C.Structure):

@@ -85,6 +85,23 @@ class FlatParams:
                 g.copy_(p.grad)
                 p.grad = g
 
+    def grad_runs(self):
+        """Contiguous [start, end) element runs of the arena that cover exactly the parameters holding a gradient right now
+        (p.grad is not None) - torch.optim skips every other parameter entirely (no weight decay, no momentum), e.g.
+        TransPose's frozen pos_embedding (transpose_h.py:129) and constructed-but-unused modules.  One run when every
+        parameter has a gradient (the usual case)."""
+        runs = []
+        for p in self.params:
+            if p.grad is None:
+                continue
+            s = self.offsets[id(p)]
+            e = s + (p.numel() + _ALIGN - 1) // _ALIGN * _ALIGN
+            if runs and runs[-1][1] == s:
+                runs[-1][1] = e
+            else:
+                runs.append([s, e])
+        return [(s, e) for s, e in runs]
+
 
 class FusedAdam(torch.optim.Optimizer):
     """torch.optim.Adam(lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=0) semantics on the flat arena."""
@@ -194,8 +211,12 @@ class FusedSGD(torch.optim.Optimizer):
         self.flat.collect()
         gscale = self.grad_sync() if self.grad_sync is not None else 1.0
         g = self.param_groups[0]
-        ops.sgd_step(self.flat.flat, self.flat.grad, self.buf, g["lr"], g["momentum"], g["weight_decay"], g["nesterov"],
-                     self.step_count == 0, gscale)
+        # torch.optim.SGD touches only parameters that hold a gradient: a parameter with p.grad None keeps its value (no
+        # weight decay) and its momentum buffer.  A zero momentum buffer makes "buf = momentum * buf + g" the first-step
+        # initialisation "buf = g" (dampening 0), so parameters that join later need no flag of their own.
+        for s, e in self.flat.grad_runs():
+            ops.sgd_step(self.flat.flat[s:e], self.flat.grad[s:e], None if self.buf is None else self.buf[s:e], g["lr"],
+                         g["momentum"], g["weight_decay"], g["nesterov"], False, gscale)
         self.step_count += 1
         ops.weights_updated()
         ops.refresh_prepared(self.flat.flat.device)

@@ -44,9 +44,18 @@ def workspace_on(stream, nbytes, device):
     key = (device.index, stream.cuda_stream)
     buf = _workspaces.get(key)
     if buf is None or buf.numel() < nbytes:
+        # growth (rare: the first step visits increasingly large shapes): the old buffer may still be written by kernels
+        # queued on `stream`, and it was allocated under whatever stream was current - keep it alive instead of handing its
+        # block back to that stream's pool, where the next torch.empty could reuse it under the running kernel
+        if buf is not None:
+            _retired_workspaces.append(buf)
         buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
+        buf.record_stream(stream)
         _workspaces[key] = buf
     return buf
+
+
+_retired_workspaces = []
 
 
 _seed_state = {"seed": None, "counter": 0}
@@ -353,10 +362,12 @@ def _conv3x3_prepared(w, flip):
     if cache is not None and cache[0] != key and cache[0][:2] == key[:2] and cache[0][3:] == key[3:] and _PREP_BATCH:
         _prep_all(w.device)       # rewritten in place by the optimizer kernel: batch-refresh all registered images
     if cache is None or cache[0] != key:
+        first = cache is None
         cache = [key, None, None]
         try:
             w._buctd_prep = cache
-            _prep_registry["weights"].append(weakref.ref(w))
+            if first:
+                _prep_registry["weights"].append(weakref.ref(w))
         except (AttributeError, RuntimeError, TypeError):
             pass
     if cache[1 + flip] is None:
@@ -430,10 +441,12 @@ def _gconv_prepared(w, kind, direction):
     if cache is not None and cache[0] != key and cache[0][:2] == key[:2] and _PREP_BATCH:
         _prep_all(w.device)           # same storage, new optimizer epoch: batch-refresh every registered image
     if cache is None or cache[0] != key or cache[1] != kind:
+        first = cache is None
         cache = [key, kind, None, None]
         try:
             w._buctd_gprep = cache
-            _gprep_registry["weights"].append(weakref.ref(w))
+            if first:                 # one registry entry per weight tensor, however often its cache key changes
+                _gprep_registry["weights"].append(weakref.ref(w))
         except (AttributeError, RuntimeError, TypeError):
             pass
     if cache[2 + direction] is None:

@@ -315,14 +315,34 @@ def pose_synthesis_case(runs=1500):
     np.savez_compressed(os.path.join(OUT, "pose_synthesis.npz"), **rec)
 
 
-def entry_batches(cfg, n_batches, batch, k=14, seed0=500, cond_channels=3):
+def entry_batches(cfg, n_batches, batch, k=14, seed0=500, cond_channels=3, align=None):
     """The in-memory loader of the entry-point goldens: (input, target, target_weight, meta) batches, fully seeded -
-    tests/test_gpu_entry.py rebuilds the same batches from the same seeds."""
+    tests/test_gpu_entry.py rebuilds the same batches from the same seeds.
+    align = (oracle model, train_mode): the targets of the even-numbered joints are rendered AT the arg-max of that model's
+    own heat-maps (a private copy, so nothing of the caller's model changes), so that accuracy() inside train() / validate()
+    sees hits as well as misses - with random targets every accuracy the entry points report is 0 and a wrong tensor handed
+    to accuracy() would go unnoticed."""
+    import copy
     from oracle import recipes
     out = []
+    amodel = None
+    if align is not None:
+        amodel = copy.deepcopy(align[0])
+        amodel.train(bool(align[1]))
+        recipes.set_dropout(amodel, 0.0)
     for i in range(n_batches):
         x, joints = recipes.make_inputs(cfg, batch, seed0 + i, cond_channels)
-        tgt, wt = recipes.make_targets(cfg, joints, seed0 + 100 + i)
+        tj = joints
+        if amodel is not None:
+            with torch.no_grad():
+                hm = amodel(x)
+            hw = hm.shape[3]
+            idx = hm.flatten(2).argmax(2)                                     # [B, K]
+            peak = torch.stack([(idx % hw).float(), (idx // hw).float()], 2)  # heat-map (x, y)
+            stride = cfg.MODEL.IMAGE_SIZE[0] / cfg.MODEL.HEATMAP_SIZE[0]
+            tj = joints.clone()
+            tj[:, 0::2] = peak[:, 0::2] * stride                              # generate_target: mu = int(j / stride + 0.5)
+        tgt, wt = recipes.make_targets(cfg, tj, seed0 + 100 + i)
         g = torch.Generator().manual_seed(seed0 + 200 + i)
         meta = {"center": torch.rand(batch, 2, generator=g) * 100 + 50, "scale": torch.rand(batch, 2, generator=g) + 0.5,
                 "score": torch.rand(batch, generator=g), "annotation_id": torch.arange(batch) + i * batch,
@@ -380,7 +400,7 @@ def entry_case():
     rmodel = ref_model_for("coam", cfg)
     rmodel.load_state_dict(omodel.state_dict(), strict=True)
     recipes.set_dropout(rmodel, 0.0)
-    loader = entry_batches(cfg, 3, 2)
+    loader = entry_batches(cfg, 3, 2, align=(omodel, True))
     opt = torch.optim.Adam(rmodel.parameters(), lr=1e-3)
     wd = {"writer": Writer(), "train_global_steps": 0}
     rf.train(cfg, loader, rmodel, RefLoss(True), opt, 1, "/tmp", "/tmp", wd)
@@ -410,7 +430,7 @@ def entry_case():
         rmodel.load_state_dict(omodel.state_dict(), strict=True)
         # mono: the ONE blurred, int-truncated channel replicated x3 (JointsDataset.py:500-516); under FLIP_TEST the
         # reference re-renders it COLORED (transforms.py:38-47, heatmap.shape[1] == 3) - the goldens pin that behaviour
-        loader = entry_batches(cfg, 2, 2, seed0=700, cond_channels=1 if "mono" in recipe else 3)
+        loader = entry_batches(cfg, 2, 2, seed0=700, cond_channels=1 if "mono" in recipe else 3, align=(omodel, False))
         ds = Dataset(4, [64, 96])
         wd = {"writer": Writer(), "valid_global_steps": 0}
         perf = rf.validate(cfg, loader, ds, rmodel, RefLoss(True), "/tmp", "/tmp", wd)

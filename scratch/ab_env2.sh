@@ -2,6 +2,6 @@
 cd $GRAFT_REPO_ROOT
 lib=$1; var=$2; shift 2
 for v in "$@"; do
-  r=$(env BUCTD_LIB_ALT=$lib $var=$v timeout 200 python bench.py --steps 20 --warmup 5 --no-cpu-baseline 2>/dev/null | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'])")
+  r=$(env $var=$v timeout 200 python scratch/run_alt.py $lib bench.py --steps 20 --warmup 5 --no-cpu-baseline 2>/dev/null | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'])")
   echo "$var=$v: $r"
 done

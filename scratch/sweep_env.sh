@@ -1,5 +1,5 @@
 cd $GRAFT_REPO_ROOT
-run() { echo "== $*"; env BUCTD_LIB_TRACE=1 "$@" timeout 200 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-kernel-timer 2>&1 | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'])"; }
+run() { echo "== $*"; env "$@" timeout 200 python scratch/run_alt.py libbuctd_hip_trace.so bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-kernel-timer 2>&1 | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'])"; }
 run A=1
 run BUCTD_SKIP=8
 run BUCTD_SKIP=16

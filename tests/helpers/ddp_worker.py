@@ -26,6 +26,28 @@ def main():
     opt = engine.get_optimizer(cfg, model)
     tgt, wt = recipes.make_targets(cfg, joints, 77)
     crit = JointsMSELoss(True)
+    if os.environ.get("BUCTD_DDP_MODE") == "shards":
+        # every rank trains on its OWN shard (seeded by the rank); rank 0 dumps the exchanged, averaged gradient of every
+        # parameter - the test holds it against the oracle's mean over the two replicas (per-replica BatchNorm)
+        xs, js = recipes.make_inputs(cfg, x.shape[0], 900 + rank, 3)
+        ts, ws = recipes.make_targets(cfg, js, 950 + rank)
+        loss = crit(model(xs.to(dev)), ts.to(dev), ws.to(dev))
+        opt.zero_grad()
+        loss.backward()
+        model.flat.collect()
+        scale = model.sync_gradients()
+        torch.cuda.synchronize()
+        if rank == 0:
+            out = {"loss": np.array(loss.item()), "world": np.array(world), "scale": np.array(scale)}
+            for name, prm in model.module.named_parameters():
+                if prm.grad is not None:
+                    out["g::" + name] = (prm.grad * scale).detach().cpu().numpy()
+            np.savez(sys.argv[1], **out)
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+            dist.destroy_process_group()
+        return
     xd, td, wd = x.to(dev), tgt.to(dev), wt.to(dev)
     losses = []
     for _ in range(2):

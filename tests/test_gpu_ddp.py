@@ -39,6 +39,47 @@ def test_two_ranks_match_one_process(tmp_path, math):
     assert np.array_equal(a["flat"], b["flat"]), f"max diff {np.abs(a['flat'] - b['flat']).max():.3e}"
 
 
+def test_two_ranks_on_different_shards_average_like_two_oracle_replicas(tmp_path):
+    """Rank-DEPENDENT data (the identical-batch test above also passes if the exchange is a no-op with a compensating
+    scale): each rank runs its own shard, and the gradient rank 0 holds after the exchange must be the mean of the two
+    replicas' gradients as the oracle computes them one replica at a time (per-replica BatchNorm statistics, like
+    nn.DataParallel in tools/train.py:147) - and must NOT be either replica's own gradient."""
+    import copy
+    import torch
+    from oracle import recipes, core as oc
+    two = str(tmp_path / "shards.npz")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", "29537", WORKER, two],
+                       env=_env(BUCTD_CONV_MATH="bf16x6", BUCTD_DIST_BACKEND="gloo", BUCTD_SINGLE_DEVICE="1",
+                                BUCTD_DDP_MODE="shards"),
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    got = np.load(two)
+    assert int(got["world"]) == 2 and float(got["scale"]) == 0.5
+    cfg, omodel, x, _ = recipes.build("coam_w16_96x64_colored")
+    grads = []
+    for rank in range(2):
+        m = copy.deepcopy(omodel).double().train()
+        recipes.set_dropout(m, 0.0)
+        xs, js = recipes.make_inputs(cfg, x.shape[0], 900 + rank, 3)
+        ts, ws = recipes.make_targets(cfg, js, 950 + rank)
+        loss = oc.JointsMSELoss(True)(m(xs.double()), ts.double(), ws.double())
+        loss.backward()
+        grads.append({k: p.grad.numpy() for k, p in m.named_parameters() if p.grad is not None})
+    rel_avg, rel_own = [], []
+    for k in grads[0]:
+        g = got["g::" + k].astype(np.float64)
+        avg = 0.5 * (grads[0][k] + grads[1][k])
+        nrm = np.linalg.norm(avg) + 1e-30
+        rel_avg.append(np.linalg.norm(g - avg) / nrm)
+        rel_own.append(np.linalg.norm(g - grads[0][k]) / nrm)
+    rel_avg, rel_own = np.array(rel_avg), np.array(rel_own)
+    # fp32-class arithmetic against the fp64 two-replica mean (the bar of the whole-network train-step tests) ...
+    assert np.median(rel_avg) <= 2e-3 and rel_avg.max() <= 2e-2, (np.median(rel_avg), rel_avg.max())
+    # ... while rank 0's own gradient is far away: the other replica's half really arrived
+    assert np.median(rel_own) >= 0.2, np.median(rel_own)
+
+
 def test_two_ranks_over_rccl_when_two_devices_are_visible(tmp_path):
     """The same check through the production transport: backend "nccl" (= RCCL over xGMI), one rank per GPU.  Needs two
     visible devices (the round-end 1-GPU box skips it; the 8-GPU scaling node runs it)."""

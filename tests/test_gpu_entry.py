@@ -187,7 +187,7 @@ def test_train_entry_point_matches_reference_train(dev):
     model = engine.DataParallel(net).cuda()
     optimizer = engine.get_optimizer(cfg, model)
     recipes.set_dropout(model, 0.0)
-    loader = entry_batches(ocfg, 3, 2)
+    loader = entry_batches(ocfg, 3, 2, align=(omodel, True))
     wd = {"writer": Writer(), "train_global_steps": 0}
     train(cfg, loader, model, JointsMSELoss(True).cuda(), optimizer, 1, "/tmp", "/tmp", wd)
     losses = np.array([v for k, v, _ in wd["writer"].scalars if k == "train_loss"])
@@ -235,7 +235,7 @@ def test_validate_entry_point_matches_reference_validate(dev, tag):
     net = models.pose_hrnet_coam.get_pose_net(cfg, is_train=False)
     net.load_state_dict(omodel.state_dict(), strict=True)
     net = net.cuda()
-    loader = entry_batches(ocfg, 2, 2, seed0=700, cond_channels=1 if mono else 3)
+    loader = entry_batches(ocfg, 2, 2, seed0=700, cond_channels=1 if mono else 3, align=(omodel, False))
     ds = FakeDataset(4, [64, 96], oc.CROWDPOSE_FLIP_PAIRS, oc.CROWDPOSE_KPT_COLORS)
     wd = {"writer": Writer(), "valid_global_steps": 0}
     perf = validate(cfg, loader, ds, net, JointsMSELoss(True).cuda(), "/tmp", "/tmp", wd)

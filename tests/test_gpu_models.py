@@ -146,7 +146,12 @@ def test_train_step_matches_reference(dev, name):
         assert med_c <= 1e-4, "the recipe is meant to be well conditioned"
         assert med_h <= 3e-4, f"{name}: tight bar on the median: {med_h:.2e}"
     assert med_h <= max(3 * med_c, 2e-3), f"{name}: median grad error vs fp64: hip {med_h:.2e}, fp32 CPU {med_c:.2e}"
-    assert worst <= max(3 * worst_ref, 5e-2), f"{name}: worst grad error vs fp64: hip {worst:.2e}, fp32 CPU {worst_ref:.2e}"
+    kept_all = [k for k in names if g64[k].norm().item() > 1e-6 * gmax]
+    worst_k = kept_all[int(np.argmax(e_hip))]
+    # same floor as the full-size train-step tests (2e-2); the failing tensor is named, so that a flipped ReLU (which moves
+    # the layers in front of ONE BatchNorm) can be told from a wiring error (which moves one tensor by >= 1e-1)
+    assert worst <= max(3 * worst_ref, 2e-2), \
+        f"{name}: worst grad error vs fp64: hip {worst:.2e} at {worst_k}, fp32 CPU {worst_ref:.2e}"
     print(f"{name}: grad rel err vs fp64 - median hip {med_h:.2e} / cpu32 {med_c:.2e}; max hip {worst:.2e} / cpu32 {worst_ref:.2e}")
     for k in ("final_layer.weight", "conv1.weight"):
         key = "grad::" + k

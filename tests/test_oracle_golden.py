@@ -93,8 +93,11 @@ def test_oracle_loops_reproduce_the_reference_entry_points():
     recipes.set_dropout(m, 0.0)
     opt = torch.optim.Adam(m.parameters(), lr=1e-3)
     losses = []
-    for x, t, w, _ in entry_batches(cfg, 3, 2):
-        loss = oc.JointsMSELoss(True)(m(x), t, w)
+    accs = []
+    for x, t, w, _ in entry_batches(cfg, 3, 2, align=(om, True)):
+        out = m(x)
+        accs.append(float(oc.accuracy(out.detach().numpy(), t.numpy())[1]))
+        loss = oc.JointsMSELoss(True)(out, t, w)
         opt.zero_grad()
         loss.backward()
         opt.step()
@@ -103,9 +106,12 @@ def test_oracle_loops_reproduce_the_reference_entry_points():
     # later losses pass through Adam's sign-like first updates: torch's CPU reductions round differently with the thread
     # count, and that round-off moves weights by ~lr (measured 2e-4 relative between 8 and 1 threads)
     assert np.allclose(losses[1:], gold["train_loss"][1:], rtol=2e-3, atol=0)
+    # the accuracies the reference's train() reported are non-trivial (half of the joints' targets sit at the net's own
+    # arg-max) and the oracle's accuracy() on the oracle's outputs reproduces them
+    assert 0.2 <= gold["train_acc"][0] <= 0.8 and accs[0] == gold["train_acc"][0], (accs, gold["train_acc"])
     om.eval()
     idx = 0
-    for x, t, w, meta in entry_batches(cfg, 2, 2, seed0=700):
+    for x, t, w, meta in entry_batches(cfg, 2, 2, seed0=700, align=(om, False)):
         with torch.no_grad():
             out = om(x).numpy()
         fp, mv = oc.get_final_preds(True, out, meta["center"].numpy(), meta["scale"].numpy())
