@@ -197,7 +197,11 @@ def test_train_entry_point_matches_reference_train(dev):
     # Adam's first updates are sign-like (m / sqrt(v) ~ +-1): round-off level gradient noise moves weights by lr, so the
     # trajectories agree to a few percent after the first step, not to round-off (same bar as the oracle-loop test)
     assert np.all(np.abs(losses[1:] - ref[1:]) <= 5e-2 * np.abs(ref[1:])), (losses, ref)
-    assert np.array_equal(accs, gold["train_acc"])
+    # the first accuracy is that of the unchanged initial weights: it is pinned exactly, at a non-trivial value (the even
+    # joints' targets sit at the net's own arg-max, oracle/make_golden.py:entry_batches); after the sign-like Adam steps a
+    # borderline joint may fall on the other side of PCK's threshold (1 of ~26 counted joints = 0.04)
+    assert 0.2 <= gold["train_acc"][0] <= 0.8 and accs[0] == gold["train_acc"][0], (accs, gold["train_acc"])
+    assert np.all(np.abs(accs[1:] - gold["train_acc"][1:]) <= 0.08), (accs, gold["train_acc"])
     sd = model.module.state_dict()
     assert int(sd["bn1.num_batches_tracked"]) == int(gold["num_batches_tracked"]) == 3
     assert [k for k, _ in model.module.named_parameters()] == list(gold["param_names"])

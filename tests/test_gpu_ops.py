@@ -471,3 +471,41 @@ def test_fused_sgd_matches_torch_sgd(dev, momentum, nesterov, wd):
         again = engine.FusedSGD(engine.FlatParams(copy.deepcopy(twin)), lr=0.01, momentum=momentum)
         again.load_state_dict(ref.state_dict())
         assert again.param_groups[0]["lr"] == 0.05 and again.step_count == 1
+
+
+def test_fused_sgd_skips_parameters_without_gradient(dev):
+    """torch.optim.SGD leaves a parameter whose .grad is None alone - no weight decay, no momentum: TransPose's frozen
+    pos_embedding (transpose_h.py:129, requires_grad=False) and modules that are constructed but never called.  The
+    flat-arena kernel must not decay them either (wd > 0, momentum > 0, three steps; one parameter joins at step 2)."""
+    import copy
+    from buctd_amd import engine
+    torch.manual_seed(5)
+
+    class Net(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.a = torch.nn.Conv2d(3, 8, 3)
+            self.frozen = torch.nn.Parameter(torch.randn(7, 5), requires_grad=False)
+            self.unused = torch.nn.Linear(6, 3)
+            self.late = torch.nn.Parameter(torch.randn(9))
+            self.b = torch.nn.Conv2d(8, 4, 1)
+
+    net = Net()
+    twin = copy.deepcopy(net).to(dev)
+    ref = torch.optim.SGD(net.parameters(), lr=0.05, momentum=0.9, weight_decay=1e-2)
+    fused = engine.FusedSGD(engine.FlatParams(twin), lr=0.05, momentum=0.9, weight_decay=1e-2)
+    frozen0, unused0 = net.frozen.detach().clone(), net.unused.weight.detach().clone()
+    for it in range(3):
+        ref.zero_grad()
+        fused.zero_grad()
+        for (n, p), q in zip(net.named_parameters(), twin.parameters()):
+            if n.startswith(("frozen", "unused")) or (n == "late" and it < 1):
+                continue
+            g = torch.randn_like(p)
+            p.grad = g.clone()
+            q.grad = g.to(dev)
+        ref.step()
+        fused.step()
+    for (n, p), q in zip(net.named_parameters(), twin.parameters()):
+        assert (p.detach() - q.detach().cpu()).abs().max().item() <= 1e-6 * max(1.0, p.abs().max().item()), n
+    assert torch.equal(twin.frozen.detach().cpu(), frozen0) and torch.equal(twin.unused.weight.detach().cpu(), unused0)
