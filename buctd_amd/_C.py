@@ -29,16 +29,14 @@ class BasicBlockDesc(C.Structure):     # mirrors buctd_basic_block
                                            "running_mean1", "running_var1", "running_mean2", "running_var2")] +
                 [(n, C.c_float) for n in ("eps1", "momentum1", "eps2", "momentum2")] +
                 [(n, C.c_void_p) for n in ("z1", "z2", "y", "part", "counts")] +
-                [("ngroups", C.c_int), ("rows_per_group", C.c_int), ("stat", C.c_void_p), ("xp", C.c_void_p),
-                 ("y1p", C.c_void_p)])
+                [("ngroups", C.c_int), ("rows_per_group", C.c_int), ("stat", C.c_void_p)])
 
 
 class BasicBlockGrads(C.Structure):    # mirrors buctd_basic_block_grads
     _fields_ = ([(n, C.c_void_p) for n in ("dy", "dz2", "dres", "dy1", "dz1", "dx", "dw1", "dw2", "dgamma1", "dbeta1",
                                            "dgamma2", "dbeta2")] +
                 [(n, C.c_int) for n in ("acc_w1", "acc_w2", "acc_bn1", "acc_bn2")] +
-                [("bn_ws", C.c_void_p), ("bn_ws_bytes", C.c_size_t), ("wg_ws", C.c_void_p), ("wg_ws_bytes", C.c_size_t),
-                 ("dz2p", C.c_void_p), ("dz1p", C.c_void_p)])
+                [("bn_ws", C.c_void_p), ("bn_ws_bytes", C.c_size_t), ("wg_ws", C.c_void_p), ("wg_ws_bytes", C.c_size_t)])
 
 
 class MatmulDesc(C.Structure):
@@ -91,21 +89,13 @@ SIGNATURES = {
     "buctd_conv3x3_bf16x6_prep": (_I, [_I, _I, _P, _I, _P, _P]),
     "buctd_conv3x3_bf16x6": (_I, [_I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P]),
     "buctd_conv3x3_bf16x6_bnin": (_I, [_I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _I, _P]),
+    "buctd_conv3x3_bf16x6_bnstat": (_I, [_I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "buctd_bn_bwd_from_partials": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _L, _I, _P, _I, _P, _P, _P, _P, _I, _P, _SZ, _P]),
+    "buctd_basic_block_bwd_workspace": (_SZ, [_I, _I, _I, _I]),
     "buctd_conv3x3_wgrad_bf16x6_bnin": (_I, [_I, _I, _I, _I, _I, _P, _P, _P, _I, _P, _P, _P, _P, _I, _P, _SZ, _P]),
     "buctd_conv3x3_wgrad_bf16x6_supported": (_I, [_I, _I, _I, _I, _I]),
     "buctd_conv3x3_wgrad_bf16x6_workspace": (_SZ, [_I, _I, _I, _I, _I]),
     "buctd_conv3x3_wgrad_bf16x6": (_I, [_I, _I, _I, _I, _I, _P, _P, _P, _I, _P, _SZ, _P]),
-    "buctd_x6p_bytes": (_SZ, [_I, _I, _I, _I]),
-    "buctd_x6p_from_nhwc": (_I, [_I, _I, _I, _I, _P, _P, _P, _P, _P, _I, _P, _P]),
-    "buctd_x6p_to_nhwc": (_I, [_I, _I, _I, _I, _P, _P, _P]),
-    "buctd_conv3x3_bf16x6_p_stats_groups": (_I, [_I, _I, _I, _I, _I, _PI, _PI]),
-    "buctd_conv3x3_bf16x6_p": (_I, [_I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P]),
-    "buctd_conv3x3_bf16x6_emit": (_I, [_I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P]),
-    "buctd_bn_bwd_p_workspace": (_SZ, [_L, _I]),
-    "buctd_bn_bwd_p": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _I, _P, _SZ, _P]),
-    "buctd_conv3x3_wgrad_bf16x6_p_supported": (_I, [_I, _I, _I, _I, _I]),
-    "buctd_conv3x3_wgrad_bf16x6_p_workspace": (_SZ, [_I, _I, _I, _I, _I]),
-    "buctd_conv3x3_wgrad_bf16x6_p": (_I, [_I, _I, _I, _I, _I, _P, _P, _P, _I, _P, _SZ, _P]),
     "buctd_bn_stats": (_I, [_P, _L, _I, _P, _PI, _PI, _P]),
     "buctd_bn_stats_groups": (_I, [_L, _I, _PI, _PI]),
     "buctd_bn_apply": (_I, [_P, _P, _P, _P, _P, _P, _I, _P, _L, _I, _P]),

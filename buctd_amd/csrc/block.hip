@@ -36,23 +36,15 @@ extern "C" int buctd_basic_block_fwd_train(const buctd_basic_block* b, void* str
   int* cnt1 = b->counts;
   int* cnt2 = b->counts + b->ngroups;
   float *mean1 = b->stat, *invstd1 = b->stat + C, *mean2 = b->stat + 2 * C, *invstd2 = b->stat + 3 * C;
-  const bool planes = b->xp && b->y1p;
-  BUCTD_CHECK_ARG((b->xp == nullptr) == (b->y1p == nullptr), "buctd_basic_block_fwd_train: xp and y1p go together");
   // (what-if bits of the forward, tuning builds: 8 convolutions, 16 finalizes, 32 the output bn_apply)
-  if (planes)     // conv1 also writes the split x it staged: the X operand of its weight gradient
-    BLK_TRY(buctd_conv3x3_bf16x6_emit(N, H, W, C, C, b->x, b->w1_fwd, b->z1, part1, cnt1, nullptr, nullptr, nullptr, nullptr, 0,
-                                      b->xp, stream));
-  else if (!BLK_SKIP(8))
+  if (!BLK_SKIP(8))
     BLK_TRY(buctd_conv3x3_bf16x6(N, H, W, C, C, b->x, b->w1_fwd, nullptr, nullptr, nullptr, nullptr, 0, b->z1, part1, cnt1,
                                  stream));
   if (!BLK_SKIP(16))
     BLK_TRY(buctd_bn_finalize(part1, cnt1, b->ngroups, b->rows_per_group, rows, C, b->eps1, b->momentum1, mean1, invstd1,
                               b->running_mean1, b->running_var1, stream));
   // conv2 applies bn1 + ReLU while it stages its input: relu(bn1(z1)) never exists in memory
-  if (planes)     // ... and here y1 = relu(bn1(z1)) reaches memory after all - as planes, for conv2's weight gradient
-    BLK_TRY(buctd_conv3x3_bf16x6_emit(N, H, W, C, C, b->z1, b->w2_fwd, b->z2, part2, cnt2, mean1, invstd1, b->gamma1, b->beta1, 1,
-                                      b->y1p, stream));
-  else if (!BLK_SKIP(8))
+  if (!BLK_SKIP(8))
     BLK_TRY(buctd_conv3x3_bf16x6_bnin(N, H, W, C, C, b->z1, b->w2_fwd, nullptr, nullptr, nullptr, nullptr, 0, b->z2, part2,
                                       cnt2, mean1, invstd1, b->gamma1, b->beta1, 1, stream));
   if (!BLK_SKIP(16))
@@ -63,13 +55,25 @@ extern "C" int buctd_basic_block_fwd_train(const buctd_basic_block* b, void* str
   return BUCTD_OK;
 }
 
-extern "C" int buctd_basic_block_bwd(const buctd_basic_block* b, const buctd_basic_block_grads* g, void* stream,
-                                     void* side_stream) {
+// Bytes of buctd_basic_block_grads::bn_ws: the BatchNorm-backward partial sums ([groups][2][C], written either by
+// bn_bwd_reduce2_kernel or by the epilogue of the data gradient in front, buctd_conv3x3_bf16x6_bnstat) + the merged sums.
+extern "C" size_t buctd_basic_block_bwd_workspace(int N, int H, int W, int C) {
+  int ng = 0, rpg = 0;
+  if (buctd_conv3x3_bf16x6_stats_groups(N, H, W, C, C, &ng, &rpg) != BUCTD_OK) return 0;
+  const size_t fused = ((size_t)ng * 2 * C + 2 * (size_t)C) * sizeof(float);
+  const size_t plain = buctd_bn_bwd_workspace((long)N * H * W, C);
+  return fused > plain ? fused : plain;
+}
+
+// prev: the block in FRONT of b in a chain (its output is b's input), or NULL.  With prev the data gradient of conv1 - whose
+// output is prev's upstream gradient - also forms the reduction pass of prev's bn2 backward (into the shared bn_ws).
+// bn2_part_ready: the block behind did that for b, so b's bn2 backward starts at the finalize.
+static int block_bwd_impl(const buctd_basic_block* b, const buctd_basic_block_grads* g, const buctd_basic_block* prev,
+                          bool bn2_part_ready, void* stream, void* side_stream) {
   BUCTD_CHECK_ARG(b && g && b->x && b->w1_bwd && b->w2_bwd && b->z1 && b->z2 && b->y && b->stat && g->dy && g->dres &&
                       g->dy1 && g->dw1 && g->dw2 && g->bn_ws && g->wg_ws,
                   "buctd_basic_block_bwd: null pointer");
-  const bool planes = b->xp && b->y1p && g->dz2p && g->dz1p;
-  BUCTD_CHECK_ARG(planes || (g->dz2 && g->dz1), "buctd_basic_block_bwd: dz2 / dz1 scratch missing");
+  BUCTD_CHECK_ARG(g->dz2 && g->dz1, "buctd_basic_block_bwd: dz2 / dz1 scratch missing");
   const int N = b->N, H = b->H, W = b->W, C = b->C;
   const long rows = (long)N * H * W;
   const float *mean1 = b->stat, *invstd1 = b->stat + C, *mean2 = b->stat + 2 * C, *invstd2 = b->stat + 3 * C;
@@ -95,46 +99,58 @@ extern "C" int buctd_basic_block_bwd(const buctd_basic_block* b, const buctd_bas
     }
     return BUCTD_OK;
   };
-  if (planes) {
-    // planes mode: the BatchNorm backward writes dz pre-split (its only consumers are the two bf16x6 kernels), the weight
-    // gradients stage both operands by LDS-DMA, the data gradients with plain copies
-    BLK_TRY(buctd_bn_bwd_p(g->dy, b->y, b->z2, mean2, invstd2, b->gamma2, nullptr, 1, N, H, W, C, g->dz2p, g->dres, g->dgamma2,
-                           g->dbeta2, g->acc_bn2, g->bn_ws, g->bn_ws_bytes, stream));
-    BLK_TRY(fork());
-    BLK_TRY(buctd_conv3x3_wgrad_bf16x6_p(N, H, W, C, C, b->y1p, g->dz2p, g->dw2, g->acc_w2, g->wg_ws, g->wg_ws_bytes, side_s));
-    BLK_TRY(buctd_conv3x3_bf16x6_p(N, H, W, C, C, g->dz2p, b->w2_bwd, nullptr, nullptr, nullptr, nullptr, 0, g->dy1, nullptr,
-                                   nullptr, stream));
-    BLK_TRY(buctd_bn_bwd_p(g->dy1, nullptr, b->z1, mean1, invstd1, b->gamma1, b->beta1, 1, N, H, W, C, g->dz1p, nullptr,
-                           g->dgamma1, g->dbeta1, g->acc_bn1, g->bn_ws, g->bn_ws_bytes, stream));
-    BLK_TRY(fork());
-    BLK_TRY(buctd_conv3x3_wgrad_bf16x6_p(N, H, W, C, C, b->xp, g->dz1p, g->dw1, g->acc_w1, g->wg_ws, g->wg_ws_bytes, side_s));
-    if (g->dx)
-      BLK_TRY(buctd_conv3x3_bf16x6_p(N, H, W, C, C, g->dz1p, b->w1_bwd, nullptr, nullptr, nullptr, g->dres, 0, g->dx, nullptr,
-                                     nullptr, stream));
-    return BUCTD_OK;
+  // The reduction pass of each BatchNorm backward (sum g, sum g zhat over the batch) is a by-product of the data gradient
+  // that PRODUCES g (its epilogue has the tile in registers): bn1's of conv2's data gradient, bn2's - in a chain - of the
+  // data gradient of the block behind.  bn_ws = [ng][2][C] partial sums | [2][C] merged sums, used strictly in stream order.
+  int ng = 0, rpg = 0;
+  BLK_TRY(buctd_conv3x3_bf16x6_stats_groups(N, H, W, C, C, &ng, &rpg));
+  const size_t need = ((size_t)ng * 2 * C + 2 * (size_t)C) * sizeof(float);
+  if (g->bn_ws_bytes < need) {
+    buctd_set_error("buctd_basic_block_bwd: bn_ws %zu bytes < required %zu (buctd_basic_block_bwd_workspace)", g->bn_ws_bytes, need);
+    return BUCTD_EWORKSPACE;
   }
+  float* part = (float*)g->bn_ws;
+  float* sums = part + (size_t)ng * 2 * C;
+  const size_t sums_bytes = 2 * (size_t)C * sizeof(float);
   // conv2 / bn2 (+ skip): dres = masked upstream gradient
-  if (!BLK_SKIP(2))
-    BLK_TRY(buctd_bn_bwd(g->dy, b->y, b->z2, mean2, invstd2, b->gamma2, nullptr, 1, rows, C, g->dz2, g->dres, g->dgamma2,
-                         g->dbeta2, g->acc_bn2, g->bn_ws, g->bn_ws_bytes, stream));
+  if (!BLK_SKIP(2)) {
+    if (bn2_part_ready)
+      BLK_TRY(buctd_bn_bwd_from_partials(g->dy, b->y, b->z2, mean2, invstd2, b->gamma2, nullptr, 1, rows, C, part, ng, g->dz2,
+                                         g->dres, g->dgamma2, g->dbeta2, g->acc_bn2, sums, sums_bytes, stream));
+    else
+      BLK_TRY(buctd_bn_bwd(g->dy, b->y, b->z2, mean2, invstd2, b->gamma2, nullptr, 1, rows, C, g->dz2, g->dres, g->dgamma2,
+                           g->dbeta2, g->acc_bn2, g->bn_ws, g->bn_ws_bytes, stream));
+  }
   BLK_TRY(fork());
   if (!BLK_SKIP(1))
     BLK_TRY(buctd_conv3x3_wgrad_bf16x6_bnin(N, H, W, C, C, b->z1, g->dz2, g->dw2, g->acc_w2, mean1, invstd1, b->gamma1,
                                             b->beta1, 1, g->wg_ws, g->wg_ws_bytes, side_s));
+  // conv2's data gradient dy1, and with it the sums of bn1's backward (ReLU mask rebuilt from z1)
   if (!BLK_SKIP(4))
-    BLK_TRY(buctd_conv3x3_bf16x6(N, H, W, C, C, g->dz2, b->w2_bwd, nullptr, nullptr, nullptr, nullptr, 0, g->dy1, nullptr,
-                                 nullptr, stream));
-  // conv1 / bn1: the ReLU mask is rebuilt from z1; the skip gradient joins in the data-gradient epilogue
+    BLK_TRY(buctd_conv3x3_bf16x6_bnstat(N, H, W, C, C, g->dz2, b->w2_bwd, nullptr, g->dy1, b->z1, nullptr, mean1, invstd1,
+                                        b->gamma1, b->beta1, part, stream));
   if (!BLK_SKIP(2))
-    BLK_TRY(buctd_bn_bwd(g->dy1, nullptr, b->z1, mean1, invstd1, b->gamma1, b->beta1, 1, rows, C, g->dz1, nullptr, g->dgamma1,
-                         g->dbeta1, g->acc_bn1, g->bn_ws, g->bn_ws_bytes, stream));
+    BLK_TRY(buctd_bn_bwd_from_partials(g->dy1, nullptr, b->z1, mean1, invstd1, b->gamma1, b->beta1, 1, rows, C, part, ng,
+                                       g->dz1, nullptr, g->dgamma1, g->dbeta1, g->acc_bn1, sums, sums_bytes, stream));
   BLK_TRY(fork());
   if (!BLK_SKIP(1))
     BLK_TRY(buctd_conv3x3_wgrad_bf16x6(N, H, W, C, C, b->x, g->dz1, g->dw1, g->acc_w1, g->wg_ws, g->wg_ws_bytes, side_s));
-  if (g->dx && !BLK_SKIP(4))
-    BLK_TRY(buctd_conv3x3_bf16x6(N, H, W, C, C, g->dz1, b->w1_bwd, nullptr, nullptr, nullptr, g->dres, 0, g->dx, nullptr,
-                                 nullptr, stream));
+  // conv1's data gradient; the skip gradient joins in its epilogue; in a chain its output is the upstream gradient of the
+  // block in front, whose bn2 sums it forms on the way out
+  if (g->dx && !BLK_SKIP(4)) {
+    if (prev)
+      BLK_TRY(buctd_conv3x3_bf16x6_bnstat(N, H, W, C, C, g->dz1, b->w1_bwd, g->dres, g->dx, prev->z2, prev->y, prev->stat + 2 * C,
+                                          prev->stat + 3 * C, prev->gamma2, nullptr, part, stream));
+    else
+      BLK_TRY(buctd_conv3x3_bf16x6(N, H, W, C, C, g->dz1, b->w1_bwd, nullptr, nullptr, nullptr, g->dres, 0, g->dx, nullptr,
+                                   nullptr, stream));
+  }
   return BUCTD_OK;
+}
+
+extern "C" int buctd_basic_block_bwd(const buctd_basic_block* b, const buctd_basic_block_grads* g, void* stream,
+                                     void* side_stream) {
+  return block_bwd_impl(b, g, nullptr, false, stream, side_stream);
 }
 
 // A residual CHAIN (the four BasicBlocks of an HRNet branch, pose_hrnet.py:165-185 _make_one_branch): the blocks' launch
@@ -149,6 +165,15 @@ extern "C" int buctd_basic_chain_fwd_train(int n, const buctd_basic_block* block
 extern "C" int buctd_basic_chain_bwd(int n, const buctd_basic_block* blocks, const buctd_basic_block_grads* grads, void* stream,
                                      void* side_stream) {
   BUCTD_CHECK_ARG(n > 0 && blocks && grads, "buctd_basic_chain_bwd: bad argument");
-  for (int k = n - 1; k >= 0; --k) BLK_TRY(buctd_basic_block_bwd(blocks + k, grads + k, stream, side_stream));
+  bool ready = false;      // block k's bn2 sums were formed by block k + 1's conv1 data gradient
+  for (int k = n - 1; k >= 0; --k) {
+    // block k - 1 can take its bn2 sums from this block's data gradient if that gradient IS its upstream gradient, the two
+    // blocks have one shape and share the workspace the sums travel in
+    const bool chain = k > 0 && grads[k].dx && grads[k].dx == grads[k - 1].dy && grads[k].bn_ws == grads[k - 1].bn_ws &&
+                       blocks[k - 1].y == blocks[k].x && blocks[k - 1].N == blocks[k].N && blocks[k - 1].H == blocks[k].H &&
+                       blocks[k - 1].W == blocks[k].W && blocks[k - 1].C == blocks[k].C && !BLK_SKIP(6);
+    BLK_TRY(block_bwd_impl(blocks + k, grads + k, chain ? blocks + k - 1 : nullptr, ready, stream, side_stream));
+    ready = chain;
+  }
   return BUCTD_OK;
 }

@@ -54,15 +54,23 @@ __device__ __forceinline__ double shfl_xor_d(double v, int o) {
   return __hiloint2double(hi, lo);
 }
 
-// one 256-thread workgroup per channel; two division-free fp64 passes over the (L2-resident) partials:
+// one 256-thread workgroup per channel; fp64 sums of the (L2-resident) partials:
 //   mean = sum n_g mean_g / N ;  M2 = sum [ M2_g + n_g (mean_g - mean)^2 ]      (Chan et al., exact)
-__device__ __forceinline__ double block_sum_d(double v, double* sm) {
+// the two sums of a finalize share ONE cross-wave exchange (two barriers instead of four): these kernels are pure latency -
+// one workgroup per channel between two convolutions that wait for it
+__device__ __forceinline__ void block_sum_d2(double& a, double& b, double (*sm)[2]) {
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += shfl_xor_d(v, o);
+  for (int o = 32; o > 0; o >>= 1) {
+    a += shfl_xor_d(a, o);
+    b += shfl_xor_d(b, o);
+  }
+  if ((threadIdx.x & 63) == 0) {
+    sm[threadIdx.x >> 6][0] = a;
+    sm[threadIdx.x >> 6][1] = b;
+  }
   __syncthreads();
-  if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = v;
-  __syncthreads();
-  return sm[0] + sm[1] + sm[2] + sm[3];
+  a = sm[0][0] + sm[1][0] + sm[2][0] + sm[3][0];
+  b = sm[0][1] + sm[1][1] + sm[2][1] + sm[3][1];
 }
 __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ part,
                                                           const int* __restrict__ counts, int ngroups, int rpg,
@@ -71,17 +79,17 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
                                                           float* __restrict__ rmean, float* __restrict__ rvar) {
   // One workgroup per channel, ONE pass: S1 = sum n_g mean_g and S2 = sum (M2_g + n_g mean_g^2) in fp64.  The products
   // of fp32 inputs are exact in fp64, so var = (S2 - S1^2/N)/N keeps ~16 - 2 log10(|mean|/std) digits - far beyond the
-  // fp32 result for any activation statistics (|mean|/std < 1e4) - while the partials are gathered once, four
-  // independent 8-byte loads in flight per thread.
-  __shared__ double sm[4];
+  // fp32 result for any activation statistics (|mean|/std < 1e4) - while the partials are gathered once, EIGHT
+  // independent 8-byte loads (+ their counts) in flight per thread: up to 2048 groups cost one memory round trip.
+  __shared__ double sm[4][2];
   const int c = blockIdx.x;
   double s1 = 0.0, s2 = 0.0;
   const float2* pp = reinterpret_cast<const float2*>(part) + c;
-  for (int g0 = threadIdx.x; g0 < ngroups; g0 += 1024) {
-    float2 v[4];
-    int n[4];
+  for (int g0 = threadIdx.x; g0 < ngroups; g0 += 2048) {
+    float2 v[8];
+    int n[8];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < 8; ++u) {
       const int g = g0 + 256 * u;
       const bool ok = g < ngroups;
       const int gc = ok ? g : 0;
@@ -91,14 +99,13 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
       n[u] = ok ? (counts ? counts[gc] : (int)cnt) : 0;
     }
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < 8; ++u) {
       const double m = (double)v[u].x, nn = (double)n[u];
       s1 += nn * m;
       if (n[u] > 0) s2 += (double)v[u].y + nn * m * m;
     }
   }
-  s1 = block_sum_d(s1, sm);
-  s2 = block_sum_d(s2, sm);
+  block_sum_d2(s1, s2, sm);
   if (threadIdx.x == 0) {
     const double mu = s1 / (double)rows;
     double m2 = s2 - s1 * mu;
@@ -271,13 +278,13 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
 __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __restrict__ part, int nchunks, int C,
                                                               float* __restrict__ s, float* __restrict__ dgamma,
                                                               float* __restrict__ dbeta, int accumulate) {
-  __shared__ double sm[4];
+  __shared__ double sm[4][2];
   const int c = blockIdx.x;
   double s1 = 0.0, s2 = 0.0;
-  for (int k0 = threadIdx.x; k0 < nchunks; k0 += 1024) {
-    float a[4], b[4];
+  for (int k0 = threadIdx.x; k0 < nchunks; k0 += 2048) {
+    float a[8], b[8];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < 8; ++u) {
       const int k = k0 + 256 * u;
       const bool ok = k < nchunks;
       const long kc = ok ? k : 0;
@@ -286,13 +293,12 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __res
       if (!ok) { a[u] = 0.f; b[u] = 0.f; }
     }
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < 8; ++u) {
       s1 += (double)a[u];
       s2 += (double)b[u];
     }
   }
-  s1 = block_sum_d(s1, sm);
-  s2 = block_sum_d(s2, sm);
+  block_sum_d2(s1, s2, sm);
   if (threadIdx.x == 0) {
     s[c] = (float)s1;
     s[C + c] = (float)s2;
@@ -483,6 +489,37 @@ extern "C" int buctd_bn_bwd(const float* dy, const float* y, const float* z, con
   return BUCTD_OK;
 }
 
+/* The rest of buctd_bn_bwd when the reduction pass already happened elsewhere (buctd_conv3x3_bf16x6_bnstat: the data
+ * gradient that produced dy formed the partial sums on its way out): part = [nparts][2][C] partial (s1, s2) sums.
+ * workspace: 2 * C floats.  Finalize (fp64 merge, dgamma / dbeta) + apply (dz, optional dres), as buctd_bn_bwd. */
+extern "C" int buctd_bn_bwd_from_partials(const float* dy, const float* y, const float* z, const float* mean,
+                                          const float* invstd, const float* gamma, const float* beta, int relu, long rows,
+                                          int C, const float* part, int nparts, float* dz, float* dres, float* dgamma,
+                                          float* dbeta, int accumulate, void* workspace, size_t workspace_bytes,
+                                          void* stream) {
+  BUCTD_CHECK_ARG(dy && z && mean && invstd && gamma && dz && part && nparts > 0 && rows > 0 && C > 0,
+                  "buctd_bn_bwd_from_partials: bad argument");
+  BUCTD_CHECK_ARG(!relu || y || beta, "buctd_bn_bwd_from_partials: relu backward needs the forward output, or beta to rebuild its sign");
+  if (!workspace || workspace_bytes < (size_t)2 * C * sizeof(float)) {
+    buctd_set_error("buctd_bn_bwd_from_partials: workspace %zu bytes < required %zu", workspace_bytes, (size_t)2 * C * sizeof(float));
+    return BUCTD_EWORKSPACE;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  float* s = (float*)workspace;
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(256), 0, st, part, nparts, C, s, dgamma, dbeta, accumulate);
+  BUCTD_CHECK_LAUNCH("buctd_bn_bwd_from_partials(finalize)");
+  const long total = rows * C;
+  const float inv_rows = 1.0f / (float)rows;
+  if (C % 4 == 0)
+    hipLaunchKernelGGL(bn_bwd_apply_kernel<true>, dim3(stream_grid(total / 4)), dim3(256), 0, st, dy, y, z, mean,
+                       invstd, gamma, beta, (const float*)s, relu, total, C, inv_rows, dz, dres);
+  else
+    hipLaunchKernelGGL(bn_bwd_apply_kernel<false>, dim3(stream_grid(total)), dim3(256), 0, st, dy, y, z, mean, invstd,
+                       gamma, beta, (const float*)s, relu, total, C, inv_rows, dz, dres);
+  BUCTD_CHECK_LAUNCH("buctd_bn_bwd_from_partials(apply)");
+  return BUCTD_OK;
+}
+
 extern "C" int buctd_bn_fold(const float* gamma, const float* beta, const float* running_mean,
                              const float* running_var, float eps, int C, float* scale, float* shift, void* stream) {
   BUCTD_CHECK_ARG(gamma && beta && running_mean && running_var && scale && shift && C > 0,
@@ -494,17 +531,12 @@ extern "C" int buctd_bn_fold(const float* gamma, const float* beta, const float*
 }
 
 // =====================================================================================================================
-// BatchNorm backward, second generation (used by the BasicBlock sequences of block.hip):
+// BatchNorm backward, second generation:
 //   * bn_bwd_reduce2_kernel: a FIXED grid of <= 1024 workgroups, each walking a contiguous range of rows with four
 //     independent 16-byte loads per tensor in flight (the first generation launched one workgroup per 64 rows - 3456 tiny
 //     workgroups for the 96x72 maps, three dependent-latency round trips each: 1.4-2.2 TB/s); the finalize then folds
 //     <= 1024 partials per channel instead of rows / 64;
-//   * bn_bwd_apply_p_kernel: writes dz as x6 PLANES (x6p.h) - the only consumers of dz are the bf16x6 data-gradient and
-//     weight-gradient kernels, which then stage it without splitting it again (6 B/elem written instead of 4).  Only
-//     pixel rows are written: the pad and guard rows of the destination are zero and stay zero (the caller hands a
-//     buffer whose non-pixel rows are zero, e.g. from ops.PlanesPool).
 // Arithmetic of every element is the expression of the first-generation kernels, in the same order.
-#include "x6p.h"
 
 #define BWD2_MAX_BLOCKS 1024
 
@@ -574,138 +606,9 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce2_kernel(const float* __rest
   }
 }
 
-struct BnPlanesGeo {
-  int H, W, SW, IB;
-  unsigned w_mul, w_sh, h_mul, h_sh;
-};
-static void bn_magic(unsigned d, unsigned* mul, unsigned* sh) {
-  if (d == 1) { *mul = 0xFFFFFFFFu; *sh = 0; return; }
-  unsigned l = 0;
-  while ((1ull << l) < d) ++l;
-  *mul = (unsigned)(((1ull << (31 + l)) + d - 1) / d);
-  *sh = l - 1;
-}
-
-// thread = (pixel, 8 channels): dz of eight channels -> three 16-byte pieces of the pixel's planes row; dres = masked dy
-__global__ __launch_bounds__(256) void bn_bwd_apply_p_kernel(const float* __restrict__ dy, const float* __restrict__ y,
-                                                             const float* __restrict__ z, const float* __restrict__ mean,
-                                                             const float* __restrict__ invstd,
-                                                             const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                             const float* __restrict__ s, int relu, long rows, int C,
-                                                             float inv_rows, BnPlanesGeo geo,
-                                                             unsigned char* __restrict__ dz_planes,
-                                                             float* __restrict__ dres) {
-  const int c8n = C >> 3;
-  const long items = rows * c8n;
-  const long step = (long)gridDim.x * 256;
-  const int dc = (int)(step % c8n);
-  const long dr = step / c8n;
-  long i = (long)blockIdx.x * 256 + threadIdx.x;
-  long row = i / c8n;
-  int c8 = (int)(i - row * c8n);
-  unsigned char* prow0 = dz_planes + (size_t)X6P_GB * (size_t)(C * 6);
-  for (; i < items; i += step) {
-    const long o = row * C + c8 * 8;
-    float g[8], zz[8];
-    {
-      const f32x4 a = *reinterpret_cast<const f32x4*>(dy + o), b = *reinterpret_cast<const f32x4*>(dy + o + 4);
-      const f32x4 c = *reinterpret_cast<const f32x4*>(z + o), d = *reinterpret_cast<const f32x4*>(z + o + 4);
-#pragma unroll
-      for (int j = 0; j < 4; ++j) { g[j] = a[j]; g[4 + j] = b[j]; zz[j] = c[j]; zz[4 + j] = d[j]; }
-    }
-    if (relu) {
-      float yy[8];
-      if (y) {
-        const f32x4 a = *reinterpret_cast<const f32x4*>(y + o), b = *reinterpret_cast<const f32x4*>(y + o + 4);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) { yy[j] = a[j]; yy[4 + j] = b[j]; }
-      } else {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          const int c = c8 * 8 + j;
-          const float sc = invstd[c] * gamma[c];
-          yy[j] = (zz[j] - mean[c]) * sc + beta[c];
-        }
-      }
-#pragma unroll
-      for (int j = 0; j < 8; ++j)
-        if (!(yy[j] > 0.f)) g[j] = 0.f;
-    }
-    float ov[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const int c = c8 * 8 + j;
-      const float is = invstd[c];
-      const float zh = (zz[j] - mean[c]) * is;
-      ov[j] = gamma[c] * is * (g[j] - s[c] * inv_rows - zh * s[C + c] * inv_rows);
-    }
-    // pixel row -> padded position p = n*IB + (y+1)*SW + (x+1)
-    const int q = (int)(__umulhi((unsigned)row, geo.w_mul) >> geo.w_sh);      // row / W = n*H + y
-    const int xx = (int)row - q * geo.W;
-    const int n = (int)(__umulhi((unsigned)q, geo.h_mul) >> geo.h_sh);          // / H
-    const int yy_ = q - n * geo.H;
-    const long pp = (long)n * geo.IB + (long)(yy_ + 1) * geo.SW + xx + 1;
-    x6p_u16x8 h, m, l;
-    x6p_split8(ov, h, m, l);
-    x6p_store8(prow0 + (size_t)pp * (size_t)(C * 6), c8, h, m, l);
-    if (dres) {
-      *reinterpret_cast<f32x4*>(dres + o) = (f32x4){g[0], g[1], g[2], g[3]};
-      *reinterpret_cast<f32x4*>(dres + o + 4) = (f32x4){g[4], g[5], g[6], g[7]};
-    }
-    c8 += dc;
-    row += dr;
-    if (c8 >= c8n) { c8 -= c8n; ++row; }
-  }
-}
-
 static long bwd2_blocks(long rows, long* rows_per_block) {
   long rpb = (rows + BWD2_MAX_BLOCKS - 1) / BWD2_MAX_BLOCKS;
   if (rpb < 64) rpb = 64;      // never more partials than the first generation's rows / 64 (its workspace size)
   *rows_per_block = rpb;
   return (rows + rpb - 1) / rpb;
-}
-
-extern "C" size_t buctd_bn_bwd_p_workspace(long rows, int C) {
-  return (size_t)(BWD2_MAX_BLOCKS * 2 * (long)C + 2 * C) * sizeof(float);
-}
-
-/* BatchNorm (+ReLU) backward of an NHWC tensor [N][H][W][C] (C % 16 == 0, C <= 1024) with dz written as x6 planes
- * (allocation base; its non-pixel rows must already be zero) and the masked upstream gradient as fp32 `dres` (optional).
- * dgamma / dbeta and the semantics of y / beta / relu as buctd_bn_bwd. */
-extern "C" int buctd_bn_bwd_p(const float* dy, const float* y, const float* z, const float* mean, const float* invstd,
-                              const float* gamma, const float* beta, int relu, int N, int H, int W, int C,
-                              void* dz_planes, float* dres, float* dgamma, float* dbeta, int accumulate, void* workspace,
-                              size_t workspace_bytes, void* stream) {
-  BUCTD_CHECK_ARG(dy && z && mean && invstd && gamma && dz_planes && N > 0 && H > 0 && W > 0 && C > 0 && C % 16 == 0 && C <= 1024,
-                  "buctd_bn_bwd_p: bad argument");
-  BUCTD_CHECK_ARG(!relu || y || beta, "buctd_bn_bwd_p: relu backward needs the forward output, or beta to rebuild its sign");
-  const long rows = (long)N * H * W;
-  BUCTD_CHECK_ARG(rows < 2147483647L, "buctd_bn_bwd_p: tensor too large");
-  const size_t need = buctd_bn_bwd_p_workspace(rows, C);
-  if (!workspace || workspace_bytes < need) {
-    buctd_set_error("buctd_bn_bwd_p: workspace %zu bytes < required %zu", workspace_bytes, need);
-    return BUCTD_EWORKSPACE;
-  }
-  hipStream_t st = (hipStream_t)stream;
-  long rpb;
-  const long nb = bwd2_blocks(rows, &rpb);
-  float* part = (float*)workspace;
-  float* s = part + (long)BWD2_MAX_BLOCKS * 2 * C;
-  hipLaunchKernelGGL(bn_bwd_reduce2_kernel, dim3((unsigned)nb), dim3(256), 0, st, dy, y, z, mean, invstd, gamma, beta, relu,
-                     rows, C, rpb, part);
-  BUCTD_CHECK_LAUNCH("buctd_bn_bwd_p(reduce)");
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(256), 0, st, (const float*)part, (int)nb, C, s, dgamma, dbeta,
-                     accumulate);
-  BUCTD_CHECK_LAUNCH("buctd_bn_bwd_p(finalize)");
-  BnPlanesGeo geo;
-  geo.H = H; geo.W = W; geo.SW = W + 2; geo.IB = (H + 1) * (W + 2);
-  bn_magic((unsigned)W, &geo.w_mul, &geo.w_sh);
-  bn_magic((unsigned)H, &geo.h_mul, &geo.h_sh);
-  const long items = rows * (C / 8);
-  long blocks = (items + 255) / 256;
-  if (blocks > 4096) blocks = 4096;
-  hipLaunchKernelGGL(bn_bwd_apply_p_kernel, dim3((unsigned)blocks), dim3(256), 0, st, dy, y, z, mean, invstd, gamma, beta,
-                     (const float*)s, relu, rows, C, 1.0f / (float)rows, geo, (unsigned char*)dz_planes, dres);
-  BUCTD_CHECK_LAUNCH("buctd_bn_bwd_p(apply)");
-  return BUCTD_OK;
 }

@@ -3,7 +3,6 @@
 // the fp32 -> bf16-piece split, and the epilogue (bias, Welford BatchNorm partials, eval-BN, residual, ReLU, store).
 #pragma once
 #include "common.h"
-#include "x6p.h"
 #include <stdlib.h>
 #include "../../include/buctd_hip.h"
 
@@ -51,14 +50,23 @@ struct C3Args {
   const float* in_beta;
   int in_relu;
   int col_major;       // bf16x6 kernel: consecutive workgroups of an XCD share the COLUMN tile (see the kernel)
-  // bf16x6, fp32 input: optional by-product - the staged (normalised, split, zero-padded) input written out as x6 planes
-  // (allocation base; rows of positions [0, ceil(P / BM) * BM) are written, pads as zeros).  The weight gradient of the
-  // same convolution stages it by LDS-DMA in the backward pass instead of splitting the tensor a second time.
-  unsigned char* planes_out;
   unsigned ib_mul, ib_sh, sw_mul, sw_sh;   // n / d == mulhi(n, mul) >> sh for 0 <= n < 2^31 (Granlund-Montgomery)
   // output map of the gathered kernels (conv_gather_x6.hip; omap = 0: the H x W grid itself): grid pixel (y, x) is written
   // to pixel (y * ost + oy0, x * ost + ox0) of an oH x oW tensor - the parity classes of a stride-2 data gradient
   int omap, oH, oW, ost, oy0, ox0;
+  // optional by-product of a DATA-GRADIENT launch (conv3x3.hip only): the reduction pass of the BatchNorm backward that
+  // consumes this launch's output g = out (after the residual was added) - per row group the partial sums
+  //   s1[c] = sum_rows m * g,   s2[c] = sum_rows m * g * (z - mean[c]) * invstd[c],   m = ReLU mask of the BatchNorm's
+  // forward output (bs_y > 0 where given, else rebuilt as (z - mean) * (invstd * gamma) + beta > 0, bn_apply's expression)
+  // - exactly the sums of bn_bwd_reduce2_kernel, formed while the tile is on its way out instead of by a kernel that
+  // reads g, z and y again.  bs_part: [groups][2][Co] floats, groups as the forward statistics (bx * WM + wave_m).
+  const float* bs_z;
+  const float* bs_y;
+  const float* bs_mean;
+  const float* bs_invstd;
+  const float* bs_gamma;
+  const float* bs_beta;
+  float* bs_part;
 };
 
 __device__ __forceinline__ int fast_div(int n, unsigned mul, unsigned sh) {
@@ -102,7 +110,15 @@ __device__ __forceinline__ void split_store(unsigned char* row, int c, f32x4 v) 
   }
 }
 
-#define MAX_SW 75          // W <= 73: the staged tile is at most BM + 152 rows
+#define MAX_SW 75          // W <= 74: the staged tile is at most BM + 152 rows
+
+// Row width of the zero-padded flattened position space  p = n*IB + (y+1)*SW + (x+1),  IB = (H+1)*SW,  P = N*IB + SW:
+// ONE pad column per row (xx = 0).  In the flattened space the position right of a row's last pixel IS the next row's
+// pad column, so it serves as the right pad of row y and the left pad of row y + 1 at once (a second pad column, as in the
+// first rounds, only added 1/(W+2) of positions that are multiplied and thrown away - and at N = 32, 96x72 made the tile
+// grid one tile too long for a balanced single round of workgroups).  Pixel (y, x) of image n: yy = y + 1 in 1..H,
+// xx = x + 1 in 1..W; yy = 0 is the pad row above image n = the pad row below image n - 1.
+static inline int c3_row_width(int W) { return W + 1; }
 
 template <int V>
 struct IC { static constexpr int value = V; };
@@ -121,7 +137,7 @@ __device__ __forceinline__ void c3_epilogue(const C3Args& p, f32x4 (&acc)[MF][NF
   constexpr int MR = MF * 16;              // rows of this wave's tile (<= 128)
   constexpr int RH = (MR + 63) / 64;       // 64-row halves: lane r owns rows r and r + 64
   constexpr int LD = NF * 16 + 4;          // staging row stride in floats: 4*LD = 16 mod 64 keeps the writes conflict-free
-  constexpr int EP = MF >= 2 ? 2 : 1;      // 16-row fragments staged per pass
+  constexpr int EP = (MF >= 2 && MF % 2 == 0) ? 2 : 1;      // 16-row fragments staged per pass (odd MF: one)
   static_assert(MR <= 128, "c3_epilogue: at most 128 rows per wave");
   float* stg = reinterpret_cast<float*>(smem) + wave * (EP * 16 * LD);
   int* rowoff = reinterpret_cast<int*>(smem) + 4 * EP * 16 * LD + wave * 128;
@@ -182,6 +198,16 @@ __device__ __forceinline__ void c3_epilogue(const C3Args& p, f32x4 (&acc)[MF][NF
       }
     }
   }
+  // BatchNorm-backward partial sums of the outgoing tile (C3Args::bs_part).  Item k of a lane has column quad
+  // c4 = (lane + 64 k) % (NF * 4): NACC distinct quads per lane, one accumulator pair each.
+  constexpr int Q4 = NF * 4;
+  constexpr int NACC = (64 % Q4 == 0) ? 1 : 3;       // NF = 3: 64 = 4 mod 12 -> three quads per lane; else one
+  static_assert(NF <= 4 && (64 % Q4 == 0 || Q4 == 12), "c3_epilogue: unexpected column count for the bs reduction");
+  f32x4 bs1[NACC], bs2[NACC];
+#pragma unroll
+  for (int j = 0; j < NACC; ++j) bs1[j] = bs2[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const bool bs_on = p.bs_part != nullptr;
+  const bool bs_rebuild = bs_on && p.bs_y == nullptr;
 #pragma unroll
   for (int ps = 0; ps < MF / EP; ++ps) {
     if (ps) __syncthreads();
@@ -217,7 +243,53 @@ __device__ __forceinline__ void c3_epilogue(const C3Args& p, f32x4 (&acc)[MF][NF
           for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
         }
         *reinterpret_cast<f32x4*>(p.out + off + n) = v;
+        if (bs_on) {
+          // the arithmetic of bn_bwd_reduce2_kernel's body, element for element
+          const f32x4 zz = *reinterpret_cast<const f32x4*>(p.bs_z + off + n);
+          const f32x4 mu = *reinterpret_cast<const f32x4*>(p.bs_mean + n);
+          const f32x4 is = *reinterpret_cast<const f32x4*>(p.bs_invstd + n);
+          f32x4 yy;
+          if (bs_rebuild) {
+            const f32x4 sc = is * *reinterpret_cast<const f32x4*>(p.bs_gamma + n);
+            yy = (zz - mu) * sc + *reinterpret_cast<const f32x4*>(p.bs_beta + n);
+          } else {
+            yy = *reinterpret_cast<const f32x4*>(p.bs_y + off + n);
+          }
+          f32x4 gm = v;
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            if (!(yy[j] > 0.f)) gm[j] = 0.f;
+          bs1[k % NACC] += gm;
+          bs2[k % NACC] += gm * (zz - mu) * is;
+        }
       }
+    }
+  }
+  if (bs_on) {
+    // lanes -> column quads in a fixed order (deterministic): every lane parks its NACC pairs in LDS (the staging area is
+    // dead after one more barrier), lane c < NF * 4 adds the entries whose quad is c, lanes in ascending order
+    __syncthreads();
+    f32x4* red = reinterpret_cast<f32x4*>(smem) + (size_t)wave * (NACC * 64 * 2);
+#pragma unroll
+    for (int j = 0; j < NACC; ++j) {
+      red[(j * 64 + lane) * 2 + 0] = bs1[j];
+      red[(j * 64 + lane) * 2 + 1] = bs2[j];
+    }
+    __syncthreads();
+    if (lane < Q4) {
+      f32x4 a1 = (f32x4){0.f, 0.f, 0.f, 0.f}, a2 = a1;
+#pragma unroll
+      for (int j = 0; j < NACC; ++j) {
+        // entries (j, l) with (l + 64 j) % Q4 == lane: l = first, first + Q4, ...
+        const int first = ((lane - (64 * j) % Q4) % Q4 + Q4) % Q4;
+        for (int l = first; l < 64; l += Q4) {
+          a1 += red[(j * 64 + l) * 2 + 0];
+          a2 += red[(j * 64 + l) * 2 + 1];
+        }
+      }
+      float* dst = p.bs_part + ((long)grp * 2) * p.Co + ncol0 + lane * 4;
+      *reinterpret_cast<f32x4*>(dst) = a1;
+      *reinterpret_cast<f32x4*>(dst + p.Co) = a2;
     }
   }
 }

@@ -12,8 +12,8 @@
 // ~300 convolutions of CoAM-W48 and ~75 % of its FLOPs, forward and (with FLIP) data gradient.
 //
 // Structure - direct convolution with an LDS-resident input tile instead of 9 separate im2col gathers:
-//   * pixels are addressed in a zero-padded flattened space  p = n*IB + (y+1)*SW + (x+1),  SW = W+2,
-//     IB = (H+1)*SW : one zero column left/right of every row, one zero row between images.  A filter tap is then
+//   * pixels are addressed in a zero-padded flattened space  p = n*IB + (y+1)*SW + (x+1),  SW = W+1,
+//     IB = (H+1)*SW : one zero column between consecutive rows (c3_common.h: c3_row_width), one zero row between images.  A filter tap is then
 //     a constant shift  (r-1)*SW + (s-1)  of p, valid across row and image boundaries alike;
 //   * a workgroup owns BM consecutive p's and all BN output channels; per channel chunk it stages the
 //     BM + 2*SW + 2 input rows it needs ONCE (fp32 -> bf16 pieces at store time) and all 9 taps read shifted rows of
@@ -227,17 +227,12 @@ __device__ unsigned long long c3_trace_wall[4096][2];   // wall clock (100 MHz) 
 #else
 #define C3_TR(k) do {} while (0)
 #endif
-// PL: the input arrives as x6 planes (x6p.h) - already padded and split by its producer.  Staging a chunk is then a plain
-// 16-byte copy (global -> register -> LDS, still one chunk ahead of the MFMAs): no split arithmetic, no zero-selects, no
-// per-row div/mod - the ~2 VALU instructions per MFMA of the fp32-input variant are gone.
-// EMIT (fp32 input only): also write the staged tiles out as x6 planes (C3Args::planes_out) - a separate instantiation, so
-// that the plain kernels keep their register allocation.
-template <int MF, int NF, int WM, int WN, bool DBUF, bool BPF_, int WPS, bool PL = false, bool EMIT = false>
+template <int MF, int NF, int WM, int WN, bool DBUF, bool BPF_, int WPS>
 __global__ __launch_bounds__(256, WPS) void conv3x3_x6_kernel(C3Args p) {
   constexpr int ROWB = Geo<3>::ROWB, PST = Geo<3>::PST, CPR = Geo<3>::CPR;
   constexpr int BM = WM * MF * 16, BN = WN * NF * 16;
   constexpr int RPP = 256 / CPR;                                 // 64 rows staged per pass
-  constexpr int PA = PL ? ((BM + 2 * MAX_SW + 2 + 31) * 6 + 255) / 256 : (BM + 2 * MAX_SW + 2 + RPP - 1) / RPP;
+  constexpr int PA = (BM + 2 * MAX_SW + 2 + RPP - 1) / RPP;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int arows = p.na * 32;
   const size_t abytes = DBUF ? (size_t)arows * ROWB : 0;         // one A buffer; smem = [DBUF ? 2 : 1][arows][ROWB]
@@ -273,79 +268,29 @@ __global__ __launch_bounds__(256, WPS) void conv3x3_x6_kernel(C3Args p) {
   const bool tr_on = t == 0 && by == 0 && bx % tr_stride == 0;
   const int tr_slot = bx / tr_stride;
 #endif
-  int goff[PL ? 1 : PA];   // fp32 input: global element offset (channel 0) of every staged row of this thread; -1 zero row,
-                           // -2 beyond the tile
-  // PL: the LDS image of a chunk tile is its 16-byte pieces in order, piece i = (row i / 6, j = i % 6); this thread moves
-  // pieces t + 256 q.  Their plane offsets are recomputed when used (a handful of integer operations per 16 bytes)
-  // instead of living in PA registers for the whole kernel.
-  const unsigned char* xpl = nullptr;
-  const int npieces = arows * 6;
-  const int rowb = p.Ci * 6;
-  const int pr0 = t / 6, pj0 = t - pr0 * 6;
-  auto piece_off = [&](int q) -> int {     // q is a compile-time constant wherever this is called
-    int i = t + 256 * q;
-    int row = pr0 + 42 * q, j = pj0 + 4 * q;
-    row += j / 6;
-    j -= (j / 6) * 6;
-    if (i >= npieces) { row = arows - 1; j = 5; }   // clamped: the load stays in bounds, the store is skipped
-    return (p0 - halo + row) * rowb + j * 16;
-  };
-  if constexpr (PL) {
-    xpl = reinterpret_cast<const unsigned char*>(p.x) + (size_t)X6P_GB * rowb;
-  } else {
+  // global element offset (channel 0) of every staged row of this thread; -1 zero row, -2 beyond the tile
+  int goff[PA];
 #pragma unroll
-    for (int q = 0; q < PA; ++q) {
-      const int row = prow + RPP * q;
-      const int pp = p0 - halo + row;
-      int o = row < arows ? -1 : -2;
-      if (row < arows && pp >= 0 && pp < p.P) {
-        const int n = fast_div(pp, p.ib_mul, p.ib_sh);
-        const int rem = pp - n * p.IB;
-        const int yy = fast_div(rem, p.sw_mul, p.sw_sh);
-        const int xx = rem - yy * p.SW;
-        if (n < p.N && yy >= 1 && xx >= 1 && xx <= p.W) o = ((n * p.H + yy - 1) * p.W + xx - 1) * p.Ci;
-      }
-      goff[q] = o;
+  for (int q = 0; q < PA; ++q) {
+    const int row = prow + RPP * q;
+    const int pp = p0 - halo + row;
+    int o = row < arows ? -1 : -2;
+    if (row < arows && pp >= 0 && pp < p.P) {
+      const int n = fast_div(pp, p.ib_mul, p.ib_sh);
+      const int rem = pp - n * p.IB;
+      const int yy = fast_div(rem, p.sw_mul, p.sw_sh);
+      const int xx = rem - yy * p.SW;
+      if (n < p.N && yy >= 1 && xx >= 1 && xx <= p.W) o = ((n * p.H + yy - 1) * p.W + xx - 1) * p.Ci;
     }
+    goff[q] = o;
   }
-  // PL + DBUF: the tile of chunk ch+1 is copied in NBT = 4 time slices during the steps of chunk ch (slice b loaded in step
-  // b, stored in step b + 1), so that only QB pieces are in registers at any time
-  constexpr int NBT = 4;
-  constexpr int QB = (PA + NBT - 1) / NBT;
-  f32x4 areg[(PL && DBUF) ? QB : PA];
-  auto load_slice = [&](int c0, int b) {
-    const unsigned char* src = xpl + (c0 >> 4) * 96;
-#pragma unroll
-    for (int u = 0; u < QB; ++u)
-      if (b * QB + u < PA && 256 * (b * QB + u) < npieces) areg[u] = *reinterpret_cast<const f32x4*>(src + piece_off(b * QB + u));
-  };
-  auto store_slice = [&](unsigned char* At, int b) {
-#pragma unroll
-    for (int u = 0; u < QB; ++u)
-      if (b * QB + u < PA && t + 256 * (b * QB + u) < npieces)
-        *reinterpret_cast<f32x4*>(At + (size_t)(t + 256 * (b * QB + u)) * 16) = areg[u];
-  };
+  f32x4 areg[PA];
   auto load_a = [&](int c0) {
-    if constexpr (PL && !DBUF) {
-      const unsigned char* src = xpl + (c0 >> 4) * 96;
 #pragma unroll
-      for (int q = 0; q < PA; ++q)
-        if (256 * q < npieces) areg[q] = *reinterpret_cast<const f32x4*>(src + piece_off(q));
-    } else if constexpr (!PL) {
-#pragma unroll
-      for (int q = 0; q < PA; ++q)
-        if (RPP * q < arows) areg[q] = *reinterpret_cast<const f32x4*>(p.x + (goff[q] >= 0 ? goff[q] + c0 + c4 : 0));
-    }
+    for (int q = 0; q < PA; ++q)
+      if (RPP * q < arows) areg[q] = *reinterpret_cast<const f32x4*>(p.x + (goff[q] >= 0 ? goff[q] + c0 + c4 : 0));
   };
   auto store_a = [&](unsigned char* At, int c0) {
-    if constexpr (PL) {
-      if constexpr (!DBUF) {
-#pragma unroll
-        for (int q = 0; q < PA; ++q)
-          if (t + 256 * q < npieces) *reinterpret_cast<f32x4*>(At + (size_t)(t + 256 * q) * 16) = areg[q];
-      }
-      return;
-    } else {
     f32x4 mu, sc, be;
     if (p.in_mean) {
       mu = *reinterpret_cast<const f32x4*>(p.in_mean + c0 + c4);
@@ -368,7 +313,6 @@ __global__ __launch_bounds__(256, WPS) void conv3x3_x6_kernel(C3Args p) {
         }
         split_store<3, PST>(At + (size_t)(prow + RPP * q) * ROWB, c4, v);
       }
-    }
   };
 
   // B fragments of this lane: image [step][Co/16][3][64][16 B]
@@ -415,32 +359,12 @@ __global__ __launch_bounds__(256, WPS) void conv3x3_x6_kernel(C3Args p) {
   };
   auto run_chunk = [&](int ch) {
     const unsigned char* abase = smem + (ch & 1) * abytes + aoff;
-    if constexpr (EMIT && !PL) {
-      if (by == 0) {
-        // the tile of this chunk is complete in LDS: rows [halo, halo + BM) are the planes rows of this workgroup's
-        // positions, chunk ch - 16-byte pieces straight from LDS to the planes (no arithmetic); a rolled loop, four
-        // pieces in flight: the registers of the MFMA loop are all taken
-        const int orowb = p.Ci * 6;
-        const unsigned char* src = smem + (ch & 1) * abytes + (size_t)halo * ROWB;
-        unsigned char* dst = p.planes_out + ((size_t)X6P_GB + p0) * orowb + ch * 96;
-        constexpr int NQ = (BM * 6 + 255) / 256;
-#pragma unroll 3
-        for (int q = 0; q < NQ; ++q) {
-          const int i = t + 256 * q;
-          if (BM * 6 % 256 == 0 || i < BM * 6) {
-            const int row = (i * 43691) >> 18, j = i - row * 6;        // i / 6 for i < 8192
-            *reinterpret_cast<f32x4*>(dst + (size_t)row * orowb + j * 16) = *reinterpret_cast<const f32x4*>(src + (size_t)i * 16);
-          }
-        }
-        __builtin_amdgcn_sched_barrier(0);
-      }
-    }
 #pragma unroll
     for (int i = 0; i < AD; ++i) read_a(abase, i, a[i]);
 #pragma unroll
     for (int s = 0; s < 5; ++s) {
       if (ch == 1) C3_TR(50 + s);
-      if (!PL && DBUF && s == 2 && ch + 1 < nchunks) {    // next chunk: registers -> pieces -> the other A buffer
+      if (DBUF && s == 2 && ch + 1 < nchunks) {    // next chunk: registers -> pieces -> the other A buffer
         // done while the fewest registers are live (no B prefetch in flight, no A fragments): the split needs ~60
         if (ch == 1) C3_TR(56);
         store_a(smem + ((ch + 1) & 1) * abytes, (ch + 1) * 16);
@@ -460,18 +384,7 @@ __global__ __launch_bounds__(256, WPS) void conv3x3_x6_kernel(C3Args p) {
       } else {
         load_b(gs, bc);          // 144 MFMAs per step: the fetch latency is small against them, the registers are not
       }
-      if constexpr (PL && DBUF) {
-        // planes input: slice s - 1 of the next chunk's tile (loaded a step ago, behind that step's B prefetch) goes to
-        // the other A buffer, then slice s is requested - again behind this step's B prefetch, so that the next step's
-        // wait for its B fragments leaves it in flight
-        if (ch + 1 < nchunks) {
-          __builtin_amdgcn_sched_barrier(0);
-          if (s >= 1) store_slice(smem + ((ch + 1) & 1) * abytes, s - 1);
-          if (s < NBT) load_slice((ch + 1) * 16, s);
-          __builtin_amdgcn_sched_barrier(0);
-        }
-      }
-      if (!PL && DBUF && s == 2 && ch + 2 < nchunks) {
+      if (DBUF && s == 2 && ch + 2 < nchunks) {
         // the global loads of chunk ch+2 go out BEHIND this step's B prefetch: vector loads return in order, so the next
         // step's wait for its B fragments (older) leaves them in flight, and only the wait two steps on needs them -
         // issued in front of the prefetch they put their whole HBM latency into the very next step
@@ -507,21 +420,11 @@ __global__ __launch_bounds__(256, WPS) void conv3x3_x6_kernel(C3Args p) {
   const unsigned tr_lin = blockIdx.y * gridDim.x + blockIdx.x;
   if (t == 0 && tr_lin < 4096) c3_trace_wall[tr_lin][0] = wall_clock64();
 #endif
-  if constexpr (PL && DBUF) {
-    if constexpr (BPF) load_b(0, bn);
-    if constexpr (BPF2) load_b(last_step > 0 ? 1 : 0, bn2);
-#pragma unroll
-    for (int b = 0; b < NBT; ++b) {
-      load_slice(0, b);
-      store_slice(smem, b);
-    }
-  } else {
-    load_a(0);
-    if constexpr (BPF) load_b(0, bn);
-    if constexpr (BPF2) load_b(last_step > 0 ? 1 : 0, bn2);
-    store_a(smem, 0);
-    if (nchunks > 1) load_a(16);
-  }
+  load_a(0);
+  if constexpr (BPF) load_b(0, bn);
+  if constexpr (BPF2) load_b(last_step > 0 ? 1 : 0, bn2);
+  store_a(smem, 0);
+  if (nchunks > 1) load_a(16);
   __syncthreads();
   C3_TR(1);
   for (int ch = 0; ch < nchunks; ++ch) {
@@ -666,10 +569,10 @@ struct C3Plan { int MF, NF, WM, WN, BM, BN, na, lean; size_t lds; };
 
 static int c3_steps(int Kc, int np) { return np == 3 ? (Kc / 16) * 5 : (Kc / CK) * 9 + ((Kc % CK) ? 5 : 0); }
 
-static bool c3_plan(int np, int N, int H, int W, int Ci, int Co, C3Plan* pl, bool planes_in = false) {
-  if (N <= 0 || H <= 0 || W <= 0 || Ci <= 0 || Co <= 0 || Ci % 16 != 0 || Co % 16 != 0 || W + 2 > MAX_SW) return false;
+static bool c3_plan(int np, int N, int H, int W, int Ci, int Co, C3Plan* pl) {
+  if (N <= 0 || H <= 0 || W <= 0 || Ci <= 0 || Co <= 0 || Ci % 16 != 0 || Co % 16 != 0 || c3_row_width(W) > MAX_SW) return false;
   const int rowb = np == 3 ? Geo<3>::ROWB : Geo<2>::ROWB, blds = np == 3 ? Geo<3>::BLDS : Geo<2>::BLDS;
-  const long P = (long)N * (H + 1) * (W + 2) + (W + 2);
+  const long P = (long)N * (H + 1) * c3_row_width(W) + c3_row_width(W);
   int nf, wn;
   if (Co % 96 == 0) { nf = 3; wn = 2; }
   else if (Co % 48 == 0) { nf = 3; wn = 1; }
@@ -692,7 +595,7 @@ static bool c3_plan(int np, int N, int H, int W, int Ci, int Co, C3Plan* pl, boo
     const long blocks = ((P + wm * cand[i] * 16 - 1) / (wm * cand[i] * 16)) * (Co / bn);
     // bf16x6 fetches its B fragments per wave, one step ahead: a 16-row wave tile (MF = 1) leaves 18 MFMAs to cover an
     // L2 round trip, so the smallest maps (384 ch @12x9: 288 workgroups at MF = 2) prefer the larger tile (measured)
-    if (blocks >= (np == 3 ? 240 : 320)) { mf = cand[i]; break; }
+    if (blocks >= (np == 3 ? 224 : 320)) { mf = cand[i]; break; }   // (238 for the 192-channel 24x18 maps at N = 32)
   }
   bool single = false;
   pl->lean = 0;
@@ -700,9 +603,13 @@ static bool c3_plan(int np, int N, int H, int W, int Ci, int Co, C3Plan* pl, boo
     // 512-position tiles in ONE round of workgroups (2 resident per CU = 512 slots) instead of 1.75 rounds of
     // 256-position tiles: the 48-channel branch at N*H*W >= ~115k positions (single A buffer: 64.5 KB at W = 72)
     const long b8 = (P + 511) / 512;
-    // (planes input: the 64 + 4 registers of a single-buffered 512-position tile's prefetch do not fit; the double-buffered
-    // 256-position tile stages in four small time slices instead)
-    if (b8 > 256 && b8 <= 512 && !planes_in) { mf = 8; single = true; }
+    if (b8 > 256 && b8 <= 512) {
+      mf = 8; single = true;
+      // the launch is ONE round of workgroups on 512 slots and a CU's two workgroups share its matrix pipe, so the launch
+      // lasts as long as a CU with two tiles: 448-position tiles (MF = 7) fill all 512 slots with 7/8 of the work each
+      // where 512-position tiles leave 63 slots empty (N = 32 @ 96x72: 449 -> 512 workgroups)
+      if ((P + 447) / 448 <= 512) mf = 7;
+    }
 #ifdef BUCTD_TUNING      // experiment builds only (scratch/build_trace_lib.sh): 3 lean workgroups per CU instead
     static const int lean_env = getenv("BUCTD_C3_LEAN") ? atoi(getenv("BUCTD_C3_LEAN")) : 0;
     if (lean_env && mf == 8) { mf = 4; pl->lean = 1; }
@@ -712,13 +619,14 @@ static bool c3_plan(int np, int N, int H, int W, int Ci, int Co, C3Plan* pl, boo
   if (const char* f = getenv("BUCTD_C3_FORCE")) {
     int fm = 0, fn = 0, fw = 0;
     if (np == 3 && sscanf(f, "%d,%d,%d", &fm, &fn, &fw) == 3 && (fw == 1 || fw == 2) && Co % (fn * 16 * fw) == 0) {
-      mf = fm; nf = fn; wn = fw; wm = 4 / wn; bn = wn * nf * 16; single = mf == 8; pl->lean = 0;
+      mf = fm; nf = fn; wn = fw; wm = 4 / wn; bn = wn * nf * 16; single = mf >= 7; pl->lean = 0;
     }
   }
 #endif
   pl->MF = mf; pl->NF = nf; pl->WM = wm; pl->WN = wn; pl->BM = wm * mf * 16; pl->BN = bn;
-  pl->na = (pl->BM + 2 * (W + 2) + 2 + 31) / 32;
-  const size_t stage = (size_t)4 * (mf >= 2 ? 2 : 1) * 16 * (nf * 16 + 4) * 4 + 4 * 128 * 4;   // epilogue staging + row offsets
+  pl->na = (pl->BM + 2 * c3_row_width(W) + 2 + 31) / 32;
+  size_t stage = (size_t)4 * (mf >= 2 ? 2 : 1) * 16 * (nf * 16 + 4) * 4 + 4 * 128 * 4;   // epilogue staging + row offsets
+  if (np == 3 && stage < (size_t)4 * 3 * 64 * 2 * 16) stage = (size_t)4 * 3 * 64 * 2 * 16;      // ... or the bs_part reduction scratch
   if (np == 3) {            // two A buffers (one for the 512-position tiles), no B stage
     const int nb = (single || pl->lean) ? 1 : 2;
     while ((size_t)nb * pl->na * 32 * rowb < stage) ++pl->na;
@@ -733,22 +641,12 @@ static bool c3_plan(int np, int N, int H, int W, int Ci, int Co, C3Plan* pl, boo
 static bool c3_np_ok(int np) { return np == 2 || np == 3; }
 
 template <int NP, int MF, int NF, int WM, int WN>
-static int c3_launch(const C3Args& a, const C3Plan& pl, hipStream_t st, bool planes_in) {
-  static bool attr_done[7] = {false, false, false, false, false, false, false};   // idempotent attribute call: a race at first use only repeats it
+static int c3_launch(const C3Args& a, const C3Plan& pl, hipStream_t st) {
+  static bool attr_done[3] = {false, false, false};   // idempotent attribute call: a race at first use only repeats it
   void (*fn)(C3Args);
   int variant = 0;
   if constexpr (NP == 3) {
-    if (planes_in) {
-      if constexpr (MF >= 8) {
-        buctd_set_error("conv3x3 (bf16x6, planes input): no 512-position tile variant");
-        return BUCTD_EINVAL;
-      } else { fn = conv3x3_x6_kernel<MF, NF, WM, WN, true, true, 2, true>; variant = 4; }
-    }
-    else if (a.planes_out) {
-      if (MF >= 8) { fn = conv3x3_x6_kernel<MF, NF, WM, WN, false, false, 2, false, true>; variant = 5; }
-      else { fn = conv3x3_x6_kernel<MF, NF, WM, WN, true, true, 2, false, true>; variant = 6; }
-    }
-    else if (MF >= 8) fn = conv3x3_x6_kernel<MF, NF, WM, WN, false, false, 2>;
+    if (MF >= 7) fn = conv3x3_x6_kernel<MF, NF, WM, WN, false, false, 2>;
 #ifdef BUCTD_TUNING
     else if (pl.lean) { fn = conv3x3_x6_kernel<MF, NF, WM, WN, false, false, 3>; variant = 1; }
 #endif
@@ -772,11 +670,11 @@ static int c3_launch(const C3Args& a, const C3Plan& pl, hipStream_t st, bool pla
 }
 
 template <int NP>
-static int c3_dispatch(const C3Args& a, const C3Plan& pl, hipStream_t st, bool planes_in = false) {
+static int c3_dispatch(const C3Args& a, const C3Plan& pl, hipStream_t st) {
 #define C3_CASE(mf, nf, wm, wn) \
-  if (pl.MF == mf && pl.NF == nf && pl.WN == wn) return c3_launch<NP, mf, nf, wm, wn>(a, pl, st, planes_in);
+  if (pl.MF == mf && pl.NF == nf && pl.WN == wn) return c3_launch<NP, mf, nf, wm, wn>(a, pl, st);
 #define C3_MF(nf, wm, wn) C3_CASE(4, nf, wm, wn) C3_CASE(2, nf, wm, wn) C3_CASE(1, nf, wm, wn)
-  if constexpr (NP == 3) { C3_CASE(8, 3, 4, 1) C3_CASE(8, 3, 2, 2) }
+  if constexpr (NP == 3) { C3_CASE(8, 3, 4, 1) C3_CASE(7, 3, 4, 1) C3_CASE(8, 3, 2, 2) }
   C3_MF(1, 4, 1) C3_MF(2, 4, 1) C3_MF(3, 4, 1) C3_MF(3, 2, 2)
   C3_CASE(2, 4, 4, 1) C3_CASE(1, 4, 4, 1) C3_CASE(2, 4, 2, 2) C3_CASE(1, 4, 2, 2)
 #undef C3_MF
@@ -799,12 +697,11 @@ static int c3_supported(int np, int N, int H, int W, int Ci, int Co) {
   return c3_np_ok(np) && c3_plan(np, N, H, W, Ci, Co, &pl) ? 1 : 0;
 }
 
-static int c3_stats_groups(int np, int N, int H, int W, int Ci, int Co, int* ngroups, int* rows_per_group,
-                           bool planes_in = false) {
+static int c3_stats_groups(int np, int N, int H, int W, int Ci, int Co, int* ngroups, int* rows_per_group) {
   C3Plan pl;
-  BUCTD_CHECK_ARG(ngroups && rows_per_group && c3_np_ok(np) && c3_plan(np, N, H, W, Ci, Co, &pl, planes_in),
+  BUCTD_CHECK_ARG(ngroups && rows_per_group && c3_np_ok(np) && c3_plan(np, N, H, W, Ci, Co, &pl),
                   "buctd_conv3x3_*_stats_groups: unsupported shape");
-  const long P = (long)N * (H + 1) * (W + 2) + (W + 2);
+  const long P = (long)N * (H + 1) * c3_row_width(W) + c3_row_width(W);
   *ngroups = ceil_div(P, pl.BM) * pl.WM;
   *rows_per_group = pl.MF * 16;
   return BUCTD_OK;
@@ -836,14 +733,16 @@ static int c3_prep(int np, int Ci, int Co, const float* w, int flip, void* wprep
 // Data gradient of a forward conv (CiF -> CoF): x = dy ([N][H][W][CoF]), y = dx ([N][H][W][CiF]), i.e. this call's
 // Ci = CoF, Co = CiF, and wprep = prep(CiF, CoF, w, 1).
 struct C3InBn { const float* mean; const float* invstd; const float* gamma; const float* beta; int relu; };
+// BatchNorm-backward reduction as a by-product of a data-gradient launch (C3Args::bs_*)
+struct C3BwdStat { const float* z; const float* y; const float* mean; const float* invstd; const float* gamma; const float* beta; float* part; };
 
 static int c3_run(int np, int N, int H, int W, int Ci, int Co, const float* x, const void* wprep, const float* bias,
                   const float* scale, const float* shift, const float* residual, int relu, float* y,
                   float* stats_partials, int* stats_counts, void* stream, const C3InBn* in_bn = nullptr,
-                  bool planes_in = false, void* planes_out = nullptr) {
+                  const C3BwdStat* bst = nullptr) {
   C3Plan pl;
   BUCTD_CHECK_ARG(x && wprep && y, "buctd_conv3x3 (split bf16): null tensor pointer");
-  BUCTD_CHECK_ARG(c3_np_ok(np) && c3_plan(np, N, H, W, Ci, Co, &pl, planes_in),
+  BUCTD_CHECK_ARG(c3_np_ok(np) && c3_plan(np, N, H, W, Ci, Co, &pl),
                   "buctd_conv3x3 (split bf16): unsupported shape N%d H%d W%d Ci%d Co%d", N, H, W, Ci, Co);
   BUCTD_CHECK_ARG((scale == nullptr) == (shift == nullptr), "buctd_conv3x3 (split bf16): scale and shift go together");
   BUCTD_CHECK_ARG((stats_partials == nullptr) == (stats_counts == nullptr),
@@ -852,16 +751,13 @@ static int c3_run(int np, int N, int H, int W, int Ci, int Co, const float* x, c
   a.x = x; a.wp = (const unsigned char*)wprep; a.out = y; a.bias = bias; a.scale = scale; a.shift = shift;
   a.res = residual; a.stats = stats_partials; a.counts = stats_counts;
   a.N = N; a.H = H; a.W = W; a.Ci = Ci; a.Co = Co;
-  a.SW = W + 2; a.IB = (H + 1) * (W + 2);
+  a.SW = c3_row_width(W); a.IB = (H + 1) * a.SW;
   const long P = (long)N * a.IB + a.SW;
   BUCTD_CHECK_ARG(P < 2147483647L && (long)N * H * W * (Ci > Co ? Ci : Co) < 2147483647L,
                   "buctd_conv3x3 (split bf16): tensor too large");
   a.P = (int)P;
   a.relu = relu; a.na = pl.na;
-  a.planes_out = (unsigned char*)planes_out;
   a.omap = 0; a.oH = H; a.oW = W; a.ost = 1; a.oy0 = a.ox0 = 0;
-  BUCTD_CHECK_ARG(!planes_out || (np == 3 && !planes_in), "buctd_conv3x3: the planes by-product is a feature of the fp32-input bf16x6 kernel");
-  BUCTD_CHECK_ARG(!planes_out || (P + X6P_GB + X6P_GA) * (long)Ci * 6 < 2147483647L, "buctd_conv3x3: tensor too large for planes");
   a.in_mean = a.in_invstd = a.in_gamma = a.in_beta = nullptr;
   a.in_relu = 0;
   if (in_bn && in_bn->mean) {
@@ -870,17 +766,21 @@ static int c3_run(int np, int N, int H, int W, int Ci, int Co, const float* x, c
     a.in_mean = in_bn->mean; a.in_invstd = in_bn->invstd; a.in_gamma = in_bn->gamma; a.in_beta = in_bn->beta;
     a.in_relu = in_bn->relu;
   }
+  a.bs_z = a.bs_y = a.bs_mean = a.bs_invstd = a.bs_gamma = a.bs_beta = nullptr;
+  a.bs_part = nullptr;
+  if (bst && bst->part) {
+    BUCTD_CHECK_ARG(np == 3 && bst->z && bst->mean && bst->invstd && (bst->y || (bst->gamma && bst->beta)),
+                    "buctd_conv3x3: the BatchNorm-backward by-product needs the bf16x6 kernel, z, mean, invstd and y or gamma + beta");
+    a.bs_z = bst->z; a.bs_y = bst->y; a.bs_mean = bst->mean; a.bs_invstd = bst->invstd; a.bs_gamma = bst->gamma;
+    a.bs_beta = bst->beta; a.bs_part = bst->part;
+  }
   a.col_major = (np == 3 && Co / pl.BN >= 2 && (size_t)c3_steps(Ci, 3) * Co * Geo<3>::BROW > ((size_t)3 << 20)) ? 1 : 0;
 #ifdef BUCTD_TUNING
   if (const char* f = getenv("BUCTD_C3_COLMAJOR")) a.col_major = np == 3 && atoi(f) != 0;
 #endif
   magic_u32((unsigned)a.IB, &a.ib_mul, &a.ib_sh);
   magic_u32((unsigned)a.SW, &a.sw_mul, &a.sw_sh);
-  if (planes_in) {
-    BUCTD_CHECK_ARG(np == 3 && !a.in_mean, "buctd_conv3x3_bf16x6_p: planes input is a bf16x6 feature without input BatchNorm");
-    BUCTD_CHECK_ARG((P + X6P_GB + X6P_GA) * (long)Ci * 6 < 2147483647L, "buctd_conv3x3_bf16x6_p: tensor too large");
-  }
-  return np == 3 ? c3_dispatch<3>(a, pl, (hipStream_t)stream, planes_in) : c3_dispatch<2>(a, pl, (hipStream_t)stream);
+  return np == 3 ? c3_dispatch<3>(a, pl, (hipStream_t)stream) : c3_dispatch<2>(a, pl, (hipStream_t)stream);
 }
 
 // ---- "bf16x3" (NP = 2) entry points --------------------------------------------------------------------------
@@ -929,28 +829,17 @@ extern "C" int buctd_conv3x3_bf16x6_bnin(int N, int H, int W, int Ci, int Co, co
   return c3_run(3, N, H, W, Ci, Co, x, wprep, bias, scale, shift, residual, relu, y, stats_partials, stats_counts, stream, &b);
 }
 
-extern "C" int buctd_conv3x3_bf16x6_p_stats_groups(int N, int H, int W, int Ci, int Co, int* ngroups, int* rows_per_group) {
-  return c3_stats_groups(3, N, H, W, Ci, Co, ngroups, rows_per_group, true);
-}
-/* buctd_conv3x3_bf16x6 with the INPUT given as x6 planes (csrc/x6p.h, buctd_x6p_bytes): the producer already padded and
- * split it, the kernel stages it with plain 16-byte copies.  Same tiling, same MFMA order: bit-identical results. */
-extern "C" int buctd_conv3x3_bf16x6_p(int N, int H, int W, int Ci, int Co, const void* x_planes, const void* wprep,
-                                      const float* bias, const float* scale, const float* shift, const float* residual,
-                                      int relu, float* y, float* stats_partials, int* stats_counts, void* stream) {
-  return c3_run(3, N, H, W, Ci, Co, (const float*)x_planes, wprep, bias, scale, shift, residual, relu, y, stats_partials,
-                stats_counts, stream, nullptr, true);
-}
-
-/* buctd_conv3x3_bf16x6(_bnin) (no bias / eval scale / residual / ReLU: the BasicBlock use) that also writes what it staged -
- * x, or relu?((x - mean) * (invstd * gamma) + beta) when in_mean != NULL - as x6 planes into x_planes_out (allocation
- * base of buctd_x6p_bytes(N, H, W, Ci) bytes whose non-pixel rows are zero or will be overwritten with zeros): the operand
- * of this convolution's weight gradient (buctd_conv3x3_wgrad_bf16x6_p), produced by the pass that splits it anyway. */
-extern "C" int buctd_conv3x3_bf16x6_emit(int N, int H, int W, int Ci, int Co, const float* x, const void* wprep, float* y,
-                                         float* stats_partials, int* stats_counts, const float* in_mean,
-                                         const float* in_invstd, const float* in_gamma, const float* in_beta, int in_relu,
-                                         void* x_planes_out, void* stream) {
-  C3InBn b{in_mean, in_invstd, in_gamma, in_beta, in_relu};
-  BUCTD_CHECK_ARG(x_planes_out, "buctd_conv3x3_bf16x6_emit: null planes pointer");
-  return c3_run(3, N, H, W, Ci, Co, x, wprep, nullptr, nullptr, nullptr, nullptr, 0, y, stats_partials, stats_counts, stream,
-                in_mean ? &b : nullptr, false, x_planes_out);
+/* Data gradient of a 3x3 convolution (buctd_conv3x3_bf16x6 on the flipped image, residual = the skip gradient) that also
+ * forms the reduction pass of the BatchNorm backward consuming its output g = dx: per row group (the groups of
+ * buctd_conv3x3_bf16x6_stats_groups(N, H, W, Ci, Co)) s1 = sum m g, s2 = sum m g zhat with m the ReLU mask of that
+ * BatchNorm's forward output (bn_y > 0 where given, else rebuilt from bn_z with gamma / beta) - bn_part [groups][2][Co],
+ * the input of buctd_bn_bwd_from_partials.  Replaces the separate pass over g, z and y (bn.hip: bn_bwd_reduce2_kernel). */
+extern "C" int buctd_conv3x3_bf16x6_bnstat(int N, int H, int W, int Ci, int Co, const float* x, const void* wprep,
+                                           const float* residual, float* y, const float* bn_z, const float* bn_y,
+                                           const float* bn_mean, const float* bn_invstd, const float* bn_gamma,
+                                           const float* bn_beta, float* bn_part, void* stream) {
+  C3BwdStat b{bn_z, bn_y, bn_mean, bn_invstd, bn_gamma, bn_beta, bn_part};
+  BUCTD_CHECK_ARG(bn_part, "buctd_conv3x3_bf16x6_bnstat: null partials pointer");
+  return c3_run(3, N, H, W, Ci, Co, x, wprep, nullptr, nullptr, nullptr, residual, 0, y, nullptr, nullptr, stream, nullptr,
+                &b);
 }

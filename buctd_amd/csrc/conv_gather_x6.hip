@@ -442,7 +442,8 @@ static int gc_run(int kind, int dir, int N, int H, int W, int Ci, int Co, const 
   e.SW = Wg + 2; e.IB = (Hg + 1) * (Wg + 2);
   e.P = (int)((long)N * e.IB + e.SW);
   e.relu = relu; e.na = 0;
-  e.in_mean = e.in_invstd = e.in_gamma = e.in_beta = nullptr; e.in_relu = 0; e.col_major = 0; e.planes_out = nullptr;
+  e.in_mean = e.in_invstd = e.in_gamma = e.in_beta = nullptr; e.in_relu = 0; e.col_major = 0;
+  e.bs_z = e.bs_y = e.bs_mean = e.bs_invstd = e.bs_gamma = e.bs_beta = nullptr; e.bs_part = nullptr;
   magic_u32((unsigned)e.IB, &e.ib_mul, &e.ib_sh);
   magic_u32((unsigned)e.SW, &e.sw_mul, &e.sw_sh);
   const bool par = kind == 2 && dir;
@@ -481,12 +482,18 @@ static int gc_run(int kind, int dir, int N, int H, int W, int Ci, int Co, const 
 extern "C" int buctd_gconv_x6_fwd(int kind, int N, int H, int W, int Ci, int Co, const float* x, const void* wprep,
                                   const float* bias, const float* scale, const float* shift, const float* residual, int relu,
                                   float* y, float* stats_partials, int* stats_counts, void* stream) {
+#ifdef WHATIF_SKIP_GCONV     // what-if builds only
+  return BUCTD_OK;
+#endif
   return gc_run(kind, 0, N, H, W, Ci, Co, x, wprep, bias, scale, shift, residual, relu, y, stats_partials, stats_counts, stream,
                 "buctd_gconv_x6_fwd");
 }
 
 extern "C" int buctd_gconv_x6_dgrad(int kind, int N, int H, int W, int Ci, int Co, const float* dy, const void* wprep,
                                     const float* residual, float* dx, void* stream) {
+#ifdef WHATIF_SKIP_GCONV
+  return BUCTD_OK;
+#endif
   return gc_run(kind, 1, N, H, W, Ci, Co, dy, wprep, nullptr, nullptr, nullptr, residual, 0, dx, nullptr, nullptr, stream,
                 "buctd_gconv_x6_dgrad");
 }

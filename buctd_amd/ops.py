@@ -477,142 +477,6 @@ def _gconv_fwd(x, w, d, bias, scale, shift, residual, relu, stats):
     return (y, part, info) if stats else y
 
 
-# ---- x6 planes (csrc/x6p.h): activations stored pre-split + zero-padded for the bf16x6 3x3 kernels ---------------------
-class Planes:
-    """A [N, H, W, C] activation as x6 planes: `buf` is the uint8 allocation (guards + padded rows, 6 bytes / element)."""
-    __slots__ = ("buf", "shape")
-
-    def __init__(self, buf, shape):
-        self.buf, self.shape = buf, tuple(shape)
-
-    def record_stream(self, stream):
-        self.buf.record_stream(stream)
-
-
-def planes_bytes(shape):
-    N, H, W, Cn = shape
-    return _memo(("x6pb", N, H, W, Cn), lambda: int(lib().buctd_x6p_bytes(N, H, W, Cn)))
-
-
-def planes_ok(shape):
-    """True when a [N, H, W, C] activation can be stored as planes (C % 16 == 0, within the kernels' 32-bit offsets)."""
-    return shape[3] % 16 == 0 and planes_bytes(shape) > 0
-
-
-def to_planes(x, bn=None, out=None):
-    """planes of x, or of relu?(bn(x)) for bn = (mean, invstd, gamma, beta, relu) - the value conv_fwd(in_bn=...) stages."""
-    _f32(x, "to_planes input")
-    N, H, W, Cn = x.shape
-    if out is None:
-        out = Planes(torch.empty(planes_bytes(x.shape), dtype=torch.uint8, device=x.device), x.shape)
-    mean = invstd = gamma = beta = None
-    relu = 0
-    if bn is not None:
-        mean, invstd, gamma, beta, relu = bn
-    check(lib().buctd_x6p_from_nhwc(N, H, W, Cn, ptr(x), ptr(mean), ptr(invstd), ptr(gamma), ptr(beta), int(bool(relu)),
-                                    ptr(out.buf), stream_ptr()), "x6p_from_nhwc")
-    return out
-
-
-def from_planes(pl):
-    N, H, W, Cn = pl.shape
-    x = torch.empty(pl.shape, dtype=torch.float32, device=pl.buf.device)
-    check(lib().buctd_x6p_to_nhwc(N, H, W, Cn, ptr(pl.buf), ptr(x), stream_ptr()), "x6p_to_nhwc")
-    return x
-
-
-def conv3x3_planes(xp, w, flip, cout, bias=None, scale=None, shift=None, residual=None, relu=False, stats=False):
-    """3x3 / s1 / p1 convolution (flip = 0) or data gradient (flip = 1) of an input given as planes (bf16x6)."""
-    N, H, W, cin = xp.shape
-    wp = _conv3x3_prepared(w, flip)
-    y = torch.empty((N, H, W, cout), dtype=torch.float32, device=xp.buf.device)
-    part = counts = info = None
-    if stats:
-        def groups():
-            ng, rpg = C.c_int(), C.c_int()
-            check(lib().buctd_conv3x3_bf16x6_p_stats_groups(N, H, W, cin, cout, C.byref(ng), C.byref(rpg)), "conv3x3_p groups")
-            return ng.value, rpg.value
-        ngv, rpgv = _memo(("c3pgrp", N, H, W, cin, cout), groups)
-        part = torch.empty((ngv, cout, 2), dtype=torch.float32, device=y.device)
-        counts = torch.empty(ngv, dtype=torch.int32, device=y.device)
-        info = (ngv, rpgv, counts)
-    check(lib().buctd_conv3x3_bf16x6_p(N, H, W, cin, cout, ptr(xp.buf), ptr(wp), ptr(bias), ptr(scale), ptr(shift),
-                                       ptr(residual), int(bool(relu)), ptr(y), ptr(part), ptr(counts), stream_ptr()),
-          "conv3x3_bf16x6_p")
-    return (y, part, info) if stats else y
-
-
-def wgrad_planes_ok(N, H, W, Ci, Co):
-    return _memo(("wg4ok", N, H, W, Ci, Co), lambda: lib().buctd_conv3x3_wgrad_bf16x6_p_supported(N, H, W, Ci, Co) == 1)
-
-
-def conv_wgrad_planes(xp, dyp, out, accumulate=0):
-    """3x3 weight gradient from both operands as planes; out: channels_last OIHW gradient tensor."""
-    N, H, W, Ci = xp.shape
-    Co = dyp.shape[3]
-    weight_rsc(out)
-    need = _memo(("wg4ws", N, H, W, Ci, Co), lambda: int(lib().buctd_conv3x3_wgrad_bf16x6_p_workspace(N, H, W, Ci, Co)))
-    ws = workspace(need, out.device)
-    check(lib().buctd_conv3x3_wgrad_bf16x6_p(N, H, W, Ci, Co, ptr(xp.buf), ptr(dyp.buf), ptr(out), int(accumulate), ptr(ws),
-                                             ws.numel(), stream_ptr()), "conv3x3_wgrad_bf16x6_p")
-    return out
-
-
-class _PlanesPool:
-    """Planes buffers whose NON-PIXEL rows (pads, guards) are zero and stay zero: they are created with torch.zeros and every
-    kernel that writes them writes pixel rows only, or pad rows as zeros (csrc/x6p.h).  Keeping them in a pool instead of
-    returning them to the caching allocator is what preserves that invariant without a memset per use.
-    Stream safety: buffers saved from a forward pass for its backward (acquire / release) are reused by the NEXT forward
-    pass at the earliest - after the end-of-backward join of the weight-gradient stream; scratch sets used inside a
-    backward pass (scratch / scratch_done) rotate through a ring and carry the event of their last reader."""
-
-    def __init__(self, ring=3):
-        self.free = {}
-        self.rings = {}
-        self.ring = ring
-
-    def acquire(self, shape, device):
-        key = (device.index, tuple(shape))
-        lst = self.free.get(key)
-        if lst:
-            return Planes(lst.pop(), shape)
-        return Planes(torch.zeros(planes_bytes(shape), dtype=torch.uint8, device=device), shape)
-
-    def release(self, pl):
-        self.free.setdefault((pl.buf.device.index, pl.shape), []).append(pl.buf)
-
-    def scratch(self, shape, device, n):
-        """n planes buffers for the current stream to write; waits (on the current stream) for the last reader of the set."""
-        key = (device.index, tuple(shape), n)
-        r = self.rings.get(key)
-        if r is None:
-            r = {"sets": [], "i": 0}
-            self.rings[key] = r
-        if len(r["sets"]) < self.ring:
-            r["sets"].append([[Planes(torch.zeros(planes_bytes(shape), dtype=torch.uint8, device=device), shape)
-                               for _ in range(n)], None])
-            st = r["sets"][-1]
-        else:
-            st = r["sets"][r["i"]]
-            r["i"] = (r["i"] + 1) % self.ring
-            if st[1] is not None:
-                torch.cuda.current_stream(device).wait_event(st[1])
-        return st
-
-    def clear(self):
-        self.free.clear()
-        self.rings.clear()
-
-
-planes_pool = _PlanesPool()
-# BasicBlocks of 48-channel-multiple widths CAN run their backward pass on x6 planes (csrc/x6p.h; read once).  Off by default:
-# measured inside the CoAM-W48 train step (profiles/r03_planes_in_step.txt) the LDS-DMA weight gradient is 10 % faster
-# (118 vs 130 us with its slab reduction) but the forward convolutions that emit the planes lose 10 us each and the
-# planes-input data gradients 5 us (6 B/elem instead of 4 through a memory system that three concurrent streams already
-# load): 406 img/s against 431.  Solo, every planes kernel is the faster one (DESIGN.md 3.9).
-_PLANES_BLOCKS = os.environ.get("BUCTD_PLANES", "0") == "1"
-
-
 _NATIVE_BLOCK = os.environ.get("BUCTD_NATIVE_BLOCK", "1") == "1"
 # experiment switches, read ONCE at import (the hot path consults module constants, never the environment)
 _FUSE_BN_IN = os.environ.get("BUCTD_FUSE_BN_IN", "1") == "1"
@@ -1437,14 +1301,7 @@ class BasicBlockFn(torch.autograd.Function):
         base, step = act.data_ptr(), 4 * N * H * W * Cn
         d.z1, d.z2, d.y = base, base + step, base + 2 * step
         d.part, d.counts, d.ngroups, d.rows_per_group, d.stat = part.data_ptr(), counts.data_ptr(), ng, rpg, stat.data_ptr()
-        planes = None
-        if _PLANES_BLOCKS and wgrad_planes_ok(N, H, W, Cn, Cn) and planes_ok((N, H, W, Cn)):
-            # the forward convolutions also write what they staged (x and y1 = relu(bn1(z1)), split and zero-padded) as
-            # planes: the X operands of the two weight gradients, which then stage them by LDS-DMA
-            planes = (planes_pool.acquire((N, H, W, Cn), dev), planes_pool.acquire((N, H, W, Cn), dev))
-            d.xp, d.y1p = planes[0].buf.data_ptr(), planes[1].buf.data_ptr()
         check(lib().buctd_basic_block_fwd_train(C.byref(d), stream_ptr()), "basic_block_fwd_train")
-        ctx.planes = planes
         if track:
             for bn in (bn1, bn2):
                 bn.count_batch() if hasattr(bn, "count_batch") else bn.num_batches_tracked.add_(1)
@@ -1461,9 +1318,6 @@ class BasicBlockFn(torch.autograd.Function):
         N, H, W, Cn = x.shape
         dev = x.device
         want_dx = ctx.needs_input_grad[0]
-        planes = getattr(ctx, "planes", None)
-        if planes is not None:
-            return BasicBlockFn._backward_planes(ctx, dy, planes)
         tmp = torch.empty((5 if want_dx else 4, N, H, W, Cn), dtype=torch.float32, device=dev)   # dz2 | dres | dy1 | dz1 | dx
         d = _C.BasicBlockDesc()
         d.N, d.H, d.W, d.C = N, H, W, Cn
@@ -1492,7 +1346,7 @@ class BasicBlockFn(torch.autograd.Function):
         g.dw1, g.dw2 = dw1.data_ptr(), dw2.data_ptr()
         g.dgamma1, g.dbeta1, g.dgamma2, g.dbeta2 = dg1.data_ptr(), db1.data_ptr(), dg2.data_ptr(), db2.data_ptr()
         g.acc_w1, g.acc_w2, g.acc_bn1, g.acc_bn2 = int(acc_w1), int(acc_w2), int(acc_g1), int(acc_g2)
-        bn_ws = workspace(lib().buctd_bn_bwd_workspace(N * H * W, Cn), dev)
+        bn_ws = workspace(_memo(("bbws", N, H, W, Cn), lambda: int(lib().buctd_basic_block_bwd_workspace(N, H, W, Cn))), dev)
         g.bn_ws, g.bn_ws_bytes = bn_ws.data_ptr(), bn_ws.numel()
         main = torch.cuda.current_stream(dev)
         use_side = _side["on"]
@@ -1513,76 +1367,6 @@ class BasicBlockFn(torch.autograd.Function):
         grad_done(bn2.weight, bn2.bias, w2)
         grad_done(bn1.weight, bn1.bias, w1)
         return (tmp[4] if want_dx else None), None, None, None, None
-
-    @staticmethod
-    def _backward_planes(ctx, dy, planes):
-        """The native backward with dz2 / dz1 as x6 planes: BatchNorm backward (fixed-grid reduction) writes them pre-split,
-        the weight gradients (LDS-DMA kernel) read them and the planes saved by the forward, the data gradients stage them
-        with plain copies."""
-        w1, bn1, w2, bn2, _ = ctx.meta
-        x, act, stat = ctx.saved_tensors
-        N, H, W, Cn = x.shape
-        dev = x.device
-        want_dx = ctx.needs_input_grad[0]
-        tmp = torch.empty((3 if want_dx else 2, N, H, W, Cn), dtype=torch.float32, device=dev)   # dres | dy1 | dx
-        d = _C.BasicBlockDesc()
-        d.N, d.H, d.W, d.C = N, H, W, Cn
-        d.x = x.data_ptr()
-        d.w1_fwd = d.w2_fwd = 0
-        d.w1_bwd = _conv3x3_prepared(w1, 1).data_ptr()
-        d.w2_bwd = _conv3x3_prepared(w2, 1).data_ptr()
-        d.gamma1, d.beta1 = bn1.weight.data_ptr(), bn1.bias.data_ptr()
-        d.gamma2, d.beta2 = bn2.weight.data_ptr(), bn2.bias.data_ptr()
-        base, step = act.data_ptr(), 4 * N * H * W * Cn
-        d.z1, d.z2, d.y = base, base + step, base + 2 * step
-        d.stat = stat.data_ptr()
-        d.xp, d.y1p = planes[0].buf.data_ptr(), planes[1].buf.data_ptr()
-        g = _C.BasicBlockGrads()
-        tb = tmp.data_ptr()
-        g.dy, g.dres, g.dy1 = dy.data_ptr(), tb, tb + step
-        g.dz2 = g.dz1 = 0
-        g.dx = tb + 2 * step if want_dx else 0
-        scratch = planes_pool.scratch((N, H, W, Cn), dev, 2)      # waits for the last reader of this set on this stream
-        g.dz2p, g.dz1p = scratch[0][0].buf.data_ptr(), scratch[0][1].buf.data_ptr()
-        dg2, acc_g2 = grad_target(bn2.weight)
-        db2, acc_b2 = grad_target(bn2.bias)
-        dw2, acc_w2 = grad_target(w2)
-        dg1, acc_g1 = grad_target(bn1.weight)
-        db1, acc_b1 = grad_target(bn1.bias)
-        dw1, acc_w1 = grad_target(w1)
-        assert acc_g2 == acc_b2 and acc_g1 == acc_b1
-        weight_rsc(dw1)
-        weight_rsc(dw2)
-        g.dw1, g.dw2 = dw1.data_ptr(), dw2.data_ptr()
-        g.dgamma1, g.dbeta1, g.dgamma2, g.dbeta2 = dg1.data_ptr(), db1.data_ptr(), dg2.data_ptr(), db2.data_ptr()
-        g.acc_w1, g.acc_w2, g.acc_bn1, g.acc_bn2 = int(acc_w1), int(acc_w2), int(acc_g1), int(acc_g2)
-        bn_ws = workspace(_memo(("bnpws", N * H * W, Cn), lambda: int(lib().buctd_bn_bwd_p_workspace(N * H * W, Cn))), dev)
-        g.bn_ws, g.bn_ws_bytes = bn_ws.data_ptr(), bn_ws.numel()
-        main = torch.cuda.current_stream(dev)
-        use_side = _side["on"]
-        side = _side_stream(dev) if use_side else main
-        need = _memo(("wg4ws", N, H, W, Cn, Cn), lambda: int(lib().buctd_conv3x3_wgrad_bf16x6_p_workspace(N, H, W, Cn, Cn)))
-        wg_ws = workspace_on(side, need, dev)      # the side stream's own scratch buffer
-        g.wg_ws, g.wg_ws_bytes = wg_ws.data_ptr(), wg_ws.numel()
-        check(lib().buctd_basic_block_bwd(C.byref(d), C.byref(g), main.cuda_stream, side.cuda_stream if use_side else None),
-              "basic_block_bwd")
-        if use_side:
-            for t in (x, act, stat, tmp):
-                t.record_stream(side)
-            ev = torch.cuda.Event()
-            ev.record(side)                         # the last reader of the scratch planes is the second weight gradient
-            scratch[1] = ev
-            _queue_join()
-        else:
-            scratch[1] = None
-            if _branch["on"]:
-                _queue_join()
-        planes_pool.release(planes[0])
-        planes_pool.release(planes[1])
-        ctx.planes = None
-        grad_done(bn2.weight, bn2.bias, w2)
-        grad_done(bn1.weight, bn1.bias, w1)
-        return (tmp[2] if want_dx else None), None, None, None, None
 
     @staticmethod
     def backward(ctx, dy):
@@ -1658,15 +1442,8 @@ class BasicChainFn(torch.autograd.Function):
             d.part, d.counts = pbase + k * 2 * ng * Cn * 8, cbase + k * 2 * ng * 4
             d.ngroups, d.rows_per_group, d.stat = ng, rpg, sbase + k * 4 * Cn * 4
             xin = d.y
-        planes = None
-        if _PLANES_BLOCKS and wgrad_planes_ok(N, H, W, Cn, Cn) and planes_ok((N, H, W, Cn)):
-            # planes mode (BasicBlockFn): every block's forward convolutions also write x and y1 as x6 planes
-            planes = [planes_pool.acquire((N, H, W, Cn), dev) for _ in range(2 * n)]
-            for k in range(n):
-                descs[k].xp, descs[k].y1p = planes[2 * k].buf.data_ptr(), planes[2 * k + 1].buf.data_ptr()
         check(lib().buctd_basic_chain_fwd_train(n, descs, stream_ptr()), "basic_chain_fwd_train")
         ctx.blocks = blocks
-        ctx.planes = planes
         ctx.save_for_backward(x, act, stat)
         return act[n - 1, 2]
 
@@ -1684,29 +1461,17 @@ class BasicChainFn(torch.autograd.Function):
         abase, sbase, tb = act.data_ptr(), stat.data_ptr(), tmp.data_ptr()
         descs = (_C.BasicBlockDesc * n)()
         grads = (_C.BasicBlockGrads * n)()
-        planes = getattr(ctx, "planes", None)
         main = torch.cuda.current_stream(dev)
         use_side = _side["on"]
         side = _side_stream(dev) if use_side else main
-        scratch = None
-        if planes is not None:
-            # dz2 / dz1 of every block exist only as planes: one scratch set of 2 n buffers per call (a ring of such sets per
-            # shape; taking one waits, on this stream, for the weight gradients that read it last)
-            bn_ws = workspace(_memo(("bnpws", N * H * W, Cn), lambda: int(lib().buctd_bn_bwd_p_workspace(N * H * W, Cn))), dev)
-            need = _memo(("wg4ws", N, H, W, Cn, Cn), lambda: int(lib().buctd_conv3x3_wgrad_bf16x6_p_workspace(N, H, W, Cn, Cn)))
-            scratch = planes_pool.scratch((N, H, W, Cn), dev, 2 * n)
-        else:
-            bn_ws = workspace(lib().buctd_bn_bwd_workspace(N * H * W, Cn), dev)
-            need = _memo(("wg3", "bf16x6", N, H, W, Cn, Cn),
-                         lambda: (lib().buctd_conv3x3_wgrad_bf16x6_workspace(N, H, W, Cn, Cn)
-                                  if lib().buctd_conv3x3_wgrad_bf16x6_supported(N, H, W, Cn, Cn) == 1 else -1))
+        bn_ws = workspace(_memo(("bbws", N, H, W, Cn), lambda: int(lib().buctd_basic_block_bwd_workspace(N, H, W, Cn))), dev)
+        need = _memo(("wg3", "bf16x6", N, H, W, Cn, Cn),
+                     lambda: (lib().buctd_conv3x3_wgrad_bf16x6_workspace(N, H, W, Cn, Cn)
+                              if lib().buctd_conv3x3_wgrad_bf16x6_supported(N, H, W, Cn, Cn) == 1 else -1))
         wg_ws = workspace_on(side, need, dev)
         xin = x.data_ptr()
         for k, (w1, bn1, w2, bn2) in enumerate(blocks):
             d, g = descs[k], grads[k]
-            if planes is not None:
-                d.xp, d.y1p = planes[2 * k].buf.data_ptr(), planes[2 * k + 1].buf.data_ptr()
-                g.dz2p, g.dz1p = scratch[0][2 * k].buf.data_ptr(), scratch[0][2 * k + 1].buf.data_ptr()
             d.N, d.H, d.W, d.C = N, H, W, Cn
             d.x = xin
             d.w1_bwd = _conv3x3_prepared(w1, 1).data_ptr()
@@ -1740,20 +1505,9 @@ class BasicChainFn(torch.autograd.Function):
         if use_side:
             for t in (x, act, stat, tmp, dy):
                 t.record_stream(side)
-            if scratch is not None:
-                ev = torch.cuda.Event()
-                ev.record(side)                     # the last readers of the scratch planes are the weight gradients
-                scratch[1] = ev
             _queue_join()
-        else:
-            if scratch is not None:
-                scratch[1] = None
-            if _branch["on"]:
-                _queue_join()
-        if planes is not None:
-            for pl in planes:
-                planes_pool.release(pl)
-            ctx.planes = None
+        elif _branch["on"]:
+            _queue_join()
         for (w1, bn1, w2, bn2) in reversed(blocks):
             grad_done(bn2.weight, bn2.bias, w2)
             grad_done(bn1.weight, bn1.bias, w1)

@@ -91,6 +91,15 @@ int buctd_conv3x3_bf16x6_bnin(int N, int H, int W, int Ci, int Co, const float* 
                               const float* scale, const float* shift, const float* residual, int relu, float* y,
                               float* stats_partials, int* stats_counts, const float* in_mean, const float* in_invstd,
                               const float* in_gamma, const float* in_beta, int in_relu, void* stream);
+/* Data gradient of a 3x3 convolution (buctd_conv3x3_bf16x6 on the flip = 1 image; residual = the skip gradient, NULL ok)
+ * that also forms the REDUCTION pass of the BatchNorm backward consuming its output g = y: per row group (the groups of
+ * buctd_conv3x3_bf16x6_stats_groups(N, H, W, Ci, Co)) s1 = sum m g, s2 = sum m g (z - mean) invstd, with m the ReLU mask of
+ * that BatchNorm's forward output (bn_y > 0 where given, else rebuilt from bn_z as (z - mean)(invstd gamma) + beta > 0) -
+ * bn_part [groups][2][Co] floats, the input of buctd_bn_bwd_from_partials.  What autograd does with three more passes over
+ * g, z and y (the sum reductions of native_batch_norm_backward, pose_hrnet.py:41-57). */
+int buctd_conv3x3_bf16x6_bnstat(int N, int H, int W, int Ci, int Co, const float* x, const void* wprep, const float* residual,
+                                float* y, const float* bn_z, const float* bn_y, const float* bn_mean, const float* bn_invstd,
+                                const float* bn_gamma, const float* bn_beta, float* bn_part, void* stream);
 int buctd_conv3x3_bf16x3_supported(int N, int H, int W, int Ci, int Co);
 int buctd_conv3x3_bf16x3_stats_groups(int N, int H, int W, int Ci, int Co, int* ngroups, int* rows_per_group);
 size_t buctd_conv3x3_bf16x3_prep_bytes(int Ci, int Co, int flip);
@@ -126,43 +135,6 @@ int buctd_conv3x3_wgrad_bf16x3_supported(int N, int H, int W, int Ci, int Co);
 size_t buctd_conv3x3_wgrad_bf16x3_workspace(int N, int H, int W, int Ci, int Co);
 int buctd_conv3x3_wgrad_bf16x3(int N, int H, int W, int Ci, int Co, const float* x, const float* dy, float* dw,
                                int accumulate, void* workspace, size_t workspace_bytes, void* stream);
-
-/* ------------------------------------------------------------ x6 planes --- */
-/* "x6 planes" (csrc/x6p.h): an activation [N][H][W][C] (C % 16 == 0) stored pre-split for the bf16x6 kernels - one row of
- * C/16 chunks [16 h | 16 m | 16 l] bf16 (x = h + m + l exactly) per position of the zero-padded flattened pixel space
- * p = n (H+1)(W+2) + (y+1)(W+2) + (x+1), pad rows and guard rows in front / behind zeroed by the producer.  6 bytes per
- * element; the consumers stage it with plain copies / LDS-DMA.  Every `planes` pointer below is the allocation base of
- * buctd_x6p_bytes(N, H, W, C) bytes.  Serves the operands of the BasicBlock convolutions, pose_hrnet.py:28-57. */
-size_t buctd_x6p_bytes(int N, int H, int W, int C);
-/* planes of x, or of relu?((x - mean) * (invstd * gamma) + beta) when mean != NULL (the expression of buctd_bn_apply) */
-int buctd_x6p_from_nhwc(int N, int H, int W, int C, const float* x, const float* mean, const float* invstd,
-                        const float* gamma, const float* beta, int relu, void* planes, void* stream);
-int buctd_x6p_to_nhwc(int N, int H, int W, int C, const void* planes, float* x, void* stream);
-/* buctd_conv3x3_bf16x6 with its input as planes (same tiling and MFMA order: bit-identical results); its statistics
- * grouping differs from the fp32-input kernel's for the largest maps, hence its own _stats_groups */
-int buctd_conv3x3_bf16x6_p_stats_groups(int N, int H, int W, int Ci, int Co, int* ngroups, int* rows_per_group);
-int buctd_conv3x3_bf16x6_p(int N, int H, int W, int Ci, int Co, const void* x_planes, const void* wprep, const float* bias,
-                           const float* scale, const float* shift, const float* residual, int relu, float* y,
-                           float* stats_partials, int* stats_counts, void* stream);
-/* buctd_conv3x3_bf16x6(_bnin) without epilogue options (the BasicBlock use) that ALSO writes what it staged - x, or
- * relu?((x - mean)(invstd gamma) + beta) when in_mean != NULL - as planes into x_planes_out: the X operand of this
- * convolution's weight gradient, produced by the pass that splits it anyway (rows of all positions are written, pads as
- * zeros; guard rows must be zero already). */
-int buctd_conv3x3_bf16x6_emit(int N, int H, int W, int Ci, int Co, const float* x, const void* wprep, float* y,
-                              float* stats_partials, int* stats_counts, const float* in_mean, const float* in_invstd,
-                              const float* in_gamma, const float* in_beta, int in_relu, void* x_planes_out, void* stream);
-/* BatchNorm(+ReLU) backward (as buctd_bn_bwd) of an NHWC tensor with dz written as planes (only pixel rows are written: the
- * buffer's pad / guard rows must be zero) and the masked upstream gradient as fp32 dres (optional); fixed-grid reduction */
-size_t buctd_bn_bwd_p_workspace(long rows, int C);
-int buctd_bn_bwd_p(const float* dy, const float* y, const float* z, const float* mean, const float* invstd,
-                   const float* gamma, const float* beta, int relu, int N, int H, int W, int C, void* dz_planes, float* dres,
-                   float* dgamma, float* dbeta, int accumulate, void* workspace, size_t workspace_bytes, void* stream);
-/* weight gradient from both operands as planes (Ci, Co multiples of 48): LDS-DMA staging, one 512-thread workgroup per CU,
- * 256 partial slabs in `workspace` summed in a fixed order (deterministic) */
-int buctd_conv3x3_wgrad_bf16x6_p_supported(int N, int H, int W, int Ci, int Co);
-size_t buctd_conv3x3_wgrad_bf16x6_p_workspace(int N, int H, int W, int Ci, int Co);
-int buctd_conv3x3_wgrad_bf16x6_p(int N, int H, int W, int Ci, int Co, const void* x_planes, const void* dy_planes, float* dw,
-                                 int accumulate, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---------------------------------------------------------------- matmul --- */
 typedef struct {
@@ -205,6 +177,12 @@ size_t buctd_bn_bwd_workspace(long rows, int C);
 int buctd_bn_bwd(const float* dy, const float* y, const float* z, const float* mean, const float* invstd,
                  const float* gamma, const float* beta, int relu, long rows, int C, float* dz, float* dres,
                  float* dgamma, float* dbeta, int accumulate, void* workspace, size_t workspace_bytes, void* stream);
+/* The rest of buctd_bn_bwd when the reduction pass already happened (buctd_conv3x3_bf16x6_bnstat): part = [nparts][2][C]
+ * partial (s1, s2) sums -> fp64 merge, dgamma / dbeta, then dz (and dres).  workspace: 2 * C floats. */
+int buctd_bn_bwd_from_partials(const float* dy, const float* y, const float* z, const float* mean, const float* invstd,
+                               const float* gamma, const float* beta, int relu, long rows, int C, const float* part,
+                               int nparts, float* dz, float* dres, float* dgamma, float* dbeta, int accumulate,
+                               void* workspace, size_t workspace_bytes, void* stream);
 /* eval-mode helpers: scale = gamma/sqrt(var+eps), shift = beta - mean*scale */
 int buctd_bn_fold(const float* gamma, const float* beta, const float* running_mean, const float* running_var,
                   float eps, int C, float* scale, float* shift, void* stream);
@@ -366,10 +344,6 @@ typedef struct {
   int* counts;
   int ngroups, rows_per_group;
   float* stat;
-  /* planes mode (both non-NULL, C % 48 == 0): the forward convolutions also write their staged inputs - x and
-   * y1 = relu(bn1(z1)) - as x6 planes (allocation bases, non-pixel rows zero); the backward's weight gradients then stage
-   * them by LDS-DMA (buctd_conv3x3_wgrad_bf16x6_p).  NULL: fp32 operands everywhere, as before. */
-  void *xp, *y1p;
 } buctd_basic_block;
 typedef struct {
   const float* dy;                      /* gradient of the block output */
@@ -377,12 +351,11 @@ typedef struct {
   float* dx;                            /* NULL: the block input needs no gradient */
   float *dw1, *dw2, *dgamma1, *dbeta1, *dgamma2, *dbeta2;
   int acc_w1, acc_w2, acc_bn1, acc_bn2; /* accumulate into (1) or overwrite (0) the gradient buffers */
-  void* bn_ws; size_t bn_ws_bytes;      /* buctd_bn_bwd_workspace, used on `stream` */
-  void* wg_ws; size_t wg_ws_bytes;      /* buctd_conv3x3_wgrad_bf16x6(_p)_workspace, used on `side_stream` */
-  /* planes mode: dz2 / dz1 exist only as planes (scratch allocations whose non-pixel rows are zero); the fp32 dz2 / dz1
-   * above are then unused (may be NULL) and bn_ws must hold buctd_bn_bwd_p_workspace bytes */
-  void *dz2p, *dz1p;
+  void* bn_ws; size_t bn_ws_bytes;      /* buctd_basic_block_bwd_workspace, used on `stream` */
+  void* wg_ws; size_t wg_ws_bytes;      /* buctd_conv3x3_wgrad_bf16x6_workspace, used on `side_stream` */
 } buctd_basic_block_grads;
+/* bytes of buctd_basic_block_grads::bn_ws for a block of this shape (>= buctd_bn_bwd_workspace) */
+size_t buctd_basic_block_bwd_workspace(int N, int H, int W, int C);
 int buctd_basic_block_fwd_train(const buctd_basic_block* b, void* stream);
 int buctd_basic_block_bwd(const buctd_basic_block* b, const buctd_basic_block_grads* g, void* stream, void* side_stream);
 /* n chained blocks (an HRNet branch, pose_hrnet.py:165-185) behind one call per direction: blocks[k].x = blocks[k-1].y,

@@ -1,0 +1,18 @@
+# interleaved A/B of library builds on one box:  bash scratch/ab_libs.sh <rounds> <workload> libA.so libB.so ...
+# (libraries under scratch/; "product" = buctd_amd/lib/libbuctd_hip.so).  Prints img/s per run and the medians.
+cd $GRAFT_REPO_ROOT
+rounds=$1; W=$2; shift 2
+for r in $(seq $rounds); do
+  for lib in "$@"; do
+    if [ "$lib" = product ]; then L=$GRAFT_REPO_ROOT/buctd_amd/lib/libbuctd_hip.so; else L=$GRAFT_REPO_ROOT/$lib; fi
+    v=$(timeout 200 python scratch/run_alt.py $L bench.py --workload $W --steps 20 --warmup 5 --no-cpu-baseline --no-kernel-timer 2>/dev/null | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['value'])")
+    echo "$lib $v"
+  done
+done | tee /tmp/ab.txt
+python - <<'PY'
+import collections, statistics
+d = collections.defaultdict(list)
+for l in open('/tmp/ab.txt'):
+    k, v = l.split(); d[k].append(float(v))
+for k, v in d.items(): print(f"{k}: median {statistics.median(v):.1f} img/s  min {min(v):.1f} max {max(v):.1f}  n={len(v)}")
+PY

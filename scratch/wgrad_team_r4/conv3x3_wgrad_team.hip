@@ -26,6 +26,9 @@ typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 #ifndef WG3_ABL
 #define WG3_ABL 0        // what-if builds only (scratch/build_alt.sh): 1 no slab stores, 2 no split / LDS stores, 4 no MFMAs, 8 no loads
 #endif
+#ifndef WGT_SCHED
+#define WGT_SCHED 2      // team kernel, scheduling of the fragment prefetch: 0 fenced blocks, 1 compiler's choice, 2 interleaved
+#endif
 #define WG_MAX_SW 75
 #define WG_PRO 96          // halo rows fetched per round of the first stage
 
@@ -266,8 +269,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_split_kernel(WG3Args p) 
           const int tap = nf / CF, cf = nf - tap * CF;
           const int shift = (tap / 3) * p.SW + tap % 3;      // X row of position k + shift(tap) (the ring starts at -halo)
           const int r0 = ring_slot(slot_base + lane_row + ks * 32 + shift, R), r1 = ring_slot(r0 + 16, R);
-          const unsigned char* q0 = Xt + (__umul24(r0, RS) + lane_col + cf * 32);     // 32-bit LDS offsets: the 64-bit
-          const unsigned char* q1 = Xt + (__umul24(r1, RS) + lane_col + cf * 32);     // form cost two v_mad_u64_u32 per fragment
+          const unsigned char* q0 = Xt + (size_t)r0 * RS + lane_col + cf * 32;
+          const unsigned char* q1 = Xt + (size_t)r1 * RS + lane_col + cf * 32;
           bf16x8 b[NP];
 #pragma unroll
           for (int pc = 0; pc < NP; ++pc) b[pc] = tr_frag2(q0 + pc * LO, q1 + pc * LO);
@@ -290,30 +293,337 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_split_kernel(WG3Args p) 
     slot_base = ring_slot(slot_base + KB, R);
   }
 
-  // partial slab in ACCUMULATOR order: element ((wave * NW + j) * CF + mf) * 64 + lane = the register quad (co = co0 + mf*16 +
-  // g*4 + 0..3, tap / ci of fragment nf = wave + 4 j) - one 16-byte store per lane and quad, whole lines per wavefront,
-  // instead of 84 scalar stores per lane into [co][tap][ci] rows; the reduction kernel sorts while it adds
+  // partial slab: [split][co][tap][ci]; accumulator (mf, j, reg): co = co0 + mf*16 + g*4 + reg, ci = ci0 + cf*16 + t16
+  float* outp = p.part + (size_t)blockIdx.z * p.Co * 9 * p.Ci;
+#pragma unroll
+  for (int j = 0; j < NW; ++j) {
+    const int nf = wave + 4 * j;
+    if (nf < NFR) {
+      const int tap = nf / CF, cf = nf - tap * CF;
+      const int ci = ci0 + cf * 16 + t16;
+#pragma unroll
+      for (int mf = 0; mf < CF; ++mf)
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) {
+          const int co = co0 + mf * 16 + g * 4 + rg;
+          if (WG3_ABL & 1) asm volatile("" :: "v"(acc[mf][j][rg]));
+          else outp[((size_t)co * 9 + tap) * p.Ci + ci] = acc[mf][j][rg];
+        }
+    }
+  }
+}
+
+// slab reduction: 16 float4 columns x 16 split-lanes per workgroup: the 48x432 gradient (5184 float4) spreads over 324
+// workgroups, every split slab is read by 16 independent lanes with four loads in flight each (the 512 slabs of the
+// six-MFMA mode are 42 MB: at 8 split-lanes and 162 workgroups this pass took 27 us)
+__global__ __launch_bounds__(256) void wg3_reduce_kernel(const float* __restrict__ part, float* __restrict__ out, long n,
+                                                         int nsplit, int accumulate) {
+  __shared__ f32x4 sm[16][16];
+  const long n4 = n >> 2;
+  const int col = threadIdx.x & 15, zl = threadIdx.x >> 4;
+  for (long base = (long)blockIdx.x * 16; base < n4; base += (long)gridDim.x * 16) {
+    const long i = base + col;
+    f32x4 s0 = (f32x4){0.f, 0.f, 0.f, 0.f}, s1 = s0, s2 = s0, s3 = s0;
+    if (i < n4) {
+      const f32x4* src = reinterpret_cast<const f32x4*>(part) + i;
+      const long zs = n4;                         // float4 stride between slabs
+      int z = zl;
+      for (; z + 48 < nsplit; z += 64) {
+        s0 += src[(long)z * zs];
+        s1 += src[(long)(z + 16) * zs];
+        s2 += src[(long)(z + 32) * zs];
+        s3 += src[(long)(z + 48) * zs];
+      }
+      for (; z < nsplit; z += 16) s0 += src[(long)z * zs];
+    }
+    sm[zl][col] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (zl == 0 && i < n4) {
+      f32x4 s = sm[0][col];
+#pragma unroll
+      for (int k = 1; k < 16; ++k) s += sm[k][col];
+      if (accumulate) s += reinterpret_cast<const f32x4*>(out)[i];
+      reinterpret_cast<f32x4*>(out)[i] = s;
+    }
+    __syncthreads();
+  }
+}
+
+// =====================================================================================================================
+// The TEAM kernel (round 4): the same GEMM, the same LDS images and fragment reads, restructured around what the ablations
+// of the kernel above showed - its matrix work (24.5 us of 57 at 48 channels) and everything else (32.5 us: split + LDS
+// stores 12, loads 5, slab stores 5, fragment reads / address arithmetic / barriers 10) simply ADD UP: the two workgroups
+// of a CU run their phases in step, and inside a wave nothing overlaps either.
+//   * ONE 512-thread workgroup per CU = two TEAMS of four wavefronts; wavefront w of team A and of team B share a SIMD.
+//     The teams take the stages of the position range alternately (A the even, B the odd ones), each into its own
+//     accumulators: while one team multiplies stage s out of LDS buffer s & 1, the other splits and stores ITS next stage
+//     (s + 1) into the other buffer - on every SIMD one wavefront issues MFMAs while its partner issues VALU / LDS stores
+//     ("Two waves per SIMD", MI355X_MICROARCH.md), one barrier per stage.  A team fetches its stage s + 2 from HBM when it
+//     starts multiplying stage s: a whole multiply phase to land.
+//   * the X ring has KB rows more than a stage needs, so that the rows of stage s + 1 can be written while stage s is read;
+//   * half as many slabs (one workgroup per CU): 256 instead of 512 at 48 channels - 21 MB instead of 42 of slab traffic -
+//     written in ACCUMULATOR order (16 bytes per lane, whole lines) instead of 84 scalar stores per lane; the reduction
+//     kernel sorts the elements into [co][tap][ci] while it adds the slabs (in a fixed order: deterministic).
+template <int NP, int CF>
+__global__ __launch_bounds__(512, 2) void conv3x3_wgrad_team_kernel(WG3Args p) {
+  constexpr int KB = 64;
+  constexpr int CH = CF * 16;
+  constexpr int LO = CH * 2;
+  constexpr int RS = (CH * 2 * NP) % 64 == 32 ? CH * 2 * NP : CH * 2 * NP + 32;
+  constexpr int C4 = CH / 4;
+  constexpr int PD = (KB * C4 + 255) / 256;       // float4 per thread (of ONE team) for the KB rows of one operand
+  constexpr int NFR = 9 * CF;
+  constexpr int NW = (NFR + 3) / 4;
+
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int R = KB + 2 * p.SW + 2;                // X rows of one stage
+  const int RING = R + KB;                        // ring size: a stage in use + the KB new rows of the next one
+  unsigned char* Dt = smem;                       // dY tiles [2][KB][RS]
+  unsigned char* Xt = smem + (size_t)2 * KB * RS; // X ring [RING][RS]
+
+  const int t = threadIdx.x, lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int team = wave >> 2, wave4 = wave & 3;   // wavefronts w and w + 4 sit on one SIMD
+  const int tt = t & 255;                         // thread index inside the team
+  const int t16 = lane & 15, g = lane >> 4;
+  const int co0 = blockIdx.x * CH, ci0 = blockIdx.y * CH;
+  const int z = blockIdx.z;
+  const int nst = p.split_q + (z < p.split_rem ? 1 : 0);             // stages of this split
+  const int k_begin = (z * p.split_q + (z < p.split_rem ? z : p.split_rem)) * KB;
+  int k_end = k_begin + nst * KB;
+  if (k_end > p.P) k_end = p.P;
+  const int halo = p.SW + 1;
+
+  auto pos_offset = [&](int pp, int C) -> int {   // element offset of pixel pp in an [N][H][W][C] tensor, -1 = pad
+    if (pp < 0 || pp >= p.P) return -1;
+    const int n = wg_fast_div(pp, p.ib_mul, p.ib_sh);
+    const int rem = pp - n * p.IB;
+    const int yy = wg_fast_div(rem, p.sw_mul, p.sw_sh);
+    const int xx = rem - yy * p.SW;
+    if (n >= p.N || yy < 1 || xx < 1 || xx > p.W) return -1;
+    return ((n * p.H + yy - 1) * p.W + xx - 1) * C;
+  };
+  auto bn_in = [&](f32x4 v, int c) -> f32x4 {
+    if (!p.x_mean) return v;
+    const f32x4 mu = *reinterpret_cast<const f32x4*>(p.x_mean + ci0 + c);
+    const f32x4 is = *reinterpret_cast<const f32x4*>(p.x_invstd + ci0 + c);
+    const f32x4 ga = *reinterpret_cast<const f32x4*>(p.x_gamma + ci0 + c);
+    const f32x4 be = *reinterpret_cast<const f32x4*>(p.x_beta + ci0 + c);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      v[j] = (v[j] - mu[j]) * (is[j] * ga[j]) + be[j];
+      if (p.x_relu) v[j] = fmaxf(v[j], 0.f);
+    }
+    return v;
+  };
+  auto ring_of = [&](int rel) -> int {            // ring slot of row `rel` (counted from position k_begin - halo)
+    return rel % RING;
+  };
+
+  // ---- prologue: all 512 threads stage the X rows [0, R) of stage 0 and its dY rows; rounds of 512 float4 ----------
   {
-    const size_t slab4 = (size_t)4 * NW * CF * 64;
+    const int items_x = R * C4;
+    for (int i0 = 0; i0 < items_x; i0 += 512 * 4) {
+      f32x4 v[4];
+      int off[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int idx = i0 + t + 512 * u;
+        const int row = idx / C4, c4 = (idx - row * C4) * 4;
+        off[u] = idx < items_x ? pos_offset(k_begin - halo + row, p.Ci) : -2;
+        v[u] = *reinterpret_cast<const f32x4*>(p.x + (off[u] >= 0 ? off[u] + ci0 + c4 : 0));
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int idx = i0 + t + 512 * u;
+        const int row = idx / C4, c4 = (idx - row * C4) * 4;
+        if (off[u] != -2)
+          wg_split_store<NP, LO>(Xt + (size_t)row * RS, c4, off[u] >= 0 ? bn_in(v[u], c4) : (f32x4){0.f, 0.f, 0.f, 0.f});
+      }
+    }
+    constexpr int PD0 = (KB * C4 + 511) / 512;
+    f32x4 v[PD0];
+    int off[PD0];
+#pragma unroll
+    for (int u = 0; u < PD0; ++u) {
+      const int idx = t + 512 * u;
+      const int row = idx / C4, c4 = (idx - row * C4) * 4;
+      const int pp = k_begin + row;
+      off[u] = row < KB ? ((pp < k_end) ? pos_offset(pp, p.Co) : -1) : -2;
+      v[u] = *reinterpret_cast<const f32x4*>(p.dy + (off[u] >= 0 ? off[u] + co0 + c4 : 0));
+    }
+#pragma unroll
+    for (int u = 0; u < PD0; ++u) {
+      const int idx = t + 512 * u;
+      const int row = idx / C4, c4 = (idx - row * C4) * 4;
+      if (off[u] != -2)
+        wg_split_store<NP, LO>(Dt + (size_t)row * RS, c4, off[u] >= 0 ? v[u] : (f32x4){0.f, 0.f, 0.f, 0.f});
+    }
+  }
+
+  // ---- a team's registers for ITS next stage: KB rows of dY and the KB new rows of X ---------------------------------
+  f32x4 dreg[PD], xreg[PD];
+  unsigned dmask = 0, xmask = 0;
+  auto load_stage = [&](int s) {                  // stage s >= 1: dY rows k_begin + s KB ..., X rows rel (s - 1) KB + R ...
+    dmask = xmask = 0;
+    const int k0 = k_begin + s * KB, rel0 = (s - 1) * KB + R;
+#pragma unroll
+    for (int q = 0; q < PD; ++q) {
+      const int idx = tt + 256 * q;
+      const int row = idx / C4, c4 = (idx - row * C4) * 4;
+      const int pp = k0 + row;
+      const int od = (row < KB && pp < k_end) ? pos_offset(pp, p.Co) : -1;
+      const int ox = row < KB ? pos_offset(k_begin - halo + rel0 + row, p.Ci) : -1;
+      dmask |= (od >= 0 ? 1u : 0u) << q;
+      xmask |= (ox >= 0 ? 1u : 0u) << q;
+      dreg[q] = *reinterpret_cast<const f32x4*>(p.dy + (od >= 0 ? od + co0 + c4 : 0));
+      xreg[q] = *reinterpret_cast<const f32x4*>(p.x + (ox >= 0 ? ox + ci0 + c4 : 0));
+    }
+  };
+  auto store_stage = [&](int s) {
+    unsigned char* D = Dt + (size_t)(s & 1) * KB * RS;
+    const int slot0 = ring_of((s - 1) * KB + R);
+#pragma unroll
+    for (int q = 0; q < PD; ++q) {
+      const int idx = tt + 256 * q;
+      const int row = idx / C4, c4 = (idx - row * C4) * 4;
+      if (row < KB) {
+        wg_split_store<NP, LO>(D + (size_t)row * RS, c4, ((dmask >> q) & 1u) ? dreg[q] : (f32x4){0.f, 0.f, 0.f, 0.f});
+        int slot = slot0 + row;
+        slot -= slot >= RING ? RING : 0;
+        wg_split_store<NP, LO>(Xt + (size_t)slot * RS, c4,
+                               ((xmask >> q) & 1u) ? bn_in(xreg[q], c4) : (f32x4){0.f, 0.f, 0.f, 0.f});
+      }
+    }
+  };
+
+  f32x4 acc[CF][NW];
+#pragma unroll
+  for (int mf = 0; mf < CF; ++mf)
+#pragma unroll
+    for (int j = 0; j < NW; ++j) acc[mf][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int lane_row = g * 4 + (t16 >> 2), lane_col = (t16 & 3) * 8;
+  const int lane_off = lane_row * RS + lane_col;
+
+  // B fragments (X operand) travel ONE n-fragment ahead of their MFMAs through two register sets: only one wavefront per
+  // SIMD multiplies at any time, so its own LDS latencies must hide behind its own MFMAs (18 per n-fragment)
+  auto compute = [&](int s) {
+    const unsigned char* D = Dt + (size_t)(s & 1) * KB * RS;
+    const int slot_base = ring_of(s * KB);        // ring slot of position k0 - halo
+    auto load_b = [&](int ks, int j, bf16x8 (&b)[NP]) {
+      const int nf = wave4 + 4 * j;
+      const int tap = nf / CF, cf = nf - tap * CF;
+      const int shift = (tap / 3) * p.SW + tap % 3;
+      int r0 = slot_base + lane_row + ks * 32 + shift;     // < 2 * RING
+      r0 -= r0 >= RING ? RING : 0;
+      int r1 = r0 + 16;
+      r1 -= r1 >= RING ? RING : 0;
+      const unsigned char* q0 = Xt + (__umul24(r0, RS) + lane_col + cf * 32);     // 32-bit LDS offsets
+      const unsigned char* q1 = Xt + (__umul24(r1, RS) + lane_col + cf * 32);
+#pragma unroll
+      for (int pc = 0; pc < NP; ++pc) b[pc] = tr_frag2(q0 + pc * LO, q1 + pc * LO);
+    };
+    bf16x8 bb[2][NP];
+    load_b(0, 0, bb[0]);
+#pragma unroll
+    for (int ks = 0; ks < KB / 32; ++ks) {
+      bf16x8 a[NP][CF];
+#pragma unroll
+      for (int mf = 0; mf < CF; ++mf) {
+        const unsigned char* q = D + (size_t)ks * 32 * RS + lane_off + mf * 32;
+#pragma unroll
+        for (int pc = 0; pc < NP; ++pc) a[pc][mf] = tr_frag(q + pc * LO, 4 * RS);
+      }
+#pragma unroll
+      for (int j = 0; j < NW; ++j) {
+        const int it = ks * NW + j;                          // flat (k-step, n-fragment) index: compile-time
+        bf16x8 (&b)[NP] = bb[it & 1];
+        // next fragment of this wave: (ks, j + 1), or (ks + 1, 0); wave 3 has no fragment j = NW - 1 when NFR % 4 != 0
+        const int jn = j + 1 < NW ? j + 1 : 0, ksn = j + 1 < NW ? ks : ks + 1;
+        if (ksn < KB / 32 && wave4 + 4 * jn < NFR) load_b(ksn, jn, bb[(it + 1) & 1]);
+#if WGT_SCHED == 0
+        __builtin_amdgcn_sched_barrier(0);
+#endif
+        if (wave4 + 4 * j < NFR) {
+#if WG3_ABL & 4
+#define WGT_MMA(qa, qb) _Pragma("unroll") for (int mf = 0; mf < CF; ++mf) asm volatile("" :: "v"(a[qa][mf]), "v"(b[qb]));
+#else
+#define WGT_MMA(qa, qb)                                                                                     \
+  _Pragma("unroll") for (int mf = 0; mf < CF; ++mf) acc[mf][j] =                                            \
+      __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[qa][mf], b[qb], acc[mf][j], 0, 0, 0);
+#endif
+          if constexpr (NP == 3) {
+            WGT_MMA(2, 0) WGT_MMA(0, 2) WGT_MMA(1, 1) WGT_MMA(1, 0) WGT_MMA(0, 1) WGT_MMA(0, 0)
+          } else {
+            WGT_MMA(1, 0) WGT_MMA(0, 1) WGT_MMA(0, 0)
+          }
+#undef WGT_MMA
+        }
+#if WGT_SCHED == 2
+        // the prefetch of the next fragment (address arithmetic + six transpose reads) rides in the issue slots between
+        // this fragment's MFMAs instead of sitting in a block of its own behind them
+#pragma unroll
+        for (int i = 0; i < 6 * CF - 6; ++i) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+#endif
+#if WGT_SCHED != 1
+        __builtin_amdgcn_sched_barrier(0);
+#endif
+      }
+    }
+  };
+
+  if (team == 1 && nst > 1) load_stage(1);
+  __syncthreads();
+  for (int s = 0; s < nst; ++s) {
+    if (team == (s & 1)) {
+      if (s + 2 < nst && !(WG3_ABL & 8)) load_stage(s + 2);         // in flight during the MFMAs below, stored a phase later
+      if (!(WG3_ABL & 16)) compute(s);
+    } else if (s + 1 < nst && !(WG3_ABL & 2)) {
+      store_stage(s + 1);
+    }
+    __syncthreads();
+  }
+
+  // ---- team B hands its accumulators to team A through LDS (everything in LDS is dead now), A adds and writes the slab
+  // in accumulator order: element ((wave4 * NW + j) * CF + mf) * 64 + lane, 16 bytes each ----------------------------
+  f32x4* xch = reinterpret_cast<f32x4*>(smem);
+  if (team == 1) {
+#pragma unroll
+    for (int j = 0; j < NW; ++j)
+#pragma unroll
+      for (int mf = 0; mf < CF; ++mf) xch[((wave4 * NW + j) * CF + mf) * 64 + lane] = acc[mf][j];
+  }
+  __syncthreads();
+  if (team == 0) {
+    const size_t slab = (size_t)4 * NW * CF * 64;      // float4 per slab
     const size_t pair = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
-    f32x4* outp = reinterpret_cast<f32x4*>(p.part) + (pair * gridDim.z + blockIdx.z) * slab4;
+    f32x4* outp = reinterpret_cast<f32x4*>(p.part) + (pair * gridDim.z + blockIdx.z) * slab;
 #pragma unroll
     for (int j = 0; j < NW; ++j)
 #pragma unroll
       for (int mf = 0; mf < CF; ++mf) {
-        if (WG3_ABL & 1) asm volatile("" :: "v"(acc[mf][j]));
-        else outp[((wave * NW + j) * CF + mf) * 64 + lane] = acc[mf][j];
+        const int e = ((wave4 * NW + j) * CF + mf) * 64 + lane;
+        if (WG3_ABL & 1) asm volatile("" :: "v"(acc[mf][j] + xch[e]));
+        else outp[e] = acc[mf][j] + xch[e];
       }
   }
 }
 
-// slab reduction: thread = (element column, split lane); an element is one accumulator register quad (wave, j, mf, lane) =
-// rows co0 + mf*16 + g*4 + 0..3 of column (tap, ci0 + cf*16 + t16), nf = wave + 4 j = tap*CF + cf.  16 elements x 16 split
-// lanes per workgroup, four slab loads in flight per lane (the 512 slabs of the six-MFMA mode are 43 MB: at 8 split-lanes
-// this pass took 27 us), fixed summation order: deterministic.
+// slabs of the team kernel -> dW: thread = (element column, split lane); an element is one accumulator register quad
+// (wave4, j, mf, lane) = rows co0 + mf*16 + g*4 + 0..3 of column (tap, ci0 + cf*16 + t16) with nf = wave4 + 4 j = tap*CF + cf.
+// 16 elements x 16 split-lanes per workgroup, four slab loads in flight per lane, fixed summation order.
 template <int CF>
-__global__ __launch_bounds__(256) void wg3_reduce_kernel(const float* __restrict__ part, float* __restrict__ out, int Ci,
-                                                         int Co, int nsplit, int accumulate) {
+__global__ __launch_bounds__(256) void wg3t_reduce_kernel(const float* __restrict__ part, float* __restrict__ out, int Ci,
+                                                          int Co, int nsplit, int accumulate) {
   constexpr int NFR = 9 * CF, NW = (NFR + 3) / 4;
   constexpr int SLAB = 4 * NW * CF * 64;              // float4 per slab
   __shared__ f32x4 sm[16][16];
@@ -343,8 +653,8 @@ __global__ __launch_bounds__(256) void wg3_reduce_kernel(const float* __restrict
 #pragma unroll
       for (int k = 1; k < 16; ++k) sv += sm[k][col];
       const int lane = e & 63, r = e >> 6;
-      const int mf = r % CF, wj = r / CF, j = wj % NW, wv = wj / NW;
-      const int nf = wv + 4 * j;
+      const int mf = r % CF, wj = r / CF, j = wj % NW, wave4 = wj / NW;
+      const int nf = wave4 + 4 * j;
       if (nf < NFR) {
         const int tap = nf / CF, cf = nf - tap * CF;
         const int ci = ci0 + cf * 16 + (lane & 15);
@@ -370,9 +680,13 @@ static void wg_magic(unsigned d, unsigned* mul, unsigned* sh) {
   *sh = l - 1;
 }
 
+#ifndef WG3_TEAM
+#define WG3_TEAM 1       // 0: the round-2 kernel (two 256-thread workgroups per CU, 512 slabs) - kept for A/B builds
+#endif
+
 static bool wg3_plan(int np, int N, int H, int W, int Ci, int Co, WG3Plan* pl) {
   if ((np != 2 && np != 3) || c3_row_width(W) > WG_MAX_SW || H < 1 || W < 2) return false;
-  const int kb = np == 3 ? WGeo<3>::KB : WGeo<2>::KB;
+  const int kb = WG3_TEAM ? 64 : (np == 3 ? WGeo<3>::KB : WGeo<2>::KB);
   int cf;
   if (Ci % 48 == 0 && Co % 48 == 0) cf = 3;
   else if (Ci % 32 == 0 && Co % 32 == 0) cf = 2;
@@ -380,14 +694,17 @@ static bool wg3_plan(int np, int N, int H, int W, int Ci, int Co, WG3Plan* pl) {
   const int ch = cf * 16;
   const long P = (long)N * (H + 1) * c3_row_width(W) + c3_row_width(W);
   const long pairs = (long)(Co / ch) * (Ci / ch);
-  // two resident workgroups per CU (512 in all) when one (co, ci) chunk pair exists; fewer splits per pair otherwise
-  // (partial-slab traffic grows with the split).  Splits take q or q + 1 stages, so no rounding loss.
+  // team kernel: ONE resident 512-thread workgroup per CU (256 in all) when one (co, ci) chunk pair exists; fewer splits per
+  // pair otherwise (partial-slab traffic grows with the split).  Splits take q or q + 1 stages, so no rounding loss.
 #ifdef BUCTD_TUNING      // experiment builds only
   static const int split_env = getenv("BUCTD_WG3_SPLIT") ? atoi(getenv("BUCTD_WG3_SPLIT")) : 0;
 #else
   constexpr int split_env = 0;
 #endif
-  long want = ((split_env > 0 ? split_env : (np == 3 ? 512 : 384)) + pairs - 1) / pairs;
+#ifndef WG3_SPLITS
+#define WG3_SPLITS (WG3_TEAM ? 256 : 512)
+#endif
+  long want = ((split_env > 0 ? split_env : (np == 3 || WG3_TEAM ? WG3_SPLITS : 384)) + pairs - 1) / pairs;
   const long stages = (P + kb - 1) / kb;
   if (want > stages) want = stages;
   if (want < 1) want = 1;
@@ -397,21 +714,36 @@ static bool wg3_plan(int np, int N, int H, int W, int Ci, int Co, WG3Plan* pl) {
   pl->rem = (int)(stages % want);
   int rs = ch * 2 * np;
   if (rs % 64 != 32) rs += 32;
-  pl->lds = (size_t)(2 * kb + 2 * c3_row_width(W) + 2) * rs;      // dY tile (KB rows) + X ring (KB + 2*SW + 2 rows)
+  if (WG3_TEAM) {
+    // two dY tiles + the X ring of KB + (KB + 2*SW + 2) rows; at least the accumulator exchange area of the epilogue
+    pl->lds = (size_t)(3 * kb + kb + 2 * c3_row_width(W) + 2) * rs;
+    const size_t xch = (size_t)4 * ((9 * cf + 3) / 4) * cf * 64 * 16;
+    if (pl->lds < xch) pl->lds = xch;
+  } else {
+    pl->lds = (size_t)(2 * kb + 2 * c3_row_width(W) + 2) * rs;      // dY tile (KB rows) + X ring (KB + 2*SW + 2 rows)
+  }
   return pl->lds <= 160 * 1024;
 }
 
-static size_t wg3_slab_floats(int cf) { return (size_t)4 * ((9 * cf + 3) / 4) * cf * 64 * 4; }     // accumulator-order slab of one pair
+static size_t wg3_slab_floats(int cf, int Ci, int Co) {     // floats of ONE partial slab of one (co, ci) chunk pair
+  return WG3_TEAM ? (size_t)4 * ((9 * cf + 3) / 4) * cf * 64 * 4 : (size_t)(cf * 16) * 9 * (cf * 16);
+}
 static size_t wg3_ws_bytes(const WG3Plan& pl, int Ci, int Co) {
+  if (!WG3_TEAM) return (size_t)pl.nsplit * Co * 9 * Ci * sizeof(float);
   const size_t pairs = (size_t)(Co / (pl.CF * 16)) * (Ci / (pl.CF * 16));
-  return pairs * pl.nsplit * wg3_slab_floats(pl.CF) * sizeof(float);
+  return pairs * pl.nsplit * wg3_slab_floats(pl.CF, Ci, Co) * sizeof(float);
 }
 
 template <int NP, int CF>
 static int wg3_launch(const WG3Args& a, const WG3Plan& pl, hipStream_t st) {
   static bool attr_set = false;     // idempotent attribute call: a race at first use only repeats it
+#if WG3_TEAM
+  auto fn = conv3x3_wgrad_team_kernel<NP, CF>;
+  const dim3 block(512);
+#else
   auto fn = conv3x3_wgrad_split_kernel<NP, CF>;
   const dim3 block(256);
+#endif
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        160 * 1024);
@@ -468,12 +800,23 @@ static int wg3_run(int np, int N, int H, int W, int Ci, int Co, const float* x, 
 #ifdef WG3_WHATIF_SKIP_REDUCE
   return BUCTD_OK;
 #endif
-  const int pairs = (Co / (pl.CF * 16)) * (Ci / (pl.CF * 16));
-  const dim3 rgrid(ceil_div((long)(wg3_slab_floats(pl.CF) / 4), 16), pairs);
-  if (pl.CF == 3)
-    hipLaunchKernelGGL(wg3_reduce_kernel<3>, rgrid, dim3(256), 0, st, (const float*)workspace, dw, Ci, Co, pl.nsplit, accumulate);
-  else
-    hipLaunchKernelGGL(wg3_reduce_kernel<2>, rgrid, dim3(256), 0, st, (const float*)workspace, dw, Ci, Co, pl.nsplit, accumulate);
+#if WG3_TEAM
+  {
+    const int pairs = (Co / (pl.CF * 16)) * (Ci / (pl.CF * 16));
+    const int slab4 = (int)(wg3_slab_floats(pl.CF, Ci, Co) / 4);
+    dim3 rgrid(ceil_div(slab4, 16), pairs);
+    if (pl.CF == 3)
+      hipLaunchKernelGGL(wg3t_reduce_kernel<3>, rgrid, dim3(256), 0, st, (const float*)workspace, dw, Ci, Co, pl.nsplit, accumulate);
+    else
+      hipLaunchKernelGGL(wg3t_reduce_kernel<2>, rgrid, dim3(256), 0, st, (const float*)workspace, dw, Ci, Co, pl.nsplit, accumulate);
+  }
+#else
+  const long n = (long)Co * 9 * Ci;
+  int blocks = ceil_div(n / 4, 16);
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(wg3_reduce_kernel, dim3(blocks), dim3(256), 0, st, (const float*)workspace, dw, n, pl.nsplit,
+                     accumulate);
+#endif
   BUCTD_CHECK_LAUNCH("buctd_conv3x3_wgrad (split bf16, reduce)");
   return BUCTD_OK;
 }

@@ -90,8 +90,8 @@ def test_high_resolution_module(dev, nb, mso):
 @pytest.mark.parametrize("shape", [(2, 24, 18, 48), (3, 12, 9, 96), (20, 96, 72, 48)])
 def test_basic_block_input_bn_fusion_is_bit_identical(dev, shape, monkeypatch):
     """bf16x6 mode: conv2 of a BasicBlock applies bn1 + ReLU while staging its input, and its weight gradient rebuilds
-    that input the same way (buctd_conv3x3_*_bnin).  Same bits as the unfused sequence conv1 -> bn_apply -> conv2:
-    output, input gradient and every parameter gradient."""
+    that input the same way (buctd_conv3x3_*_bnin).  Same bits as the unfused sequence conv1 -> bn_apply -> conv2 in the
+    forward; gradients equal to the round-off of the BatchNorm-backward sums (formed in another fixed order)."""
     import torch.nn as tnn
     from buctd_amd import ops
     N, H, W, Cn = shape
@@ -102,7 +102,6 @@ def test_basic_block_input_bn_fusion_is_bit_identical(dev, shape, monkeypatch):
     w2 = tnn.Parameter((torch.randn(Cn, Cn, 3, 3, generator=g) * 0.08).contiguous(memory_format=torch.channels_last).to(dev))
     dy = torch.randn(N, H, W, Cn, generator=g).to(dev)
     res = {}
-    monkeypatch.setattr(ops, "_PLANES_BLOCKS", False)    # the planes backward (other reduction orders) has its own test below
     for flag in ("1", "0"):
         monkeypatch.setattr(ops, "_FUSE_BN_IN", flag == "1")
         assert ops.bn_in_fusable((N, H, W, Cn), w2) == (flag == "1")
@@ -121,60 +120,27 @@ def test_basic_block_input_bn_fusion_is_bit_identical(dev, shape, monkeypatch):
         torch.cuda.synchronize()
         res[flag] = [y.detach().clone(), xi.grad.clone(), w1.grad.clone(), w2.grad.clone(), bns[0].weight.grad.clone(),
                      bns[0].bias.grad.clone(), bns[1].weight.grad.clone(), bns[1].running_var.clone()]
-    for a, b in zip(res["1"], res["0"]):
-        assert torch.equal(a, b), f"fused vs unfused differ by {(a - b).abs().max().item():.3e}"
+    names = ["y", "dx", "dw1", "dw2", "dgamma1", "dbeta1", "dgamma2", "running_var2"]
+    for n, a, b in zip(names, res["1"], res["0"]):
+        if n in ("y", "running_var2"):
+            # the forward: the very same arithmetic per element, same bits
+            assert torch.equal(a, b), f"{n}: fused vs unfused differ by {(a - b).abs().max().item():.3e}"
+        else:
+            # the backward: the native sequence forms the BatchNorm-backward sums in the data-gradient epilogue (per row group
+            # of the tile grid, buctd_conv3x3_bf16x6_bnstat), the step-by-step path with bn_bwd_reduce2_kernel (per block of
+            # rows) - same element arithmetic, other (fixed) summation order: fp32 round-off of those sums
+            sc = b.abs().max().item()
+            err = (a - b).abs().max().item()
+            assert err <= 5e-6 * sc, f"{n}: native vs step-by-step backward differ by {err:.3e} (scale {sc:.3e})"
 
 
-@pytest.mark.parametrize("shape", [(2, 24, 18, 48), (3, 12, 9, 96), (4, 6, 5, 192), (20, 96, 72, 48)])
-def test_basic_block_planes_backward_matches_fp32_operand_backward(dev, shape, monkeypatch):
-    """BasicBlocks of 48-channel-multiple widths run their backward on x6 planes (forward convs emit the split x / y1, the
-    BatchNorm backward writes dz pre-split, LDS-DMA weight gradient).  Forward: same kernels, same bits.  Backward: the
-    same arithmetic per element with other (fixed) summation orders in the BatchNorm reductions and the weight-gradient
-    split - agreement to fp32 round-off of the respective sums, and run-to-run bit-reproducible."""
+def test_block_chain_equals_single_blocks(dev):
+    """BasicChainFn (one library call per direction for a whole branch) against n BasicBlockFn calls.  Forward: the same
+    launches, same bits.  Backward: inside a chain the sums of bn2's backward of block k - 1 are a by-product of block k's
+    conv1 data gradient (block.hip), a single block forms them with bn_bwd_reduce2_kernel: same element arithmetic, another
+    fixed summation order - equal to fp32 round-off of those sums, and run-to-run bit-reproducible."""
     import torch.nn as tnn
     from buctd_amd import ops
-    N, H, W, Cn = shape
-    g = torch.Generator().manual_seed(H + Cn + 1)
-    x = torch.randn(N, H, W, Cn, generator=g).to(dev)
-    w1 = tnn.Parameter((torch.randn(Cn, Cn, 3, 3, generator=g) * 0.08).contiguous(memory_format=torch.channels_last).to(dev))
-    w2 = tnn.Parameter((torch.randn(Cn, Cn, 3, 3, generator=g) * 0.08).contiguous(memory_format=torch.channels_last).to(dev))
-    dy = torch.randn(N, H, W, Cn, generator=g).to(dev)
-    res = {}
-    for mode in ("planes", "fp32", "planes2"):
-        monkeypatch.setattr(ops, "_PLANES_BLOCKS", mode != "fp32")
-        bns = []
-        for s in (1, 2):
-            bn = tnn.BatchNorm2d(Cn).to(dev).train()
-            with torch.no_grad():
-                bn.weight.copy_(torch.rand(Cn, generator=torch.Generator().manual_seed(s)) + 0.5)
-                bn.bias.copy_(torch.randn(Cn, generator=torch.Generator().manual_seed(10 + s)) * 0.2)
-            bns.append(bn)
-        for p in (w1, w2):
-            p.grad = None
-        xi = x.clone().requires_grad_(True)
-        y = ops.BasicBlockFn.apply(xi, w1, bns[0], w2, bns[1])
-        y.backward(dy)
-        torch.cuda.synchronize()
-        res[mode] = [y.detach().clone(), xi.grad.clone(), w1.grad.clone(), w2.grad.clone(), bns[0].weight.grad.clone(),
-                     bns[0].bias.grad.clone(), bns[1].weight.grad.clone(), bns[1].bias.grad.clone()]
-    assert torch.equal(res["planes"][0], res["fp32"][0]), "forward must not change"
-    for a, b in zip(res["planes"], res["planes2"]):
-        assert torch.equal(a, b), "planes backward is not run-to-run reproducible"
-    names = ["y", "dx", "dw1", "dw2", "dgamma1", "dbeta1", "dgamma2", "dbeta2"]
-    for n, a, b in zip(names, res["planes"], res["fp32"]):
-        sc = b.abs().max().item()
-        err = (a - b).abs().max().item()
-        assert err <= 2e-5 * sc, f"{n}: planes vs fp32-operand backward differ by {err:.3e} (scale {sc:.3e})"
-
-
-@pytest.mark.parametrize("planes", [False, True])
-def test_block_chain_equals_single_blocks(dev, planes, monkeypatch):
-    """BasicChainFn (one library call per direction for a whole branch) runs the launches of n BasicBlockFn calls: same bits
-    for the output, the input gradient and every parameter gradient - with fp32 operands and in planes mode (per-block planes
-    from the pool, one scratch set of 2 n dz planes per call)."""
-    import torch.nn as tnn
-    from buctd_amd import ops
-    monkeypatch.setattr(ops, "_PLANES_BLOCKS", planes)
     N, H, W, Cn, n = 3, 12, 10, 48, 3
     g = torch.Generator().manual_seed(77)
     x = torch.randn(N, H, W, Cn, generator=g).to(dev)
@@ -211,8 +177,13 @@ def test_block_chain_equals_single_blocks(dev, planes, monkeypatch):
         torch.cuda.synchronize()
         res[mode] = [y.detach().clone(), xi.grad.clone()] + [q.grad.clone() for q in params] + \
             [blocks[-1][3].running_var.clone()]
-    for a, b, c in zip(res["chain"], res["single"], res["chain2"]):
-        assert torch.equal(a, b) and torch.equal(a, c)
+    for i, (a, b, c) in enumerate(zip(res["chain"], res["single"], res["chain2"])):
+        assert torch.equal(a, c), "the chain is not run-to-run reproducible"
+        if i == 0 or i == len(res["chain"]) - 1:
+            assert torch.equal(a, b), "forward output / running statistics must not change"
+        else:
+            sc = b.abs().max().item()
+            assert (a - b).abs().max().item() <= 5e-6 * sc, f"tensor {i}: chain vs single blocks {(a - b).abs().max().item():.3e} (scale {sc:.3e})"
 
 
 def test_eval_bn_fold_cache_follows_training_updates(dev):
