@@ -137,7 +137,8 @@ __device__ __forceinline__ void c3_epilogue(const C3Args& p, f32x4 (&acc)[MF][NF
   constexpr int MR = MF * 16;              // rows of this wave's tile (<= 128)
   constexpr int RH = (MR + 63) / 64;       // 64-row halves: lane r owns rows r and r + 64
   constexpr int LD = NF * 16 + 4;          // staging row stride in floats: 4*LD = 16 mod 64 keeps the writes conflict-free
-  constexpr int EP = (MF >= 2 && MF % 2 == 0) ? 2 : 1;      // 16-row fragments staged per pass (odd MF: one)
+  constexpr int EP = 1;                    // 16-row fragments staged per pass (one: the look-ahead registers of the
+                                           // store loop scale with it, and a pass costs no workgroup barrier)
   static_assert(MR <= 128, "c3_epilogue: at most 128 rows per wave");
   float* stg = reinterpret_cast<float*>(smem) + wave * (EP * 16 * LD);
   int* rowoff = reinterpret_cast<int*>(smem) + 4 * EP * 16 * LD + wave * 128;
@@ -208,9 +209,36 @@ __device__ __forceinline__ void c3_epilogue(const C3Args& p, f32x4 (&acc)[MF][NF
   for (int j = 0; j < NACC; ++j) bs1[j] = bs2[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
   const bool bs_on = p.bs_part != nullptr;
   const bool bs_rebuild = bs_on && p.bs_y == nullptr;
+  // Every wave stages through ITS OWN slice of LDS (stg, rowoff) and the LDS executes one wave's operations in order, so
+  // the passes need no workgroup barrier - only the compiler must keep the stores in front of the loads (wave_barrier).
+#define C3_EPI_SYNC() __builtin_amdgcn_wave_barrier()
+  // The tensors the store loop reads beside the tile - the residual, and z / y of the BatchNorm-backward by-product - travel
+  // ONE PASS AHEAD through two register sets: loaded inside the loop they cost a memory round trip per pass, and in a launch
+  // that is one round of workgroups every CU sits in its epilogue at the same time, so nothing else hides it (measured at
+  // 48 channels: + 6 us for the residual, + 13 / + 22 us for the by-product).  EP * NF items per lane and pass.
+  constexpr int NI = EP * NF;
+  constexpr int NPASS = MF / EP;
+  f32x4 pre_r[2][NI], pre_z[2][NI], pre_y[2][NI];
+  const bool has_res = p.res != nullptr;
+  const bool has_y = bs_on && !bs_rebuild;
+  C3_EPI_SYNC();     // rowoff is complete
+  auto issue = [&](int ps, int buf) {
 #pragma unroll
-  for (int ps = 0; ps < MF / EP; ++ps) {
-    if (ps) __syncthreads();
+    for (int k = 0; k < NI; ++k) {
+      const int item = lane + 64 * k;
+      const int row = item / (NF * 4), c4 = item - row * (NF * 4);
+      const int off = rowoff[ps * EP * 16 + row];
+      const int o = off >= 0 ? off + ncol0 + c4 * 4 : 0;       // pad rows: any valid address, the value is not used
+      if (has_res) pre_r[buf][k] = *reinterpret_cast<const f32x4*>(p.res + o);
+      if (bs_on) pre_z[buf][k] = *reinterpret_cast<const f32x4*>(p.bs_z + o);
+      if (has_y) pre_y[buf][k] = *reinterpret_cast<const f32x4*>(p.bs_y + o);
+    }
+  };
+  if (has_res || bs_on) issue(0, 0);
+#pragma unroll
+  for (int ps = 0; ps < NPASS; ++ps) {
+    if (ps) C3_EPI_SYNC();
+    if ((has_res || bs_on) && ps + 1 < NPASS) issue(ps + 1, (ps + 1) & 1);
 #pragma unroll
     for (int e = 0; e < EP; ++e)
 #pragma unroll
@@ -218,9 +246,9 @@ __device__ __forceinline__ void c3_epilogue(const C3Args& p, f32x4 (&acc)[MF][NF
 #pragma unroll
         for (int rg = 0; rg < 4; ++rg)
           stg[(e * 16 + g * 4 + rg) * LD + nf * 16 + i16] = acc[ps * EP + e][nf][rg] + bv[nf];
-    __syncthreads();
+    C3_EPI_SYNC();
 #pragma unroll
-    for (int k = 0; k < EP * NF; ++k) {
+    for (int k = 0; k < NI; ++k) {
       const int item = lane + 64 * k;
       const int row = item / (NF * 4), c4 = item - row * (NF * 4);
       f32x4 v = *reinterpret_cast<const f32x4*>(stg + row * LD + c4 * 4);
@@ -233,8 +261,8 @@ __device__ __forceinline__ void c3_epilogue(const C3Args& p, f32x4 (&acc)[MF][NF
 #pragma unroll
           for (int j = 0; j < 4; ++j) v[j] = v[j] * sc[j] + sh[j];
         }
-        if (p.res) {
-          const f32x4 r = *reinterpret_cast<const f32x4*>(p.res + off + n);
+        if (has_res) {
+          const f32x4 r = pre_r[ps & 1][k];
 #pragma unroll
           for (int j = 0; j < 4; ++j) v[j] += r[j];
         }
@@ -245,7 +273,7 @@ __device__ __forceinline__ void c3_epilogue(const C3Args& p, f32x4 (&acc)[MF][NF
         *reinterpret_cast<f32x4*>(p.out + off + n) = v;
         if (bs_on) {
           // the arithmetic of bn_bwd_reduce2_kernel's body, element for element
-          const f32x4 zz = *reinterpret_cast<const f32x4*>(p.bs_z + off + n);
+          const f32x4 zz = pre_z[ps & 1][k];
           const f32x4 mu = *reinterpret_cast<const f32x4*>(p.bs_mean + n);
           const f32x4 is = *reinterpret_cast<const f32x4*>(p.bs_invstd + n);
           f32x4 yy;
@@ -253,7 +281,7 @@ __device__ __forceinline__ void c3_epilogue(const C3Args& p, f32x4 (&acc)[MF][NF
             const f32x4 sc = is * *reinterpret_cast<const f32x4*>(p.bs_gamma + n);
             yy = (zz - mu) * sc + *reinterpret_cast<const f32x4*>(p.bs_beta + n);
           } else {
-            yy = *reinterpret_cast<const f32x4*>(p.bs_y + off + n);
+            yy = pre_y[ps & 1][k];
           }
           f32x4 gm = v;
 #pragma unroll
