@@ -27,12 +27,16 @@ PEAK_FP32_MFMA_TFLOPS = 157.3
 PEAK_BF16_MFMA_TFLOPS = 2500.0
 PEAK_HBM_GBPS = 8000.0
 MFMAS_PER_PRODUCT = {"bf16x6": 6, "bf16x3": 3}
-# HBM-side bytes per launch of the roofline kernels at N = 32 from separate rocprofv3 --pmc passes (2 x FETCH_SIZE +
-# WRITE_SIZE, gfx950 correction; profiles/r02_pmc_*.txt).  Counters cannot be read inside the timed run, so the figure is
-# quoted only for the math mode and batch it was collected at.
-PMC_TRAFFIC_BYTES_N32 = {"bf16x6": {"fwd": 102.8e6,      # 2 x 30.33 MB fetched + 42.17 MB written (x6 kernel, 512-position tiles)
-                                    "wgrad": 181.1e6}}   # kernel 2 x 48.65 + 42.17 (slabs), reduce 2 x 20.76 + 0.08
-# (profiles/r02_pmc_conv3x3_bf16x6.txt; re-measured unchanged in round 3: profiles/r03_pmc_conv3x3_default_path.txt)
+# Counters cannot be read inside the timed run.  HBM bytes per launch (2 x FETCH_SIZE + WRITE_SIZE, gfx950 correction) and
+# the kernels' durations INSIDE the step (rocprofv3 --kernel-trace of this very command) are therefore measured by
+# scratch/r04_profiles.sh on the build that is committed and quoted from the files it wrote - with their name and date - and
+# only for the math mode / batch / shape they were collected at.  A missing file means null, never a stale constant.
+def _profile_json(name):
+    try:
+        with open(os.path.join(ROOT, "profiles", name)) as f:
+            return json.load(f)
+    except (OSError, ValueError):
+        return None
 
 
 def coam_w48_cfg(batch):
@@ -199,9 +203,10 @@ def install_timer(timer):
     ops.native_block_veto["fn"] = veto
 
 
-def roofline_entry(math, batch, kind, in_step, solo, traffic, shape=(48, 96, 72)):
+def roofline_entry(math, batch, kind, in_step, solo, traffic, shape=(48, 96, 72), kernel_us=None, sources=None):
     """One roofline object.  Algorithmic work of one launch (SURVEY 8d x batch): 2*N*H*W*C*C*9 FLOP (C4: 96x72, 48
-    channels) and fp32 bytes in + out + weights.  in_step / solo = (average launch us, launches)."""
+    channels) and fp32 bytes in + out + weights.  in_step / solo = (average launch us, launches); kernel_us = the kernel's
+    average DURATION inside the step from the committed rocprofv3 trace of this command (None: not collected)."""
     n = batch
     cw, hh, ww = shape
     flops = 2.0 * n * hh * ww * cw * cw * 9
@@ -221,7 +226,7 @@ def roofline_entry(math, batch, kind, in_step, solo, traffic, shape=(48, 96, 72)
         peak = PEAK_BF16_MFMA_TFLOPS / k
         unit_note = (f"dense bf16 MFMA peak 2500 TFLOP/s / {k} MFMAs per fp32 product (split operands) = "
                      f"{peak:.1f} TFLOP/s-equivalent")
-        kernel = {("bf16x6", "fwd"): "conv3x3_x6_kernel<MF=8,NF=3,WM=4,WN=1> (512-position tiles)",
+        kernel = {("bf16x6", "fwd"): "conv3x3_x6_kernel<MF=7,NF=3,WM=4,WN=1> (448-position tiles, one round of 506 workgroups)",
                   ("bf16x3", "fwd"): "conv3x3_split_kernel<NP=2,4,3,4,1>"}.get(
                       (math, "fwd" if kind == "fwd" else "wgrad"),
                       "conv3x3_wgrad_split_kernel<NP=%d,3> + wg3_reduce_kernel" % (3 if math == "bf16x6" else 2))
@@ -242,17 +247,21 @@ def roofline_entry(math, batch, kind, in_step, solo, traffic, shape=(48, 96, 72)
             "peak": round(peak, 1) if bound == "mfma" else PEAK_HBM_GBPS,
             "unit": "TFLOP/s" if bound == "mfma" else "GB/s",
             "frac": frac(t_head),
+            "avg_kernel_us_in_step": kernel_us, "frac_in_step_kernel": frac(kernel_us),
             "traffic": traffic, "traffic_unit": "HBM bytes/launch (PMC, standalone launches)" if traffic else None,
+            "sources": sources,
             "algorithmic_flops": flops, "algorithmic_bytes": bytes_,
             "avg_launch_us": round(t_head, 2), "launches_timed": in_step[1] if in_step[0] else solo[1],
             "avg_launch_us_solo": round(solo[0], 2) if solo[0] else None, "launches_timed_solo": solo[1],
             "frac_solo": frac(solo[0]),
             "hbm_gbps": round(gbps, 1), "hbm_frac": round(gbps / PEAK_HBM_GBPS, 4),
             "roof_times_us": {"mfma": round(mfma_us, 2), "hbm": round(hbm_us, 2)},
-            "timing": "HIP events on the launching stream around each launch. avg_launch_us: every launch of this "
-                      "shape inside the timed steps (the step keeps 4 streams busy, so a launch shares the GPU with "
-                      "its co-runners); avg_launch_us_solo: 60 launches of the same kernel alone on the GPU right "
-                      "after the timed steps and 150 warm-up rounds (settled clock)",
+            "timing": "HIP events on the launching stream around each launch. avg_launch_us / frac: every launch of this "
+                      "shape inside the step (event to event: the step keeps 4 streams busy, so it contains the co-runners' "
+                      "share of the GPU and the time the launch queues behind them); avg_kernel_us_in_step / "
+                      "frac_in_step_kernel: the kernel's own duration inside the step, from the committed rocprofv3 "
+                      "trace of this command (sources); avg_launch_us_solo / frac_solo: 60 launches of the same kernel "
+                      "alone on the GPU right after the timed steps and 150 warm-up rounds (settled clock)",
             "note": f"binding roof = {bound}: {unit_note}; HBM roof 8 TB/s on {bytes_ / 1e6:.1f} MB/launch"}
 
 
@@ -582,6 +591,23 @@ def main():
         t = torch.tensor([sum(ts) / len(ts)], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         comm_ms = round(1e3 * float(t.item()), 3)
+        # one more step with timing events around every bucket's exchange on the communication stream: when (ms after the
+        # backward pass started on the GPU) each bucket's all-reduce began and ended, against the end of the backward pass -
+        # what is hidden behind the backward and what sticks out shows at a glance
+        model.bucket_trace = []
+        bw0, bw1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        outp = model(x)
+        lossp = criterion(outp, target, weight)
+        optimizer.zero_grad()
+        bw0.record()
+        lossp.backward()
+        bw1.record()
+        optimizer.step()
+        fence()
+        bucket_rows = [{"bucket": i, "mb": round(nb / 2 ** 20, 1), "start_ms": round(bw0.elapsed_time(e0), 2),
+                        "end_ms": round(bw0.elapsed_time(e1), 2)} for i, nb, e0, e1 in model.bucket_trace]
+        backward_ms = round(bw0.elapsed_time(bw1), 2)
+        model.bucket_trace = None
     solo = {k: (None, 0) for k in in_step}
     if not args.no_kernel_timer and rank == 0:
         # the same kernels alone on the GPU: 60 launches each (after 150 warm-up rounds) on a stage-4-branch-0 sized activation with one of the
@@ -627,20 +653,54 @@ def main():
         if comm_ms is not None:
             out["allreduce_exposed_ms_per_step"] = comm_ms
             out["allreduce"] = ("flat fp32 gradient arena in ~48 MB buckets (tensors >= a bucket travel alone), one "
-                                "RCCL all-reduce per bucket on a communication stream, launched from the backward pass as "
-                                "soon as the bucket's last gradient kernel is enqueued")
+                                "RCCL all-reduce per bucket on a highest-priority communication stream, launched from the "
+                                "backward pass as soon as the bucket's last gradient kernel is enqueued")
+            out["allreduce_buckets"] = {"backward_ms": backward_ms, "rank0": bucket_rows,
+                                        "note": "start / end of every bucket's all-reduce on the communication stream, ms after "
+                                                "the backward pass started on the GPU (one extra step behind the timed region)"}
         def merge(a, b):     # forward and data-gradient launches run the same kernel on the same bytes
             n = a[1] + b[1]
             return ((a[0] * a[1] + b[0] * b[1]) / n, n) if n else (None, 0)
 
-        traffic = PMC_TRAFFIC_BYTES_N32.get(args.conv_math, {}) if (args.batch == 32 and rshape == (48, 96, 72)) else {}
+        # this round's measurements of the committed build (scratch/r04_profiles.sh), quoted with their file and date
+        quoted = args.conv_math == "bf16x6" and args.batch == 32 and rshape == (48, 96, 72) and args.workload == "train_c4"
+        pmc = _profile_json("r04_pmc_traffic.json") if quoted else None
+        trace = _profile_json("r04_in_step_kernel_us.json") if quoted else None
+
+        def kernel_us(*subs):      # calls-weighted duration of the kernels whose name contains any of `subs`, summed per launch
+            if not trace:
+                return None
+            tot = 0.0
+            for sub in subs:
+                rows = [v for k, v in trace["kernels"].items() if sub in k]
+                if not rows:
+                    return None
+                tot += sum(v["ms_per_step"] for v in rows) / sum(v["calls_per_step"] for v in rows) * 1e3
+            return round(tot, 1)
+
+        def src(kind):
+            out_ = {}
+            if pmc:
+                out_["traffic"] = f"{pmc['source']}, {pmc['date']}"
+            if trace:
+                out_["avg_kernel_us_in_step"] = f"{trace['source']}, {trace['date']}"
+            return out_ or None
+
+        fwd_traffic = None
+        if pmc:
+            fwd_traffic = round((pmc["fwd"]["bytes"] + pmc["dgrad"]["bytes"]) / 2)
         main = roofline_entry(args.conv_math, args.batch, "fwd", merge(in_step["fwd"], in_step["dgrad"]),
-                              merge(solo["fwd"], solo["dgrad"]), traffic.get("fwd"), rshape)
-        wg = roofline_entry(args.conv_math, args.batch, "wgrad", in_step["wgrad"], solo["wgrad"], traffic.get("wgrad"), rshape)
-        if main is not None:
-            out["roofline"] = main
+                              merge(solo["fwd"], solo["dgrad"]), fwd_traffic, rshape,
+                              kernel_us("conv3x3_x6_kernel<7, 3, 4, 1"), src("fwd"))
+        wg = roofline_entry(args.conv_math, args.batch, "wgrad", in_step["wgrad"], solo["wgrad"],
+                            pmc["wgrad"]["bytes"] if pmc else None, rshape,
+                            kernel_us("conv3x3_wgrad_split_kernel<3, 3>", "wg3_reduce_kernel"), src("wgrad"))
+        # `roofline` = the dominant kernel of the step by time (the weight gradient: 214 launches, kernel + slab reduction);
+        # the forward / data-gradient launches of the same shape ride beside it
         if wg is not None:
-            out["roofline_wgrad"] = wg
+            out["roofline"] = wg
+        if main is not None:
+            out["roofline_fwd_dgrad"] = main
         if world == 1 and not args.no_cpu_baseline and args.workload == "train_c4":
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)

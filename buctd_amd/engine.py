@@ -320,6 +320,9 @@ class DataParallel(torch.nn.Module):
         self._dirty = False
         self._entry_stream = None
         self._comm_stream = None
+        # bench.py: set to a list to get one (bucket index, bytes, start event, end event) per bucket exchange on the
+        # communication stream (timing events; None = off, the production setting)
+        self.bucket_trace = None
 
     # -- construction-time helpers ---------------------------------------------------------
     def cuda(self, device=None):
@@ -334,7 +337,10 @@ class DataParallel(torch.nn.Module):
                 self.broadcast_buffers()
                 self.buckets = GradBuckets(self.flat, self.bucket_bytes)
                 if self.overlap and self.flat.flat.is_cuda:
-                    self._comm_stream = torch.cuda.Stream()
+                    # the exchange runs at the HIGHEST stream priority: an RCCL kernel occupies a few CUs per channel and
+                    # must not queue behind the four compute streams' workgroups (it would start when they drain, i.e.
+                    # exposed); what it takes away from them is its channel count (RCCL's default: <= 32 CUs of 256)
+                    self._comm_stream = torch.cuda.Stream(priority=-1)
                     ops.set_grad_ready_callback(self._grad_ready)
         return self.flat
 
@@ -377,7 +383,14 @@ class DataParallel(torch.nn.Module):
                 ev.record(st)
                 self._comm_stream.wait_event(ev)
             with torch.cuda.stream(self._comm_stream):
+                if self.bucket_trace is not None:
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record(self._comm_stream)
                 self._handles.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, async_op=True))
+                if self.bucket_trace is not None:
+                    self._handles[-1].wait()          # stream-side wait only: orders e1 behind the collective
+                    e1.record(self._comm_stream)
+                    self.bucket_trace.append((i, 4 * (e - s), e0, e1))
         else:
             if view.is_cuda:
                 ops.wait_side_stream()

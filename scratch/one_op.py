@@ -51,11 +51,7 @@ x = torch.randn(N, H, W, Ci, device=dev)
 dy = torch.randn(N, H, W, Co, device=dev)
 w = (torch.randn(Co, Ci, 3, 3, device=dev) * 0.05).contiguous(memory_format=torch.channels_last)
 gw = torch.empty_like(w)
-xp, dyp = ops.to_planes(x), ops.to_planes(dy)
-fn = {"pfwd": lambda: ops.conv3x3_planes(xp, w, 0, Co, stats=True),
-      "pdgrad": lambda: ops.conv3x3_planes(dyp, w, 1, Ci),
-      "pwgrad": lambda: ops.conv_wgrad_planes(xp, dyp, gw),
-      "fwd": lambda: ops.conv_fwd(x, w, None, 1, 1, stats=True),
+fn = {"fwd": lambda: ops.conv_fwd(x, w, None, 1, 1, stats=True),
       "dgrad": lambda: ops.conv_dgrad(dy, w, tuple(x.shape), 1, 1),
       "wgrad": lambda: ops.conv_wgrad(x, dy, w, 1, 1, out=gw, accumulate=0)}[kind]
 fn()

@@ -176,3 +176,33 @@ def test_bench_launches_its_own_ranks(tmp_path):
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["steps"] == 2 and out["scaling"] == "weak" and out["value"] > 0
     assert out["config"]["global_batch"] == 8 and out["allreduce_exposed_ms_per_step"] >= 0
+    _check_bucket_rows(out)
+
+
+def _check_bucket_rows(out):
+    """the per-bucket exchange timeline of the --gpus N line: every bucket once, exchanges begin after the backward pass
+    started, in launch order on the communication stream, and their sizes add up to the gradient arena"""
+    b = out["allreduce_buckets"]
+    rows = b["rank0"]
+    assert b["backward_ms"] > 0 and len(rows) >= 2
+    assert sorted(r["bucket"] for r in rows) == list(range(len(rows)))
+    assert all(r["end_ms"] >= r["start_ms"] >= 0 for r in rows)
+    assert all(rows[i]["start_ms"] <= rows[i + 1]["start_ms"] + 1e-3 for i in range(len(rows) - 1))
+    assert abs(sum(r["mb"] for r in rows) * 2 ** 20 - 4 * out["config"]["params"]) <= 0.02 * 4 * out["config"]["params"] + 2 ** 20
+
+
+def test_bench_with_four_ranks_on_one_device(tmp_path):
+    """`python bench.py --gpus 4`: four ranks (all on GPU 0 over gloo on a 1-GPU box) - the launch, rendezvous, bucketed
+    exchange from the backward callbacks and the max-over-ranks clock of the 4-GPU point of the scaling curve."""
+    import json
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--steps", "2", "--warmup", "1",
+                        "--workload", "train_c2", "--batch", "2", "--no-kernel-timer"],
+                       env=_env(BUCTD_DIST_BACKEND="gloo", BUCTD_SINGLE_DEVICE="1"), capture_output=True, text=True,
+                       timeout=1200)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-2500:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 4 and out["config"]["global_batch"] == 8 and out["config"]["parallelism"] == "dp4"
+    assert out["value"] > 0 and out["allreduce_exposed_ms_per_step"] >= 0
+    _check_bucket_rows(out)
