@@ -10,6 +10,6 @@ lib, script = sys.argv[1], sys.argv[2]
 if not os.path.isabs(lib):
     lib = os.path.join(ROOT, "scratch", lib)
 from buctd_amd import _C  # noqa: E402
-_C.LIB_PATH = lib
+_C.LIB_PATH = lib if os.path.exists(lib) else os.path.join(ROOT, sys.argv[1])
 sys.argv = sys.argv[2:]
 runpy.run_path(script, run_name="__main__")

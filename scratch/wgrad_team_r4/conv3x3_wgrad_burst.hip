@@ -307,6 +307,257 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_split_kernel(WG3Args p) 
   }
 }
 
+#ifndef WG3_BURST
+#define WG3_BURST 0      // 1: the producer / consumer kernel below instead of conv3x3_wgrad_split_kernel (A/B builds)
+#endif
+// ---- BURST kernel (round 4, second attempt at de-phasing the two wavefronts of a SIMD) -----------------------------------
+// One 512-thread workgroup per CU = two teams of four wavefronts (wavefronts w and w + 4 share a SIMD).  The teams split
+// the N side of the GEMM: team A owns the n-fragments (tap, ci16) 0 .. NA-1, team B the rest - 48 accumulator registers per
+// wavefront instead of 84, no exchange at the end.  Time is cut into PHASES, two per k-step (32 positions): in phase 2k team A
+// runs a BURST - the <= 72 MFMAs of its fragments of k-step k out of REGISTERS only (3 x 3 A fragments + 4 x 3 B fragments,
+// read from LDS in the phase before) - while team B reads ITS fragments of k-step k; in phase 2k + 1 team B bursts and team A
+// reads its fragments of k-step k + 1.  The team that is not multiplying also splits and stores its share of an upcoming
+// stage (A the dY tile, B the new X rows) and issues the global loads of the stage after that.  The multiplying wavefront
+// touches neither LDS nor memory; its partner on the SIMD does VALU / LDS / VMEM work only.  One workgroup barrier per phase.
+// dY tiles double buffered, X ring + KB rows; 256 slabs (one workgroup per CU).
+template <int CF> struct WGBurst {
+  static constexpr int NFR = 9 * CF;
+  static constexpr int NA = (NFR + 1) / 2;          // n-fragments of team A (14 of 27; 9 of 18)
+  static constexpr int NJ = (NA + 3) / 4;           // n-fragments per wavefront, at most (4; 3)
+  static constexpr int SLAB4 = 8 * NJ * CF * 64;    // float4 per slab: element ((wave8 * NJ + j) * CF + mf) * 64 + lane
+};
+template <int NP, int CF>
+__global__ __launch_bounds__(512, 2) void conv3x3_wgrad_burst_kernel(WG3Args p) {
+  constexpr int KB = 64;
+  constexpr int CH = CF * 16;
+  constexpr int LO = CH * 2;
+  constexpr int RS = (CH * 2 * NP) % 64 == 32 ? CH * 2 * NP : CH * 2 * NP + 32;
+  constexpr int C4 = CH / 4;
+  constexpr int PD = (KB * C4 + 255) / 256;       // float4 per thread of ONE team for the KB rows of one operand
+  constexpr int NFR = WGBurst<CF>::NFR, NA = WGBurst<CF>::NA, NJ = WGBurst<CF>::NJ;
+
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int R = KB + 2 * p.SW + 2;                // X rows of one stage
+  const int RING = R + KB;
+  unsigned char* Dt = smem;                       // dY tiles [2][KB][RS]
+  unsigned char* Xt = smem + (size_t)2 * KB * RS; // X ring [RING][RS]
+
+  const int t = threadIdx.x, lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int team = wave >> 2, wave4 = wave & 3;
+  const int tt = t & 255;
+  const int t16 = lane & 15, g = lane >> 4;
+  const int co0 = blockIdx.x * CH, ci0 = blockIdx.y * CH;
+  const int z = blockIdx.z;
+  const int nst = p.split_q + (z < p.split_rem ? 1 : 0);
+  const int k_begin = (z * p.split_q + (z < p.split_rem ? z : p.split_rem)) * KB;
+  int k_end = k_begin + nst * KB;
+  if (k_end > p.P) k_end = p.P;
+  const int halo = p.SW + 1;
+  const int nf0 = team ? NA : 0, nf1 = team ? NFR : NA;      // this team's n-fragments [nf0, nf1)
+
+  auto pos_offset = [&](int pp, int C) -> int {
+    if (pp < 0 || pp >= p.P) return -1;
+    const int n = wg_fast_div(pp, p.ib_mul, p.ib_sh);
+    const int rem = pp - n * p.IB;
+    const int yy = wg_fast_div(rem, p.sw_mul, p.sw_sh);
+    const int xx = rem - yy * p.SW;
+    if (n >= p.N || yy < 1 || xx < 1 || xx > p.W) return -1;
+    return ((n * p.H + yy - 1) * p.W + xx - 1) * C;
+  };
+  auto bn_in = [&](f32x4 v, int c) -> f32x4 {
+    if (!p.x_mean) return v;
+    const f32x4 mu = *reinterpret_cast<const f32x4*>(p.x_mean + ci0 + c);
+    const f32x4 is = *reinterpret_cast<const f32x4*>(p.x_invstd + ci0 + c);
+    const f32x4 ga = *reinterpret_cast<const f32x4*>(p.x_gamma + ci0 + c);
+    const f32x4 be = *reinterpret_cast<const f32x4*>(p.x_beta + ci0 + c);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      v[j] = (v[j] - mu[j]) * (is[j] * ga[j]) + be[j];
+      if (p.x_relu) v[j] = fmaxf(v[j], 0.f);
+    }
+    return v;
+  };
+
+  // synchronous staging by all 512 threads (prologue): X rows [rel0, rel0 + nrows) of the ring, dY rows of a stage
+  auto stage_x_sync = [&](int rel0, int nrows) {
+    const int items = nrows * C4;
+    for (int i0 = 0; i0 < items; i0 += 512 * 4) {
+      f32x4 v[4];
+      int off[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int idx = i0 + t + 512 * u;
+        const int row = idx / C4, c4 = (idx - row * C4) * 4;
+        off[u] = idx < items ? pos_offset(k_begin - halo + rel0 + row, p.Ci) : -2;
+        v[u] = *reinterpret_cast<const f32x4*>(p.x + (off[u] >= 0 ? off[u] + ci0 + c4 : 0));
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int idx = i0 + t + 512 * u;
+        const int row = idx / C4, c4 = (idx - row * C4) * 4;
+        if (off[u] != -2)
+          wg_split_store<NP, LO>(Xt + (size_t)((rel0 + row) % RING) * RS, c4,
+                                 off[u] >= 0 ? bn_in(v[u], c4) : (f32x4){0.f, 0.f, 0.f, 0.f});
+      }
+    }
+  };
+  auto stage_d_sync = [&](int s) {
+    constexpr int PD0 = (KB * C4 + 511) / 512;
+    f32x4 v[PD0];
+    int off[PD0];
+#pragma unroll
+    for (int u = 0; u < PD0; ++u) {
+      const int idx = t + 512 * u;
+      const int row = idx / C4, c4 = (idx - row * C4) * 4;
+      const int pp = k_begin + s * KB + row;
+      off[u] = row < KB ? ((pp < k_end) ? pos_offset(pp, p.Co) : -1) : -2;
+      v[u] = *reinterpret_cast<const f32x4*>(p.dy + (off[u] >= 0 ? off[u] + co0 + c4 : 0));
+    }
+#pragma unroll
+    for (int u = 0; u < PD0; ++u) {
+      const int idx = t + 512 * u;
+      const int row = idx / C4, c4 = (idx - row * C4) * 4;
+      if (off[u] != -2)
+        wg_split_store<NP, LO>(Dt + (size_t)(s & 1) * KB * RS + (size_t)row * RS, c4,
+                               off[u] >= 0 ? v[u] : (f32x4){0.f, 0.f, 0.f, 0.f});
+    }
+  };
+
+  // a team's staging registers: team A carries the dY rows of a stage, team B its KB new X rows
+  f32x4 sreg[PD];
+  unsigned smask = 0;
+  auto load_stage = [&](int s) {                  // s >= 1
+    smask = 0;
+#pragma unroll
+    for (int q = 0; q < PD; ++q) {
+      const int idx = tt + 256 * q;
+      const int row = idx / C4, c4 = (idx - row * C4) * 4;
+      int o;
+      if (team == 0) {
+        const int pp = k_begin + s * KB + row;
+        o = (row < KB && pp < k_end) ? pos_offset(pp, p.Co) : -1;
+        sreg[q] = *reinterpret_cast<const f32x4*>(p.dy + (o >= 0 ? o + co0 + c4 : 0));
+      } else {
+        o = row < KB ? pos_offset(k_begin - halo + (s - 1) * KB + R + row, p.Ci) : -1;
+        sreg[q] = *reinterpret_cast<const f32x4*>(p.x + (o >= 0 ? o + ci0 + c4 : 0));
+      }
+      smask |= (o >= 0 ? 1u : 0u) << q;
+    }
+  };
+  auto store_stage = [&](int s) {
+    const int slot0 = ((s - 1) * KB + R) % RING;
+#pragma unroll
+    for (int q = 0; q < PD; ++q) {
+      const int idx = tt + 256 * q;
+      const int row = idx / C4, c4 = (idx - row * C4) * 4;
+      if (row < KB) {
+        const f32x4 zero = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (team == 0) {
+          wg_split_store<NP, LO>(Dt + (size_t)(s & 1) * KB * RS + (size_t)row * RS, c4, ((smask >> q) & 1u) ? sreg[q] : zero);
+        } else {
+          int slot = slot0 + row;
+          slot -= slot >= RING ? RING : 0;
+          wg_split_store<NP, LO>(Xt + (size_t)slot * RS, c4, ((smask >> q) & 1u) ? bn_in(sreg[q], c4) : zero);
+        }
+      }
+    }
+  };
+
+  f32x4 acc[CF][NJ];
+#pragma unroll
+  for (int mf = 0; mf < CF; ++mf)
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) acc[mf][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  bf16x8 fa[NP][CF], fb[NJ][NP];                  // the team's fragments of ONE k-step: 36 + 48 registers
+
+  const int lane_row = g * 4 + (t16 >> 2), lane_col = (t16 & 3) * 8;
+  const int lane_off = lane_row * RS + lane_col;
+  auto load_frags = [&](int q) {                  // k-step q: stage q >> 1, k-step q & 1 of it
+    const int s = q >> 1, ks = q & 1;
+    const int slot_base = (s * KB) % RING;
+    const unsigned char* D = Dt + (size_t)(s & 1) * KB * RS + (size_t)ks * 32 * RS + lane_off;
+#pragma unroll
+    for (int mf = 0; mf < CF; ++mf)
+#pragma unroll
+      for (int pc = 0; pc < NP; ++pc) fa[pc][mf] = tr_frag(D + mf * 32 + pc * LO, 4 * RS);
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      const int nf = nf0 + wave4 + 4 * j;
+      if (nf < nf1) {
+        const int tap = nf / CF, cf = nf - tap * CF;
+        const int shift = (tap / 3) * p.SW + tap % 3;
+        int r0 = slot_base + lane_row + ks * 32 + shift;
+        r0 -= r0 >= RING ? RING : 0;
+        int r1 = r0 + 16;
+        r1 -= r1 >= RING ? RING : 0;
+        const unsigned char* q0 = Xt + (__umul24(r0, RS) + lane_col + cf * 32);
+        const unsigned char* q1 = Xt + (__umul24(r1, RS) + lane_col + cf * 32);
+#pragma unroll
+        for (int pc = 0; pc < NP; ++pc) fb[j][pc] = tr_frag2(q0 + pc * LO, q1 + pc * LO);
+      }
+    }
+  };
+  auto burst = [&]() {
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      if (nf0 + wave4 + 4 * j < nf1) {
+#define WGB_MMA(qa, qb)                                                                                     \
+  _Pragma("unroll") for (int mf = 0; mf < CF; ++mf) acc[mf][j] =                                            \
+      __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[qa][mf], fb[j][qb], acc[mf][j], 0, 0, 0);
+        if constexpr (NP == 3) {
+          WGB_MMA(2, 0) WGB_MMA(0, 2) WGB_MMA(1, 1) WGB_MMA(1, 0) WGB_MMA(0, 1) WGB_MMA(0, 0)
+        } else {
+          WGB_MMA(1, 0) WGB_MMA(0, 1) WGB_MMA(0, 0)
+        }
+#undef WGB_MMA
+      }
+    }
+  };
+
+  // ---- prologue: stages 0 and 1 complete in LDS, each team's share of stage 2 in its registers, team A's first fragments
+  stage_x_sync(0, R);
+  stage_d_sync(0);
+  if (nst > 1) {
+    stage_x_sync(R, KB);
+    stage_d_sync(1);
+  }
+  if (nst > 2) load_stage(2);
+  __syncthreads();
+  if (team == 0) load_frags(0);
+  const int NK = 2 * nst, NPH = 4 * nst;
+  // Phase f = 2k + T: team T multiplies k-step k.  The other team reads its fragments - B those of k-step k (f even), A those
+  // of k-step k + 1 (f odd) - and, once per stage, stores its share of stage S = f / 4 + 1 (team A at f % 4 == 1: the dY tile;
+  // team B at f % 4 == 2: the new X rows; the stage's first fragment read is in phase 4 S - 1) and fetches its share of S + 1.
+  for (int f = 0; f < NPH; ++f) {
+    if (team == (f & 1)) {
+      if (!(WG3_ABL & 4)) burst();
+    } else {
+      const int q = team ? (f >> 1) : (f >> 1) + 1;
+      if (q < NK && !(WG3_ABL & 16)) load_frags(q);
+      if ((f & 3) == 1 + team && !(WG3_ABL & 2)) {
+        const int S = (f >> 2) + 1;
+        if (S >= 2 && S < nst) {
+          store_stage(S);
+          if (S + 1 < nst) load_stage(S + 1);
+        }
+      }
+    }
+    __syncthreads();
+  }
+
+  // ---- every wavefront writes its own accumulators: slab element ((wave * NJ + j) * CF + mf) * 64 + lane ----------------------
+  {
+    const size_t slab4 = (size_t)WGBurst<CF>::SLAB4;
+    const size_t pair = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
+    f32x4* outp = reinterpret_cast<f32x4*>(p.part) + (pair * gridDim.z + blockIdx.z) * slab4;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+      for (int mf = 0; mf < CF; ++mf) outp[((wave * NJ + j) * CF + mf) * 64 + lane] = acc[mf][j];
+  }
+}
+
 // slab reduction: thread = (element column, split lane); an element is one accumulator register quad (wave, j, mf, lane) =
 // rows co0 + mf*16 + g*4 + 0..3 of column (tap, ci0 + cf*16 + t16), nf = wave + 4 j = tap*CF + cf.  16 elements x 16 split
 // lanes per workgroup, four slab loads in flight per lane (the 512 slabs of the six-MFMA mode are 43 MB: at 8 split-lanes
@@ -315,8 +566,13 @@ template <int CF>
 __global__ __launch_bounds__(256) void wg3_reduce_kernel(const float* __restrict__ part, float* __restrict__ out, int Ci,
                                                          int Co, int nsplit, int accumulate) {
   constexpr int NFR = 9 * CF;
+#if WG3_BURST
+  constexpr int NW = WGBurst<CF>::NJ;                 // slabs of the burst kernel: 8 wavefronts x NJ fragments
+  constexpr int SLAB = WGBurst<CF>::SLAB4;
+#else
   constexpr int NW = (NFR + 3) / 4;
   constexpr int SLAB = 4 * NW * CF * 64;              // float4 per slab
+#endif
   __shared__ f32x4 sm[16][16];
   const int col = threadIdx.x & 15, zl = threadIdx.x >> 4;
   const int pair = blockIdx.y;                          // pair = ci_chunk * (Co / CH) + co_chunk
@@ -345,8 +601,14 @@ __global__ __launch_bounds__(256) void wg3_reduce_kernel(const float* __restrict
       for (int k = 1; k < 16; ++k) sv += sm[k][col];
       const int lane = e & 63, r = e >> 6;
       const int mf = r % CF, wj = r / CF, j = wj % NW, wv = wj / NW;
+#if WG3_BURST
+      const int nf = ((wv >> 2) ? WGBurst<CF>::NA : 0) + (wv & 3) + 4 * j;
+      const bool nf_ok = nf < ((wv >> 2) ? NFR : WGBurst<CF>::NA);
+#else
       const int nf = wv + 4 * j;
-      if (nf < NFR) {
+      const bool nf_ok = nf < NFR;
+#endif
+      if (nf_ok) {
         const int tap = nf / CF, cf = nf - tap * CF;
         const int ci = ci0 + cf * 16 + (lane & 15);
 #pragma unroll
@@ -373,7 +635,7 @@ static void wg_magic(unsigned d, unsigned* mul, unsigned* sh) {
 
 static bool wg3_plan(int np, int N, int H, int W, int Ci, int Co, WG3Plan* pl) {
   if ((np != 2 && np != 3) || c3_row_width(W) > WG_MAX_SW || H < 1 || W < 2) return false;
-  const int kb = np == 3 ? WGeo<3>::KB : WGeo<2>::KB;
+  const int kb = WG3_BURST ? 64 : (np == 3 ? WGeo<3>::KB : WGeo<2>::KB);
   int cf;
   if (Ci % 48 == 0 && Co % 48 == 0) cf = 3;
   else if (Ci % 32 == 0 && Co % 32 == 0) cf = 2;
@@ -388,7 +650,7 @@ static bool wg3_plan(int np, int N, int H, int W, int Ci, int Co, WG3Plan* pl) {
 #else
   constexpr int split_env = 0;
 #endif
-  long want = ((split_env > 0 ? split_env : (np == 3 ? 512 : 384)) + pairs - 1) / pairs;
+  long want = ((split_env > 0 ? split_env : (WG3_BURST ? 256 : (np == 3 ? 512 : 384))) + pairs - 1) / pairs;
   const long stages = (P + kb - 1) / kb;
   if (want > stages) want = stages;
   if (want < 1) want = 1;
@@ -399,10 +661,14 @@ static bool wg3_plan(int np, int N, int H, int W, int Ci, int Co, WG3Plan* pl) {
   int rs = ch * 2 * np;
   if (rs % 64 != 32) rs += 32;
   pl->lds = (size_t)(2 * kb + 2 * c3_row_width(W) + 2) * rs;      // dY tile (KB rows) + X ring (KB + 2*SW + 2 rows)
+  if (WG3_BURST) {        // two dY tiles + a ring of KB more rows; at least the accumulator exchange area of the epilogue
+    pl->lds = (size_t)(4 * kb + 2 * c3_row_width(W) + 2) * rs;
+  }
   return pl->lds <= 160 * 1024;
 }
 
 static size_t wg3_slab_floats(int cf) {     // accumulator-order slab of one pair
+  if (WG3_BURST) return (size_t)(cf == 3 ? WGBurst<3>::SLAB4 : WGBurst<2>::SLAB4) * 4;
   return (size_t)4 * ((9 * cf + 3) / 4) * cf * 64 * 4;
 }
 static size_t wg3_ws_bytes(const WG3Plan& pl, int Ci, int Co) {
@@ -413,8 +679,13 @@ static size_t wg3_ws_bytes(const WG3Plan& pl, int Ci, int Co) {
 template <int NP, int CF>
 static int wg3_launch(const WG3Args& a, const WG3Plan& pl, hipStream_t st) {
   static bool attr_set = false;     // idempotent attribute call: a race at first use only repeats it
+#if WG3_BURST
+  auto fn = conv3x3_wgrad_burst_kernel<NP, CF>;
+  const dim3 block(512);
+#else
   auto fn = conv3x3_wgrad_split_kernel<NP, CF>;
   const dim3 block(256);
+#endif
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        160 * 1024);

@@ -67,10 +67,14 @@ def test_two_ranks_on_different_shards_average_like_two_oracle_replicas(tmp_path
         loss.backward()
         grads.append({k: p.grad.numpy() for k, p in m.named_parameters() if p.grad is not None})
     rel_avg, rel_own = [], []
+    gmax = max(np.linalg.norm(0.5 * (grads[0][k] + grads[1][k])) for k in grads[0])
     for k in grads[0]:
         g = got["g::" + k].astype(np.float64)
         avg = 0.5 * (grads[0][k] + grads[1][k])
-        nrm = np.linalg.norm(avg) + 1e-30
+        nrm = np.linalg.norm(avg)
+        if nrm <= 1e-6 * gmax:      # mathematically-zero gradients (a conv bias in front of a BatchNorm): round-off only
+            assert np.linalg.norm(g) <= 1e-4 * gmax, k
+            continue
         rel_avg.append(np.linalg.norm(g - avg) / nrm)
         rel_own.append(np.linalg.norm(g - grads[0][k]) / nrm)
     rel_avg, rel_own = np.array(rel_avg), np.array(rel_own)
