@@ -628,13 +628,20 @@ _side = {"on": os.environ.get("BUCTD_WGRAD_STREAM", "1") == "1", "streams": {}, 
          "n": max(1, int(os.environ.get("BUCTD_WGRAD_STREAMS", "1")))}   # more than one measured slower (L2 contention)
 
 
+# The weight-gradient stream runs at HIGH HIP priority: the critical path of the backward pass runs along it for half of the
+# time (profiles/r04_critical_path.txt: 12.9 ms of weight gradients + 3.5 ms of their slab reductions on the chain), so its
+# kernels should get free workgroup slots before the main stream's: 454.0 -> 457.2 img/s (interleaved A/B on one box, round
+# 4; the branch streams at high priority cost 1 %).
+_SIDE_PRIO = int(os.environ.get("BUCTD_WGRAD_PRIO", "-1"))
+
+
 def _side_stream(device):
     """Weight-gradient streams, used round-robin (consecutive layers' gradients are independent of each other)."""
     _side["rr"] = (_side["rr"] + 1) % _side["n"]
     key = (device.index, _side["rr"])
     st = _side["streams"].get(key)
     if st is None:
-        st = torch.cuda.Stream(device=device)
+        st = torch.cuda.Stream(device=device, priority=_SIDE_PRIO)
         _side["streams"][key] = st
     return st
 
@@ -673,7 +680,7 @@ def _branch_stream(device, i):
     key = (device.index, i)
     st = _branch["streams"].get(key)
     if st is None:
-        st = torch.cuda.Stream(device=device)
+        st = torch.cuda.Stream(device=device, priority=int(os.environ.get("BUCTD_BRANCH_PRIO", "0")))
         _branch["streams"][key] = st
     return st
 
