@@ -171,22 +171,30 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef unsigned short u16x4 __attribute__((ext_vector_type(4)));
 
-// channels c..c+3 of one LDS row -> NP bf16 pieces (exact residual chain), piece q at byte q * LO + 2c
+// Two fp32 values -> NP packed bf16 pairs (exact residual chain): one v_cvt_pk_bf16_f32 per piece delivers the packed
+// word that is stored, the two residuals come from its halves (shift / mask) - same roundings as the element-wise form,
+// 5 instead of 8-9 VALU instructions per value and piece pair.
+typedef float a_f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 a_bf16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned a_u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned a_u32x4 __attribute__((ext_vector_type(4)));
+template <int NP>
+__device__ __forceinline__ void split_pair(float x0, float x1, unsigned (&w)[NP]) {
+  a_f32x2 r = {x0, x1};
+#pragma unroll
+  for (int q = 0; q < NP; ++q) {
+    w[q] = __builtin_bit_cast(unsigned, __builtin_convertvector(r, a_bf16x2));
+    if (q + 1 < NP) r -= (a_f32x2){__uint_as_float(w[q] << 16), __uint_as_float(w[q] & 0xffff0000u)};
+  }
+}
+// channels c..c+3 of one LDS row -> NP bf16 pieces, piece q at byte q * LO + 2c
 template <int LO, int NP>
 __device__ __forceinline__ void split_store4(unsigned char* row, int c, f32x4 v) {
-  u16x4 pc[NP];
+  unsigned lo[NP], hi[NP];
+  split_pair<NP>(v[0], v[1], lo);
+  split_pair<NP>(v[2], v[3], hi);
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    float r = v[j];
-#pragma unroll
-    for (int q = 0; q < NP; ++q) {
-      const __bf16 h = (__bf16)r;
-      pc[q][j] = __builtin_bit_cast(unsigned short, h);
-      r -= (float)h;
-    }
-  }
-#pragma unroll
-  for (int q = 0; q < NP; ++q) *reinterpret_cast<u16x4*>(row + q * LO + 2 * c) = pc[q];
+  for (int q = 0; q < NP; ++q) *reinterpret_cast<a_u32x2*>(row + q * LO + 2 * c) = (a_u32x2){lo[q], hi[q]};
 }
 // gfx950 transpose read: the 16 lanes of a group address 4 rows x 16 bf16; lane c receives the 4 rows of column c.
 // Two of them (rows +0..3 at p, rows +0..3 at q) give the 8 reduction slots of one MFMA operand.
@@ -198,16 +206,11 @@ __device__ __forceinline__ bf16x8 tr_pair(const unsigned char* p, const unsigned
 }
 template <int NP>
 __device__ __forceinline__ void split8(const float (&x)[8], bf16x8 (&pc)[NP]) {
+  unsigned w[4][NP];
 #pragma unroll
-  for (int e = 0; e < 8; ++e) {
-    float r = x[e];
+  for (int e = 0; e < 4; ++e) split_pair<NP>(x[2 * e], x[2 * e + 1], w[e]);
 #pragma unroll
-    for (int q = 0; q < NP; ++q) {
-      const __bf16 h = (__bf16)r;
-      pc[q][e] = h;
-      r -= (float)h;
-    }
-  }
+  for (int q = 0; q < NP; ++q) pc[q] = __builtin_bit_cast(bf16x8, (a_u32x4){w[0][q], w[1][q], w[2][q], w[3][q]});
 }
 // acc += a . b on split operands, smallest terms first.  NP = 2: the three terms of weight >= 2^-8 (bf16x3, product
 // error ~2^-16); NP = 3: the six terms of weight >= 2^-16 (bf16x6, fp32 class - see conv3x3.hip)
