@@ -125,6 +125,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_split_kernel(WG3Args p) 
   int k_end = k_begin + (p.split_q + (z < p.split_rem ? 1 : 0)) * KB;
   if (k_end > p.P) k_end = p.P;
   const int halo = p.SW + 1;
+  const int ci_lim = p.Ci - ci0;             // input channels this chunk really has (< CH only in a ragged last chunk: zeros beyond)
 
   auto pos_offset = [&](int pp, int C) -> int {   // element offset of pixel pp in an [N][H][W][C] tensor, -1 = pad
     if (pp < 0 || pp >= p.P) return -1;
@@ -171,7 +172,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_split_kernel(WG3Args p) 
     for (int q = 0; q < PD; ++q) {
       const int idx = t + 256 * q;
       const int row = idx / C4, c4 = (idx - row * C4) * 4;
-      const int o = row < KB ? pos_offset(k_begin - halo + rel0 + row, p.Ci) : -1;
+      const int o = (row < KB && c4 < ci_lim) ? pos_offset(k_begin - halo + rel0 + row, p.Ci) : -1;
       xmask |= (o >= 0 ? 1u : 0u) << q;
       xreg[q] = *reinterpret_cast<const f32x4*>(p.x + (o >= 0 ? o + ci0 + c4 : 0));
     }
@@ -218,7 +219,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_split_kernel(WG3Args p) 
       for (int q = 0; q < PP; ++q) {
         const int idx = t + 256 * q;
         const int row = idx / C4, c4 = (idx - row * C4) * 4;
-        const int o = (row < WG_PRO && r0 + row < pro) ? pos_offset(k_begin - halo + r0 + row, p.Ci) : -1;
+        const int o = (row < WG_PRO && r0 + row < pro && c4 < ci_lim) ? pos_offset(k_begin - halo + r0 + row, p.Ci) : -1;
         pmask |= (o >= 0 ? 1u : 0u) << q;
         preg[q] = *reinterpret_cast<const f32x4*>(p.x + (o >= 0 ? o + ci0 + c4 : 0));
       }
@@ -349,6 +350,7 @@ __global__ __launch_bounds__(256) void wg3_reduce_kernel(const float* __restrict
       if (nf < NFR) {
         const int tap = nf / CF, cf = nf - tap * CF;
         const int ci = ci0 + cf * 16 + (lane & 15);
+        if (ci < Ci)                     // ragged last chunk: the columns beyond Ci were multiplied with zeros
 #pragma unroll
         for (int rg = 0; rg < 4; ++rg) {
           const int co = co0 + mf * 16 + (lane >> 4) * 4 + rg;
@@ -377,10 +379,13 @@ static bool wg3_plan(int np, int N, int H, int W, int Ci, int Co, WG3Plan* pl) {
   int cf;
   if (Ci % 48 == 0 && Co % 48 == 0) cf = 3;
   else if (Ci % 32 == 0 && Co % 32 == 0) cf = 2;
+  // 48-column tiles over an input width that is only a multiple of 16 (the 256 -> 48 transition of HRNet-W48): the last
+  // 48-channel chunk of the input is ragged, its missing channels are staged as zeros and dropped by the reduction
+  else if (Co % 48 == 0 && Ci % 16 == 0 && Ci > 48) cf = 3;
   else return false;
   const int ch = cf * 16;
   const long P = (long)N * (H + 1) * c3_row_width(W) + c3_row_width(W);
-  const long pairs = (long)(Co / ch) * (Ci / ch);
+  const long pairs = (long)(Co / ch) * ((Ci + ch - 1) / ch);
   // two resident workgroups per CU (512 in all) when one (co, ci) chunk pair exists; fewer splits per pair otherwise
   // (partial-slab traffic grows with the split).  Splits take q or q + 1 stages, so no rounding loss.
 #ifdef BUCTD_TUNING      // experiment builds only
@@ -406,7 +411,7 @@ static size_t wg3_slab_floats(int cf) {     // accumulator-order slab of one pai
   return (size_t)4 * ((9 * cf + 3) / 4) * cf * 64 * 4;
 }
 static size_t wg3_ws_bytes(const WG3Plan& pl, int Ci, int Co) {
-  const size_t pairs = (size_t)(Co / (pl.CF * 16)) * (Ci / (pl.CF * 16));
+  const size_t pairs = (size_t)(Co / (pl.CF * 16)) * ((Ci + pl.CF * 16 - 1) / (pl.CF * 16));
   return pairs * pl.nsplit * wg3_slab_floats(pl.CF) * sizeof(float);
 }
 
@@ -424,7 +429,7 @@ static int wg3_launch(const WG3Args& a, const WG3Plan& pl, hipStream_t st) {
     }
     attr_set = true;
   }
-  dim3 grid(a.Co / (CF * 16), a.Ci / (CF * 16), pl.nsplit);
+  dim3 grid(a.Co / (CF * 16), (a.Ci + CF * 16 - 1) / (CF * 16), pl.nsplit);
   hipLaunchKernelGGL(fn, grid, block, pl.lds, st, a);
   BUCTD_CHECK_LAUNCH("buctd_conv3x3_wgrad (split bf16)");
   return BUCTD_OK;
@@ -454,6 +459,8 @@ static int wg3_run(int np, int N, int H, int W, int Ci, int Co, const float* x, 
   a.x_mean = a.x_invstd = a.x_gamma = a.x_beta = nullptr;
   a.x_relu = 0;
   if (x_bn && x_bn->mean) {
+    BUCTD_CHECK_ARG(Ci % (pl.CF * 16) == 0, "buctd_conv3x3_wgrad: the fused input BatchNorm needs whole %d-channel chunks (Ci = %d)",
+                    pl.CF * 16, Ci);
     BUCTD_CHECK_ARG(x_bn->invstd && x_bn->gamma && x_bn->beta, "buctd_conv3x3_wgrad: fused input BatchNorm needs all four arrays");
     a.x_mean = x_bn->mean; a.x_invstd = x_bn->invstd; a.x_gamma = x_bn->gamma; a.x_beta = x_bn->beta;
     a.x_relu = x_bn->relu;
@@ -471,7 +478,7 @@ static int wg3_run(int np, int N, int H, int W, int Ci, int Co, const float* x, 
 #ifdef WG3_WHATIF_SKIP_REDUCE
   return BUCTD_OK;
 #endif
-  const int pairs = (Co / (pl.CF * 16)) * (Ci / (pl.CF * 16));
+  const int pairs = (Co / (pl.CF * 16)) * ((Ci + pl.CF * 16 - 1) / (pl.CF * 16));
   const dim3 rgrid(ceil_div((long)(wg3_slab_floats(pl.CF) / 4), 16), pairs);
   if (pl.CF == 3)
     hipLaunchKernelGGL(wg3_reduce_kernel<3>, rgrid, dim3(256), 0, st, (const float*)workspace, dw, Ci, Co, pl.nsplit, accumulate);
