@@ -61,6 +61,11 @@ class Bottleneck(nn.Module):
         self.stride = stride
 
     def forward(self, x):
+        if (self.training and x.is_cuda and torch.is_grad_enabled() and ops.fused_bottleneck_on()
+                and (self.downsample is None or type(self.downsample) is nn.ConvBN and not self.downsample._relu)):
+            for c in (self.conv1, self.conv2, self.conv3) + (() if self.downsample is None else (self.downsample[0],)):
+                nn._as_channels_last_(c.weight)
+            return ops.BottleneckFn.apply(x, self.conv1.weight, self)
         residual = x if self.downsample is None else self.downsample(x)
         out = nn.conv_bn_act(x, self.conv1, self.bn1, relu=True)
         out = nn.conv_bn_act(out, self.conv2, self.bn2, relu=True)

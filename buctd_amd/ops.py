@@ -478,6 +478,18 @@ def _gconv_fwd(x, w, d, bias, scale, shift, residual, relu, stats):
 
 
 _NATIVE_BLOCK = os.environ.get("BUCTD_NATIVE_BLOCK", "1") == "1"
+_FUSED_BOTTLENECK = {"on": os.environ.get("BUCTD_FUSED_BOTTLENECK", "1") == "1"}
+
+
+def fused_bottleneck_on():
+    """Bottlenecks of a training forward as one autograd node (BottleneckFn); off = three / four ConvBnAct nodes (tests)."""
+    return _FUSED_BOTTLENECK["on"]
+
+
+def set_fused_bottleneck(on):
+    old = _FUSED_BOTTLENECK["on"]
+    _FUSED_BOTTLENECK["on"] = bool(on)
+    return old
 # experiment switches, read ONCE at import (the hot path consults module constants, never the environment)
 _FUSE_BN_IN = os.environ.get("BUCTD_FUSE_BN_IN", "1") == "1"
 _FC_O_X6 = os.environ.get("BUCTD_FC_O_X6", "1") != "0"
@@ -1218,7 +1230,9 @@ class ConvBnAct(torch.autograd.Function):
         dx = None
         if transposed_shape is None:
             if ctx.needs_input_grad[0]:
-                dx = conv_dgrad(dz, conv_w, x_shape, stride, pad)
+                # dx_residual: a gradient that reaches x on another path of the same autograd node (BottleneckFn) - added
+                # in the epilogue of the data-gradient kernel instead of by an accumulation pass of autograd
+                dx = conv_dgrad(dz, conv_w, x_shape, stride, pad, residual=getattr(ctx, "dx_residual", None))
             dw, acc_w = grad_target(conv_w)
             conv_wgrad_async(x, dz, conv_w, stride, pad, dw, acc_w)
         else:
@@ -1233,6 +1247,60 @@ class ConvBnAct(torch.autograd.Function):
             colsum(dz, dz.shape[-1], db, acc)
         grad_done(bn.weight, bn.bias, conv_w, conv_b)
         return dx, None, None, None, dres, None, None, None, None, None
+
+
+class _SubCtx:
+    """What ConvBnAct.forward / backward need of an autograd context, for nodes that chain several of them."""
+
+    def __init__(self, needs_x=True):
+        self.needs_input_grad = (needs_x,)
+        self.saved_tensors = ()
+
+    def save_for_backward(self, *tensors):
+        self.saved_tensors = tensors
+
+
+class BottleneckFn(torch.autograd.Function):
+    """One autograd node for the residual Bottleneck (reference lib/models/pose_hrnet.py:60-98, train mode):
+    y = relu(bn3(conv3(relu(bn2(conv2(relu(bn1(conv1(x)))))))) + residual),  residual = x or downsample(x).
+    The same kernels in the same order as the three (four) ConvBnAct nodes it replaces; what the single node buys: the
+    gradient of the skip path is added in the epilogue of the data-gradient kernel that produces the other gradient of x,
+    where autograd ran an accumulation pass over the 256-channel stem-resolution tensor (three reads / writes of 226 MB per
+    block at CoAM-W48) - and the host walks one node instead of four."""
+
+    @staticmethod
+    def forward(ctx, x, w1, m):
+        need = ctx.needs_input_grad[0]
+        c1, c2, c3 = _SubCtx(need), _SubCtx(), _SubCtx()
+        cd = None
+        residual = x
+        if m.downsample is not None:
+            cd = _SubCtx(need)
+            ds_conv, ds_bn = m.downsample[0], m.downsample[1]
+            s, p = ds_conv._geom()
+            residual = ConvBnAct.forward(cd, x, ds_conv.weight, ds_conv.bias, ds_bn, None, False, s, p, True, None)
+        out = ConvBnAct.forward(c1, x, m.conv1.weight, None, m.bn1, None, True, 1, 0, True, None)
+        out = ConvBnAct.forward(c2, out, m.conv2.weight, None, m.bn2, None, True, m.stride, 1, True, None)
+        y = ConvBnAct.forward(c3, out, m.conv3.weight, None, m.bn3, residual, True, 1, 0, True, None)
+        ctx.sub = (c1, c2, c3, cd)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        c1, c2, c3, cd = ctx.sub
+        ctx.sub = None
+        r3 = ConvBnAct.backward(c3, dy)
+        d_out2, dres = r3[0], r3[4]
+        d_out1 = ConvBnAct.backward(c2, d_out2)[0]
+        dx = None
+        if ctx.needs_input_grad[0]:
+            if cd is not None:
+                dres = ConvBnAct.backward(cd, dres)[0]
+            c1.dx_residual = dres
+        elif cd is not None:
+            ConvBnAct.backward(cd, dres)
+        dx = ConvBnAct.backward(c1, d_out1)[0]
+        return dx, None, None
 
 
 class BasicBlockFn(torch.autograd.Function):

@@ -76,6 +76,36 @@ def test_residual_chains(dev):
     _run(dev, "2 bottlenecks (layer1 head)", o, p, torch.randn(2, 64, 12, 8))
 
 
+def test_fused_bottleneck_node_is_bit_identical(dev):
+    """ops.BottleneckFn (one autograd node, the skip gradient added in a data-gradient epilogue) against the three / four
+    ConvBnAct nodes it replaces: same kernels, same order - every output and gradient bit for bit."""
+    from buctd_amd import ops
+    from buctd_amd.models import hrnet_common as hc
+    torch.manual_seed(12)
+    ref, _ = hc.make_residual_layer(hc.Bottleneck, 64, 64, 3)
+    x0 = torch.randn(2, 12, 8, 64)
+    w0 = torch.randn(2, 12, 8, 256)
+    res = {}
+    for fused in (True, False):
+        old = ops.set_fused_bottleneck(fused)
+        try:
+            m = copy.deepcopy(ref).to(dev).train()
+            x = x0.clone().to(dev).requires_grad_(True)
+            y = m(x)
+            assert (type(y.grad_fn).__name__ == "BottleneckFnBackward") == fused
+            y.backward(w0.to(dev))
+            torch.cuda.synchronize()
+            res[fused] = (y.detach().cpu(), x.grad.cpu(), {k: p.grad.cpu() for k, p in m.named_parameters()},
+                          {k: b.cpu() for k, b in m.named_buffers()})
+        finally:
+            ops.set_fused_bottleneck(old)
+    assert torch.equal(res[True][0], res[False][0]) and torch.equal(res[True][1], res[False][1])
+    for k in res[True][2]:
+        assert torch.equal(res[True][2][k], res[False][2][k]), k
+    for k in res[True][3]:
+        assert torch.equal(res[True][3][k], res[False][3][k]), k
+
+
 @pytest.mark.parametrize("nb,mso", [(2, True), (3, True), (4, True), (4, False)])
 def test_high_resolution_module(dev, nb, mso):
     from oracle import models as om
