@@ -255,6 +255,22 @@ class HRNetTrunk(nn.Module):
         trans = getattr(self, "transition%d" % (s - 1))
         n = getattr(self, "stage%d_cfg" % s)["NUM_BRANCHES"]
         if first:
+            heads = [trans[i] if isinstance(trans[i], nn.ConvBN) else trans[i][0] if isinstance(trans[i], nn.Chain) else None
+                     for i in range(n)]
+            if (self.training and prev.is_cuda and torch.is_grad_enabled() and ops.fused_bottleneck_on() and n > 1
+                    and all(type(h) is nn.ConvBN for h in heads)):
+                # every new branch starts with a conv + BN + ReLU on the same tensor: one autograd node (ops.ForkConvBnFn)
+                for h in heads:
+                    nn._as_channels_last_(h[0].weight)
+                ys = ops.ForkConvBnFn.apply(prev, heads[0][0].weight, [(h[0], h[1], h._relu) for h in heads])
+                out = []
+                for i in range(n):
+                    y = ys[i]
+                    if isinstance(trans[i], nn.Chain):
+                        for m in list(trans[i])[1:]:
+                            y = m(y)
+                    out.append(y)
+                return out
             return [trans[i](prev) if trans[i] is not None else prev for i in range(n)]
         return [trans[i](prev[-1]) if trans[i] is not None else prev[i] for i in range(n)]
 

@@ -1288,7 +1288,6 @@ class BottleneckFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         c1, c2, c3, cd = ctx.sub
-        ctx.sub = None
         r3 = ConvBnAct.backward(c3, dy)
         d_out2, dres = r3[0], r3[4]
         d_out1 = ConvBnAct.backward(c2, d_out2)[0]
@@ -1300,6 +1299,37 @@ class BottleneckFn(torch.autograd.Function):
         elif cd is not None:
             ConvBnAct.backward(cd, dres)
         dx = ConvBnAct.backward(c1, d_out1)[0]
+        return dx, None, None
+
+
+class ForkConvBnFn(torch.autograd.Function):
+    """Several conv -> BatchNorm (-> ReLU) groups reading the SAME input as one autograd node (the first transition of
+    HRNet, reference lib/models/pose_hrnet.py:374-402: layer1's 256-channel output feeds both new branches): the data
+    gradients chain through each other's epilogue (dx = dgrad_1(dz_1) + dgrad_0(dz_0)) instead of meeting in an
+    accumulation pass of autograd.  Same kernels as the separate ConvBnAct nodes."""
+
+    @staticmethod
+    def forward(ctx, x, w0, groups):
+        need = ctx.needs_input_grad[0]
+        subs, outs = [], []
+        for conv, bn, relu in groups:
+            c = _SubCtx(need)
+            s, p = conv._geom()
+            outs.append(ConvBnAct.forward(c, x, conv.weight, conv.bias, bn, None, relu, s, p, True, None))
+            subs.append(c)
+        ctx.sub = subs
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *dys):
+        subs = ctx.sub
+        dx = None
+        for c, dy in zip(subs, dys):
+            if dy is None:      # this output took no part in the loss
+                continue
+            c.dx_residual = dx
+            r = ConvBnAct.backward(c, dy)[0]
+            dx = r if r is not None else dx
         return dx, None, None
 
 

@@ -106,6 +106,36 @@ def test_fused_bottleneck_node_is_bit_identical(dev):
         assert torch.equal(res[True][3][k], res[False][3][k]), k
 
 
+def test_first_transition_as_one_node_is_bit_identical(dev):
+    """ops.ForkConvBnFn: the two conv+BN+ReLU heads of transition1 read the same tensor; as one node their data gradients
+    chain through a kernel epilogue - bit-identical to the two ConvBnAct nodes plus autograd's accumulation."""
+    from buctd_amd import ops
+    from buctd_amd.models import hrnet_common as hc
+    torch.manual_seed(13)
+    trunk = hc.HRNetTrunk()
+    trunk.transition1 = hc.make_transition_layer([64], [16, 32])
+    trunk.stage2_cfg = {"NUM_BRANCHES": 2}
+    x0 = torch.randn(2, 12, 8, 64)
+    res = {}
+    for fused in (True, False):
+        old = ops.set_fused_bottleneck(fused)
+        try:
+            m = copy.deepcopy(trunk).to(dev).train()
+            x = x0.clone().to(dev).requires_grad_(True)
+            ys = m.enter_stage(2, x, first=True)
+            assert (type(ys[0].grad_fn).__name__ == "ForkConvBnFnBackward") == fused
+            ((ys[0] * 0.5).sum() + (ys[1] * torch.linspace(-1, 1, ys[1].numel(), device=dev).view(ys[1].shape)).sum()).backward()
+            torch.cuda.synchronize()
+            res[fused] = ([y.detach().cpu() for y in ys], x.grad.cpu(), {k: p.grad.cpu() for k, p in m.named_parameters()})
+        finally:
+            ops.set_fused_bottleneck(old)
+    for a, b in zip(res[True][0], res[False][0]):
+        assert torch.equal(a, b)
+    assert torch.equal(res[True][1], res[False][1])
+    for k in res[True][2]:
+        assert torch.equal(res[True][2][k], res[False][2][k]), k
+
+
 @pytest.mark.parametrize("nb,mso", [(2, True), (3, True), (4, True), (4, False)])
 def test_high_resolution_module(dev, nb, mso):
     from oracle import models as om
