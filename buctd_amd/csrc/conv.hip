@@ -616,6 +616,87 @@ __global__ __launch_bounds__(256) void conv_fwd_thin_kernel(ThinFwdArgs p) {
   }
 }
 
+// Wide-input variant (Ci a multiple of 8: the 64 -> 3 7x7 of the preNet).  The kernel above reads five LDS vectors per 16
+// FMAs (one pixel per thread, four accumulators of which the preNet uses three) and ran at 19 % of the fp32 vector rate:
+// 1.33 ms at 256x192, N = 32 - the largest kernel of the HRNet-W32 step.  Here a thread owns FOUR adjacent pixels of a
+// 32 x 32 tile and Co <= 3 accumulators per pixel: the R + 3 input pixels of a filter row are read once for the four
+// outputs (10 instead of 28 LDS vectors per row and 4 channels), the filter values are wave-uniform and come through the
+// scalar cache (no LDS), and channel pairs go through v_pk_fma_f32 (even / odd channel partial sums, added at the end).
+// The input tile is de-interleaved by column mod 4 so that the eight threads of a tile row read consecutive 32-byte
+// pixels, rows 16 bytes apart in the bank map.
+constexpr int THIN4_T = 32, THIN4_CH = 8;
+typedef float thin_f32x2 __attribute__((ext_vector_type(2)));
+template <int R, int CO>
+__global__ __launch_bounds__(256) void conv_fwd_thin_px4_kernel(ThinFwdArgs p) {
+  constexpr int PADR = R / 2, XH = THIN4_T + R - 1, XW = THIN4_T + R - 1, SL = (XW + 3) / 4;   // SL slots per column plane
+  constexpr int ROWF = 4 * SL * THIN4_CH + 4;                                                  // floats per tile row (+16 B)
+  __shared__ __attribute__((aligned(16))) float xs[XH * ROWF];
+  const int t = threadIdx.x;
+  const int tile = blockIdx.x;
+  const int n = tile / (p.tiles_y * p.tiles_x);
+  const int rem = tile - n * p.tiles_y * p.tiles_x;
+  const int y0 = (rem / p.tiles_x) * THIN4_T, x0 = (rem - (rem / p.tiles_x) * p.tiles_x) * THIN4_T;
+  const int ty = t >> 3, tx = t & 7;
+  thin_f32x2 acc[4][CO];
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int co = 0; co < CO; ++co) acc[j][co] = (thin_f32x2){0.f, 0.f};
+  for (int c0 = 0; c0 < p.Ci; c0 += THIN4_CH) {
+    __syncthreads();
+    for (int i = t; i < XH * XW * 2; i += 256) {
+      const int pix = i >> 1, q = i & 1;
+      const int ry = pix / XW, cx = pix - ry * XW;
+      const int yy = y0 + ry - PADR, xx = x0 + cx - PADR;
+      f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
+      if (yy >= 0 && yy < p.H && xx >= 0 && xx < p.W)
+        v = *reinterpret_cast<const f32x4*>(p.x + ((long)(n * p.H + yy) * p.W + xx) * p.Ci + c0 + q * 4);
+      *reinterpret_cast<f32x4*>(xs + ry * ROWF + ((cx & 3) * SL + (cx >> 2)) * THIN4_CH + q * 4) = v;
+    }
+    __syncthreads();
+#pragma unroll 1
+    for (int r = 0; r < R; ++r) {
+      // the R + 3 pixels this thread's four outputs read in filter row r: column 4 tx + k, k = 0 .. R + 2
+      f32x4 xw[R + 3][2];
+      const float* xr = xs + (ty + r) * ROWF + tx * THIN4_CH;
+#pragma unroll
+      for (int k = 0; k < R + 3; ++k)
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+          xw[k][q] = *reinterpret_cast<const f32x4*>(xr + ((k & 3) * SL + (k >> 2)) * THIN4_CH + q * 4);
+#pragma unroll
+      for (int sx = 0; sx < R; ++sx)
+#pragma unroll
+        for (int co = 0; co < CO; ++co) {
+          const float* wp = p.w + ((long)(co * R + r) * R + sx) * p.Ci + c0;      // wave-uniform: scalar loads
+          const f32x4 w0 = *reinterpret_cast<const f32x4*>(wp), w1 = *reinterpret_cast<const f32x4*>(wp + 4);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const f32x4 a = xw[j + sx][0], b = xw[j + sx][1];
+            thin_f32x2 s = acc[j][co];
+            s = __builtin_elementwise_fma((thin_f32x2){a.x, a.y}, (thin_f32x2){w0.x, w0.y}, s);
+            s = __builtin_elementwise_fma((thin_f32x2){a.z, a.w}, (thin_f32x2){w0.z, w0.w}, s);
+            s = __builtin_elementwise_fma((thin_f32x2){b.x, b.y}, (thin_f32x2){w1.x, w1.y}, s);
+            s = __builtin_elementwise_fma((thin_f32x2){b.z, b.w}, (thin_f32x2){w1.z, w1.w}, s);
+            acc[j][co] = s;
+          }
+        }
+    }
+  }
+  const int yy = y0 + ty;
+  if (yy < p.H) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int xx = x0 + 4 * tx + j;
+      if (xx < p.W) {
+        float* o = p.y + ((long)(n * p.H + yy) * p.W + xx) * p.Co;
+#pragma unroll
+        for (int co = 0; co < CO; ++co) o[co] = (acc[j][co].x + acc[j][co].y) + (p.bias ? p.bias[co] : 0.f);
+      }
+    }
+  }
+}
+
 // Data gradient of the same convolutions (<= 4 OUTPUT channels of the forward conv: dy is thin, dx wide): one thread per
 // dx pixel, 16 input channels per pass; dy tile (halo) in LDS, filter chunk [tap][co][16 ci] read as broadcasts.
 struct ThinDgradArgs {
@@ -789,6 +870,15 @@ extern "C" int buctd_conv2d_fwd(const buctd_conv_desc* d, const float* x, const 
     ThinFwdArgs ta;
     ta.x = x; ta.w = w; ta.bias = bias; ta.y = y;
     ta.N = d->N; ta.H = d->H; ta.W = d->W; ta.Ci = d->Ci; ta.Co = d->Co;
+    if (d->Ci % THIN4_CH == 0 && d->Co <= 3) {          // wide input (64 -> 3): four pixels per thread
+      ta.tiles_y = ceil_div(d->H, THIN4_T); ta.tiles_x = ceil_div(d->W, THIN4_T);
+      const dim3 grid(d->N * ta.tiles_y * ta.tiles_x);
+      if (d->Co == 3) hipLaunchKernelGGL((conv_fwd_thin_px4_kernel<7, 3>), grid, dim3(256), 0, (hipStream_t)stream, ta);
+      else if (d->Co == 2) hipLaunchKernelGGL((conv_fwd_thin_px4_kernel<7, 2>), grid, dim3(256), 0, (hipStream_t)stream, ta);
+      else hipLaunchKernelGGL((conv_fwd_thin_px4_kernel<7, 1>), grid, dim3(256), 0, (hipStream_t)stream, ta);
+      BUCTD_CHECK_LAUNCH("buctd_conv2d_fwd(thin, four pixels per thread)");
+      return BUCTD_OK;
+    }
     ta.tiles_y = ceil_div(d->H, THIN_TH); ta.tiles_x = ceil_div(d->W, THIN_TW);
     hipLaunchKernelGGL((conv_fwd_thin_kernel<7>), dim3(d->N * ta.tiles_y * ta.tiles_x), dim3(256), 0, (hipStream_t)stream, ta);
     BUCTD_CHECK_LAUNCH("buctd_conv2d_fwd(thin)");

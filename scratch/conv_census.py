@@ -1,4 +1,4 @@
-"""Histogram of convolution calls (shape, direction, math path) in one CoAM-W48 train step."""
+"""Histogram of convolution calls outside the native blocks (shape, direction, math path) in one train step: python scratch/conv_census.py [train_c4|train_c3|train_c2]"""
 import collections, os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench
@@ -6,8 +6,9 @@ from buctd_amd import engine, models, ops
 ops.set_conv_math("bf16x6")
 import buctd_amd.ops as _o; _o._side["on"] = False; _o._branch["on"] = False   # serial streams: event brackets = kernel time
 dev = torch.device("cuda:0")
-cfg = bench.coam_w48_cfg(32)
-model = models.pose_hrnet_coam.get_pose_net(cfg, is_train=True).to(dev).train()
+WL = sys.argv[1] if len(sys.argv) > 1 else "train_c4"
+cfg = bench.TRAIN_WORKLOADS[WL][0](32)
+model = getattr(models, bench.TRAIN_WORKLOADS[WL][1]).get_pose_net(cfg, is_train=True).to(dev).train()
 x, tgt, wt = bench.synthetic_batch(cfg, 32, dev, 1)
 from buctd_amd.core.loss import JointsMSELoss
 crit = JointsMSELoss(True)

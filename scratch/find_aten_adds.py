@@ -26,5 +26,5 @@ for e in prof.events():
     if e.name.startswith("aten::") and e.name.split("::")[1] in ("add", "add_", "mul", "mul_", "copy_", "clone", "contiguous", "sum", "cat", "zeros", "zero_", "fill_", "sub", "div", "to", "_to_copy", "index", "slice", "select", "empty_like", "zeros_like"):
         st = [s for s in (e.stack or []) if "buctd_amd" in s or "bench" in s]
         agg[(e.name, str(e.input_shapes)[:90], st[0][-70:] if st else "(autograd engine)")] += 1
-for k, v in sorted(agg.items(), key=lambda kv: -kv[1])[:60]:
-    print(v, k)
+for k, v in sorted(agg.items(), key=lambda kv: -kv[1]):
+    if os.environ.get("ONLY") is None or k[0].split("::")[1] in os.environ["ONLY"].split(","): print(v, k)

@@ -33,7 +33,8 @@ def test_thin_wgrad_vs_fp64(Ci, Co, k, N, H, W):
     assert err <= 2e-5
 
 
-@pytest.mark.parametrize("Ci,Co,N,H,W", [(64, 3, 2, 192, 256), (3, 3, 3, 160, 144), (32, 2, 1, 300, 250), (17, 4, 2, 181, 203)])
+@pytest.mark.parametrize("Ci,Co,N,H,W", [(64, 3, 2, 192, 256), (3, 3, 3, 160, 144), (32, 2, 1, 300, 250), (17, 4, 2, 181, 203),
+                                         (8, 1, 2, 70, 45), (64, 3, 2, 65, 63), (16, 3, 3, 15, 130)])
 def test_thin_forward_vs_fp64(Ci, Co, N, H, W):
     """7x7 'same' convolutions with <= 4 output channels (preNet): forward incl. bias and the BatchNorm partials"""
     from buctd_amd import ops
