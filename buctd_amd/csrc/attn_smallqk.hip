@@ -560,13 +560,9 @@ __global__ __launch_bounds__(256) void attn_bwd_kv_b3_kernel(AttnArgs p) {
         for (int kk = 0; kk < NK; ++kk) {
           bf16x8 aa[NP];
 #pragma unroll
-          for (int q = 0; q < NP; ++q) {
-            aa[q] = *reinterpret_cast<const bf16x8*>(drow + boff[kk] + q * LO);
-            if (32 * kk + 8 * kq >= C) {       // zero-padded tail of the channel contraction
-#pragma unroll
-              for (int e = 0; e < 8; ++e) aa[q][e] = (__bf16)0.f;
-            }
-          }
+          // lanes of the zero-padded tail of the channel contraction (32 kk + 8 kq >= C) read the row's first channels
+          // (boff is clamped): finite values against the zeros load_split8 put into vv - the product is 0 either way
+          for (int q = 0; q < NP; ++q) aa[q] = *reinterpret_cast<const bf16x8*>(drow + boff[kk] + q * LO);
           mfma_split<NP>(dp4, aa, vv[kk]);
         }
 #pragma unroll
