@@ -483,8 +483,17 @@ def prime_gpu():
     if os.environ.get("BUCTD_BENCH_NO_PRIME") == "1":
         return
     import subprocess
+    # (the child also writes 60 % of the free HBM once and keeps the matrix cores busy for about a second: the mechanism
+    # behind the slow first process is not known; memory that no process has touched since the box came up is slow to touch
+    # the first time - 50 ms per GB against 0.4 - and after a child that touched 160 GB three of three fresh boxes ran the
+    # step at full speed, after one that touched 8 GB two of three)
     code = ("import os, torch; d = int(os.environ.get('LOCAL_RANK', '0')) % max(1, torch.cuda.device_count()); "
-            "x = torch.zeros(1 << 20, device='cuda:%d' % d); print((x + 1).sum().item())")
+            "dev = 'cuda:%d' % d; x = torch.zeros(1 << 20, device=dev); s = (x + 1).sum().item(); "
+            "n = int(torch.cuda.mem_get_info(d)[0] * 0.6) >> 30; "
+            "bufs = [torch.empty(1 << 28, dtype=torch.float32, device=dev).fill_(1.0) for _ in range(n)]; "
+            "a = torch.randn(8192, 8192, device=dev); b = a\n"
+            "for _ in range(40): b = (a @ b) * 1e-4\n"
+            "print(s, float(b.sum()), sum(float(t[0]) for t in bufs))")
     try:
         subprocess.run([sys.executable, "-c", code], timeout=900, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
     except Exception:       # the child is a courtesy to the clock, never a reason to fail
