@@ -624,60 +624,92 @@ __global__ __launch_bounds__(256) void conv_fwd_thin_kernel(ThinFwdArgs p) {
 // scalar cache (no LDS), and channel pairs go through v_pk_fma_f32 (even / odd channel partial sums, added at the end).
 // The input tile is de-interleaved by column mod 4 so that the eight threads of a tile row read consecutive 32-byte
 // pixels, rows 16 bytes apart in the bank map.
+// CH = 4 serves the convolutions that are thin on BOTH sides (the 3 -> 3 7x7 of the condition branch: 441 FMAs per pixel, 0.48 ms
+// at 384x288 on the kernel above, which pads 3 channels to 16 and 3 outputs to 4) and, with TR, their data gradient: the same
+// correlation with the filter read transposed and flipped, kernel(out o, r, s, in i) = w[i][R-1-r][R-1-s][o].
 constexpr int THIN4_T = 32, THIN4_CH = 8;
 typedef float thin_f32x2 __attribute__((ext_vector_type(2)));
-template <int R, int CO>
+template <int R, int CO, int CH, bool TR>
 __global__ __launch_bounds__(256) void conv_fwd_thin_px4_kernel(ThinFwdArgs p) {
   constexpr int PADR = R / 2, XH = THIN4_T + R - 1, XW = THIN4_T + R - 1, SL = (XW + 3) / 4;   // SL slots per column plane
-  constexpr int ROWF = 4 * SL * THIN4_CH + 4;                                                  // floats per tile row (+16 B)
+  constexpr int Q = CH / 4;                                                                    // 16-byte pieces per pixel
+  constexpr int ROWF = 4 * SL * CH + 4;                                                        // floats per tile row (+16 B)
   __shared__ __attribute__((aligned(16))) float xs[XH * ROWF];
+  __shared__ __attribute__((aligned(16))) float wsm[CH == 4 ? CO * R * R * 4 : 4];   // CH = 4: the whole filter, [co][r][s][4 ci]
   const int t = threadIdx.x;
   const int tile = blockIdx.x;
   const int n = tile / (p.tiles_y * p.tiles_x);
   const int rem = tile - n * p.tiles_y * p.tiles_x;
   const int y0 = (rem / p.tiles_x) * THIN4_T, x0 = (rem - (rem / p.tiles_x) * p.tiles_x) * THIN4_T;
   const int ty = t >> 3, tx = t & 7;
+  const bool vec = (p.Ci & 3) == 0;
+  if constexpr (CH == 4) {
+    // (one scalar load per filter value in the loop below paced the kernel: 441 dependent s_load_dword per thread)
+    for (int i = t; i < CO * R * R * 4; i += 256) {
+      const int e = i & 3, tap = (i >> 2) % (R * R), co = (i >> 2) / (R * R);
+      const int r = tap / R, sx = tap - r * R;
+      float w = 0.f;
+      if (e < p.Ci)
+        w = TR ? p.w[((long)(e * R + (R - 1 - r)) * R + (R - 1 - sx)) * p.Co + co] : p.w[((long)(co * R + r) * R + sx) * p.Ci + e];
+      wsm[i] = w;
+    }
+  }
   thin_f32x2 acc[4][CO];
 #pragma unroll
   for (int j = 0; j < 4; ++j)
 #pragma unroll
     for (int co = 0; co < CO; ++co) acc[j][co] = (thin_f32x2){0.f, 0.f};
-  for (int c0 = 0; c0 < p.Ci; c0 += THIN4_CH) {
+  for (int c0 = 0; c0 < p.Ci; c0 += CH) {
     __syncthreads();
-    for (int i = t; i < XH * XW * 2; i += 256) {
-      const int pix = i >> 1, q = i & 1;
+    for (int i = t; i < XH * XW * Q; i += 256) {
+      const int pix = i / Q, q = i - pix * Q;
       const int ry = pix / XW, cx = pix - ry * XW;
       const int yy = y0 + ry - PADR, xx = x0 + cx - PADR;
       f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
-      if (yy >= 0 && yy < p.H && xx >= 0 && xx < p.W)
-        v = *reinterpret_cast<const f32x4*>(p.x + ((long)(n * p.H + yy) * p.W + xx) * p.Ci + c0 + q * 4);
-      *reinterpret_cast<f32x4*>(xs + ry * ROWF + ((cx & 3) * SL + (cx >> 2)) * THIN4_CH + q * 4) = v;
+      if (yy >= 0 && yy < p.H && xx >= 0 && xx < p.W) {
+        const float* src = p.x + ((long)(n * p.H + yy) * p.W + xx) * p.Ci + c0 + q * 4;
+        if (vec) v = *reinterpret_cast<const f32x4*>(src);
+        else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (c0 + q * 4 + e < p.Ci) v[e] = src[e];
+        }
+      }
+      *reinterpret_cast<f32x4*>(xs + ry * ROWF + ((cx & 3) * SL + (cx >> 2)) * CH + q * 4) = v;
     }
     __syncthreads();
 #pragma unroll 1
     for (int r = 0; r < R; ++r) {
       // the R + 3 pixels this thread's four outputs read in filter row r: column 4 tx + k, k = 0 .. R + 2
-      f32x4 xw[R + 3][2];
-      const float* xr = xs + (ty + r) * ROWF + tx * THIN4_CH;
+      f32x4 xw[R + 3][Q];
+      const float* xr = xs + (ty + r) * ROWF + tx * CH;
 #pragma unroll
       for (int k = 0; k < R + 3; ++k)
 #pragma unroll
-        for (int q = 0; q < 2; ++q)
-          xw[k][q] = *reinterpret_cast<const f32x4*>(xr + ((k & 3) * SL + (k >> 2)) * THIN4_CH + q * 4);
+        for (int q = 0; q < Q; ++q)
+          xw[k][q] = *reinterpret_cast<const f32x4*>(xr + ((k & 3) * SL + (k >> 2)) * CH + q * 4);
 #pragma unroll
       for (int sx = 0; sx < R; ++sx)
 #pragma unroll
         for (int co = 0; co < CO; ++co) {
-          const float* wp = p.w + ((long)(co * R + r) * R + sx) * p.Ci + c0;      // wave-uniform: scalar loads
-          const f32x4 w0 = *reinterpret_cast<const f32x4*>(wp), w1 = *reinterpret_cast<const f32x4*>(wp + 4);
+          // wave-uniform filter values: scalar loads
+          f32x4 wv[Q];
+          if constexpr (CH == 8) {
+            const float* wp = p.w + ((long)(co * R + r) * R + sx) * p.Ci + c0;
+            wv[0] = *reinterpret_cast<const f32x4*>(wp);
+            wv[1] = *reinterpret_cast<const f32x4*>(wp + 4);
+          } else {
+            wv[0] = *reinterpret_cast<const f32x4*>(wsm + ((co * R + r) * R + sx) * 4);     // broadcast read (Ci <= 4: one chunk)
+          }
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
-            const f32x4 a = xw[j + sx][0], b = xw[j + sx][1];
             thin_f32x2 s = acc[j][co];
-            s = __builtin_elementwise_fma((thin_f32x2){a.x, a.y}, (thin_f32x2){w0.x, w0.y}, s);
-            s = __builtin_elementwise_fma((thin_f32x2){a.z, a.w}, (thin_f32x2){w0.z, w0.w}, s);
-            s = __builtin_elementwise_fma((thin_f32x2){b.x, b.y}, (thin_f32x2){w1.x, w1.y}, s);
-            s = __builtin_elementwise_fma((thin_f32x2){b.z, b.w}, (thin_f32x2){w1.z, w1.w}, s);
+#pragma unroll
+            for (int q = 0; q < Q; ++q) {
+              const f32x4 a = xw[j + sx][q];
+              s = __builtin_elementwise_fma((thin_f32x2){a.x, a.y}, (thin_f32x2){wv[q].x, wv[q].y}, s);
+              s = __builtin_elementwise_fma((thin_f32x2){a.z, a.w}, (thin_f32x2){wv[q].z, wv[q].w}, s);
+            }
             acc[j][co] = s;
           }
         }
@@ -695,6 +727,13 @@ __global__ __launch_bounds__(256) void conv_fwd_thin_px4_kernel(ThinFwdArgs p) {
       }
     }
   }
+}
+
+template <int CH, bool TR>
+static void launch_thin_px4(const ThinFwdArgs& ta, dim3 grid, hipStream_t st) {
+  if (ta.Co == 3) hipLaunchKernelGGL((conv_fwd_thin_px4_kernel<7, 3, CH, TR>), grid, dim3(256), 0, st, ta);
+  else if (ta.Co == 2) hipLaunchKernelGGL((conv_fwd_thin_px4_kernel<7, 2, CH, TR>), grid, dim3(256), 0, st, ta);
+  else hipLaunchKernelGGL((conv_fwd_thin_px4_kernel<7, 1, CH, TR>), grid, dim3(256), 0, st, ta);
 }
 
 // Data gradient of the same convolutions (<= 4 OUTPUT channels of the forward conv: dy is thin, dx wide): one thread per
@@ -870,12 +909,11 @@ extern "C" int buctd_conv2d_fwd(const buctd_conv_desc* d, const float* x, const 
     ThinFwdArgs ta;
     ta.x = x; ta.w = w; ta.bias = bias; ta.y = y;
     ta.N = d->N; ta.H = d->H; ta.W = d->W; ta.Ci = d->Ci; ta.Co = d->Co;
-    if (d->Ci % THIN4_CH == 0 && d->Co <= 3) {          // wide input (64 -> 3): four pixels per thread
+    if ((d->Ci % THIN4_CH == 0 || d->Ci <= 4) && d->Co <= 3) {          // four pixels per thread (64 -> 3, 3 -> 3)
       ta.tiles_y = ceil_div(d->H, THIN4_T); ta.tiles_x = ceil_div(d->W, THIN4_T);
       const dim3 grid(d->N * ta.tiles_y * ta.tiles_x);
-      if (d->Co == 3) hipLaunchKernelGGL((conv_fwd_thin_px4_kernel<7, 3>), grid, dim3(256), 0, (hipStream_t)stream, ta);
-      else if (d->Co == 2) hipLaunchKernelGGL((conv_fwd_thin_px4_kernel<7, 2>), grid, dim3(256), 0, (hipStream_t)stream, ta);
-      else hipLaunchKernelGGL((conv_fwd_thin_px4_kernel<7, 1>), grid, dim3(256), 0, (hipStream_t)stream, ta);
+      if (d->Ci <= 4) launch_thin_px4<4, false>(ta, grid, (hipStream_t)stream);
+      else launch_thin_px4<8, false>(ta, grid, (hipStream_t)stream);
       BUCTD_CHECK_LAUNCH("buctd_conv2d_fwd(thin, four pixels per thread)");
       return BUCTD_OK;
     }
@@ -911,6 +949,15 @@ extern "C" int buctd_conv2d_dgrad(const buctd_conv_desc* d, const float* dy, con
     hipLaunchKernelGGL(conv_dgrad_thin_s2_kernel, dim3((unsigned)ceil_div(px, 256)), dim3(256), (size_t)9 * d->Co * 4 * sizeof(float),
                        (hipStream_t)stream, ta);
     BUCTD_CHECK_LAUNCH("buctd_conv2d_dgrad(thin s2)");
+    return BUCTD_OK;
+  }
+  if (fwd_thin_ok(d) && d->Ci <= 3 && !bias && !stats_partials) {      // thin on both sides (3 -> 3 7x7): the forward kernel, filter transposed
+    ThinFwdArgs ta;
+    ta.x = dy; ta.w = w; ta.bias = nullptr; ta.y = dx;
+    ta.N = d->N; ta.H = d->H; ta.W = d->W; ta.Ci = d->Co; ta.Co = d->Ci;
+    ta.tiles_y = ceil_div(d->H, THIN4_T); ta.tiles_x = ceil_div(d->W, THIN4_T);
+    launch_thin_px4<4, true>(ta, dim3(d->N * ta.tiles_y * ta.tiles_x), (hipStream_t)stream);
+    BUCTD_CHECK_LAUNCH("buctd_conv2d_dgrad(thin, four pixels per thread)");
     return BUCTD_OK;
   }
   if (fwd_thin_ok(d) && !bias && !stats_partials) {      // the preNet 7x7 with <= 4 output channels: thin dy, wide dx

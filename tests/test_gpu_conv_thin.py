@@ -34,7 +34,9 @@ def test_thin_wgrad_vs_fp64(Ci, Co, k, N, H, W):
 
 
 @pytest.mark.parametrize("Ci,Co,N,H,W", [(64, 3, 2, 192, 256), (3, 3, 3, 160, 144), (32, 2, 1, 300, 250), (17, 4, 2, 181, 203),
-                                         (8, 1, 2, 70, 45), (64, 3, 2, 65, 63), (16, 3, 3, 15, 130)])
+                                         (8, 1, 2, 70, 45), (64, 3, 2, 65, 63), (16, 3, 3, 15, 130),
+                                         # thin on both sides: the four-pixel kernel with 4-channel pixels
+                                         (3, 2, 2, 70, 90), (2, 3, 1, 95, 77), (4, 1, 2, 64, 80), (1, 3, 1, 66, 70)])
 def test_thin_forward_vs_fp64(Ci, Co, N, H, W):
     """7x7 'same' convolutions with <= 4 output channels (preNet): forward incl. bias and the BatchNorm partials"""
     from buctd_amd import ops
@@ -64,7 +66,8 @@ def test_thin_forward_vs_fp64(Ci, Co, N, H, W):
     assert ((invstd.cpu().double() - (rv + 1e-5).rsqrt()).abs() / (rv + 1e-5).rsqrt()).max().item() <= 1e-5
 
 
-@pytest.mark.parametrize("Ci,Co,N,H,W", [(64, 3, 2, 192, 256), (3, 3, 3, 160, 144), (32, 2, 1, 300, 250), (17, 4, 2, 181, 203)])
+@pytest.mark.parametrize("Ci,Co,N,H,W", [(64, 3, 2, 192, 256), (3, 3, 3, 160, 144), (32, 2, 1, 300, 250), (17, 4, 2, 181, 203),
+                                         (2, 4, 2, 70, 90), (3, 2, 1, 95, 77), (1, 3, 2, 64, 80), (3, 1, 1, 66, 70)])
 def test_thin_dgrad_vs_fp64(Ci, Co, N, H, W):
     from buctd_amd import ops
     dev = torch.device("cuda:0")
