@@ -866,6 +866,174 @@ __global__ __launch_bounds__(256) void conv_dgrad_thin_s2_kernel(ThinS2Args p) {
   for (int e = 0; e < p.Ci; ++e) o[e] = acc[e];
 }
 
+// ---- thin INPUT, 64 outputs: the first convolution of the preNet (3 -> 64, 3x3, 'same') -----------------------------------
+// The implicit-GEMM kernel pads the 27-deep reduction to 32 and reads the 3-channel pixels scalar: 0.59 ms at 384x288 (N = 32)
+// with a second pass over the 906 MB output for the BatchNorm partials.  Output-bound work (27 FMAs and 256 bytes per pixel):
+// lane = output channel with its 27 filter values in registers; a workgroup owns one image row, each of its four wavefronts a
+// quarter of it (= one statistics group), four pixels per step: their 3 x 6 input pixels are wave-uniform and come out of the
+// three zero-padded rows in LDS as aligned 16-byte broadcast reads, pixel pairs go through v_pk_fma_f32, every pixel leaves as
+// one 256-byte store, and the Welford partial of the group (shifted sums: K = the group's first value) is formed on the way.
+struct ThinInArgs {
+  const float* x;
+  const float* w;      // [64][3][3][Ci]
+  const float* bias;
+  float* y;
+  float* part;         // [groups][64][2] (mean, M2) or null
+  int N, H, W, Ci;
+};
+template <int CI>
+__global__ __launch_bounds__(256) void conv3x3_thin_in_fwd_kernel(ThinInArgs p) {
+  extern __shared__ __attribute__((aligned(16))) float xrows[];          // [3][(W + 2) * CI, padded to 16 B] + one zero row
+  const int t = threadIdx.x, lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int n = blockIdx.x / p.H, yy = blockIdx.x - n * p.H;
+  const int rowf = ((p.W + 2) * CI + 3) & ~3;                            // floats per padded row
+  for (int i = t; i < 3 * rowf; i += 256) {
+    const int rr = i / rowf, c = i - rr * rowf;                          // c = (xx + 1) * CI + ci
+    const int ry = yy - 1 + rr, px = c / CI - 1;
+    float v = 0.f;
+    if (ry >= 0 && ry < p.H && px >= 0 && px < p.W) v = p.x[((long)(n * p.H + ry) * p.W) * CI + c - CI];
+    xrows[i] = v;
+  }
+  float wr[9 * CI];
+#pragma unroll
+  for (int k = 0; k < 9 * CI; ++k) wr[k] = p.w[lane * 9 * CI + k];
+  const float b = p.bias ? p.bias[lane] : 0.f;
+  __syncthreads();
+  const int q = p.W >> 2;                                                // pixels per wavefront (a multiple of 4)
+  const int xa = wave * q;
+  float K = 0.f, s1 = 0.f, s2 = 0.f;
+  float* yo = p.y + ((long)blockIdx.x * p.W + xa) * 64 + lane;
+  for (int x0 = 0; x0 < q; x0 += 4) {
+    // padded pixels xa + x0 .. xa + x0 + 5 of the three rows: 6 * CI floats from a 16-byte aligned offset (4 pixels * CI floats)
+    constexpr int NV = (6 * CI + 3) / 4;
+    thin_f32x2 acc[2] = {(thin_f32x2){b, b}, (thin_f32x2){b, b}};
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      float xv[NV * 4];
+      const float* src = xrows + r * rowf + (xa + x0) * CI;
+#pragma unroll
+      for (int v = 0; v < NV; ++v) {
+        const f32x4 u = *reinterpret_cast<const f32x4*>(src + 4 * v);
+        xv[4 * v] = u.x; xv[4 * v + 1] = u.y; xv[4 * v + 2] = u.z; xv[4 * v + 3] = u.w;
+      }
+#pragma unroll
+      for (int dx = 0; dx < 3; ++dx)
+#pragma unroll
+        for (int ci = 0; ci < CI; ++ci) {
+          const float w = wr[(r * 3 + dx) * CI + ci];
+          const thin_f32x2 ww = {w, w};
+#pragma unroll
+          for (int pr = 0; pr < 2; ++pr)      // pixels 2 pr, 2 pr + 1: padded columns 2 pr + dx, 2 pr + 1 + dx
+            acc[pr] = __builtin_elementwise_fma((thin_f32x2){xv[(2 * pr + dx) * CI + ci], xv[(2 * pr + 1 + dx) * CI + ci]}, ww, acc[pr]);
+        }
+    }
+    const float o[4] = {acc[0].x, acc[0].y, acc[1].x, acc[1].y};
+    if (x0 == 0) K = o[0];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      yo[(long)(x0 + j) * 64] = o[j];
+      const float d = o[j] - K;
+      s1 += d;
+      s2 = __builtin_fmaf(d, d, s2);
+    }
+  }
+  if (p.part) {
+    const float inv = 1.f / (float)q;
+    float m2 = s2 - s1 * s1 * inv;
+    if (m2 < 0.f) m2 = 0.f;
+    float* o = p.part + (((long)blockIdx.x * 4 + wave) * 64 + lane) * 2;
+    o[0] = K + s1 * inv;
+    o[1] = m2;
+  }
+}
+static bool fwd_thin_in_ok(const buctd_conv_desc* d) {
+  return d->stride == 1 && d->R == 3 && d->S == 3 && d->pad == 1 && d->Co == 64 && d->Ci >= 1 && d->Ci <= 4 && d->Ho == d->H &&
+         d->Wo == d->W && d->W % 16 == 0 && d->W >= 64 && (size_t)3 * (d->W + 3) * d->Ci * sizeof(float) <= 60 * 1024 &&
+         (long)d->N * d->H * d->W >= 4096;
+}
+
+// Weight gradient of the same convolution, same traversal: lane = output channel holds dW[co][3][3][Ci] (27 accumulators),
+// a workgroup walks whole image rows (the three padded input rows in LDS, wave-uniform 16-byte broadcast reads, four pixels
+// per step), each wavefront a quarter of the row: one coalesced 256-byte dY read and 27 FMAs per pixel.  The implicit-GEMM
+// kernel took 0.78 ms at 384x288 (N = 32) for the one 906 MB pass over dY.  One slab [64][27] per wavefront, reduced by
+// splitk_reduce_kernel (the usual [split][Co][R][S][Ci] layout).
+constexpr int THIN_IN_WG = 1024;       // workgroups (each walks N * H / THIN_IN_WG image rows)
+struct ThinInWgradArgs {
+  const float* x;
+  const float* dy;
+  float* part;
+  int N, H, W, Ci;
+};
+template <int CI>
+__global__ __launch_bounds__(256) void conv3x3_thin_in_wgrad_kernel(ThinInWgradArgs p) {
+  extern __shared__ __attribute__((aligned(16))) float xrows[];
+  const int t = threadIdx.x, lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int rowf = ((p.W + 2) * CI + 3) & ~3;
+  const int q = p.W >> 2, xa = wave * q;
+  float acc[9 * CI];
+#pragma unroll
+  for (int k = 0; k < 9 * CI; ++k) acc[k] = 0.f;
+  for (int row = blockIdx.x; row < p.N * p.H; row += gridDim.x) {
+    const int n = row / p.H, yy = row - n * p.H;
+    __syncthreads();                 // the previous row's reads are done
+    for (int i = t; i < 3 * rowf; i += 256) {
+      const int rr = i / rowf, c = i - rr * rowf;
+      const int ry = yy - 1 + rr, px = c / CI - 1;
+      float v = 0.f;
+      if (ry >= 0 && ry < p.H && px >= 0 && px < p.W) v = p.x[((long)(n * p.H + ry) * p.W) * CI + c - CI];
+      xrows[i] = v;
+    }
+    __syncthreads();
+    const float* dyp = p.dy + ((long)row * p.W + xa) * 64 + lane;
+    for (int x0 = 0; x0 < q; x0 += 4) {
+      constexpr int NV = (6 * CI + 3) / 4;
+      float g[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) g[j] = dyp[(long)(x0 + j) * 64];
+#pragma unroll
+      for (int r = 0; r < 3; ++r) {
+        float xv[NV * 4];
+        const float* src = xrows + r * rowf + (xa + x0) * CI;
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+          const f32x4 u = *reinterpret_cast<const f32x4*>(src + 4 * v);
+          xv[4 * v] = u.x; xv[4 * v + 1] = u.y; xv[4 * v + 2] = u.z; xv[4 * v + 3] = u.w;
+        }
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx)
+#pragma unroll
+          for (int ci = 0; ci < CI; ++ci)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+              acc[(r * 3 + dx) * CI + ci] = __builtin_fmaf(g[j], xv[(j + dx) * CI + ci], acc[(r * 3 + dx) * CI + ci]);
+      }
+    }
+  }
+  // the four wavefronts' sums meet in LDS: one slab per workgroup
+  __syncthreads();
+  float* red = xrows;                                  // [4][9 * CI][64]
+#pragma unroll
+  for (int k = 0; k < 9 * CI; ++k) red[(wave * 9 * CI + k) * 64 + lane] = acc[k];
+  __syncthreads();
+  float* o = p.part + (size_t)blockIdx.x * 64 * (9 * CI);
+  for (int i = t; i < 64 * 9 * CI; i += 256) {
+    const int co = i / (9 * CI), k = i - co * (9 * CI);
+    o[i] = (red[(0 * 9 * CI + k) * 64 + co] + red[(1 * 9 * CI + k) * 64 + co]) +
+           (red[(2 * 9 * CI + k) * 64 + co] + red[(3 * 9 * CI + k) * 64 + co]);
+  }
+}
+static size_t thin_in_wgrad_lds(const buctd_conv_desc* d) {
+  const size_t rows = (size_t)3 * ((((size_t)d->W + 2) * d->Ci + 3) & ~(size_t)3) * sizeof(float);
+  const size_t red = (size_t)4 * 9 * d->Ci * 64 * sizeof(float);
+  return rows > red ? rows : red;
+}
+static int thin_in_wgs(const buctd_conv_desc* d) {
+  const int rows = d->N * d->H;
+  return rows < THIN_IN_WG ? rows : THIN_IN_WG;
+}
+
 static bool dgrad_thin_s2_ok(const buctd_conv_desc* d) {
   return d->stride == 2 && d->R == 3 && d->S == 3 && d->pad == 1 && d->Ci <= 4 && d->Co % 4 == 0 && d->Co <= 256 &&
          (long)d->N * d->H * d->W >= 4096;
@@ -888,6 +1056,11 @@ extern "C" int buctd_conv2d_stats_groups(const buctd_conv_desc* d, int transpose
   BUCTD_CHECK_ARG(ngroups && rows_per_group, "buctd_conv2d_stats_groups: null output");
   const long M = transposed ? (long)d->N * d->H * d->W : (long)d->N * d->Ho * d->Wo;
   const int oc = transposed ? d->Ci : d->Co;
+  if (!transposed && fwd_thin_in_ok(d)) {        // one group per wavefront of conv3x3_thin_in_fwd_kernel: a quarter image row
+    *rows_per_group = d->W / 4;
+    *ngroups = d->N * d->H * 4;
+    return BUCTD_OK;
+  }
   const ConvTileSel ts = conv_tile_select(oc, M, transposed ? dgrad_vec_ok(d) : fwd_vec_ok(d));
   *rows_per_group = ts.MF * 16;
   *ngroups = ceil_div(M, ts.BM) * ts.WM;
@@ -920,6 +1093,20 @@ extern "C" int buctd_conv2d_fwd(const buctd_conv_desc* d, const float* x, const 
     ta.tiles_y = ceil_div(d->H, THIN_TH); ta.tiles_x = ceil_div(d->W, THIN_TW);
     hipLaunchKernelGGL((conv_fwd_thin_kernel<7>), dim3(d->N * ta.tiles_y * ta.tiles_x), dim3(256), 0, (hipStream_t)stream, ta);
     BUCTD_CHECK_LAUNCH("buctd_conv2d_fwd(thin)");
+    return BUCTD_OK;
+  }
+  if (fwd_thin_in_ok(d) && !scale && !residual && !relu) {      // 3 -> 64 3x3 of the preNet: lane = output channel
+    ThinInArgs ta;
+    ta.x = x; ta.w = w; ta.bias = bias; ta.y = y; ta.part = stats_partials;
+    ta.N = d->N; ta.H = d->H; ta.W = d->W; ta.Ci = d->Ci;
+    const dim3 grid(d->N * d->H);
+    const size_t lds = (size_t)3 * ((((size_t)d->W + 2) * d->Ci + 3) & ~(size_t)3) * sizeof(float);
+    hipStream_t st = (hipStream_t)stream;
+    if (d->Ci == 3) hipLaunchKernelGGL(conv3x3_thin_in_fwd_kernel<3>, grid, dim3(256), lds, st, ta);
+    else if (d->Ci == 4) hipLaunchKernelGGL(conv3x3_thin_in_fwd_kernel<4>, grid, dim3(256), lds, st, ta);
+    else if (d->Ci == 2) hipLaunchKernelGGL(conv3x3_thin_in_fwd_kernel<2>, grid, dim3(256), lds, st, ta);
+    else hipLaunchKernelGGL(conv3x3_thin_in_fwd_kernel<1>, grid, dim3(256), lds, st, ta);
+    BUCTD_CHECK_LAUNCH("buctd_conv2d_fwd(thin input)");
     return BUCTD_OK;
   }
   ConvArgs a;
@@ -1142,6 +1329,7 @@ static void wgrad_plan(const buctd_conv_desc* d, int* bm, int* bn, int* nsplit, 
 extern "C" size_t buctd_conv2d_wgrad_workspace(const buctd_conv_desc* d) {
   if (check_desc(d, "buctd_conv2d_wgrad_workspace")) return 0;
   if (wgrad_thin_ok(d)) return (size_t)thin_splits(d) * d->Co * d->R * d->S * d->Ci * sizeof(float);
+  if (fwd_thin_in_ok(d)) return (size_t)thin_in_wgs(d) * d->Co * d->R * d->S * d->Ci * sizeof(float);
   int bm, bn, ns, pps;
   wgrad_plan(d, &bm, &bn, &ns, &pps);
   return (size_t)ns * d->Co * d->R * d->S * d->Ci * sizeof(float);
@@ -1164,7 +1352,9 @@ extern "C" int buctd_conv2d_wgrad(const buctd_conv_desc* d, const float* x, cons
   int bm, bn, ns, pps;
   wgrad_plan(d, &bm, &bn, &ns, &pps);
   const bool thin = wgrad_thin_ok(d);
+  const bool thin_in = !thin && fwd_thin_in_ok(d);       // 3 -> 64 3x3: lane = output channel
   if (thin) ns = thin_splits(d);
+  if (thin_in) ns = thin_in_wgs(d);
   const size_t need = (size_t)ns * d->Co * d->R * d->S * d->Ci * sizeof(float);
   if (workspace == nullptr || workspace_bytes < need) {
     buctd_set_error("buctd_conv2d_wgrad: workspace %zu bytes < required %zu", workspace_bytes, need);
@@ -1194,6 +1384,17 @@ extern "C" int buctd_conv2d_wgrad(const buctd_conv_desc* d, const float* x, cons
   a.Mpix = d->N * d->Ho * d->Wo; a.Ncols = d->R * d->S * d->Ci; a.pix_per_split = pps;
   hipStream_t st = (hipStream_t)stream;
   const bool vec = (d->Ci % 4 == 0) && (d->Co % 4 == 0);
+  if (thin_in) {
+    ThinInWgradArgs ta;
+    ta.x = x; ta.dy = dy; ta.part = (float*)workspace;
+    ta.N = d->N; ta.H = d->H; ta.W = d->W; ta.Ci = d->Ci;
+    const dim3 grid(thin_in_wgs(d));
+    const size_t lds = thin_in_wgrad_lds(d);
+    if (d->Ci == 3) hipLaunchKernelGGL(conv3x3_thin_in_wgrad_kernel<3>, grid, dim3(256), lds, st, ta);
+    else if (d->Ci == 4) hipLaunchKernelGGL(conv3x3_thin_in_wgrad_kernel<4>, grid, dim3(256), lds, st, ta);
+    else if (d->Ci == 2) hipLaunchKernelGGL(conv3x3_thin_in_wgrad_kernel<2>, grid, dim3(256), lds, st, ta);
+    else hipLaunchKernelGGL(conv3x3_thin_in_wgrad_kernel<1>, grid, dim3(256), lds, st, ta);
+  } else
   if (thin) {}                                                             // launched above
   else if (!vec) launch_wgrad<TileCfg<2, 2, 2, 2>, false>(a, ns, st);     // 64x64 generic
   else if (bm == 48) launch_wgrad<TileCfg<1, 4, 3, 1>, true>(a, ns, st);  // 48x64

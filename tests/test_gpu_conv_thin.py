@@ -8,7 +8,10 @@ pytestmark = pytest.mark.gpu
 
 
 @pytest.mark.parametrize("Ci,Co,k,N,H,W", [(3, 64, 3, 2, 192, 256), (64, 3, 7, 2, 192, 256), (3, 3, 7, 3, 160, 144),
-                                             (4, 48, 3, 2, 181, 203), (32, 2, 7, 1, 300, 250)])
+                                             (4, 48, 3, 2, 181, 203), (32, 2, 7, 1, 300, 250),
+                                             # 3x3 from <= 4 channels to 64, W a multiple of 16: lane = output channel
+                                             (4, 64, 3, 1, 70, 144), (1, 64, 3, 2, 33, 128), (2, 64, 3, 1, 50, 80),
+                                             (3, 64, 3, 40, 40, 64)])
 def test_thin_wgrad_vs_fp64(Ci, Co, k, N, H, W):
     from buctd_amd import ops
     dev = torch.device("cuda:0")
@@ -101,3 +104,30 @@ def test_thin_stride2_dgrad_vs_fp64(Ci, Co, N, H, W):
     dx = ops.conv_dgrad(dyd, wd, (N, H, W, Ci), 2, 1)
     err = (dx.cpu().double() - ref).abs().max().item() / ref.abs().max().item()
     assert err <= 2e-6, f"thin stride-2 dgrad {Ci}->{Co} {H}x{W}: rel err {err:.2e}"
+
+
+@pytest.mark.parametrize("Ci,N,H,W", [(3, 2, 192, 256), (4, 1, 70, 144), (1, 2, 33, 128), (2, 3, 41, 197), (3, 1, 64, 64), (3, 2, 50, 80)])
+def test_thin_input_3x3_forward_vs_fp64(Ci, N, H, W):
+    """3x3 'same' convolutions from <= 4 input channels to 64 (first preNet convolution): forward incl. bias and the
+    BatchNorm partials formed in the same launch (W < 128 takes the general kernel)"""
+    from buctd_amd import ops
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(Ci * 31 + W)
+    x = torch.randn(N, Ci, H, W, generator=g, dtype=torch.float64) + 0.3
+    w = torch.randn(64, Ci, 3, 3, generator=g, dtype=torch.float64) * (9 * Ci) ** -0.5
+    b = torch.randn(64, generator=g, dtype=torch.float64)
+    ref = F.conv2d(x, w, b, 1, 1).permute(0, 2, 3, 1)
+    xd = x.float().permute(0, 2, 3, 1).contiguous().to(dev)
+    wd = w.float().contiguous(memory_format=torch.channels_last).to(dev)
+    bd = b.float().to(dev)
+    y = ops.conv_fwd(xd, wd, bd, 1, 1)
+    err = (y.cpu().double() - ref).abs().max().item() / ref.abs().max().item()
+    assert err <= 2e-6, f"thin-input forward {Ci}->64: rel err {err:.2e}"
+    y2, part, info = ops.conv_fwd(xd, wd, bd, 1, 1, stats=True)
+    assert torch.equal(y, y2)
+    rows = N * H * W
+    mean, invstd = ops.bn_finalize(part, info, rows, 64, 1e-5, 0.1, None, None)
+    rm = ref.reshape(-1, 64).mean(0)
+    rv = ref.reshape(-1, 64).var(0, unbiased=False)
+    assert (mean.cpu().double() - rm).abs().max().item() <= 2e-6 * ref.abs().max().item()
+    assert ((invstd.cpu().double() - (rv + 1e-5).rsqrt()).abs() / (rv + 1e-5).rsqrt()).max().item() <= 1e-5
