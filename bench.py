@@ -474,32 +474,6 @@ def self_launch(n):
     return subprocess.call(cmd, env=env)
 
 
-def prime_gpu():
-    """Open the GPU once in a throw-away child before this process does.  Measured on the gpurun boxes (round 4,
-    scratch/first_run_probe.py): the FIRST process that opens the GPU after the box comes up runs the train step at
-    100-220 ms, erratically, for its whole life (60 steps watched; clocks at 2.3 GHz all along), while every later process -
-    also one started right after a 1.5 s `torch.zeros(1, device='cuda')` - runs it at 71 ms from its second step on.
-    Nothing of the measured work moves: the child computes nothing that the timed region uses."""
-    if os.environ.get("BUCTD_BENCH_NO_PRIME") == "1" or os.environ.get("BUCTD_SINGLE_DEVICE") == "1":
-        return      # (several ranks on one GPU, tests only: their children would compete for its memory)
-    import subprocess
-    # (the child also writes 60 % of the free HBM once and keeps the matrix cores busy for about a second: the mechanism
-    # behind the slow first process is not known; memory that no process has touched since the box came up is slow to touch
-    # the first time - 50 ms per GB against 0.4 - and after a child that touched 160 GB three of three fresh boxes ran the
-    # step at full speed, after one that touched 8 GB two of three)
-    code = ("import os, torch; d = int(os.environ.get('LOCAL_RANK', '0')) % max(1, torch.cuda.device_count()); "
-            "dev = 'cuda:%d' % d; x = torch.zeros(1 << 20, device=dev); s = (x + 1).sum().item(); "
-            "n = min(int(torch.cuda.mem_get_info(d)[0] * 0.6) >> 30, 160); "
-            "bufs = [torch.empty(1 << 28, dtype=torch.float32, device=dev).fill_(1.0) for _ in range(n)]; "
-            "a = torch.randn(8192, 8192, device=dev); b = a\n"
-            "for _ in range(40): b = (a @ b) * 1e-4\n"
-            "print(s, float(b.sum()), sum(float(t[0]) for t in bufs))")
-    try:
-        subprocess.run([sys.executable, "-c", code], timeout=900, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
-    except Exception:       # the child is a courtesy to the clock, never a reason to fail
-        pass
-
-
 def main():
     if os.environ.get("BUCTD_BENCH_CPU_WORKER") == "1":
         print(json.dumps(_cpu_baseline_worker()))
@@ -526,7 +500,6 @@ def main():
         # rendezvous on 127.0.0.1) and pass rank 0's JSON line through
         raise SystemExit(self_launch(args.gpus))
 
-    prime_gpu()
     from buctd_amd import engine, models, ops
     from buctd_amd.core.function import _DeferredStats, AverageMeter
     from buctd_amd.core.loss import JointsMSELoss

@@ -172,7 +172,7 @@ def test_bench_launches_its_own_ranks(tmp_path):
     import json
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
                         "--workload", "train_c2", "--batch", "4", "--no-kernel-timer"],
-                       env=_env(BUCTD_DIST_BACKEND="gloo", BUCTD_SINGLE_DEVICE="1", BUCTD_BENCH_NO_PRIME="1"), capture_output=True, text=True,
+                       env=_env(BUCTD_DIST_BACKEND="gloo", BUCTD_SINGLE_DEVICE="1"), capture_output=True, text=True,
                        timeout=900)
     assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-2500:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
@@ -201,7 +201,7 @@ def test_bench_with_four_ranks_on_one_device(tmp_path):
     import json
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--steps", "2", "--warmup", "1",
                         "--workload", "train_c2", "--batch", "2", "--no-kernel-timer"],
-                       env=_env(BUCTD_DIST_BACKEND="gloo", BUCTD_SINGLE_DEVICE="1", BUCTD_BENCH_NO_PRIME="1"), capture_output=True, text=True,
+                       env=_env(BUCTD_DIST_BACKEND="gloo", BUCTD_SINGLE_DEVICE="1"), capture_output=True, text=True,
                        timeout=1200)
     assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-2500:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
