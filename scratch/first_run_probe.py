@@ -14,6 +14,10 @@ x, tgt, wt = bench.synthetic_batch(cfg, 32, dev, 1)
 crit = JointsMSELoss(True)
 def step():
     loss = crit(model(x), tgt, wt); opt.zero_grad(); loss.backward(); opt.step()
+import contextlib
+mp = os.environ.get("MAINPRIO")
+ctx = torch.cuda.stream(torch.cuda.Stream(priority=int(mp))) if mp is not None else contextlib.nullcontext()
+ctx.__enter__()
 for blk in range(int(os.environ.get("BLOCKS", "12"))):
     torch.cuda.synchronize(); t0 = time.time()
     for _ in range(5): step()
