@@ -474,6 +474,22 @@ def self_launch(n):
     return subprocess.call(cmd, env=env)
 
 
+def first_touch(device):
+    """Write a large block of device memory once and hand it back to the driver before anything is measured.  Device memory
+    that no process has used since a box came up costs 10-50 ms per GB on its first touch (0.4 ms later; measured on the
+    gpurun boxes, scratch/first_run_probe2.py), and the caching allocator still maps a few new segments in the first dozen
+    steps after the warm-up: as the first process on a fresh box a short run measured that instead of the step.  Nothing of
+    the measured work moves; several ranks on one device (tests) skip it."""
+    if os.environ.get("BUCTD_BENCH_NO_FIRST_TOUCH") == "1" or os.environ.get("BUCTD_SINGLE_DEVICE") == "1":
+        return
+    free = torch.cuda.mem_get_info(device)[0]
+    n = min(int(free * 0.5), 128 << 30) >> 30
+    blocks = [torch.empty(1 << 30, dtype=torch.uint8, device=device).fill_(0) for _ in range(n)]
+    torch.cuda.synchronize(device)
+    del blocks
+    torch.cuda.empty_cache()
+
+
 def main():
     if os.environ.get("BUCTD_BENCH_CPU_WORKER") == "1":
         print(json.dumps(_cpu_baseline_worker()))
@@ -510,6 +526,7 @@ def main():
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
     ops.set_conv_math(args.conv_math)
+    first_touch(device)
     if args.workload == "infer_c5":
         bench_infer_c5(args, rank, world, device)
         if world > 1:
