@@ -105,7 +105,9 @@ class Linear(tnn.Linear):
 
     def forward(self, x, relu=False):
         B, T, Cin = x.shape
-        y = ops.Conv.apply(x.view(B, 1, T, Cin), self.weight, self.bias, 1, 0, relu)
+        # any 2-D arrangement of the B * T rows is the same 1x1 convolution; as ONE image of B rows the zero-padded position
+        # space of the gathered kernels carries one pad row per B (as B images of one row: one per row - half the tiles)
+        y = ops.Conv.apply(x.view(1, B, T, Cin), self.weight, self.bias, 1, 0, relu)
         return y.view(B, T, self.out_features)
 
 
