@@ -879,18 +879,19 @@ struct ThinInArgs {
   const float* bias;
   float* y;
   float* part;         // [groups][64][2] (mean, M2) or null
-  int N, H, W, Ci;
+  int N, H, W, Ci;     // input size
+  int Ho, Wo;          // output size (stride ST: the stem's first convolution is the stride-2 case)
 };
-template <int CI>
+template <int CI, int ST>
 __global__ __launch_bounds__(256) void conv3x3_thin_in_fwd_kernel(ThinInArgs p) {
   extern __shared__ __attribute__((aligned(16))) float xrows[];          // [3][(W + 2) * CI, padded to 16 B] + one zero row
   const int t = threadIdx.x, lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
-  const int n = blockIdx.x / p.H, yy = blockIdx.x - n * p.H;
+  const int n = blockIdx.x / p.Ho, oy = blockIdx.x - n * p.Ho;      // one OUTPUT row per workgroup
   const int rowf = ((p.W + 2) * CI + 3) & ~3;                            // floats per padded row
   for (int i = t; i < 3 * rowf; i += 256) {
     const int rr = i / rowf, c = i - rr * rowf;                          // c = (xx + 1) * CI + ci
-    const int ry = yy - 1 + rr, px = c / CI - 1;
+    const int ry = ST * oy - 1 + rr, px = c / CI - 1;
     float v = 0.f;
     if (ry >= 0 && ry < p.H && px >= 0 && px < p.W) v = p.x[((long)(n * p.H + ry) * p.W) * CI + c - CI];
     xrows[i] = v;
@@ -900,18 +901,18 @@ __global__ __launch_bounds__(256) void conv3x3_thin_in_fwd_kernel(ThinInArgs p) 
   for (int k = 0; k < 9 * CI; ++k) wr[k] = p.w[lane * 9 * CI + k];
   const float b = p.bias ? p.bias[lane] : 0.f;
   __syncthreads();
-  const int q = p.W >> 2;                                                // pixels per wavefront (a multiple of 4)
+  const int q = p.Wo >> 2;                                               // output pixels per wavefront (a multiple of 4)
   const int xa = wave * q;
   float K = 0.f, s1 = 0.f, s2 = 0.f;
-  float* yo = p.y + ((long)blockIdx.x * p.W + xa) * 64 + lane;
+  float* yo = p.y + ((long)blockIdx.x * p.Wo + xa) * 64 + lane;
   for (int x0 = 0; x0 < q; x0 += 4) {
-    // padded pixels xa + x0 .. xa + x0 + 5 of the three rows: 6 * CI floats from a 16-byte aligned offset (4 pixels * CI floats)
-    constexpr int NV = (6 * CI + 3) / 4;
+    // padded input pixels ST (xa + x0) .. + 3 ST + 2 of the three rows: (3 ST + 3) * CI floats from a 16-byte aligned offset
+    constexpr int NV = ((3 * ST + 3) * CI + 3) / 4;
     thin_f32x2 acc[2] = {(thin_f32x2){b, b}, (thin_f32x2){b, b}};
 #pragma unroll
     for (int r = 0; r < 3; ++r) {
       float xv[NV * 4];
-      const float* src = xrows + r * rowf + (xa + x0) * CI;
+      const float* src = xrows + r * rowf + ST * (xa + x0) * CI;
 #pragma unroll
       for (int v = 0; v < NV; ++v) {
         const f32x4 u = *reinterpret_cast<const f32x4*>(src + 4 * v);
@@ -925,7 +926,7 @@ __global__ __launch_bounds__(256) void conv3x3_thin_in_fwd_kernel(ThinInArgs p) 
           const thin_f32x2 ww = {w, w};
 #pragma unroll
           for (int pr = 0; pr < 2; ++pr)      // pixels 2 pr, 2 pr + 1: padded columns 2 pr + dx, 2 pr + 1 + dx
-            acc[pr] = __builtin_elementwise_fma((thin_f32x2){xv[(2 * pr + dx) * CI + ci], xv[(2 * pr + 1 + dx) * CI + ci]}, ww, acc[pr]);
+            acc[pr] = __builtin_elementwise_fma((thin_f32x2){xv[(ST * 2 * pr + dx) * CI + ci], xv[(ST * (2 * pr + 1) + dx) * CI + ci]}, ww, acc[pr]);
         }
     }
     const float o[4] = {acc[0].x, acc[0].y, acc[1].x, acc[1].y};
@@ -948,9 +949,12 @@ __global__ __launch_bounds__(256) void conv3x3_thin_in_fwd_kernel(ThinInArgs p) 
   }
 }
 static bool fwd_thin_in_ok(const buctd_conv_desc* d) {
-  return d->stride == 1 && d->R == 3 && d->S == 3 && d->pad == 1 && d->Co == 64 && d->Ci >= 1 && d->Ci <= 4 && d->Ho == d->H &&
-         d->Wo == d->W && d->W % 16 == 0 && d->W >= 64 && (size_t)3 * (d->W + 3) * d->Ci * sizeof(float) <= 60 * 1024 &&
-         (long)d->N * d->H * d->W >= 4096;
+  if (!(d->R == 3 && d->S == 3 && d->pad == 1 && d->Co == 64 && d->Ci >= 1 && d->Ci <= 4)) return false;
+  if (d->stride == 1) { if (d->Ho != d->H || d->Wo != d->W) return false; }
+  else if (d->stride == 2) { if ((d->H & 1) || (d->W & 1) || d->Ho != d->H / 2 || d->Wo != d->W / 2) return false; }
+  else return false;
+  return d->Wo % 16 == 0 && d->Wo >= 64 && (size_t)3 * (d->W + 3) * d->Ci * sizeof(float) <= 60 * 1024 &&
+         (long)d->N * d->Ho * d->Wo >= 4096;
 }
 
 // Weight gradient of the same convolution, same traversal: lane = output channel holds dW[co][3][3][Ci] (27 accumulators),
@@ -963,39 +967,39 @@ struct ThinInWgradArgs {
   const float* x;
   const float* dy;
   float* part;
-  int N, H, W, Ci;
+  int N, H, W, Ci, Ho, Wo;
 };
-template <int CI>
+template <int CI, int ST>
 __global__ __launch_bounds__(256) void conv3x3_thin_in_wgrad_kernel(ThinInWgradArgs p) {
   extern __shared__ __attribute__((aligned(16))) float xrows[];
   const int t = threadIdx.x, lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
   const int rowf = ((p.W + 2) * CI + 3) & ~3;
-  const int q = p.W >> 2, xa = wave * q;
+  const int q = p.Wo >> 2, xa = wave * q;
   float acc[9 * CI];
 #pragma unroll
   for (int k = 0; k < 9 * CI; ++k) acc[k] = 0.f;
-  for (int row = blockIdx.x; row < p.N * p.H; row += gridDim.x) {
-    const int n = row / p.H, yy = row - n * p.H;
+  for (int row = blockIdx.x; row < p.N * p.Ho; row += gridDim.x) {      // output rows
+    const int n = row / p.Ho, oy = row - n * p.Ho;
     __syncthreads();                 // the previous row's reads are done
     for (int i = t; i < 3 * rowf; i += 256) {
       const int rr = i / rowf, c = i - rr * rowf;
-      const int ry = yy - 1 + rr, px = c / CI - 1;
+      const int ry = ST * oy - 1 + rr, px = c / CI - 1;
       float v = 0.f;
       if (ry >= 0 && ry < p.H && px >= 0 && px < p.W) v = p.x[((long)(n * p.H + ry) * p.W) * CI + c - CI];
       xrows[i] = v;
     }
     __syncthreads();
-    const float* dyp = p.dy + ((long)row * p.W + xa) * 64 + lane;
+    const float* dyp = p.dy + ((long)row * p.Wo + xa) * 64 + lane;
     for (int x0 = 0; x0 < q; x0 += 4) {
-      constexpr int NV = (6 * CI + 3) / 4;
+      constexpr int NV = ((3 * ST + 3) * CI + 3) / 4;
       float g[4];
 #pragma unroll
       for (int j = 0; j < 4; ++j) g[j] = dyp[(long)(x0 + j) * 64];
 #pragma unroll
       for (int r = 0; r < 3; ++r) {
         float xv[NV * 4];
-        const float* src = xrows + r * rowf + (xa + x0) * CI;
+        const float* src = xrows + r * rowf + ST * (xa + x0) * CI;
 #pragma unroll
         for (int v = 0; v < NV; ++v) {
           const f32x4 u = *reinterpret_cast<const f32x4*>(src + 4 * v);
@@ -1007,7 +1011,7 @@ __global__ __launch_bounds__(256) void conv3x3_thin_in_wgrad_kernel(ThinInWgradA
           for (int ci = 0; ci < CI; ++ci)
 #pragma unroll
             for (int j = 0; j < 4; ++j)
-              acc[(r * 3 + dx) * CI + ci] = __builtin_fmaf(g[j], xv[(j + dx) * CI + ci], acc[(r * 3 + dx) * CI + ci]);
+              acc[(r * 3 + dx) * CI + ci] = __builtin_fmaf(g[j], xv[(ST * j + dx) * CI + ci], acc[(r * 3 + dx) * CI + ci]);
       }
     }
   }
@@ -1030,7 +1034,7 @@ static size_t thin_in_wgrad_lds(const buctd_conv_desc* d) {
   return rows > red ? rows : red;
 }
 static int thin_in_wgs(const buctd_conv_desc* d) {
-  const int rows = d->N * d->H;
+  const int rows = d->N * d->Ho;
   return rows < THIN_IN_WG ? rows : THIN_IN_WG;
 }
 
@@ -1057,8 +1061,8 @@ extern "C" int buctd_conv2d_stats_groups(const buctd_conv_desc* d, int transpose
   const long M = transposed ? (long)d->N * d->H * d->W : (long)d->N * d->Ho * d->Wo;
   const int oc = transposed ? d->Ci : d->Co;
   if (!transposed && fwd_thin_in_ok(d)) {        // one group per wavefront of conv3x3_thin_in_fwd_kernel: a quarter image row
-    *rows_per_group = d->W / 4;
-    *ngroups = d->N * d->H * 4;
+    *rows_per_group = d->Wo / 4;
+    *ngroups = d->N * d->Ho * 4;
     return BUCTD_OK;
   }
   const ConvTileSel ts = conv_tile_select(oc, M, transposed ? dgrad_vec_ok(d) : fwd_vec_ok(d));
@@ -1098,14 +1102,17 @@ extern "C" int buctd_conv2d_fwd(const buctd_conv_desc* d, const float* x, const 
   if (fwd_thin_in_ok(d) && !scale && !residual && !relu) {      // 3 -> 64 3x3 of the preNet: lane = output channel
     ThinInArgs ta;
     ta.x = x; ta.w = w; ta.bias = bias; ta.y = y; ta.part = stats_partials;
-    ta.N = d->N; ta.H = d->H; ta.W = d->W; ta.Ci = d->Ci;
-    const dim3 grid(d->N * d->H);
+    ta.N = d->N; ta.H = d->H; ta.W = d->W; ta.Ci = d->Ci; ta.Ho = d->Ho; ta.Wo = d->Wo;
+    const dim3 grid(d->N * d->Ho);
     const size_t lds = (size_t)3 * ((((size_t)d->W + 2) * d->Ci + 3) & ~(size_t)3) * sizeof(float);
     hipStream_t st = (hipStream_t)stream;
-    if (d->Ci == 3) hipLaunchKernelGGL(conv3x3_thin_in_fwd_kernel<3>, grid, dim3(256), lds, st, ta);
-    else if (d->Ci == 4) hipLaunchKernelGGL(conv3x3_thin_in_fwd_kernel<4>, grid, dim3(256), lds, st, ta);
-    else if (d->Ci == 2) hipLaunchKernelGGL(conv3x3_thin_in_fwd_kernel<2>, grid, dim3(256), lds, st, ta);
-    else hipLaunchKernelGGL(conv3x3_thin_in_fwd_kernel<1>, grid, dim3(256), lds, st, ta);
+#define THIN_IN_FWD(ci) \
+    if (d->Ci == ci) { \
+      if (d->stride == 1) hipLaunchKernelGGL((conv3x3_thin_in_fwd_kernel<ci, 1>), grid, dim3(256), lds, st, ta); \
+      else hipLaunchKernelGGL((conv3x3_thin_in_fwd_kernel<ci, 2>), grid, dim3(256), lds, st, ta); \
+    }
+    THIN_IN_FWD(1) THIN_IN_FWD(2) THIN_IN_FWD(3) THIN_IN_FWD(4)
+#undef THIN_IN_FWD
     BUCTD_CHECK_LAUNCH("buctd_conv2d_fwd(thin input)");
     return BUCTD_OK;
   }
@@ -1387,13 +1394,16 @@ extern "C" int buctd_conv2d_wgrad(const buctd_conv_desc* d, const float* x, cons
   if (thin_in) {
     ThinInWgradArgs ta;
     ta.x = x; ta.dy = dy; ta.part = (float*)workspace;
-    ta.N = d->N; ta.H = d->H; ta.W = d->W; ta.Ci = d->Ci;
+    ta.N = d->N; ta.H = d->H; ta.W = d->W; ta.Ci = d->Ci; ta.Ho = d->Ho; ta.Wo = d->Wo;
     const dim3 grid(thin_in_wgs(d));
     const size_t lds = thin_in_wgrad_lds(d);
-    if (d->Ci == 3) hipLaunchKernelGGL(conv3x3_thin_in_wgrad_kernel<3>, grid, dim3(256), lds, st, ta);
-    else if (d->Ci == 4) hipLaunchKernelGGL(conv3x3_thin_in_wgrad_kernel<4>, grid, dim3(256), lds, st, ta);
-    else if (d->Ci == 2) hipLaunchKernelGGL(conv3x3_thin_in_wgrad_kernel<2>, grid, dim3(256), lds, st, ta);
-    else hipLaunchKernelGGL(conv3x3_thin_in_wgrad_kernel<1>, grid, dim3(256), lds, st, ta);
+#define THIN_IN_WG(ci) \
+    if (d->Ci == ci) { \
+      if (d->stride == 1) hipLaunchKernelGGL((conv3x3_thin_in_wgrad_kernel<ci, 1>), grid, dim3(256), lds, st, ta); \
+      else hipLaunchKernelGGL((conv3x3_thin_in_wgrad_kernel<ci, 2>), grid, dim3(256), lds, st, ta); \
+    }
+    THIN_IN_WG(1) THIN_IN_WG(2) THIN_IN_WG(3) THIN_IN_WG(4)
+#undef THIN_IN_WG
   } else
   if (thin) {}                                                             // launched above
   else if (!vec) launch_wgrad<TileCfg<2, 2, 2, 2>, false>(a, ns, st);     // 64x64 generic

@@ -131,3 +131,34 @@ def test_thin_input_3x3_forward_vs_fp64(Ci, N, H, W):
     rv = ref.reshape(-1, 64).var(0, unbiased=False)
     assert (mean.cpu().double() - rm).abs().max().item() <= 2e-6 * ref.abs().max().item()
     assert ((invstd.cpu().double() - (rv + 1e-5).rsqrt()).abs() / (rv + 1e-5).rsqrt()).max().item() <= 1e-5
+
+
+@pytest.mark.parametrize("Ci,N,H,W", [(3, 2, 192, 256), (4, 1, 140, 288), (1, 2, 66, 128), (3, 1, 64, 64), (2, 1, 130, 160)])
+def test_thin_input_3x3_stride2_vs_fp64(Ci, N, H, W):
+    """the stem's first convolution (<= 4 channels -> 64, 3x3, stride 2, pad 1): forward with bias and BatchNorm partials, and
+    the weight gradient, on the lane-per-output-channel kernels where the output width is a multiple of 16 (else the general path)"""
+    from buctd_amd import ops
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(Ci * 17 + W)
+    x = torch.randn(N, Ci, H, W, generator=g, dtype=torch.float64) - 0.2
+    w = (torch.randn(64, Ci, 3, 3, generator=g, dtype=torch.float64) * (9 * Ci) ** -0.5).requires_grad_(True)
+    b = torch.randn(64, generator=g, dtype=torch.float64)
+    ref = F.conv2d(x, w, b, 2, 1)
+    dy = torch.randn(ref.shape, generator=g, dtype=torch.float64)
+    ref.backward(dy)
+    refy = ref.detach().permute(0, 2, 3, 1)
+    xd = x.float().permute(0, 2, 3, 1).contiguous().to(dev)
+    wd = w.detach().float().contiguous(memory_format=torch.channels_last).to(dev)
+    y, part, info = ops.conv_fwd(xd, wd, b.float().to(dev), 2, 1, stats=True)
+    err = (y.cpu().double() - refy).abs().max().item() / refy.abs().max().item()
+    assert err <= 2e-6, f"thin-input stride-2 forward {Ci}->64: rel err {err:.2e}"
+    rows = refy.numel() // 64
+    mean, invstd = ops.bn_finalize(part, info, rows, 64, 1e-5, 0.1, None, None)
+    rm, rv = refy.reshape(-1, 64).mean(0), refy.reshape(-1, 64).var(0, unbiased=False)
+    assert (mean.cpu().double() - rm).abs().max().item() <= 2e-6 * refy.abs().max().item()
+    assert ((invstd.cpu().double() - (rv + 1e-5).rsqrt()).abs() / (rv + 1e-5).rsqrt()).max().item() <= 1e-5
+    dyd = dy.float().permute(0, 2, 3, 1).contiguous().to(dev)
+    out = torch.empty_like(wd)
+    ops.conv_wgrad(xd, dyd, wd, 2, 1, out=out, accumulate=0)
+    err = (out.cpu().double() - w.grad).abs().max().item() / w.grad.abs().max().item()
+    assert err <= 2e-5, f"thin-input stride-2 wgrad {Ci}->64: rel err {err:.2e}"
