@@ -368,10 +368,14 @@ extern "C" int buctd_gconv_x6_prep_batched(const void* items_device, int n, void
 // ---- launch ----------------------------------------------------------------------------------------------------------------
 struct GcPlan { int MF, NF, WM, WN, BM, BN; };
 
-static bool gc_plan(int nout, GcPlan* pl) {
+static bool gc_plan(int nout, long P, GcPlan* pl) {
   // 96-wide tiles gather every source piece once per 96 outputs; the barrier-free 48-wide ones would win only where the
   // contraction is long and the source tiny (192 -> 384 at 24 x 18: 79 -> 55 us) and lose elsewhere (48 -> 96 at 96 x 72: 43 -> 57)
   if (nout % 96 == 0) *pl = {4, 3, 2, 2, 128, 96};
+  // 128-wide tiles where they still make a full round of workgroups (the 1x1 convolutions of layer1 on 256 channels: every
+  // 64-wide column tile gathers and splits the same rows again - 64 -> 256 at 96 x 72: 146 -> 113 us, the data gradient of
+  // 256 -> 64: 115 -> 94); small maps keep the 64-wide tiles (128 -> 256 at 16 x 12: 15 -> 17-21 us with the wide ones)
+  else if (nout % 128 == 0 && ((P + 127) / 128) * (nout / 128) >= 512) *pl = {4, 4, 2, 2, 128, 128};
   else if (nout % 64 == 0) *pl = {2, 4, 4, 1, 128, 64};
   else if (nout % 48 == 0) *pl = {2, 3, 4, 1, 128, 48};
   else return false;
@@ -392,7 +396,7 @@ static bool gc_geo(int kind, int dir, int N, int H, int W, int Ci, int Co, int* 
   const long P = (long)N * (*Hg + 1) * (*Wg + 2) + *Wg + 2;
   const long big = (long)N * H * W * (Ci > Co ? Ci : Co);
   GcPlan pl;
-  return gc_plan(*nout, &pl) && P < 2147483647L && big < 2147483647L;
+  return gc_plan(*nout, P, &pl) && P < 2147483647L && big < 2147483647L;
 }
 
 extern "C" int buctd_gconv_x6_supported(int kind, int N, int H, int W, int Ci, int Co, int dir) {
@@ -405,8 +409,8 @@ extern "C" int buctd_gconv_x6_stats_groups(int kind, int N, int H, int W, int Ci
   BUCTD_CHECK_ARG(ngroups && rows_per_group && gc_geo(kind, 0, N, H, W, Ci, Co, &Hg, &Wg, &SH, &SWd, &SC, &nout),
                   "buctd_gconv_x6_stats_groups: unsupported shape");
   GcPlan pl;
-  gc_plan(nout, &pl);
   const long P = (long)N * (Hg + 1) * (Wg + 2) + Wg + 2;
+  gc_plan(nout, P, &pl);
   *ngroups = (int)((P + pl.BM - 1) / pl.BM) * pl.WM;
   *rows_per_group = pl.MF * 16;
   return BUCTD_OK;
@@ -433,7 +437,7 @@ static int gc_run(int kind, int dir, int N, int H, int W, int Ci, int Co, const 
   BUCTD_CHECK_ARG((stats_partials == nullptr) == (stats_counts == nullptr), "%s: stats partials and counts go together", who);
   BUCTD_CHECK_ARG(!(dir && stats_partials), "%s: no statistics on the data gradient", who);
   GcPlan pl;
-  gc_plan(nout, &pl);
+  gc_plan(nout, (long)N * (Hg + 1) * (Wg + 2) + Wg + 2, &pl);
   GcArgs a;
   C3Args& e = a.e;
   e.x = nullptr; e.wp = nullptr; e.out = out; e.bias = bias; e.scale = scale; e.shift = shift; e.res = residual;
@@ -473,6 +477,7 @@ static int gc_run(int kind, int dir, int N, int H, int W, int Ci, int Co, const 
   const int tiles = (e.P + pl.BM - 1) / pl.BM, ncol = nout / pl.BN;
   hipStream_t st = (hipStream_t)stream;
   if (pl.NF == 3 && pl.WM == 2) gc_launch<4, 3, 2, 2>(a, tiles, ncol, st);
+  else if (pl.NF == 4 && pl.WM == 2) gc_launch<4, 4, 2, 2>(a, tiles, ncol, st);
   else if (pl.NF == 4) gc_launch<2, 4, 4, 1>(a, tiles, ncol, st);
   else gc_launch<2, 3, 4, 1>(a, tiles, ncol, st);
   BUCTD_CHECK_LAUNCH(who);
