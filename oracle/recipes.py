@@ -217,6 +217,8 @@ FINAL_SCALE_LOG2 = {
 # The TransPose trunk is the worst conditioned of the small nets: per seed, one of {fp32 CPU oracle, HIP with / without the
 # gathered bf16x6 convolutions} sits 1e-3..2e-2 from fp64 (seed: cpu32 median / HIP median - 1234: 1e-5 / 5e-3, 1: 4e-3 / 4e-5,
 # 2: 2e-5 / 2e-3, 4: 2e-5 / 3e-3); seed 5 has no pre-activation near zero for any of them (2e-5 / 1e-4).
+# The original seed 1234 of the last two stays a test case under a flip-aware metric (tests/test_gpu_models.py:
+# test_train_step_at_the_original_seed_differs_by_a_relu_flip_only): the same weights meet the bars on perturbed inputs.
 SEEDS = {"coam_w16_96x64_channel_only": 1, "coam_w16_96x64_mono_default_att": 1, "transpose_w16_96x64": 5}
 
 

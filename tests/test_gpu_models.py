@@ -195,6 +195,61 @@ def test_train_step_matches_reference(dev, name):
         assert abs(bufs[k].norm().item() - bn) <= 1e-4 * max(bn, 1.0), f"{name}: buffer {k}"
 
 
+def _grad_errors(m, omodel, xin, tgt, wt, dev):
+    """(median hip, median cpu32, worst hip, worst cpu32, worst tensor) of the parameter gradients of one train step against
+    the fp64 evaluation of the oracle."""
+    from buctd_amd.core.loss import JointsMSELoss
+    for q in m.parameters():
+        q.grad = None
+    JointsMSELoss(True)(m(xin.to(dev)), tgt.to(dev), wt.to(dev)).backward()
+    g64, g32 = _oracle_grads(omodel, xin, tgt, wt, torch.float64), _oracle_grads(omodel, xin, tgt, wt, torch.float32)
+    gmax = max(v.norm().item() for v in g64.values())
+    params = dict(m.named_parameters())
+    eh, ec, keys = [], [], []
+    for k, ref in g64.items():
+        den = ref.norm().item()
+        if den <= 1e-6 * gmax:
+            continue
+        eh.append((params[k].grad.detach().cpu().double() - ref).norm().item() / den)
+        ec.append((g32[k].double() - ref).norm().item() / den)
+        keys.append(k)
+    return float(np.median(eh)), float(np.median(ec)), max(eh), max(ec), keys[int(np.argmax(eh))]
+
+
+@pytest.mark.parametrize("name", ["coam_w16_96x64_mono_default_att", "transpose_w16_96x64"])
+def test_train_step_at_the_original_seed_differs_by_a_relu_flip_only(dev, name):
+    """The goldens of these two nets use recipe seeds other than 1234 (oracle/recipes.py:SEEDS) because at 1234 one
+    pre-activation sits within fp32 round-off of zero and lands on different sides of its ReLU in different implementations.
+    The original seed stays a case, under the metric that tells a flip from a bug: the gradients meet the statistical bars on
+    the recipe input, or - a flip being a property of ONE input - the same weights meet them on two perturbed inputs while the
+    recipe input stays an order of magnitude under what a wiring or scaling error produces."""
+    from oracle import recipes
+    cfg, omodel, x, joints = recipes.build(name, seed=1234)
+    tgt, wt = recipes.make_targets(cfg, joints, 77)
+    m = product_model(cfg, omodel, dev).train()
+    recipes.set_dropout(m, 0.0)
+
+    def bars(mh, mc, wh, wc):
+        return mh <= max(3 * mc, 2e-3) and wh <= max(3 * wc, 2e-2)
+
+    mh, mc, wh, wc, wk = _grad_errors(m, omodel, x, tgt, wt, dev)
+    print(f"{name} @ seed 1234: median hip {mh:.2e} / cpu32 {mc:.2e}, worst hip {wh:.2e} at {wk} / cpu32 {wc:.2e}")
+    if bars(mh, mc, wh, wc):
+        return
+    others = []
+    for alt in (1, 2):
+        ga = torch.Generator().manual_seed(9100 + alt)
+        xa = x + 0.25 * torch.randn(x.shape, generator=ga) * (torch.arange(x.shape[1]).view(1, -1, 1, 1) < 3)   # RGB only
+        others.append(_grad_errors(m, omodel, xa, tgt, wt, dev))
+    print(f"{name} @ seed 1234: two perturbed inputs: {others}")
+    assert all(bars(*o[:4]) for o in others), f"{name} @ seed 1234: beyond the bars on perturbed inputs too {others}: not a flipped ReLU"
+    # the discriminator is the line above (a wiring or scaling error does not care which input it sees); the size of a flip's
+    # effect only gets a loose cap: with 12 samples per BatchNorm channel in the 3x2-pixel branch of the CoAM net one flipped
+    # unit moves most gradients by 5-10 % (oracle/recipes.py), measured here 5e-2 median / 0.19 worst against 3e-5 / 1e-3 on
+    # the perturbed inputs
+    assert mh <= 1e-1 and wh <= 5e-1, f"{name} @ seed 1234: median {mh:.2e} / worst {wh:.2e} at {wk}"
+
+
 @pytest.mark.parametrize("name", FULL)
 def test_full_size_baseline_configs_forward(dev, name):
     """Every BASELINE.json config at full size, engine default math mode: eval forward of the HIP path against the
