@@ -820,6 +820,89 @@ __global__ __launch_bounds__(256) void conv_dgrad_thin_kernel(ThinDgradArgs p) {
   }
 }
 
+// The same data gradient with FOUR adjacent dx pixels per thread (whole 16-channel chunks, at most three dY channels: the
+// 64 -> 3 convolution).  The kernel above reads 13 LDS vectors per tap for 48 FMAs and is paced by the LDS, not by the VALU
+// (v_pk_fma_f32 alone changes nothing: 1.13 ms at 384x288); here the 12 broadcast filter vectors of a tap serve four pixels
+// and the R + 3 dY pixels of a filter row are read once for them: 94 LDS reads against 672 packed FMAs per filter row.
+template <int R>
+__global__ __launch_bounds__(256) void conv_dgrad_thin_px4_kernel(ThinDgradArgs p) {
+  constexpr int PADR = R / 2, XH = THIN4_T + R - 1, XW = THIN4_T + R - 1, SL = (XW + 3) / 4;
+  constexpr int ROWF = 4 * SL * 4 + 4;                                       // floats per tile row: [column mod 4][slot][4]
+  __shared__ __attribute__((aligned(16))) float ds[XH * ROWF];
+  __shared__ __attribute__((aligned(16))) float ws[R * R * 3 * 16];          // [tap][co (3)][16 input channels]
+  const int t = threadIdx.x;
+  const int tile = blockIdx.x;
+  const int n = tile / (p.tiles_y * p.tiles_x);
+  const int rem = tile - n * p.tiles_y * p.tiles_x;
+  const int y0 = (rem / p.tiles_x) * THIN4_T, x0 = (rem - (rem / p.tiles_x) * p.tiles_x) * THIN4_T;
+  const int ty = t >> 3, tx = t & 7;
+  for (int i = t; i < XH * XW; i += 256) {
+    const int ry = i / XW, cx = i - ry * XW;
+    const int yy = y0 + ry - PADR, xx = x0 + cx - PADR;
+    f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (yy >= 0 && yy < p.H && xx >= 0 && xx < p.W) {
+      const float* src = p.dy + ((long)(n * p.H + yy) * p.W + xx) * p.Co;
+#pragma unroll
+      for (int e = 0; e < 3; ++e)
+        if (e < p.Co) v[e] = src[e];
+    }
+    *reinterpret_cast<f32x4*>(ds + ry * ROWF + ((cx & 3) * SL + (cx >> 2)) * 4) = v;
+  }
+  const int yy = y0 + ty;
+  for (int c0 = 0; c0 < p.Ci; c0 += 16) {
+    __syncthreads();
+    for (int i = t; i < R * R * 3 * 16; i += 256) {
+      const int ch = i & 15, co = (i >> 4) % 3, tap = i / 48;
+      ws[i] = co < p.Co ? p.w[((long)co * R * R + tap) * p.Ci + c0 + ch] : 0.f;
+    }
+    __syncthreads();
+    thin_f32x2 acc[4][8];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int k = 0; k < 8; ++k) acc[j][k] = (thin_f32x2){0.f, 0.f};
+#pragma unroll 1
+    for (int r = 0; r < R; ++r) {
+      // dY pixels (ty + R - 1 - r, 4 tx + k), k = 0 .. R + 2, in tile coordinates: pixel j and tap sx read k = j + R - 1 - sx
+      f32x4 dw[R + 3];
+      const float* dr = ds + (ty + R - 1 - r) * ROWF + tx * 4;
+#pragma unroll
+      for (int k = 0; k < R + 3; ++k) dw[k] = *reinterpret_cast<const f32x4*>(dr + ((k & 3) * SL + (k >> 2)) * 4);
+#pragma unroll
+      for (int sx = 0; sx < R; ++sx)
+#pragma unroll
+        for (int co = 0; co < 3; ++co) {
+          const float* wp = ws + ((r * R + sx) * 3 + co) * 16;
+          f32x4 wv[4];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) wv[q] = *reinterpret_cast<const f32x4*>(wp + q * 4);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const float d = dw[j + R - 1 - sx][co];
+            const thin_f32x2 dd = {d, d};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              acc[j][2 * q] = __builtin_elementwise_fma(dd, (thin_f32x2){wv[q].x, wv[q].y}, acc[j][2 * q]);
+              acc[j][2 * q + 1] = __builtin_elementwise_fma(dd, (thin_f32x2){wv[q].z, wv[q].w}, acc[j][2 * q + 1]);
+            }
+          }
+        }
+    }
+    if (yy < p.H) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int xx = x0 + 4 * tx + j;
+        if (xx < p.W) {
+          float* o = p.dx + ((long)(n * p.H + yy) * p.W + xx) * p.Ci + c0;
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+            *reinterpret_cast<f32x4*>(o + q * 4) = (f32x4){acc[j][2 * q].x, acc[j][2 * q].y, acc[j][2 * q + 1].x, acc[j][2 * q + 1].y};
+        }
+      }
+    }
+  }
+}
+
 // Data gradient of a stride-2 3x3 convolution with <= 4 INPUT channels (the HRNet stem conv1 behind a preNet, whose
 // 3-channel output needs a gradient: pose_hrnet.py:287 fed by 452-458).  One thread per dx pixel; of the nine taps only
 // those whose output coordinate is an integer contribute (2.25 on average); dy rows come through L1, the filter from LDS.
@@ -1151,6 +1234,15 @@ extern "C" int buctd_conv2d_dgrad(const buctd_conv_desc* d, const float* dy, con
     ta.N = d->N; ta.H = d->H; ta.W = d->W; ta.Ci = d->Co; ta.Co = d->Ci;
     ta.tiles_y = ceil_div(d->H, THIN4_T); ta.tiles_x = ceil_div(d->W, THIN4_T);
     launch_thin_px4<4, true>(ta, dim3(d->N * ta.tiles_y * ta.tiles_x), (hipStream_t)stream);
+    BUCTD_CHECK_LAUNCH("buctd_conv2d_dgrad(thin, four pixels per thread)");
+    return BUCTD_OK;
+  }
+  if (fwd_thin_ok(d) && !bias && !stats_partials && d->Ci % 16 == 0 && d->Co <= 3) {      // 64 -> 3: four dx pixels per thread
+    ThinDgradArgs ta;
+    ta.dy = dy; ta.w = w; ta.dx = dx;
+    ta.N = d->N; ta.H = d->H; ta.W = d->W; ta.Ci = d->Ci; ta.Co = d->Co;
+    ta.tiles_y = ceil_div(d->H, THIN4_T); ta.tiles_x = ceil_div(d->W, THIN4_T);
+    hipLaunchKernelGGL((conv_dgrad_thin_px4_kernel<7>), dim3(d->N * ta.tiles_y * ta.tiles_x), dim3(256), 0, (hipStream_t)stream, ta);
     BUCTD_CHECK_LAUNCH("buctd_conv2d_dgrad(thin, four pixels per thread)");
     return BUCTD_OK;
   }
