@@ -1401,6 +1401,158 @@ static bool wgrad_thin_ok(const buctd_conv_desc* d) {
          d->Ho == d->H && d->Wo == d->W && (long)d->N * d->H * d->W >= 4096;
 }
 
+// 64 -> 3 7x7 ('same'): the weight gradient with a ROLLING window of input rows.  The tile kernel above reads one LDS vector
+// of x for every 12 useful FMAs (a thread owns ONE tap: every x value it reads meets three dY channels) and is paced by the
+// LDS at 38 TFLOP/s.  Here a thread owns a filter ROW r and a channel pair: the x value of tile column c serves the seven taps
+// (r, s) of that row at once - 42 FMAs (21 v_pk_fma_f32) per 8-byte LDS read - against the dY row of the strip, held in
+// registers.  A workgroup walks a 32-column strip of one image top to bottom; the R + 1 input rows it needs live in an LDS ring,
+// one new row per output row (the next one is staged while the current one is multiplied).  7 x 32 = 224 of 256 threads
+// multiply.  One slab [3][7][7][64] per workgroup, reduced by splitk_reduce_kernel.
+constexpr int TR_W = 32, TR_RING = 8, TR_XW = TR_W + 6;
+struct ThinRowsArgs {
+  const float* x;      // [N][H][W][64]
+  const float* dy;     // [N][H][W][Co], Co <= 3
+  float* part;
+  int N, H, W, Co, strips, segs, rows_per_seg;
+};
+__global__ __launch_bounds__(256) void conv_wgrad_thin_rows_kernel(ThinRowsArgs p) {
+  constexpr int R = 7, CI = 64;
+  extern __shared__ __attribute__((aligned(16))) float tr_smem[];
+  float* xring = tr_smem;                                   // [TR_RING][TR_XW][64]
+  float* dyrow = tr_smem + TR_RING * TR_XW * CI;            // [2][TR_W][4]
+  const int t = threadIdx.x;
+  int id = blockIdx.x;
+  const int seg = id % p.segs; id /= p.segs;
+  const int strip = id % p.strips, n = id / p.strips;
+  const int x0 = strip * TR_W;
+  const int ys = seg * p.rows_per_seg;
+  int ye = ys + p.rows_per_seg;
+  if (ye > p.H) ye = p.H;
+  const int r = t >> 5, cg = t & 31;                        // filter row, channel pair (t < 224)
+  thin_f32x2 acc[R][3];
+#pragma unroll
+  for (int sx = 0; sx < R; ++sx)
+#pragma unroll
+    for (int co = 0; co < 3; ++co) acc[sx][co] = (thin_f32x2){0.f, 0.f};
+  // input row `row` of the image (any integer: rows outside are zeros) -> ring slot (row - (ys - 3)) % TR_RING
+  auto stage_x = [&](int row) {
+    float* dst = xring + ((row - (ys - 3)) & (TR_RING - 1)) * (TR_XW * CI);
+    const bool rok = row >= 0 && row < p.H;
+    for (int i = t; i < TR_XW * (CI / 4); i += 256) {
+      const int c = i >> 4, q = i & 15;
+      const int xx = x0 + c - 3;
+      f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
+      if (rok && xx >= 0 && xx < p.W) v = *reinterpret_cast<const f32x4*>(p.x + ((long)(n * p.H + row) * p.W + xx) * CI + q * 4);
+      *reinterpret_cast<f32x4*>(dst + c * CI + q * 4) = v;
+    }
+  };
+  auto stage_dy = [&](int row, int buf) {
+    if (t < TR_W) {
+      const int xx = x0 + t;
+      f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
+      if (row < ye && xx < p.W) {
+        const float* src = p.dy + ((long)(n * p.H + row) * p.W + xx) * p.Co;
+#pragma unroll
+        for (int e = 0; e < 3; ++e)
+          if (e < p.Co) v[e] = src[e];
+      }
+      *reinterpret_cast<f32x4*>(dyrow + (buf * TR_W + t) * 4) = v;
+    }
+  };
+  if (ys < ye) {
+    for (int row = ys - 3; row <= ys + 3; ++row) stage_x(row);
+    stage_dy(ys, 0);
+  }
+  __syncthreads();
+  for (int py = ys; py < ye; ++py) {
+    // the row the NEXT output row adds (its ring slot held row py - 4: nobody reads it now) and the next dY row travel through
+    // registers: loaded in front of the multiplication, stored behind it
+    const bool more = py + 1 < ye;
+    constexpr int NPC = (TR_XW * (CI / 4) + 255) / 256;
+    f32x4 nx[NPC], nd = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (more) {
+      const int row = py + 4;
+      const bool rok = row >= 0 && row < p.H;
+#pragma unroll
+      for (int u = 0; u < NPC; ++u) {
+        const int i = t + 256 * u, c = i >> 4, q = i & 15;
+        const int xx = x0 + c - 3;
+        nx[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (i < TR_XW * (CI / 4) && rok && xx >= 0 && xx < p.W)
+          nx[u] = *reinterpret_cast<const f32x4*>(p.x + ((long)(n * p.H + row) * p.W + xx) * CI + q * 4);
+      }
+      if (t < TR_W && x0 + t < p.W) {
+        const float* src = p.dy + ((long)(n * p.H + py + 1) * p.W + x0 + t) * p.Co;
+#pragma unroll
+        for (int e = 0; e < 3; ++e)
+          if (e < p.Co) nd[e] = src[e];
+      }
+    }
+    if (t < R * 32) {
+      const float* xr = xring + ((py + r - 3 - (ys - 3)) & (TR_RING - 1)) * (TR_XW * CI) + 2 * cg;
+      const float* dr = dyrow + ((py - ys) & 1) * TR_W * 4;
+      f32x4 dv[TR_W];
+#pragma unroll
+      for (int px = 0; px < TR_W; ++px) dv[px] = *reinterpret_cast<const f32x4*>(dr + px * 4);
+#pragma unroll
+      for (int c = 0; c < TR_XW; ++c) {
+        const thin_f32x2 xv = *reinterpret_cast<const thin_f32x2*>(xr + c * CI);
+#pragma unroll
+        for (int sx = 0; sx < R; ++sx) {
+          const int px = c - sx;                            // output pixel whose tap (r, sx) reads tile column c
+          if (px >= 0 && px < TR_W) {
+#pragma unroll
+            for (int co = 0; co < 3; ++co) {
+              const float d = dv[px][co];
+              acc[sx][co] = __builtin_elementwise_fma(xv, (thin_f32x2){d, d}, acc[sx][co]);
+            }
+          }
+        }
+      }
+    }
+    if (more) {
+      float* dst = xring + ((py + 4 - (ys - 3)) & (TR_RING - 1)) * (TR_XW * CI);
+#pragma unroll
+      for (int u = 0; u < NPC; ++u) {
+        const int i = t + 256 * u;
+        if (i < TR_XW * (CI / 4)) *reinterpret_cast<f32x4*>(dst + (i >> 4) * CI + (i & 15) * 4) = nx[u];
+      }
+      if (t < TR_W) *reinterpret_cast<f32x4*>(dyrow + (((py + 1 - ys) & 1) * TR_W + t) * 4) = nd;
+    }
+    __syncthreads();
+  }
+  if (t < R * 32) {
+    float* outp = p.part + (size_t)blockIdx.x * p.Co * R * R * CI;
+#pragma unroll
+    for (int sx = 0; sx < R; ++sx)
+#pragma unroll
+      for (int co = 0; co < 3; ++co)
+        if (co < p.Co) {
+          float* o = outp + ((size_t)(co * R + r) * R + sx) * CI + 2 * cg;
+          o[0] = acc[sx][co].x;
+          o[1] = acc[sx][co].y;
+        }
+  }
+}
+static bool wgrad_thin_rows_ok(const buctd_conv_desc* d) {
+  return d->stride == 1 && d->R == 7 && d->S == 7 && d->pad == 3 && d->Ci == 64 && d->Co >= 1 && d->Co <= 3 && d->Ho == d->H &&
+         d->Wo == d->W && (long)d->N * d->H * d->W >= 4096;
+}
+static void thin_rows_geo(const buctd_conv_desc* d, int* strips, int* segs, int* rps) {
+  *strips = ceil_div(d->W, TR_W);
+  int sg = ceil_div(768, d->N * *strips);                // about three workgroups per CU ...
+  const int maxsg = d->H / 16 > 0 ? d->H / 16 : 1;       // ... of at least 16 rows (each re-stages six halo rows)
+  if (sg > maxsg) sg = maxsg;
+  if (sg < 1) sg = 1;
+  *rps = ceil_div(d->H, sg);
+  *segs = ceil_div(d->H, *rps);
+}
+static int thin_rows_wgs(const buctd_conv_desc* d) {
+  int st, sg, rps;
+  thin_rows_geo(d, &st, &sg, &rps);
+  return d->N * st * sg;
+}
+
 static int thin_splits(const buctd_conv_desc* d) {      // one slab per workgroup; small inputs get fewer
   const long tiles = (long)d->N * ceil_div(d->H, THIN_TH) * ceil_div(d->W, THIN_TW);
   return (int)(tiles < THIN_SPLITS ? tiles : THIN_SPLITS);
@@ -1427,6 +1579,7 @@ static void wgrad_plan(const buctd_conv_desc* d, int* bm, int* bn, int* nsplit, 
 
 extern "C" size_t buctd_conv2d_wgrad_workspace(const buctd_conv_desc* d) {
   if (check_desc(d, "buctd_conv2d_wgrad_workspace")) return 0;
+  if (wgrad_thin_rows_ok(d)) return (size_t)thin_rows_wgs(d) * d->Co * d->R * d->S * d->Ci * sizeof(float);
   if (wgrad_thin_ok(d)) return (size_t)thin_splits(d) * d->Co * d->R * d->S * d->Ci * sizeof(float);
   if (fwd_thin_in_ok(d)) return (size_t)thin_in_wgs(d) * d->Co * d->R * d->S * d->Ci * sizeof(float);
   int bm, bn, ns, pps;
@@ -1451,14 +1604,34 @@ extern "C" int buctd_conv2d_wgrad(const buctd_conv_desc* d, const float* x, cons
   int bm, bn, ns, pps;
   wgrad_plan(d, &bm, &bn, &ns, &pps);
   const bool thin = wgrad_thin_ok(d);
+  const bool thin_rows = thin && wgrad_thin_rows_ok(d);  // 64 -> 3 7x7: rolling rows
   const bool thin_in = !thin && fwd_thin_in_ok(d);       // 3 -> 64 3x3: lane = output channel
   if (thin) ns = thin_splits(d);
+  if (thin_rows) ns = thin_rows_wgs(d);
   if (thin_in) ns = thin_in_wgs(d);
   const size_t need = (size_t)ns * d->Co * d->R * d->S * d->Ci * sizeof(float);
   if (workspace == nullptr || workspace_bytes < need) {
     buctd_set_error("buctd_conv2d_wgrad: workspace %zu bytes < required %zu", workspace_bytes, need);
     return BUCTD_EWORKSPACE;
   }
+  if (thin_rows) {
+    ThinRowsArgs ta;
+    ta.x = x; ta.dy = dy; ta.part = (float*)workspace;
+    ta.N = d->N; ta.H = d->H; ta.W = d->W; ta.Co = d->Co;
+    thin_rows_geo(d, &ta.strips, &ta.segs, &ta.rows_per_seg);
+    const size_t lds = ((size_t)TR_RING * TR_XW * 64 + 2 * TR_W * 4) * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_thin_rows_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)lds) != hipSuccess) {
+        buctd_set_error("buctd_conv2d_wgrad(thin rows): cannot raise the dynamic LDS limit");
+        return BUCTD_ELAUNCH;
+      }
+      attr_set = true;
+    }
+    hipLaunchKernelGGL(conv_wgrad_thin_rows_kernel, dim3(ns), dim3(256), lds, (hipStream_t)stream, ta);
+    BUCTD_CHECK_LAUNCH("buctd_conv2d_wgrad(thin rows)");
+  } else
   if (thin) {
     ThinArgs ta;
     ta.x = x; ta.dy = dy; ta.part = (float*)workspace;

@@ -11,7 +11,9 @@ pytestmark = pytest.mark.gpu
                                              (4, 48, 3, 2, 181, 203), (32, 2, 7, 1, 300, 250),
                                              # 3x3 from <= 4 channels to 64, W a multiple of 16: lane = output channel
                                              (4, 64, 3, 1, 70, 144), (1, 64, 3, 2, 33, 128), (2, 64, 3, 1, 50, 80),
-                                             (3, 64, 3, 40, 40, 64)])
+                                             (3, 64, 3, 40, 40, 64),
+                                             # 64 -> <= 3 channels, 7x7: the rolling-row kernel (ragged strips, short images, segments)
+                                             (64, 2, 7, 1, 70, 90), (64, 3, 7, 1, 33, 200), (64, 1, 7, 2, 50, 64), (64, 3, 7, 3, 17, 100)])
 def test_thin_wgrad_vs_fp64(Ci, Co, k, N, H, W):
     from buctd_amd import ops
     dev = torch.device("cuda:0")
