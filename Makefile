@@ -9,7 +9,7 @@ OBJS := $(CSRC)/conv.o $(CSRC)/conv3x3.o $(CSRC)/conv_gather_x6.o $(CSRC)/conv3x
 
 all: $(OUT)
 
-$(CSRC)/%.o: $(CSRC)/%.hip $(CSRC)/common.h $(CSRC)/gemm_core.h $(CSRC)/c3_common.h include/buctd_hip.h
+$(CSRC)/%.o: $(CSRC)/%.hip $(CSRC)/common.h $(CSRC)/gemm_core.h $(CSRC)/c3_common.h $(CSRC)/bn_acc.h include/buctd_hip.h
 	$(HIPCC) $(HIPFLAGS) -x hip -c $< -o $@
 
 $(CSRC)/error.o: $(CSRC)/error.cpp

@@ -28,15 +28,20 @@ class BasicBlockDesc(C.Structure):     # mirrors buctd_basic_block
                 [(n, C.c_void_p) for n in ("x", "w1_fwd", "w2_fwd", "w1_bwd", "w2_bwd", "gamma1", "beta1", "gamma2", "beta2",
                                            "running_mean1", "running_var1", "running_mean2", "running_var2")] +
                 [(n, C.c_float) for n in ("eps1", "momentum1", "eps2", "momentum2")] +
-                [(n, C.c_void_p) for n in ("z1", "z2", "y", "part", "counts")] +
-                [("ngroups", C.c_int), ("rows_per_group", C.c_int), ("stat", C.c_void_p)])
+                [(n, C.c_void_p) for n in ("z1", "z2", "y", "acc", "stat")])
 
 
 class BasicBlockGrads(C.Structure):    # mirrors buctd_basic_block_grads
     _fields_ = ([(n, C.c_void_p) for n in ("dy", "dz2", "dres", "dy1", "dz1", "dx", "dw1", "dw2", "dgamma1", "dbeta1",
                                            "dgamma2", "dbeta2")] +
                 [(n, C.c_int) for n in ("acc_w1", "acc_w2", "acc_bn1", "acc_bn2")] +
-                [("bn_ws", C.c_void_p), ("bn_ws_bytes", C.c_size_t), ("wg_ws", C.c_void_p), ("wg_ws_bytes", C.c_size_t)])
+                [("bn_acc", C.c_void_p), ("wg_ws", C.c_void_p), ("wg_ws_bytes", C.c_size_t)])
+
+
+class BnAccIn(C.Structure):            # mirrors buctd_bn_acc_in
+    _fields_ = [("acc", C.c_void_p), ("rows", C.c_long), ("eps", C.c_float), ("momentum", C.c_float),
+                ("mean_out", C.c_void_p), ("invstd_out", C.c_void_p), ("running_mean", C.c_void_p),
+                ("running_var", C.c_void_p)]
 
 
 class MatmulDesc(C.Structure):
@@ -91,7 +96,6 @@ SIGNATURES = {
     "buctd_conv3x3_bf16x6_bnin": (_I, [_I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _I, _P]),
     "buctd_conv3x3_bf16x6_bnstat": (_I, [_I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "buctd_bn_bwd_from_partials": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _L, _I, _P, _I, _P, _P, _P, _P, _I, _P, _SZ, _P]),
-    "buctd_basic_block_bwd_workspace": (_SZ, [_I, _I, _I, _I]),
     "buctd_conv3x3_wgrad_bf16x6_bnin": (_I, [_I, _I, _I, _I, _I, _P, _P, _P, _I, _P, _P, _P, _P, _I, _P, _SZ, _P]),
     "buctd_conv3x3_wgrad_bf16x6_supported": (_I, [_I, _I, _I, _I, _I]),
     "buctd_conv3x3_wgrad_bf16x6_workspace": (_SZ, [_I, _I, _I, _I, _I]),
@@ -102,6 +106,12 @@ SIGNATURES = {
     "buctd_bn_bwd_workspace": (_SZ, [_L, _I]),
     "buctd_bn_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _L, _I, _P, _P, _P, _P, _I, _P, _SZ, _P]),
     "buctd_bn_fold": (_I, [_P, _P, _P, _P, _F, _I, _P, _P, _P]),
+    "buctd_bn_acc_bytes": (_SZ, [_I]),
+    "buctd_bn_apply_acc": (_I, [_P, C.POINTER(BnAccIn), _P, _P, _P, _I, _P, _L, _I, _P]),
+    "buctd_bn_bwd_acc": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _L, _I, _P, _P, _P, _P, _I, _P, _I, _P]),
+    "buctd_conv3x3_bf16x6_acc": (_I, [_I] * 5 + [_P, _P, _P, _I, _P, _P, C.POINTER(BnAccIn), _P, _P, _I, _P]),
+    "buctd_conv3x3_bf16x6_bnstat_acc": (_I, [_I] * 5 + [_P] * 12),
+    "buctd_gconv_x6_fwd_acc": (_I, [_I] * 6 + [_P] * 6),
     "buctd_basic_block_fwd_train": (_I, [C.POINTER(BasicBlockDesc), _P]),
     "buctd_basic_block_bwd": (_I, [C.POINTER(BasicBlockDesc), C.POINTER(BasicBlockGrads), _P, _P]),
     "buctd_basic_chain_fwd_train": (_I, [_I, C.POINTER(BasicBlockDesc), _P]),

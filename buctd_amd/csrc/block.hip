@@ -6,20 +6,6 @@
 #include "common.h"
 #include "../../include/buctd_hip.h"
 
-// Experiment builds only (scratch/build_trace_lib.sh, -DBUCTD_TUNING): BUCTD_SKIP = bit mask of launches to leave out of the
-// backward sequence - 1: weight gradients, 2: BatchNorm backward, 4: data gradients - for "what if this were free"
-// timings of the train step (results are garbage).  The product build reads no environment.
-#ifdef BUCTD_TUNING
-#include <stdlib.h>
-static int blk_skip() {
-  static const int v = getenv("BUCTD_SKIP") ? atoi(getenv("BUCTD_SKIP")) : 0;
-  return v;
-}
-#define BLK_SKIP(bit) (blk_skip() & (bit))
-#else
-#define BLK_SKIP(bit) 0
-#endif
-
 #define BLK_TRY(call)      \
   do {                     \
     const int rc_ = (call); \
@@ -27,51 +13,32 @@ static int blk_skip() {
   } while (0)
 
 extern "C" int buctd_basic_block_fwd_train(const buctd_basic_block* b, void* stream) {
-  BUCTD_CHECK_ARG(b && b->x && b->w1_fwd && b->w2_fwd && b->z1 && b->z2 && b->y && b->part && b->counts && b->stat,
+  BUCTD_CHECK_ARG(b && b->x && b->w1_fwd && b->w2_fwd && b->z1 && b->z2 && b->y && b->acc && b->stat,
                   "buctd_basic_block_fwd_train: null pointer");
   const int N = b->N, H = b->H, W = b->W, C = b->C;
   const long rows = (long)N * H * W;
-  float* part1 = b->part;
-  float* part2 = b->part + (size_t)b->ngroups * C * 2;
-  int* cnt1 = b->counts;
-  int* cnt2 = b->counts + b->ngroups;
+  // the two statistics accumulators (bn_acc.h; zero on entry): conv1's output, conv2's output
+  void* acc1 = b->acc;
+  void* acc2 = (char*)b->acc + buctd_bn_acc_bytes(C);
   float *mean1 = b->stat, *invstd1 = b->stat + C, *mean2 = b->stat + 2 * C, *invstd2 = b->stat + 3 * C;
-  // (what-if bits of the forward, tuning builds: 8 convolutions, 16 finalizes, 32 the output bn_apply)
-  if (!BLK_SKIP(8))
-    BLK_TRY(buctd_conv3x3_bf16x6(N, H, W, C, C, b->x, b->w1_fwd, nullptr, nullptr, nullptr, nullptr, 0, b->z1, part1, cnt1,
-                                 stream));
-  if (!BLK_SKIP(16))
-    BLK_TRY(buctd_bn_finalize(part1, cnt1, b->ngroups, b->rows_per_group, rows, C, b->eps1, b->momentum1, mean1, invstd1,
-                              b->running_mean1, b->running_var1, stream));
-  // conv2 applies bn1 + ReLU while it stages its input: relu(bn1(z1)) never exists in memory
-  if (!BLK_SKIP(8))
-    BLK_TRY(buctd_conv3x3_bf16x6_bnin(N, H, W, C, C, b->z1, b->w2_fwd, nullptr, nullptr, nullptr, nullptr, 0, b->z2, part2,
-                                      cnt2, mean1, invstd1, b->gamma1, b->beta1, 1, stream));
-  if (!BLK_SKIP(16))
-    BLK_TRY(buctd_bn_finalize(part2, cnt2, b->ngroups, b->rows_per_group, rows, C, b->eps2, b->momentum2, mean2, invstd2,
-                              b->running_mean2, b->running_var2, stream));
-  if (BLK_SKIP(32)) return BUCTD_OK;
-  BLK_TRY(buctd_bn_apply(b->z2, mean2, invstd2, b->gamma2, b->beta2, b->x, 1, b->y, rows, C, stream));
+  BLK_TRY(buctd_conv3x3_bf16x6_acc(N, H, W, C, C, b->x, b->w1_fwd, nullptr, 0, b->z1, acc1, nullptr, nullptr, nullptr, 0, stream));
+  // conv2 decodes bn1's statistics from acc1 in its prologue (its first tile leaves mean1 / invstd1 for the backward pass and
+  // updates the running statistics) and applies bn1 + ReLU while it stages its input: no finalize launch, and
+  // relu(bn1(z1)) never exists in memory
+  const buctd_bn_acc_in st1 = {acc1, rows, b->eps1, b->momentum1, mean1, invstd1, b->running_mean1, b->running_var1};
+  BLK_TRY(buctd_conv3x3_bf16x6_acc(N, H, W, C, C, b->z1, b->w2_fwd, nullptr, 0, b->z2, acc2, &st1, b->gamma1, b->beta1, 1, stream));
+  const buctd_bn_acc_in st2 = {acc2, rows, b->eps2, b->momentum2, mean2, invstd2, b->running_mean2, b->running_var2};
+  BLK_TRY(buctd_bn_apply_acc(b->z2, &st2, b->gamma2, b->beta2, b->x, 1, b->y, rows, C, stream));
   return BUCTD_OK;
 }
 
-// Bytes of buctd_basic_block_grads::bn_ws: the BatchNorm-backward partial sums ([groups][2][C], written either by
-// bn_bwd_reduce2_kernel or by the epilogue of the data gradient in front, buctd_conv3x3_bf16x6_bnstat) + the merged sums.
-extern "C" size_t buctd_basic_block_bwd_workspace(int N, int H, int W, int C) {
-  int ng = 0, rpg = 0;
-  if (buctd_conv3x3_bf16x6_stats_groups(N, H, W, C, C, &ng, &rpg) != BUCTD_OK) return 0;
-  const size_t fused = ((size_t)ng * 2 * C + 2 * (size_t)C) * sizeof(float);
-  const size_t plain = buctd_bn_bwd_workspace((long)N * H * W, C);
-  return fused > plain ? fused : plain;
-}
-
 // prev: the block in FRONT of b in a chain (its output is b's input), or NULL.  With prev the data gradient of conv1 - whose
-// output is prev's upstream gradient - also forms the reduction pass of prev's bn2 backward (into the shared bn_ws).
-// bn2_part_ready: the block behind did that for b, so b's bn2 backward starts at the finalize.
+// output is prev's upstream gradient - also forms the sums of prev's bn2 backward (into prev's accumulator).
+// bn2_ready: the block behind did that for b, so b's bn2 backward needs no reduction pass.
 static int block_bwd_impl(const buctd_basic_block* b, const buctd_basic_block_grads* g, const buctd_basic_block* prev,
-                          bool bn2_part_ready, void* stream, void* side_stream) {
+                          const buctd_basic_block_grads* gprev, bool bn2_ready, void* stream, void* side_stream) {
   BUCTD_CHECK_ARG(b && g && b->x && b->w1_bwd && b->w2_bwd && b->z1 && b->z2 && b->y && b->stat && g->dy && g->dres &&
-                      g->dy1 && g->dw1 && g->dw2 && g->bn_ws && g->wg_ws,
+                      g->dy1 && g->dw1 && g->dw2 && g->bn_acc && g->wg_ws,
                   "buctd_basic_block_bwd: null pointer");
   BUCTD_CHECK_ARG(g->dz2 && g->dz1, "buctd_basic_block_bwd: dz2 / dz1 scratch missing");
   const int N = b->N, H = b->H, W = b->W, C = b->C;
@@ -99,48 +66,31 @@ static int block_bwd_impl(const buctd_basic_block* b, const buctd_basic_block_gr
     }
     return BUCTD_OK;
   };
-  // The reduction pass of each BatchNorm backward (sum g, sum g zhat over the batch) is a by-product of the data gradient
-  // that PRODUCES g (its epilogue has the tile in registers): bn1's of conv2's data gradient, bn2's - in a chain - of the
-  // data gradient of the block behind.  bn_ws = [ng][2][C] partial sums | [2][C] merged sums, used strictly in stream order.
-  int ng = 0, rpg = 0;
-  BLK_TRY(buctd_conv3x3_bf16x6_stats_groups(N, H, W, C, C, &ng, &rpg));
-  const size_t need = ((size_t)ng * 2 * C + 2 * (size_t)C) * sizeof(float);
-  if (g->bn_ws_bytes < need) {
-    buctd_set_error("buctd_basic_block_bwd: bn_ws %zu bytes < required %zu (buctd_basic_block_bwd_workspace)", g->bn_ws_bytes, need);
-    return BUCTD_EWORKSPACE;
-  }
-  float* part = (float*)g->bn_ws;
-  float* sums = part + (size_t)ng * 2 * C;
-  const size_t sums_bytes = 2 * (size_t)C * sizeof(float);
+  // The sums of each BatchNorm backward (sum g, sum g zhat over the batch) are a by-product of the data gradient that
+  // PRODUCES g (its epilogue has the tile in registers): bn1's of conv2's data gradient, bn2's - in a chain - of the data
+  // gradient of the block behind.  They travel as integer accumulators (bn_acc.h): g->bn_acc = [bn1 | bn2], zero on entry.
+  void* acc_bn1 = g->bn_acc;
+  void* acc_bn2 = (char*)g->bn_acc + buctd_bn_acc_bytes(C);
   // conv2 / bn2 (+ skip): dres = masked upstream gradient
-  if (!BLK_SKIP(2)) {
-    if (bn2_part_ready)
-      BLK_TRY(buctd_bn_bwd_from_partials(g->dy, b->y, b->z2, mean2, invstd2, b->gamma2, nullptr, 1, rows, C, part, ng, g->dz2,
-                                         g->dres, g->dgamma2, g->dbeta2, g->acc_bn2, sums, sums_bytes, stream));
-    else
-      BLK_TRY(buctd_bn_bwd(g->dy, b->y, b->z2, mean2, invstd2, b->gamma2, nullptr, 1, rows, C, g->dz2, g->dres, g->dgamma2,
-                           g->dbeta2, g->acc_bn2, g->bn_ws, g->bn_ws_bytes, stream));
-  }
+  BLK_TRY(buctd_bn_bwd_acc(g->dy, b->y, b->z2, mean2, invstd2, b->gamma2, nullptr, 1, rows, C, g->dz2, g->dres, g->dgamma2,
+                           g->dbeta2, g->acc_bn2, acc_bn2, bn2_ready ? 1 : 0, stream));
   BLK_TRY(fork());
-  if (!BLK_SKIP(1))
-    BLK_TRY(buctd_conv3x3_wgrad_bf16x6_bnin(N, H, W, C, C, b->z1, g->dz2, g->dw2, g->acc_w2, mean1, invstd1, b->gamma1,
-                                            b->beta1, 1, g->wg_ws, g->wg_ws_bytes, side_s));
+  BLK_TRY(buctd_conv3x3_wgrad_bf16x6_bnin(N, H, W, C, C, b->z1, g->dz2, g->dw2, g->acc_w2, mean1, invstd1, b->gamma1,
+                                          b->beta1, 1, g->wg_ws, g->wg_ws_bytes, side_s));
   // conv2's data gradient dy1, and with it the sums of bn1's backward (ReLU mask rebuilt from z1)
-  if (!BLK_SKIP(4))
-    BLK_TRY(buctd_conv3x3_bf16x6_bnstat(N, H, W, C, C, g->dz2, b->w2_bwd, nullptr, g->dy1, b->z1, nullptr, mean1, invstd1,
-                                        b->gamma1, b->beta1, part, stream));
-  if (!BLK_SKIP(2))
-    BLK_TRY(buctd_bn_bwd_from_partials(g->dy1, nullptr, b->z1, mean1, invstd1, b->gamma1, b->beta1, 1, rows, C, part, ng,
-                                       g->dz1, nullptr, g->dgamma1, g->dbeta1, g->acc_bn1, sums, sums_bytes, stream));
+  BLK_TRY(buctd_conv3x3_bf16x6_bnstat_acc(N, H, W, C, C, g->dz2, b->w2_bwd, nullptr, g->dy1, b->z1, nullptr, mean1, invstd1,
+                                          b->gamma1, b->beta1, acc_bn1, stream));
+  BLK_TRY(buctd_bn_bwd_acc(g->dy1, nullptr, b->z1, mean1, invstd1, b->gamma1, b->beta1, 1, rows, C, g->dz1, nullptr, g->dgamma1,
+                           g->dbeta1, g->acc_bn1, acc_bn1, 1, stream));
   BLK_TRY(fork());
-  if (!BLK_SKIP(1))
-    BLK_TRY(buctd_conv3x3_wgrad_bf16x6(N, H, W, C, C, b->x, g->dz1, g->dw1, g->acc_w1, g->wg_ws, g->wg_ws_bytes, side_s));
+  BLK_TRY(buctd_conv3x3_wgrad_bf16x6(N, H, W, C, C, b->x, g->dz1, g->dw1, g->acc_w1, g->wg_ws, g->wg_ws_bytes, side_s));
   // conv1's data gradient; the skip gradient joins in its epilogue; in a chain its output is the upstream gradient of the
   // block in front, whose bn2 sums it forms on the way out
-  if (g->dx && !BLK_SKIP(4)) {
+  if (g->dx) {
     if (prev)
-      BLK_TRY(buctd_conv3x3_bf16x6_bnstat(N, H, W, C, C, g->dz1, b->w1_bwd, g->dres, g->dx, prev->z2, prev->y, prev->stat + 2 * C,
-                                          prev->stat + 3 * C, prev->gamma2, nullptr, part, stream));
+      BLK_TRY(buctd_conv3x3_bf16x6_bnstat_acc(N, H, W, C, C, g->dz1, b->w1_bwd, g->dres, g->dx, prev->z2, prev->y, prev->stat + 2 * C,
+                                              prev->stat + 3 * C, prev->gamma2, nullptr,
+                                              (char*)gprev->bn_acc + buctd_bn_acc_bytes(C), stream));
     else
       BLK_TRY(buctd_conv3x3_bf16x6(N, H, W, C, C, g->dz1, b->w1_bwd, nullptr, nullptr, nullptr, g->dres, 0, g->dx, nullptr,
                                    nullptr, stream));
@@ -150,7 +100,7 @@ static int block_bwd_impl(const buctd_basic_block* b, const buctd_basic_block_gr
 
 extern "C" int buctd_basic_block_bwd(const buctd_basic_block* b, const buctd_basic_block_grads* g, void* stream,
                                      void* side_stream) {
-  return block_bwd_impl(b, g, nullptr, false, stream, side_stream);
+  return block_bwd_impl(b, g, nullptr, nullptr, false, stream, side_stream);
 }
 
 // A residual CHAIN (the four BasicBlocks of an HRNet branch, pose_hrnet.py:165-185 _make_one_branch): the blocks' launch
@@ -169,10 +119,11 @@ extern "C" int buctd_basic_chain_bwd(int n, const buctd_basic_block* blocks, con
   for (int k = n - 1; k >= 0; --k) {
     // block k - 1 can take its bn2 sums from this block's data gradient if that gradient IS its upstream gradient, the two
     // blocks have one shape and share the workspace the sums travel in
-    const bool chain = k > 0 && grads[k].dx && grads[k].dx == grads[k - 1].dy && grads[k].bn_ws == grads[k - 1].bn_ws &&
+    const bool chain = k > 0 && grads[k].dx && grads[k].dx == grads[k - 1].dy && grads[k - 1].bn_acc &&
                        blocks[k - 1].y == blocks[k].x && blocks[k - 1].N == blocks[k].N && blocks[k - 1].H == blocks[k].H &&
-                       blocks[k - 1].W == blocks[k].W && blocks[k - 1].C == blocks[k].C && !BLK_SKIP(6);
-    BLK_TRY(block_bwd_impl(blocks + k, grads + k, chain ? blocks + k - 1 : nullptr, ready, stream, side_stream));
+                       blocks[k - 1].W == blocks[k].W && blocks[k - 1].C == blocks[k].C;
+    BLK_TRY(block_bwd_impl(blocks + k, grads + k, chain ? blocks + k - 1 : nullptr, chain ? grads + k - 1 : nullptr, ready, stream,
+                           side_stream));
     ready = chain;
   }
   return BUCTD_OK;

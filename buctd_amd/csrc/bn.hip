@@ -9,6 +9,7 @@
 // tiled so that a wave reads whole 64B+ segments.
 #include "common.h"
 #include "../../include/buctd_hip.h"
+#include "bn_acc.h"
 
 #define STAT_ROWS 64  // rows per Welford group for bn_stats_kernel
 
@@ -642,4 +643,248 @@ static long bwd2_blocks(long rows, long* rows_per_block) {
   if (rpb < 64) rpb = 64;      // never more partials than the first generation's rows / 64 (its workspace size)
   *rows_per_block = rpb;
   return (rows + rpb - 1) / rpb;
+}
+
+// =====================================================================================================================
+// BatchNorm without finalize launches (bn_acc.h): the statistics arrive as exact integer accumulators filled by the
+// producing kernel; the streaming kernels below decode them in their prologue into an LDS table - every workgroup for
+// itself (C x 256 B from L2), workgroup 0 also leaves them in the form later kernels read (mean / invstd for the backward
+// pass, running statistics, dgamma / dbeta).  The per-element arithmetic is that of bn_apply_kernel / bn_bwd_apply_kernel.
+
+// grid: few, fat workgroups - each one pays the C-channel prologue, so at least 16 float4 per thread
+static int acc_grid(long n4) {
+  long b = (n4 + 256 * 16 - 1) / (256 * 16);
+  if (b > 1024) b = 1024;
+  if (b < 1) b = 1;
+  return (int)b;
+}
+
+// y = act((z - mean) * (invstd * gamma) + beta (+ residual)); LDS: [3][C] floats
+__global__ __launch_bounds__(256) void bn_apply_acc_kernel(const float* __restrict__ z, BnAccFwd a, const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta, const float* __restrict__ res,
+                                                           int relu, float* __restrict__ y, long total, int C) {
+  extern __shared__ float tab[];
+  for (int c = threadIdx.x; c < C; c += 256) {
+    const BnFwdStat st = bnacc_fwd_stat(a.acc, C, c, a.rows, a.eps);
+    tab[c] = st.mean;
+    tab[C + c] = st.invstd * gamma[c];
+    tab[2 * C + c] = beta[c];
+    if (blockIdx.x == 0) {
+      a.mean_out[c] = st.mean;
+      a.invstd_out[c] = st.invstd;
+      if (a.rmean) bnacc_running(st, a.rows, a.momentum, a.rmean, a.rvar, c);
+    }
+  }
+  __syncthreads();
+  const long n4 = total >> 2;
+  const long step = (long)gridDim.x * 256;
+  const int dc = (int)((step * 4) % C);
+  int c = (int)((((long)blockIdx.x * 256 + threadIdx.x) * 4) % C) - dc;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += step) {
+    c += dc;
+    if (c >= C) c -= C;
+    const f32x4 v = reinterpret_cast<const f32x4*>(z)[i];
+    const f32x4 mu = *reinterpret_cast<const f32x4*>(tab + c);
+    const f32x4 sc = *reinterpret_cast<const f32x4*>(tab + C + c);
+    const f32x4 be = *reinterpret_cast<const f32x4*>(tab + 2 * C + c);
+    f32x4 o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o[j] = (v[j] - mu[j]) * sc[j] + be[j];
+    if (res) {
+      const f32x4 r = reinterpret_cast<const f32x4*>(res)[i];
+      o += r;
+    }
+    if (relu) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) o[j] = fmaxf(o[j], 0.f);
+    }
+    reinterpret_cast<f32x4*>(y)[i] = o;
+  }
+}
+
+extern "C" size_t buctd_bn_acc_bytes(int C) { return C > 0 ? bnacc_bytes(C) : 0; }
+
+static int acc_in_check(const buctd_bn_acc_in* st, const char* who) {
+  BUCTD_CHECK_ARG(st && st->acc && st->rows > 0 && st->mean_out && st->invstd_out &&
+                      (st->running_mean == nullptr) == (st->running_var == nullptr),
+                  "%s: statistics accumulator, rows, mean_out and invstd_out are required; running_mean/var go together", who);
+  return BUCTD_OK;
+}
+static BnAccFwd acc_in(const buctd_bn_acc_in* st) {
+  BnAccFwd a;
+  a.acc = (const long long*)st->acc; a.rows = (double)st->rows; a.eps = st->eps; a.momentum = st->momentum;
+  a.mean_out = st->mean_out; a.invstd_out = st->invstd_out; a.rmean = st->running_mean; a.rvar = st->running_var;
+  return a;
+}
+
+extern "C" int buctd_bn_apply_acc(const float* z, const buctd_bn_acc_in* st, const float* gamma, const float* beta,
+                                  const float* residual, int relu, float* y, long rows, int C, void* stream) {
+  BUCTD_CHECK_ARG(z && gamma && beta && y && rows > 0 && C > 0 && C % 4 == 0 && C <= 4096,
+                  "buctd_bn_apply_acc: bad argument (C must be a multiple of 4, <= 4096)");
+  const int rc = acc_in_check(st, "buctd_bn_apply_acc");
+  if (rc) return rc;
+  BUCTD_CHECK_ARG(st->rows == rows, "buctd_bn_apply_acc: the statistics cover %ld rows, the tensor has %ld", st->rows, rows);
+  const long total = rows * C;
+  hipLaunchKernelGGL(bn_apply_acc_kernel, dim3(acc_grid(total / 4)), dim3(256), (size_t)3 * C * sizeof(float), (hipStream_t)stream,
+                     z, acc_in(st), gamma, beta, residual, relu, y, total, C);
+  BUCTD_CHECK_LAUNCH("buctd_bn_apply_acc");
+  return BUCTD_OK;
+}
+
+// backward reduction into an accumulator: bn_bwd_reduce2_kernel with one exact integer addition per workgroup, channel and sum
+__global__ __launch_bounds__(256) void bn_bwd_reduce_acc_kernel(const float* __restrict__ dy, const float* __restrict__ y,
+                                                                const float* __restrict__ z, const float* __restrict__ mean,
+                                                                const float* __restrict__ invstd,
+                                                                const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                int relu, long rows, int C, long rows_per_block,
+                                                                long long* __restrict__ acc) {
+  __shared__ f32x4 sm[2][256];
+  const int c4n = C >> 2;                 // C % 4 == 0, C / 4 <= 256
+  const int rl = 256 / c4n;
+  const int tc = threadIdx.x % c4n, tr = threadIdx.x / c4n;
+  const long r0 = (long)blockIdx.x * rows_per_block;
+  long r1 = r0 + rows_per_block;
+  if (r1 > rows) r1 = rows;
+  f32x4 s1 = (f32x4){0.f, 0.f, 0.f, 0.f}, s2 = s1;
+  if (tr < rl) {
+    const f32x4 mu = reinterpret_cast<const f32x4*>(mean)[tc];
+    const f32x4 is = reinterpret_cast<const f32x4*>(invstd)[tc];
+    f32x4 sc = is, be = is;
+    const bool rebuild = relu && !y;      // mask recomputed exactly as bn_apply formed its output
+    if (rebuild) {
+      sc = is * reinterpret_cast<const f32x4*>(gamma)[tc];
+      be = reinterpret_cast<const f32x4*>(beta)[tc];
+    }
+    auto body = [&](f32x4 g, f32x4 zz, f32x4 yy) {
+      if (relu) {
+        if (rebuild) yy = (zz - mu) * sc + be;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (!(yy[j] > 0.f)) g[j] = 0.f;
+      }
+      s1 += g;
+      s2 += g * (zz - mu) * is;
+    };
+    long r = r0 + tr;
+    const long step = rl;
+    for (; r + 3 * step < r1; r += 4 * step) {
+      f32x4 g[4], zz[4], yy[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const long o = (r + u * step) * c4n + tc;
+        g[u] = reinterpret_cast<const f32x4*>(dy)[o];
+        zz[u] = reinterpret_cast<const f32x4*>(z)[o];
+        yy[u] = (relu && y) ? reinterpret_cast<const f32x4*>(y)[o] : zz[u];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) body(g[u], zz[u], yy[u]);
+    }
+    for (; r < r1; r += step) {
+      const long o = r * c4n + tc;
+      const f32x4 zz = reinterpret_cast<const f32x4*>(z)[o];
+      body(reinterpret_cast<const f32x4*>(dy)[o], zz, (relu && y) ? reinterpret_cast<const f32x4*>(y)[o] : zz);
+    }
+  }
+  sm[0][threadIdx.x] = s1;
+  sm[1][threadIdx.x] = s2;
+  __syncthreads();
+  if (tr == 0) {
+    for (int k = 1; k < rl; ++k) {
+      s1 += sm[0][k * c4n + tc];
+      s2 += sm[1][k * c4n + tc];
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) bnacc_add(acc, C, blockIdx.x, tc * 4 + j, (double)s1[j], (double)s2[j]);
+  }
+}
+
+// dz = gamma * invstd * (g - s1 / M - zhat * s2 / M); dres = g.  LDS: [6][C] floats (mean, invstd, gamma, beta, s1, s2)
+__global__ __launch_bounds__(256) void bn_bwd_apply_acc_kernel(const float* __restrict__ dy, const float* __restrict__ y,
+                                                               const float* __restrict__ z, const float* __restrict__ mean,
+                                                               const float* __restrict__ invstd,
+                                                               const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                               const long long* __restrict__ acc, int relu, long total, int C,
+                                                               float inv_rows, float* __restrict__ dz, float* __restrict__ dres,
+                                                               float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                               int accumulate) {
+  extern __shared__ float tab[];
+  for (int c = threadIdx.x; c < C; c += 256) {
+    double s1, s2;
+    bnacc_read(acc, C, c, &s1, &s2);
+    tab[c] = mean[c];
+    tab[C + c] = invstd[c];
+    tab[2 * C + c] = gamma[c];
+    tab[3 * C + c] = (relu && !y) ? beta[c] : 0.f;
+    tab[4 * C + c] = (float)s1;
+    tab[5 * C + c] = (float)s2;
+    if (blockIdx.x == 0) {
+      if (dbeta) dbeta[c] = accumulate ? dbeta[c] + (float)s1 : (float)s1;
+      if (dgamma) dgamma[c] = accumulate ? dgamma[c] + (float)s2 : (float)s2;
+    }
+  }
+  __syncthreads();
+  const long n4 = total >> 2;
+  const long step = (long)gridDim.x * 256;
+  const int dc = (int)((step * 4) % C);
+  int c = (int)((((long)blockIdx.x * 256 + threadIdx.x) * 4) % C) - dc;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += step) {
+    c += dc;
+    if (c >= C) c -= C;
+    f32x4 g = reinterpret_cast<const f32x4*>(dy)[i];
+    const f32x4 zz = reinterpret_cast<const f32x4*>(z)[i];
+    const f32x4 mu = *reinterpret_cast<const f32x4*>(tab + c);
+    const f32x4 is = *reinterpret_cast<const f32x4*>(tab + C + c);
+    const f32x4 ga = *reinterpret_cast<const f32x4*>(tab + 2 * C + c);
+    if (relu) {
+      f32x4 yy;
+      if (y) yy = reinterpret_cast<const f32x4*>(y)[i];
+      else {
+        const f32x4 be = *reinterpret_cast<const f32x4*>(tab + 3 * C + c);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float sc = is[j] * ga[j];
+          yy[j] = (zz[j] - mu[j]) * sc + be[j];
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (!(yy[j] > 0.f)) g[j] = 0.f;
+    }
+    const f32x4 s1 = *reinterpret_cast<const f32x4*>(tab + 4 * C + c);
+    const f32x4 s2 = *reinterpret_cast<const f32x4*>(tab + 5 * C + c);
+    f32x4 o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float zh = (zz[j] - mu[j]) * is[j];
+      o[j] = ga[j] * is[j] * (g[j] - s1[j] * inv_rows - zh * s2[j] * inv_rows);
+    }
+    reinterpret_cast<f32x4*>(dz)[i] = o;
+    if (dres) reinterpret_cast<f32x4*>(dres)[i] = g;
+  }
+}
+
+/* buctd_bn_bwd on an accumulator (buctd_bn_acc_bytes(C), zero on entry unless acc_ready): acc_ready = 0 runs the
+ * streaming reduction into it first; acc_ready = 1: the data gradient that produced dy already did
+ * (buctd_conv3x3_bf16x6_bnstat_acc).  No finalize launch: the apply kernel decodes the sums itself and its first workgroup
+ * writes dgamma / dbeta. */
+extern "C" int buctd_bn_bwd_acc(const float* dy, const float* y, const float* z, const float* mean, const float* invstd,
+                                const float* gamma, const float* beta, int relu, long rows, int C, float* dz, float* dres,
+                                float* dgamma, float* dbeta, int accumulate, void* acc, int acc_ready, void* stream) {
+  BUCTD_CHECK_ARG(dy && z && mean && invstd && gamma && dz && acc && rows > 0 && C > 0 && C % 4 == 0 && C / 4 <= 256,
+                  "buctd_bn_bwd_acc: bad argument (C must be a multiple of 4, <= 1024)");
+  BUCTD_CHECK_ARG(!relu || y || beta, "buctd_bn_bwd_acc: relu backward needs the forward output, or beta to rebuild its sign");
+  hipStream_t st = (hipStream_t)stream;
+  if (!acc_ready) {
+    long rpb;
+    const long nb = bwd2_blocks(rows, &rpb);
+    hipLaunchKernelGGL(bn_bwd_reduce_acc_kernel, dim3((unsigned)nb), dim3(256), 0, st, dy, y, z, mean, invstd, gamma, beta, relu,
+                       rows, C, rpb, (long long*)acc);
+    BUCTD_CHECK_LAUNCH("buctd_bn_bwd_acc(reduce)");
+  }
+  const long total = rows * C;
+  hipLaunchKernelGGL(bn_bwd_apply_acc_kernel, dim3(acc_grid(total / 4)), dim3(256), (size_t)6 * C * sizeof(float), st, dy, y, z,
+                     mean, invstd, gamma, beta, (const long long*)acc, relu, total, C, 1.0f / (float)rows, dz, dres, dgamma, dbeta,
+                     accumulate);
+  BUCTD_CHECK_LAUNCH("buctd_bn_bwd_acc(apply)");
+  return BUCTD_OK;
 }

@@ -5,6 +5,7 @@
 #include "common.h"
 #include <stdlib.h>
 #include "../../include/buctd_hip.h"
+#include "bn_acc.h"
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned short u16x4 __attribute__((ext_vector_type(4)));
@@ -67,7 +68,21 @@ struct C3Args {
   const float* bs_gamma;
   const float* bs_beta;
   float* bs_part;
+  // The same two by-products as exact integer accumulators (bn_acc.h) instead of per-group partials: the consumer of the
+  // statistics decodes two numbers per channel in its prologue and no finalize launch sits between the two kernels.
+  //   stats_acc: forward statistics (sum z, sum z^2) of this launch's output;  bs_acc: the BatchNorm-backward sums above.
+  long long* stats_acc;
+  long long* bs_acc;
+  // in_acc.acc != null: the producer's statistics (in_mean / in_invstd) are decoded from ITS accumulator in this launch's
+  // prologue; the workgroup of tile (0, 0) also writes them out (in_acc.mean_out / invstd_out, running statistics)
+  BnAccFwd in_acc;
 };
+
+// LDS the epilogue needs at the front of `smem`: row staging + row offsets (<= 19.5 KB), the lane reduction of the
+// BatchNorm-backward by-product (<= 24 KB, reuses the staging area), and behind them the cross-wave exchange of the
+// accumulator paths (WM * BN <= 256 pairs of doubles)
+#define C3_EPI_EXCH_OFF 24576
+#define C3_EPI_LDS (C3_EPI_EXCH_OFF + 256 * 16)
 
 __device__ __forceinline__ int fast_div(int n, unsigned mul, unsigned sh) {
   return (int)(__umulhi((unsigned)n, mul) >> sh);
@@ -171,7 +186,8 @@ __device__ __forceinline__ void c3_epilogue(const C3Args& p, f32x4 (&acc)[MF][NF
   float bv[NF];
 #pragma unroll
   for (int nf = 0; nf < NF; ++nf) bv[nf] = p.bias ? p.bias[ncol0 + nf * 16 + i16] : 0.f;
-  if (p.stats) {
+  double2* exch = reinterpret_cast<double2*>(smem + C3_EPI_EXCH_OFF);      // [wave_m][BN]
+  if (p.stats || p.stats_acc) {
     const float inv_cnt = cnt > 0 ? 1.f / (float)cnt : 0.f;
 #pragma unroll
     for (int nf = 0; nf < NF; ++nf) {
@@ -195,7 +211,26 @@ __device__ __forceinline__ void c3_epilogue(const C3Args& p, f32x4 (&acc)[MF][NF
       s2 += __shfl_xor(s2, 32, 64);
       if (g == 0) {
         const int n = ncol0 + nf * 16 + i16;
-        *reinterpret_cast<float2*>(p.stats + ((long)grp * p.Co + n) * 2) = make_float2(mean, s2);
+        if (p.stats) *reinterpret_cast<float2*>(p.stats + ((long)grp * p.Co + n) * 2) = make_float2(mean, s2);
+        if (p.stats_acc) {
+          // this wave's rows as (sum, sum of squares) in fp64 - the terms bn_finalize_kernel forms from a Welford partial
+          const double nn = (double)cnt, m = (double)mean;
+          exch[wave_m * (WN * NF * 16) + wave_n * NF * 16 + nf * 16 + i16] = make_double2(nn * m, (double)s2 + nn * m * m);
+        }
+      }
+    }
+    if (p.stats_acc) {
+      // the workgroup's waves in a fixed order, then ONE exact integer addition per channel and sum
+      __syncthreads();
+      if (t < WN * NF * 16) {
+        double a1 = 0.0, a2 = 0.0;
+#pragma unroll
+        for (int w = 0; w < WM; ++w) {
+          const double2 v = exch[w * (WN * NF * 16) + t];
+          a1 += v.x;
+          a2 += v.y;
+        }
+        bnacc_add(p.stats_acc, p.Co, (unsigned)(bx + by), n0 + t, a1, a2);
       }
     }
   }
@@ -207,7 +242,7 @@ __device__ __forceinline__ void c3_epilogue(const C3Args& p, f32x4 (&acc)[MF][NF
   f32x4 bs1[NACC], bs2[NACC];
 #pragma unroll
   for (int j = 0; j < NACC; ++j) bs1[j] = bs2[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  const bool bs_on = p.bs_part != nullptr;
+  const bool bs_on = p.bs_part != nullptr || p.bs_acc != nullptr;
   const bool bs_rebuild = bs_on && p.bs_y == nullptr;
   // Every wave stages through ITS OWN slice of LDS (stg, rowoff) and the LDS executes one wave's operations in order, so
   // the passes need no workgroup barrier - only the compiler must keep the stores in front of the loads (wave_barrier).
@@ -315,9 +350,30 @@ __device__ __forceinline__ void c3_epilogue(const C3Args& p, f32x4 (&acc)[MF][NF
           a2 += red[(j * 64 + l) * 2 + 1];
         }
       }
-      float* dst = p.bs_part + ((long)grp * 2) * p.Co + ncol0 + lane * 4;
-      *reinterpret_cast<f32x4*>(dst) = a1;
-      *reinterpret_cast<f32x4*>(dst + p.Co) = a2;
+      if (p.bs_part) {
+        float* dst = p.bs_part + ((long)grp * 2) * p.Co + ncol0 + lane * 4;
+        *reinterpret_cast<f32x4*>(dst) = a1;
+        *reinterpret_cast<f32x4*>(dst + p.Co) = a2;
+      }
+      if (p.bs_acc) {
+        // [wave_m][BN] pairs: the wave's fp32 sums of its rows, channel by channel
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          exch[wave_m * (WN * NF * 16) + wave_n * NF * 16 + lane * 4 + j] = make_double2((double)a1[j], (double)a2[j]);
+      }
+    }
+    if (p.bs_acc) {
+      __syncthreads();
+      if (t < WN * NF * 16) {
+        double a1 = 0.0, a2 = 0.0;
+#pragma unroll
+        for (int w = 0; w < WM; ++w) {
+          const double2 v = exch[w * (WN * NF * 16) + t];
+          a1 += v.x;
+          a2 += v.y;
+        }
+        bnacc_add(p.bs_acc, p.Co, (unsigned)(bx + by), n0 + t, a1, a2);
+      }
     }
   }
 }

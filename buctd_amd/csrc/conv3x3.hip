@@ -29,6 +29,7 @@
 //   * epilogue as in conv.hip: bias, Welford BN partials (+ per-group valid-row counts, since pad positions are
 //     skipped), eval-BN scale/shift, residual, ReLU.
 #include "c3_common.h"
+#include <string.h>
 
 template <int NP, int MF, int NF, int WM, int WN>
 __global__ __launch_bounds__(256, 2) void conv3x3_split_kernel(C3Args p) {
@@ -227,38 +228,25 @@ __device__ unsigned long long c3_trace_wall[4096][2];   // wall clock (100 MHz) 
 #else
 #define C3_TR(k) do {} while (0)
 #endif
-template <int MF, int NF, int WM, int WN, bool DBUF, bool BPF_, int WPS>
-__global__ __launch_bounds__(256, WPS) void conv3x3_x6_kernel(C3Args p) {
+// One output tile (bx, by) of a launch described by p: the body of conv3x3_x6_kernel (one tile per workgroup) and of
+// conv3x3_x6_group_kernel (a persistent workgroup walking a tile table over several convolutions).
+// smem = [DBUF ? 2 : 1][arows][ROWB] A buffers | [3][Ci] floats: the input-BatchNorm table (mean, invstd * gamma, beta)
+template <int MF, int NF, int WM, int WN, bool DBUF, bool BPF_>
+__device__ __forceinline__ void c3x6_tile(const C3Args& p, unsigned char* smem, int bx, int by) {
   constexpr int ROWB = Geo<3>::ROWB, PST = Geo<3>::PST, CPR = Geo<3>::CPR;
   constexpr int BM = WM * MF * 16, BN = WN * NF * 16;
   constexpr int RPP = 256 / CPR;                                 // 64 rows staged per pass
   constexpr int PA = (BM + 2 * MAX_SW + 2 + RPP - 1) / RPP;
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int arows = p.na * 32;
-  const size_t abytes = DBUF ? (size_t)arows * ROWB : 0;         // one A buffer; smem = [DBUF ? 2 : 1][arows][ROWB]
+  const size_t abytes = DBUF ? (size_t)arows * ROWB : 0;         // one A buffer
+  float* bntab = reinterpret_cast<float*>(smem + (size_t)(DBUF ? 2 : 1) * arows * ROWB);
 
   const int t = threadIdx.x, lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);      // wave-uniform: keeps the B addressing scalar
   const int i16 = lane & 15, g = lane >> 4;
   const int wave_m = wave % WM, wave_n = wave / WM;
-  int bx, by;
-  {
-    const unsigned gx = gridDim.x, gy = gridDim.y, total = gx * gy;
-    const unsigned lin = blockIdx.y * gx + blockIdx.x;
-    const unsigned xcd = lin & 7, idx = lin >> 3, per = total >> 3, rem = total & 7;
-    const unsigned L = xcd < rem ? xcd * (per + 1) + idx : rem * (per + 1) + (xcd - rem) * per + idx;
-    if (p.col_major) {
-      // large filters (384 -> 384: 8 MB of prepared B, two L2s' worth): an XCD's run of workgroups walks the position
-      // tiles of ONE column tile, so its L2 keeps that column tile's 1/gy of B for all of them; position-major order
-      // streams the whole image through every L2 and each B fetch pays a MALL / HBM round trip
-      by = (int)(L / gx);
-      bx = (int)(L - (unsigned)by * gx);
-    } else {
-      bx = (int)(L / gy);
-      by = (int)(L - (unsigned)bx * gy);
-    }
-  }
   const int p0 = bx * BM, n0 = by * BN;
+  const bool in_bn = p.in_mean != nullptr || p.in_acc.acc != nullptr;
   const int halo = p.SW + 1;
   const int c4 = (t % CPR) * 4, prow = t / CPR;
 
@@ -292,19 +280,16 @@ __global__ __launch_bounds__(256, WPS) void conv3x3_x6_kernel(C3Args p) {
   };
   auto store_a = [&](unsigned char* At, int c0) {
     f32x4 mu, sc, be;
-    if (p.in_mean) {
-      mu = *reinterpret_cast<const f32x4*>(p.in_mean + c0 + c4);
-      const f32x4 is = *reinterpret_cast<const f32x4*>(p.in_invstd + c0 + c4);
-      const f32x4 ga = *reinterpret_cast<const f32x4*>(p.in_gamma + c0 + c4);
-      be = *reinterpret_cast<const f32x4*>(p.in_beta + c0 + c4);
-#pragma unroll
-      for (int j = 0; j < 4; ++j) sc[j] = is[j] * ga[j];
+    if (in_bn) {
+      mu = *reinterpret_cast<const f32x4*>(bntab + c0 + c4);
+      sc = *reinterpret_cast<const f32x4*>(bntab + p.Ci + c0 + c4);
+      be = *reinterpret_cast<const f32x4*>(bntab + 2 * p.Ci + c0 + c4);
     }
 #pragma unroll
     for (int q = 0; q < PA; ++q)
       if (RPP * q < arows && goff[q] != -2) {
         f32x4 v = goff[q] >= 0 ? areg[q] : (f32x4){0.f, 0.f, 0.f, 0.f};
-        if (p.in_mean && goff[q] >= 0) {             // zero padding stays zero: it pads the NORMALISED tensor
+        if (in_bn && goff[q] >= 0) {                 // zero padding stays zero: it pads the NORMALISED tensor
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
             v[j] = (v[j] - mu[j]) * sc[j] + be[j];
@@ -423,6 +408,31 @@ __global__ __launch_bounds__(256, WPS) void conv3x3_x6_kernel(C3Args p) {
   load_a(0);
   if constexpr (BPF) load_b(0, bn);
   if constexpr (BPF2) load_b(last_step > 0 ? 1 : 0, bn2);
+  if (in_bn) {
+    // the producer's BatchNorm as (mean, invstd * gamma, beta) per input channel, under the first chunk's loads: from the
+    // arrays a finalize launch left, or decoded from the producer's accumulator (bn_acc.h) - then tile (0, 0) also
+    // leaves mean / invstd for the backward kernels and updates the running statistics
+    for (int c = t; c < p.Ci; c += 256) {
+      float m, is;
+      if (p.in_acc.acc) {
+        const BnFwdStat st = bnacc_fwd_stat(p.in_acc.acc, p.Ci, c, p.in_acc.rows, p.in_acc.eps);
+        m = st.mean;
+        is = st.invstd;
+        if (bx == 0 && by == 0) {
+          p.in_acc.mean_out[c] = m;
+          p.in_acc.invstd_out[c] = is;
+          if (p.in_acc.rmean) bnacc_running(st, p.in_acc.rows, p.in_acc.momentum, p.in_acc.rmean, p.in_acc.rvar, c);
+        }
+      } else {
+        m = p.in_mean[c];
+        is = p.in_invstd[c];
+      }
+      bntab[c] = m;
+      bntab[p.Ci + c] = is * p.in_gamma[c];
+      bntab[2 * p.Ci + c] = p.in_beta[c];
+    }
+    __syncthreads();
+  }
   store_a(smem, 0);
   if (nchunks > 1) load_a(16);
   __syncthreads();
@@ -452,11 +462,29 @@ __global__ __launch_bounds__(256, WPS) void conv3x3_x6_kernel(C3Args p) {
   C3_TR(60);
   if (PRIO) __builtin_amdgcn_s_setprio(0);
   c3_epilogue<MF, NF, WM, WN>(p, acc, smem, bx, by, p0, n0);
-  C3_TR(61);
-#ifdef C3_TRACE
-  if (tr_on) c3_trace_buf[tr_slot][63] = wall_clock64();
-  if (t == 0 && tr_lin < 4096) c3_trace_wall[tr_lin][1] = wall_clock64();
-#endif
+}
+
+template <int MF, int NF, int WM, int WN, bool DBUF, bool BPF_, int WPS>
+__global__ __launch_bounds__(256, WPS) void conv3x3_x6_kernel(C3Args p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  int bx, by;
+  {
+    const unsigned gx = gridDim.x, gy = gridDim.y, total = gx * gy;
+    const unsigned lin = blockIdx.y * gx + blockIdx.x;
+    const unsigned xcd = lin & 7, idx = lin >> 3, per = total >> 3, rem = total & 7;
+    const unsigned L = xcd < rem ? xcd * (per + 1) + idx : rem * (per + 1) + (xcd - rem) * per + idx;
+    if (p.col_major) {
+      // large filters (384 -> 384: 8 MB of prepared B, two L2s' worth): an XCD's run of workgroups walks the position
+      // tiles of ONE column tile, so its L2 keeps that column tile's 1/gy of B for all of them; position-major order
+      // streams the whole image through every L2 and each B fetch pays a MALL / HBM round trip
+      by = (int)(L / gx);
+      bx = (int)(L - (unsigned)by * gx);
+    } else {
+      bx = (int)(L / gy);
+      by = (int)(L - (unsigned)bx * gy);
+    }
+  }
+  c3x6_tile<MF, NF, WM, WN, DBUF, BPF_>(p, smem, bx, by);
 }
 
 // ------------------------------------------------------------------------------------- weight preparation ----
@@ -626,11 +654,11 @@ static bool c3_plan(int np, int N, int H, int W, int Ci, int Co, C3Plan* pl) {
   pl->MF = mf; pl->NF = nf; pl->WM = wm; pl->WN = wn; pl->BM = wm * mf * 16; pl->BN = bn;
   pl->na = (pl->BM + 2 * c3_row_width(W) + 2 + 31) / 32;
   size_t stage = (size_t)4 * (mf >= 2 ? 2 : 1) * 16 * (nf * 16 + 4) * 4 + 4 * 128 * 4;   // epilogue staging + row offsets
-  if (np == 3 && stage < (size_t)4 * 3 * 64 * 2 * 16) stage = (size_t)4 * 3 * 64 * 2 * 16;      // ... or the bs_part reduction scratch
-  if (np == 3) {            // two A buffers (one for the 512-position tiles), no B stage
+  if (np == 3 && stage < (size_t)C3_EPI_LDS) stage = C3_EPI_LDS;      // ... the bs reduction scratch and the accumulator exchange
+  if (np == 3) {            // two A buffers (one for the 512-position tiles), no B stage; behind them the input-BatchNorm table
     const int nb = (single || pl->lean) ? 1 : 2;
     while ((size_t)nb * pl->na * 32 * rowb < stage) ++pl->na;
-    pl->lds = (size_t)nb * pl->na * 32 * rowb;
+    pl->lds = (size_t)nb * pl->na * 32 * rowb + (size_t)3 * Ci * sizeof(float);
   } else {
     while ((size_t)pl->na * 32 * rowb < stage) ++pl->na;
     pl->lds = (size_t)pl->na * 32 * rowb + (size_t)2 * pl->BN * blds;
@@ -734,12 +762,14 @@ static int c3_prep(int np, int Ci, int Co, const float* w, int flip, void* wprep
 // Ci = CoF, Co = CiF, and wprep = prep(CiF, CoF, w, 1).
 struct C3InBn { const float* mean; const float* invstd; const float* gamma; const float* beta; int relu; };
 // BatchNorm-backward reduction as a by-product of a data-gradient launch (C3Args::bs_*)
-struct C3BwdStat { const float* z; const float* y; const float* mean; const float* invstd; const float* gamma; const float* beta; float* part; };
+struct C3BwdStat { const float* z; const float* y; const float* mean; const float* invstd; const float* gamma; const float* beta; float* part; long long* acc; };
+// accumulator forms (bn_acc.h): the launch's own forward statistics, and the input BatchNorm's statistics decoded in the prologue
+struct C3Acc { long long* stats_acc; const buctd_bn_acc_in* in; };
 
 static int c3_run(int np, int N, int H, int W, int Ci, int Co, const float* x, const void* wprep, const float* bias,
                   const float* scale, const float* shift, const float* residual, int relu, float* y,
                   float* stats_partials, int* stats_counts, void* stream, const C3InBn* in_bn = nullptr,
-                  const C3BwdStat* bst = nullptr) {
+                  const C3BwdStat* bst = nullptr, const C3Acc* accs = nullptr) {
   C3Plan pl;
   BUCTD_CHECK_ARG(x && wprep && y, "buctd_conv3x3 (split bf16): null tensor pointer");
   BUCTD_CHECK_ARG(c3_np_ok(np) && c3_plan(np, N, H, W, Ci, Co, &pl),
@@ -766,13 +796,28 @@ static int c3_run(int np, int N, int H, int W, int Ci, int Co, const float* x, c
     a.in_mean = in_bn->mean; a.in_invstd = in_bn->invstd; a.in_gamma = in_bn->gamma; a.in_beta = in_bn->beta;
     a.in_relu = in_bn->relu;
   }
+  a.stats_acc = nullptr; a.bs_acc = nullptr;
+  memset(&a.in_acc, 0, sizeof(a.in_acc));
+  if (accs) {
+    BUCTD_CHECK_ARG(np == 3, "buctd_conv3x3: statistics accumulators need the bf16x6 kernel");
+    a.stats_acc = accs->stats_acc;
+    if (accs->in && accs->in->acc) {
+      const buctd_bn_acc_in& i = *accs->in;
+      BUCTD_CHECK_ARG(in_bn && !in_bn->mean && in_bn->gamma && in_bn->beta && i.rows > 0 && i.mean_out && i.invstd_out &&
+                          (i.running_mean == nullptr) == (i.running_var == nullptr),
+                      "buctd_conv3x3: input BatchNorm from an accumulator needs gamma, beta, rows, mean_out and invstd_out");
+      a.in_gamma = in_bn->gamma; a.in_beta = in_bn->beta; a.in_relu = in_bn->relu;
+      a.in_acc.acc = (const long long*)i.acc; a.in_acc.rows = (double)i.rows; a.in_acc.eps = i.eps; a.in_acc.momentum = i.momentum;
+      a.in_acc.mean_out = i.mean_out; a.in_acc.invstd_out = i.invstd_out; a.in_acc.rmean = i.running_mean; a.in_acc.rvar = i.running_var;
+    }
+  }
   a.bs_z = a.bs_y = a.bs_mean = a.bs_invstd = a.bs_gamma = a.bs_beta = nullptr;
   a.bs_part = nullptr;
-  if (bst && bst->part) {
+  if (bst && (bst->part || bst->acc)) {
     BUCTD_CHECK_ARG(np == 3 && bst->z && bst->mean && bst->invstd && (bst->y || (bst->gamma && bst->beta)),
                     "buctd_conv3x3: the BatchNorm-backward by-product needs the bf16x6 kernel, z, mean, invstd and y or gamma + beta");
     a.bs_z = bst->z; a.bs_y = bst->y; a.bs_mean = bst->mean; a.bs_invstd = bst->invstd; a.bs_gamma = bst->gamma;
-    a.bs_beta = bst->beta; a.bs_part = bst->part;
+    a.bs_beta = bst->beta; a.bs_part = bst->part; a.bs_acc = bst->acc;
   }
   a.col_major = (np == 3 && Co / pl.BN >= 2 && (size_t)c3_steps(Ci, 3) * Co * Geo<3>::BROW > ((size_t)3 << 20)) ? 1 : 0;
 #ifdef BUCTD_TUNING
@@ -838,8 +883,33 @@ extern "C" int buctd_conv3x3_bf16x6_bnstat(int N, int H, int W, int Ci, int Co, 
                                            const float* residual, float* y, const float* bn_z, const float* bn_y,
                                            const float* bn_mean, const float* bn_invstd, const float* bn_gamma,
                                            const float* bn_beta, float* bn_part, void* stream) {
-  C3BwdStat b{bn_z, bn_y, bn_mean, bn_invstd, bn_gamma, bn_beta, bn_part};
+  C3BwdStat b{bn_z, bn_y, bn_mean, bn_invstd, bn_gamma, bn_beta, bn_part, nullptr};
   BUCTD_CHECK_ARG(bn_part, "buctd_conv3x3_bf16x6_bnstat: null partials pointer");
+  return c3_run(3, N, H, W, Ci, Co, x, wprep, nullptr, nullptr, nullptr, residual, 0, y, nullptr, nullptr, stream, nullptr,
+                &b);
+}
+
+/* The accumulator forms (include/buctd_hip.h: "BatchNorm statistics without finalize launches").
+ * buctd_conv3x3_bf16x6_acc: forward convolution whose output statistics go to stats_acc (may be null) and whose input may
+ * be the raw output of a producing convolution, normalised on the fly with that producer's statistics - decoded from ITS
+ * accumulator (in_bn: acc + rows + eps, gamma, beta) in the prologue; tile (0, 0) writes mean / invstd out and updates the
+ * running statistics.  buctd_conv3x3_bf16x6_bnstat_acc: the data gradient with the BatchNorm-backward sums as accumulator. */
+extern "C" int buctd_conv3x3_bf16x6_acc(int N, int H, int W, int Ci, int Co, const float* x, const void* wprep,
+                                        const float* residual, int relu, float* y, void* stats_acc,
+                                        const buctd_bn_acc_in* in_bn, const float* in_gamma, const float* in_beta, int in_relu,
+                                        void* stream) {
+  C3InBn b{nullptr, nullptr, in_gamma, in_beta, in_relu};
+  C3Acc a{(long long*)stats_acc, in_bn};
+  BUCTD_CHECK_ARG(!in_bn || in_bn->acc, "buctd_conv3x3_bf16x6_acc: in_bn without an accumulator");
+  return c3_run(3, N, H, W, Ci, Co, x, wprep, nullptr, nullptr, nullptr, residual, relu, y, nullptr, nullptr, stream,
+                in_bn ? &b : nullptr, nullptr, &a);
+}
+extern "C" int buctd_conv3x3_bf16x6_bnstat_acc(int N, int H, int W, int Ci, int Co, const float* x, const void* wprep,
+                                               const float* residual, float* y, const float* bn_z, const float* bn_y,
+                                               const float* bn_mean, const float* bn_invstd, const float* bn_gamma,
+                                               const float* bn_beta, void* bn_acc, void* stream) {
+  C3BwdStat b{bn_z, bn_y, bn_mean, bn_invstd, bn_gamma, bn_beta, nullptr, (long long*)bn_acc};
+  BUCTD_CHECK_ARG(bn_acc, "buctd_conv3x3_bf16x6_bnstat_acc: null accumulator");
   return c3_run(3, N, H, W, Ci, Co, x, wprep, nullptr, nullptr, nullptr, residual, 0, y, nullptr, nullptr, stream, nullptr,
                 &b);
 }

@@ -23,6 +23,7 @@
 //     one step ahead.
 // VALU per MFMA: 16 gathered floats per thread and step x ~4 instructions against 72 MFMAs per wave (BN = 96) - under one.
 #include "c3_common.h"
+#include <string.h>
 
 #define GC_MAXT 9
 #ifndef GC_ABL
@@ -428,7 +429,7 @@ static int gc_launch(const GcArgs& a, int tiles, int ncol, hipStream_t st) {
 
 static int gc_run(int kind, int dir, int N, int H, int W, int Ci, int Co, const float* src, const void* wprep, const float* bias,
                   const float* scale, const float* shift, const float* residual, int relu, float* out, float* stats_partials,
-                  int* stats_counts, void* stream, const char* who) {
+                  int* stats_counts, void* stream, const char* who, long long* stats_acc = nullptr) {
   int Hg, Wg, SH, SWd, SC, nout;
   BUCTD_CHECK_ARG(src && wprep && out, "%s: null tensor pointer", who);
   BUCTD_CHECK_ARG(gc_geo(kind, dir, N, H, W, Ci, Co, &Hg, &Wg, &SH, &SWd, &SC, &nout),
@@ -448,6 +449,9 @@ static int gc_run(int kind, int dir, int N, int H, int W, int Ci, int Co, const 
   e.relu = relu; e.na = 0;
   e.in_mean = e.in_invstd = e.in_gamma = e.in_beta = nullptr; e.in_relu = 0; e.col_major = 0;
   e.bs_z = e.bs_y = e.bs_mean = e.bs_invstd = e.bs_gamma = e.bs_beta = nullptr; e.bs_part = nullptr;
+  e.stats_acc = stats_acc; e.bs_acc = nullptr;
+  memset(&e.in_acc, 0, sizeof(e.in_acc));
+  BUCTD_CHECK_ARG(!(dir && stats_acc), "%s: no statistics on the data gradient", who);
   magic_u32((unsigned)e.IB, &e.ib_mul, &e.ib_sh);
   magic_u32((unsigned)e.SW, &e.sw_mul, &e.sw_sh);
   const bool par = kind == 2 && dir;
@@ -492,6 +496,14 @@ extern "C" int buctd_gconv_x6_fwd(int kind, int N, int H, int W, int Ci, int Co,
 #endif
   return gc_run(kind, 0, N, H, W, Ci, Co, x, wprep, bias, scale, shift, residual, relu, y, stats_partials, stats_counts, stream,
                 "buctd_gconv_x6_fwd");
+}
+
+/* forward with the output statistics as an accumulator (bn_acc.h; buctd_bn_acc_bytes(Co) zeroed bytes) instead of partials */
+extern "C" int buctd_gconv_x6_fwd_acc(int kind, int N, int H, int W, int Ci, int Co, const float* x, const void* wprep,
+                                      const float* bias, float* y, void* stats_acc, void* stream) {
+  BUCTD_CHECK_ARG(stats_acc, "buctd_gconv_x6_fwd_acc: null accumulator");
+  return gc_run(kind, 0, N, H, W, Ci, Co, x, wprep, bias, nullptr, nullptr, nullptr, 0, y, nullptr, nullptr, stream,
+                "buctd_gconv_x6_fwd_acc", (long long*)stats_acc);
 }
 
 extern "C" int buctd_gconv_x6_dgrad(int kind, int N, int H, int W, int Ci, int Co, const float* dy, const void* wprep,

@@ -128,6 +128,8 @@ class FusedAdam(torch.optim.Optimizer):
                       g["betas"][1], g["eps"], self.step_count, gscale)
         ops.weights_updated()  # the kernel wrote the parameters through raw pointers: prepared filter images are stale
         ops.refresh_prepared(self.flat.flat.device)   # ... and are rebuilt here, by one launch behind the Adam kernel
+        if self.flat.flat.is_cuda:
+            ops.acc_pool.reset(self.flat.flat.device)  # BatchNorm accumulators of the step: one fill, every stream is joined here
 
     def zero_grad(self, set_to_none=True):
         for p in self.flat.params:
@@ -220,6 +222,8 @@ class FusedSGD(torch.optim.Optimizer):
         self.step_count += 1
         ops.weights_updated()
         ops.refresh_prepared(self.flat.flat.device)
+        if self.flat.flat.is_cuda:
+            ops.acc_pool.reset(self.flat.flat.device)
 
     def zero_grad(self, set_to_none=True):
         for p in self.flat.params:

@@ -58,6 +58,75 @@ def workspace_on(stream, nbytes, device):
 _retired_workspaces = []
 
 
+# --------------------------------------------------------------------------------------
+# zeroed accumulator pool (BatchNorm statistics without finalize launches, csrc/bn_acc.h)
+# --------------------------------------------------------------------------------------
+class _AccPool:
+    """Hands out slices of a ZEROED device buffer.  A BatchNorm statistics accumulator must be zero when its producing
+    kernel starts and is dead once its consumer ran - within one forward or backward call - so a slice is never returned:
+    `reset()` (the optimizer step: every stream has been joined) zeroes what was handed out with ONE fill and rewinds; a
+    process that never resets (tests, plain forward passes) gets a fresh zeroed chunk whenever the current one is used up.
+    Streams other than the one that zeroed a chunk are ordered behind the fill by an event, once."""
+
+    CHUNK = 32 << 20
+
+    def __init__(self):
+        self.state = {}
+
+    def _new_chunk(self, device, nbytes):
+        cur = torch.cuda.current_stream(device)
+        buf = torch.zeros(max(self.CHUNK, nbytes), dtype=torch.uint8, device=device)
+        ev = torch.cuda.Event()
+        ev.record(cur)
+        st = {"buf": buf, "off": 0, "ev": ev, "stream": cur.cuda_stream, "seen": {cur.cuda_stream}}
+        self.state[device.index] = st
+        return st
+
+    def take(self, nbytes, device):
+        """-> device address of `nbytes` zero bytes (256-byte aligned), usable on the current stream"""
+        nbytes = (int(nbytes) + 255) & ~255
+        st = self.state.get(device.index)
+        if st is None or st["off"] + nbytes > st["buf"].numel():
+            st = self._new_chunk(device, nbytes)
+        cur = torch.cuda.current_stream(device)
+        if cur.cuda_stream not in st["seen"]:
+            cur.wait_event(st["ev"])
+            st["buf"].record_stream(cur)
+            st["seen"].add(cur.cuda_stream)
+        p = st["buf"].data_ptr() + st["off"]
+        st["off"] += nbytes
+        return p
+
+    def reset(self, device):
+        """Call where every stream that used the pool has been joined into the current one (FusedAdam.step)."""
+        st = self.state.get(device.index)
+        if st is None or st["off"] == 0:
+            return
+        cur = torch.cuda.current_stream(device)
+        st["buf"][:st["off"]].zero_()
+        st["off"] = 0
+        ev = torch.cuda.Event()
+        ev.record(cur)
+        st["ev"], st["stream"], st["seen"] = ev, cur.cuda_stream, {cur.cuda_stream}
+        st["buf"].record_stream(cur)
+
+
+acc_pool = _AccPool()
+
+
+def acc_bytes(Cn):
+    return _memo(("accb", Cn), lambda: int(lib().buctd_bn_acc_bytes(Cn)))
+
+
+class AccRef:
+    """A statistics accumulator of Cn channels taken from the pool (device address only: the pool owns the memory)."""
+    __slots__ = ("ptr", "Cn")
+
+    def __init__(self, Cn, device, n=1):
+        self.Cn = Cn
+        self.ptr = acc_pool.take(n * acc_bytes(Cn), device)
+
+
 _seed_state = {"seed": None, "counter": 0}
 
 
@@ -384,6 +453,23 @@ def _conv3x3_bf16x3(x, w, flip, cin, cout, bias, scale, shift, residual, relu, s
     wp = _conv3x3_prepared(w, flip)
     y = torch.empty((N, H, W, cout), dtype=torch.float32, device=x.device)
     part = counts = info = None
+    acc_mode = (_conv_math["mode"] == "bf16x6" and bias is None and scale is None
+                and (stats == "acc" or isinstance(in_bn, BnAccInput)))
+    if acc_mode:
+        # statistics as integer accumulators (csrc/bn_acc.h): no partials, no finalize launch
+        acc = AccRef(cout, x.device) if stats else None
+        st = in_bn.struct() if isinstance(in_bn, BnAccInput) else None
+        if in_bn is not None and st is None:
+            raise _C.BuctdHipError("conv3x3: the accumulator path takes its input BatchNorm as a BnAccInput")
+        check(lib().buctd_conv3x3_bf16x6_acc(N, H, W, cin, cout, ptr(x), ptr(wp), ptr(residual), int(bool(relu)), ptr(y),
+                                             C.c_void_p(acc.ptr) if acc is not None else None,
+                                             C.byref(st) if st is not None else None,
+                                             ptr(in_bn.gamma) if st is not None else None,
+                                             ptr(in_bn.beta) if st is not None else None,
+                                             int(bool(in_bn.relu)) if st is not None else 0, stream_ptr()), "conv3x3_bf16x6_acc")
+        return (y, acc, ("acc",)) if stats else y
+    if isinstance(in_bn, BnAccInput):
+        raise _C.BuctdHipError("conv3x3: BnAccInput needs the bf16x6 accumulator path (no bias / eval scale)")
     if stats:
         def groups():
             ng, rpg = C.c_int(), C.c_int()
@@ -463,6 +549,11 @@ def _gconv_fwd(x, w, d, bias, scale, shift, residual, relu, stats):
     wp = _gconv_prepared(w, kind, 0)
     y = torch.empty((d.N, d.Ho, d.Wo, d.Co), dtype=torch.float32, device=x.device)
     part = counts = info = None
+    if stats == "acc" and scale is None and residual is None and not relu:
+        acc = AccRef(d.Co, x.device)
+        check(lib().buctd_gconv_x6_fwd_acc(kind, d.N, d.H, d.W, d.Ci, d.Co, ptr(x), ptr(wp), ptr(bias), ptr(y),
+                                           C.c_void_p(acc.ptr), stream_ptr()), "gconv_x6_fwd_acc")
+        return y, acc, ("acc",)
     if stats:
         def groups():
             ng, rpg = C.c_int(), C.c_int()
@@ -522,8 +613,10 @@ def bn_in_fusable(x_shape, w):
 
 def conv_fwd(x, w, bias=None, stride=1, pad=0, scale=None, shift=None, residual=None, relu=False, stats=False,
              in_bn=None):
-    """in_bn = (mean, invstd, gamma, beta, relu): x is the raw output of the producing convolution and its BatchNorm
-    (+ReLU) is applied while the input is staged (only where bn_in_fusable() says so)."""
+    """in_bn = (mean, invstd, gamma, beta, relu) or a BnAccInput: x is the raw output of the producing convolution and its
+    BatchNorm (+ReLU) is applied while the input is staged (only where bn_in_fusable() says so).
+    stats: True -> (y, Welford partials, info) for bn_finalize; "acc" -> (y, AccRef, ("acc",)) where the kernel supports the
+    accumulator form (csrc/bn_acc.h: no finalize launch), the partials form elsewhere."""
     _f32(x, "conv input")
     weight_rsc(w)
     d = conv_desc(x.shape, _wshape(w), stride, pad)
@@ -854,6 +947,46 @@ def bn_finalize(part, info, rows, Cn, eps, momentum, running_mean, running_var):
     return mean, invstd
 
 
+class BnAccInput:
+    """The BatchNorm(+ReLU) of a producing layer whose statistics are still in its accumulator: the consumer derives
+    mean / invstd itself and its first workgroup writes them to `mean` / `invstd` (fresh [Cn] tensors kept for the backward
+    pass) and updates the running statistics.  Passed as conv_fwd(in_bn=...)."""
+
+    def __init__(self, acc, rows, bn, training=True, relu=True):
+        Cn = acc.Cn
+        dev = bn.weight.device
+        self.acc, self.rows, self.gamma, self.beta, self.relu = acc, int(rows), bn.weight, bn.bias, relu
+        self.eps = bn.eps
+        self.momentum = 0.1 if bn.momentum is None else bn.momentum
+        stat = torch.empty((2, Cn), dtype=torch.float32, device=dev)
+        self.mean, self.invstd = stat[0], stat[1]
+        track = bn.track_running_stats and training
+        self.rm = bn.running_mean if track else None
+        self.rv = bn.running_var if track else None
+
+    def struct(self):
+        st = _C.BnAccIn()
+        st.acc, st.rows, st.eps, st.momentum = self.acc.ptr, self.rows, self.eps, self.momentum
+        st.mean_out, st.invstd_out = self.mean.data_ptr(), self.invstd.data_ptr()
+        st.running_mean = self.rm.data_ptr() if self.rm is not None else None
+        st.running_var = self.rv.data_ptr() if self.rv is not None else None
+        return st
+
+
+def bn_apply_acc(z, bnin, residual=None, relu=False):
+    """y = act(bn(z) (+ residual)) with the statistics taken from bnin.acc; bnin.mean / bnin.invstd are filled on the way."""
+    Cn = z.shape[-1]
+    y = torch.empty_like(z)
+    st = bnin.struct()
+    check(lib().buctd_bn_apply_acc(ptr(z), C.byref(st), ptr(bnin.gamma), ptr(bnin.beta), ptr(residual), int(bool(relu)), ptr(y),
+                                   z.numel() // Cn, Cn, stream_ptr()), "bn_apply_acc")
+    return y
+
+
+def bn_acc_ok(Cn):
+    return Cn % 4 == 0 and Cn <= 1024
+
+
 def bn_stats(z):
     Cn = z.shape[-1]
     rows = z.numel() // Cn
@@ -872,16 +1005,25 @@ def bn_apply(z, mean, invstd, gamma, beta, residual=None, relu=False):
     return y
 
 
-def bn_bwd(dy, y, z, mean, invstd, gamma, relu, want_dres, dgamma, dbeta, accumulate, beta=None):
-    """y=None with relu: the ReLU mask is rebuilt from z, gamma and beta (forward without residual only)."""
+def bn_bwd(dy, y, z, mean, invstd, gamma, relu, want_dres, dgamma, dbeta, accumulate, beta=None, acc=None, acc_ready=False):
+    """y=None with relu: the ReLU mask is rebuilt from z, gamma and beta (forward without residual only).
+    acc / acc_ready: an accumulator that already holds the backward sums (formed by the data gradient that produced dy)."""
     Cn = z.shape[-1]
     rows = z.numel() // Cn
     dz = torch.empty_like(z)
     dres = torch.empty_like(z) if want_dres else None
-    need = lib().buctd_bn_bwd_workspace(rows, Cn)
-    ws = workspace(need, z.device)
     if relu and y is None and beta is None:
         raise _C.BuctdHipError("bn_bwd: ReLU backward needs the forward output or beta")
+    if bn_acc_ok(Cn):
+        # reduction into an integer accumulator, decoded by the apply kernel: two launches, no finalize in between
+        acc = acc if acc is not None else AccRef(Cn, z.device)
+        check(lib().buctd_bn_bwd_acc(ptr(dy), ptr(y) if relu else None, ptr(z), ptr(mean), ptr(invstd), ptr(gamma),
+                                     ptr(beta) if (relu and y is None) else None, int(bool(relu)), rows, Cn, ptr(dz), ptr(dres),
+                                     ptr(dgamma), ptr(dbeta), int(accumulate), C.c_void_p(acc.ptr), int(bool(acc_ready)),
+                                     stream_ptr()), "bn_bwd_acc")
+        return dz, dres
+    need = lib().buctd_bn_bwd_workspace(rows, Cn)
+    ws = workspace(need, z.device)
     check(lib().buctd_bn_bwd(ptr(dy), ptr(y) if relu else None, ptr(z), ptr(mean), ptr(invstd), ptr(gamma),
                              ptr(beta) if (relu and y is None) else None, int(bool(relu)), rows, Cn, ptr(dz), ptr(dres), ptr(dgamma), ptr(dbeta), int(accumulate),
                              ptr(ws), ws.numel(), stream_ptr()), "bn_bwd")
@@ -1186,17 +1328,22 @@ class ConvBnAct(torch.autograd.Function):
         if training or bn.running_mean is None:
             momentum = 0.1 if bn.momentum is None else bn.momentum
             if transposed_shape is None:
-                z, part, info = conv_fwd(x, conv_w, conv_b, stride, pad, stats=True)
+                z, part, info = conv_fwd(x, conv_w, conv_b, stride, pad, stats="acc")
             else:
-                z, part, info = conv_dgrad(x, conv_w, transposed_shape, stride, pad, bias=conv_b, stats=True)
+                z, part, info = conv_dgrad(x, conv_w, transposed_shape, stride, pad, bias=conv_b, stats="acc")
             Cn = z.shape[-1]
             rows = z.numel() // Cn
             track = bn.track_running_stats and training
-            mean, invstd = bn_finalize(part, info, rows, Cn, eps, momentum,
-                                       bn.running_mean if track else None, bn.running_var if track else None)
+            if info[0] == "acc":
+                bnin = BnAccInput(part, rows, bn, training)
+                y = bn_apply_acc(z, bnin, residual, relu)
+                mean, invstd = bnin.mean, bnin.invstd
+            else:
+                mean, invstd = bn_finalize(part, info, rows, Cn, eps, momentum,
+                                           bn.running_mean if track else None, bn.running_var if track else None)
+                y = bn_apply(z, mean, invstd, gamma, beta, residual, relu)
             if track:
                 bn.count_batch() if hasattr(bn, "count_batch") else bn.num_batches_tracked.add_(1)
-            y = bn_apply(z, mean, invstd, gamma, beta, residual, relu)
             ctx.has_res = residual is not None
             # without a residual the ReLU mask is rebuilt from z in the backward kernels: y is not kept (nor re-read)
             ctx.save_for_backward(x, z, mean, invstd, y if (relu and ctx.has_res) else None)
@@ -1383,27 +1530,37 @@ class BasicBlockFn(torch.autograd.Function):
         if (fuse and _NATIVE_BLOCK and bn_in_fusable(tuple(x.shape), w1) and bn1.track_running_stats == bn2.track_running_stats
                 and not (veto is not None and veto(tuple(x.shape)))):
             return BasicBlockFn._forward_native(ctx, x, w1, bn1, w2, bn2)
-        stats = []
-        for w, bn in ((w1, bn1), (w2, bn2)):
-            momentum = 0.1 if bn.momentum is None else bn.momentum
-            if w is w1:
-                z, part, info = conv_fwd(x, w, None, 1, 1, stats=True)
-            elif fuse:
-                z, part, info = conv_fwd(stats[0][0], w, None, 1, 1, stats=True,
-                                         in_bn=(stats[0][1], stats[0][2], bn1.weight, bn1.bias, True))
+        z1, part, info = conv_fwd(x, w1, None, 1, 1, stats="acc")
+        Cn = z1.shape[-1]
+        rows = z1.numel() // Cn
+        y1 = None
+        if info[0] == "acc":
+            # statistics as accumulators: the consumer of a BatchNorm decodes them, no finalize launch
+            bnin1 = BnAccInput(part, rows, bn1, True, relu=True)
+            if fuse:
+                z2, part2, info2 = conv_fwd(z1, w2, None, 1, 1, stats="acc", in_bn=bnin1)
             else:
-                z, part, info = conv_fwd(y1, w, None, 1, 1, stats=True)
-            Cn = z.shape[-1]
-            track = bn.track_running_stats
-            mean, invstd = bn_finalize(part, info, z.numel() // Cn, Cn, bn.eps, momentum,
-                                       bn.running_mean if track else None, bn.running_var if track else None)
-            if track:
+                y1 = bn_apply_acc(z1, bnin1, None, True)
+                z2, part2, info2 = conv_fwd(y1, w2, None, 1, 1, stats="acc")
+            bnin2 = BnAccInput(part2, rows, bn2, True)
+            y = bn_apply_acc(z2, bnin2, x, True)
+            mean1, invstd1, mean2, invstd2 = bnin1.mean, bnin1.invstd, bnin2.mean, bnin2.invstd
+        else:
+            def fin(bn, part, info):
+                track = bn.track_running_stats
+                return bn_finalize(part, info, rows, Cn, bn.eps, 0.1 if bn.momentum is None else bn.momentum,
+                                   bn.running_mean if track else None, bn.running_var if track else None)
+            mean1, invstd1 = fin(bn1, part, info)
+            if fuse:
+                z2, part2, info2 = conv_fwd(z1, w2, None, 1, 1, stats=True, in_bn=(mean1, invstd1, bn1.weight, bn1.bias, True))
+            else:
+                y1 = bn_apply(z1, mean1, invstd1, bn1.weight, bn1.bias, None, True)
+                z2, part2, info2 = conv_fwd(y1, w2, None, 1, 1, stats=True)
+            mean2, invstd2 = fin(bn2, part2, info2)
+            y = bn_apply(z2, mean2, invstd2, bn2.weight, bn2.bias, x, True)
+        for bn in (bn1, bn2):
+            if bn.track_running_stats:
                 bn.count_batch() if hasattr(bn, "count_batch") else bn.num_batches_tracked.add_(1)
-            stats.append((z, mean, invstd))
-            if w is w1 and not fuse:
-                y1 = bn_apply(z, mean, invstd, bn.weight, bn.bias, None, True)
-        (z1, mean1, invstd1), (z2, mean2, invstd2) = stats
-        y = bn_apply(z2, mean2, invstd2, bn2.weight, bn2.bias, x, True)
         ctx.meta = (w1, bn1, w2, bn2, fuse)
         ctx.save_for_backward(x, z1, mean1, invstd1, None if fuse else y1, z2, mean2, invstd2, y)
         return y
@@ -1414,14 +1571,7 @@ class BasicBlockFn(torch.autograd.Function):
         the step-by-step path cost ~95 us of host time per block - more than HRNet-W32 needs on the GPU."""
         N, H, W, Cn = x.shape
         dev = x.device
-        def groups():
-            ng, rpg = C.c_int(), C.c_int()
-            check(lib().buctd_conv3x3_bf16x6_stats_groups(N, H, W, Cn, Cn, C.byref(ng), C.byref(rpg)), "conv3x3 groups")
-            return ng.value, rpg.value
-        ng, rpg = _memo(("c3grp", "bf16x6", N, H, W, Cn, Cn), groups)
         act = torch.empty((3, N, H, W, Cn), dtype=torch.float32, device=dev)       # z1 | z2 | y
-        part = torch.empty((2, ng, Cn, 2), dtype=torch.float32, device=dev)
-        counts = torch.empty((2, ng), dtype=torch.int32, device=dev)
         stat = torch.empty((4, Cn), dtype=torch.float32, device=dev)               # mean1 | invstd1 | mean2 | invstd2
         d = _C.BasicBlockDesc()
         d.N, d.H, d.W, d.C = N, H, W, Cn
@@ -1438,7 +1588,7 @@ class BasicBlockFn(torch.autograd.Function):
         d.eps2, d.momentum2 = bn2.eps, 0.1 if bn2.momentum is None else bn2.momentum
         base, step = act.data_ptr(), 4 * N * H * W * Cn
         d.z1, d.z2, d.y = base, base + step, base + 2 * step
-        d.part, d.counts, d.ngroups, d.rows_per_group, d.stat = part.data_ptr(), counts.data_ptr(), ng, rpg, stat.data_ptr()
+        d.acc, d.stat = AccRef(Cn, dev, 2).ptr, stat.data_ptr()
         check(lib().buctd_basic_block_fwd_train(C.byref(d), stream_ptr()), "basic_block_fwd_train")
         if track:
             for bn in (bn1, bn2):
@@ -1484,8 +1634,7 @@ class BasicBlockFn(torch.autograd.Function):
         g.dw1, g.dw2 = dw1.data_ptr(), dw2.data_ptr()
         g.dgamma1, g.dbeta1, g.dgamma2, g.dbeta2 = dg1.data_ptr(), db1.data_ptr(), dg2.data_ptr(), db2.data_ptr()
         g.acc_w1, g.acc_w2, g.acc_bn1, g.acc_bn2 = int(acc_w1), int(acc_w2), int(acc_g1), int(acc_g2)
-        bn_ws = workspace(_memo(("bbws", N, H, W, Cn), lambda: int(lib().buctd_basic_block_bwd_workspace(N, H, W, Cn))), dev)
-        g.bn_ws, g.bn_ws_bytes = bn_ws.data_ptr(), bn_ws.numel()
+        g.bn_acc = AccRef(Cn, dev, 2).ptr
         main = torch.cuda.current_stream(dev)
         use_side = _side["on"]
         side = _side_stream(dev) if use_side else main
@@ -1547,18 +1696,12 @@ class BasicChainFn(torch.autograd.Function):
         n = len(blocks)
         N, H, W, Cn = x.shape
         dev = x.device
-        def groups():
-            ng, rpg = C.c_int(), C.c_int()
-            check(lib().buctd_conv3x3_bf16x6_stats_groups(N, H, W, Cn, Cn, C.byref(ng), C.byref(rpg)), "conv3x3 groups")
-            return ng.value, rpg.value
-        ng, rpg = _memo(("c3grp", "bf16x6", N, H, W, Cn, Cn), groups)
         act = torch.empty((n, 3, N, H, W, Cn), dtype=torch.float32, device=dev)        # per block: z1 | z2 | y
-        part = torch.empty((n, 2, ng, Cn, 2), dtype=torch.float32, device=dev)
-        counts = torch.empty((n, 2, ng), dtype=torch.int32, device=dev)
         stat = torch.empty((n, 4, Cn), dtype=torch.float32, device=dev)
         descs = (_C.BasicBlockDesc * n)()
         step = 4 * N * H * W * Cn
-        abase, pbase, cbase, sbase = act.data_ptr(), part.data_ptr(), counts.data_ptr(), stat.data_ptr()
+        accb = acc_bytes(Cn)
+        abase, pbase, sbase = act.data_ptr(), AccRef(Cn, dev, 2 * n).ptr, stat.data_ptr()
         xin = x.data_ptr()
         for k, (w1, bn1, w2, bn2) in enumerate(blocks):
             d = descs[k]
@@ -1577,8 +1720,7 @@ class BasicChainFn(torch.autograd.Function):
             d.eps2, d.momentum2 = bn2.eps, 0.1 if bn2.momentum is None else bn2.momentum
             b0 = abase + 3 * step * k
             d.z1, d.z2, d.y = b0, b0 + step, b0 + 2 * step
-            d.part, d.counts = pbase + k * 2 * ng * Cn * 8, cbase + k * 2 * ng * 4
-            d.ngroups, d.rows_per_group, d.stat = ng, rpg, sbase + k * 4 * Cn * 4
+            d.acc, d.stat = pbase + k * 2 * accb, sbase + k * 4 * Cn * 4
             xin = d.y
         check(lib().buctd_basic_chain_fwd_train(n, descs, stream_ptr()), "basic_chain_fwd_train")
         ctx.blocks = blocks
@@ -1602,7 +1744,8 @@ class BasicChainFn(torch.autograd.Function):
         main = torch.cuda.current_stream(dev)
         use_side = _side["on"]
         side = _side_stream(dev) if use_side else main
-        bn_ws = workspace(_memo(("bbws", N, H, W, Cn), lambda: int(lib().buctd_basic_block_bwd_workspace(N, H, W, Cn))), dev)
+        accb = acc_bytes(Cn)
+        bn_acc = AccRef(Cn, dev, 2 * n).ptr
         need = _memo(("wg3", "bf16x6", N, H, W, Cn, Cn),
                      lambda: (lib().buctd_conv3x3_wgrad_bf16x6_workspace(N, H, W, Cn, Cn)
                               if lib().buctd_conv3x3_wgrad_bf16x6_supported(N, H, W, Cn, Cn) == 1 else -1))
@@ -1636,7 +1779,7 @@ class BasicChainFn(torch.autograd.Function):
             g.dw1, g.dw2 = dw1.data_ptr(), dw2.data_ptr()
             g.dgamma1, g.dbeta1, g.dgamma2, g.dbeta2 = dg1.data_ptr(), db1.data_ptr(), dg2.data_ptr(), db2.data_ptr()
             g.acc_w1, g.acc_w2, g.acc_bn1, g.acc_bn2 = int(acc_w1), int(acc_w2), int(acc_g1), int(acc_g2)
-            g.bn_ws, g.bn_ws_bytes = bn_ws.data_ptr(), bn_ws.numel()
+            g.bn_acc = bn_acc + k * 2 * accb
             g.wg_ws, g.wg_ws_bytes = wg_ws.data_ptr(), wg_ws.numel()
         check(lib().buctd_basic_chain_bwd(n, descs, grads, main.cuda_stream, side.cuda_stream if use_side else None),
               "basic_chain_bwd")

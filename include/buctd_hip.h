@@ -100,6 +100,19 @@ int buctd_conv3x3_bf16x6_bnin(int N, int H, int W, int Ci, int Co, const float* 
 int buctd_conv3x3_bf16x6_bnstat(int N, int H, int W, int Ci, int Co, const float* x, const void* wprep, const float* residual,
                                 float* y, const float* bn_z, const float* bn_y, const float* bn_mean, const float* bn_invstd,
                                 const float* bn_gamma, const float* bn_beta, float* bn_part, void* stream);
+/* The accumulator forms (see "BatchNorm statistics without finalize launches" below).
+ * _acc: forward convolution whose output statistics are added to stats_acc (NULL: none) and whose input may be the raw
+ * output of the producing convolution, normalised while it is staged with THAT layer's statistics decoded from its
+ * accumulator (in_bn != NULL: with in_gamma / in_beta / in_relu; the launch's first tile writes mean / invstd out and updates
+ * the running statistics).  _bnstat_acc: buctd_conv3x3_bf16x6_bnstat with the sums added to the accumulator bn_acc. */
+struct buctd_bn_acc_in_;
+int buctd_conv3x3_bf16x6_acc(int N, int H, int W, int Ci, int Co, const float* x, const void* wprep, const float* residual,
+                             int relu, float* y, void* stats_acc, const struct buctd_bn_acc_in_* in_bn, const float* in_gamma,
+                             const float* in_beta, int in_relu, void* stream);
+int buctd_conv3x3_bf16x6_bnstat_acc(int N, int H, int W, int Ci, int Co, const float* x, const void* wprep,
+                                    const float* residual, float* y, const float* bn_z, const float* bn_y,
+                                    const float* bn_mean, const float* bn_invstd, const float* bn_gamma, const float* bn_beta,
+                                    void* bn_acc, void* stream);
 int buctd_conv3x3_bf16x3_supported(int N, int H, int W, int Ci, int Co);
 int buctd_conv3x3_bf16x3_stats_groups(int N, int H, int W, int Ci, int Co, int* ngroups, int* rows_per_group);
 size_t buctd_conv3x3_bf16x3_prep_bytes(int Ci, int Co, int flip);
@@ -183,6 +196,34 @@ int buctd_bn_bwd_from_partials(const float* dy, const float* y, const float* z, 
                                const float* gamma, const float* beta, int relu, long rows, int C, const float* part,
                                int nparts, float* dz, float* dres, float* dgamma, float* dbeta, int accumulate,
                                void* workspace, size_t workspace_bytes, void* stream);
+/* ---- BatchNorm statistics without finalize launches (csrc/bn_acc.h) ----
+ * The kernel that produces a tensor reduces it to one pair of sums per workgroup and channel and adds the pair into an
+ * ACCUMULATOR with integer atomics (fixed point, two 64-bit limbs per sum: order-independent, so bit-deterministic); the
+ * kernel that consumes the statistics decodes two numbers per channel in its prologue.  Nothing is launched between the
+ * two (the mean/var reduction of native_batch_norm and the sum reductions of native_batch_norm_backward,
+ * pose_hrnet.py:41-57, as by-products of their neighbours).  An accumulator is buctd_bn_acc_bytes(C) bytes and must be ZERO
+ * when its producer is launched.
+ * buctd_bn_acc_in: how a consumer takes FORWARD statistics from an accumulator holding (sum z, sum z^2) over `rows` values per
+ * channel: it derives mean / invstd (biased variance, eps) itself; ONE workgroup of the launch also writes them to
+ * mean_out / invstd_out ([C] each: what the backward kernels read) and updates running_mean / running_var (NULL: not
+ * tracked) with `momentum` and the unbiased variance, like nn.BatchNorm2d in train mode. */
+size_t buctd_bn_acc_bytes(int C);
+typedef struct buctd_bn_acc_in_ {
+  const void* acc;
+  long rows;
+  float eps, momentum;
+  float *mean_out, *invstd_out;
+  float *running_mean, *running_var;
+} buctd_bn_acc_in;
+/* buctd_bn_apply with the statistics taken from an accumulator (C % 4 == 0) */
+int buctd_bn_apply_acc(const float* z, const buctd_bn_acc_in* st, const float* gamma, const float* beta,
+                       const float* residual, int relu, float* y, long rows, int C, void* stream);
+/* buctd_bn_bwd on an accumulator of the backward sums (sum g, sum g zhat): acc_ready = 0 runs the streaming reduction into
+ * `acc` (zero on entry) first; acc_ready = 1: the data gradient that produced dy already filled it
+ * (buctd_conv3x3_bf16x6_bnstat_acc).  The apply kernel decodes the sums and writes dgamma / dbeta.  C % 4 == 0, C <= 1024. */
+int buctd_bn_bwd_acc(const float* dy, const float* y, const float* z, const float* mean, const float* invstd,
+                     const float* gamma, const float* beta, int relu, long rows, int C, float* dz, float* dres,
+                     float* dgamma, float* dbeta, int accumulate, void* acc, int acc_ready, void* stream);
 /* eval-mode helpers: scale = gamma/sqrt(var+eps), shift = beta - mean*scale */
 int buctd_bn_fold(const float* gamma, const float* beta, const float* running_mean, const float* running_var,
                   float eps, int C, float* scale, float* shift, void* stream);
@@ -320,17 +361,21 @@ int buctd_gconv_x6_stats_groups(int kind, int N, int H, int W, int Ci, int Co, i
 int buctd_gconv_x6_fwd(int kind, int N, int H, int W, int Ci, int Co, const float* x, const void* wprep, const float* bias,
                        const float* scale, const float* shift, const float* residual, int relu, float* y,
                        float* stats_partials, int* stats_counts, void* stream);
+/* forward with the output statistics added to an accumulator (buctd_bn_acc_bytes(Co), zero on entry) instead of partials */
+int buctd_gconv_x6_fwd_acc(int kind, int N, int H, int W, int Ci, int Co, const float* x, const void* wprep, const float* bias,
+                           float* y, void* stats_acc, void* stream);
 int buctd_gconv_x6_dgrad(int kind, int N, int H, int W, int Ci, int Co, const float* dy, const void* wprep,
                          const float* residual, float* dx, void* stream);
 
 /* ------------------------------------------------------- BasicBlock sequences --- */
 /* The kernel sequence of one residual BasicBlock in train mode (pose_hrnet.py:28-57: stride 1, C -> C, no downsample,
- * bf16x6 math) behind ONE call per direction: conv1 + statistics, finalize, conv2 with bn1 + ReLU applied in its input
- * staging + statistics, finalize, bn2 + skip + ReLU - and the mirrored backward with the two weight gradients on
- * `side_stream` (NULL: same stream).  Pure launch sequences of the entry points above (bit-identical results); they
- * exist because nine calls per block through a Python binding cost more host time than HRNet-W32 needs GPU time.
- * part: 2 * ngroups * C * 2 floats, counts: 2 * ngroups ints (buctd_conv3x3_bf16x6_stats_groups), stat: 4 * C floats
- * receiving mean1, invstd1, mean2, invstd2 (saved for the backward).  running_* may be NULL. */
+ * bf16x6 math) behind ONE call per direction: conv1 (+ statistics), conv2 with bn1 + ReLU applied in its input staging
+ * (+ statistics), bn2 + skip + ReLU - three launches, the BatchNorm statistics travel as accumulators (no finalize) - and
+ * the mirrored backward (two BatchNorm-backward applies, two data gradients that also form the BatchNorm sums, two weight
+ * gradients on `side_stream`; NULL: same stream).  Pure launch sequences of the entry points above (bit-identical
+ * results); they exist because a dozen calls per block through a Python binding cost more host time than HRNet-W32 needs
+ * GPU time.  acc: 2 * buctd_bn_acc_bytes(C) ZEROED bytes (forward statistics of conv1 | conv2); stat: 4 * C floats receiving
+ * mean1, invstd1, mean2, invstd2 (saved for the backward).  running_* may be NULL. */
 typedef struct {
   int N, H, W, C;
   const float* x;
@@ -340,9 +385,7 @@ typedef struct {
   float *running_mean1, *running_var1, *running_mean2, *running_var2;
   float eps1, momentum1, eps2, momentum2;
   float *z1, *z2, *y;
-  float* part;
-  int* counts;
-  int ngroups, rows_per_group;
+  void* acc;
   float* stat;
 } buctd_basic_block;
 typedef struct {
@@ -351,11 +394,9 @@ typedef struct {
   float* dx;                            /* NULL: the block input needs no gradient */
   float *dw1, *dw2, *dgamma1, *dbeta1, *dgamma2, *dbeta2;
   int acc_w1, acc_w2, acc_bn1, acc_bn2; /* accumulate into (1) or overwrite (0) the gradient buffers */
-  void* bn_ws; size_t bn_ws_bytes;      /* buctd_basic_block_bwd_workspace, used on `stream` */
+  void* bn_acc;                         /* 2 * buctd_bn_acc_bytes(C) ZEROED bytes: backward sums of bn1 | bn2 */
   void* wg_ws; size_t wg_ws_bytes;      /* buctd_conv3x3_wgrad_bf16x6_workspace, used on `side_stream` */
 } buctd_basic_block_grads;
-/* bytes of buctd_basic_block_grads::bn_ws for a block of this shape (>= buctd_bn_bwd_workspace) */
-size_t buctd_basic_block_bwd_workspace(int N, int H, int W, int C);
 int buctd_basic_block_fwd_train(const buctd_basic_block* b, void* stream);
 int buctd_basic_block_bwd(const buctd_basic_block* b, const buctd_basic_block_grads* g, void* stream, void* side_stream);
 /* n chained blocks (an HRNet branch, pose_hrnet.py:165-185) behind one call per direction: blocks[k].x = blocks[k-1].y,
