@@ -651,21 +651,45 @@ static long bwd2_blocks(long rows, long* rows_per_block) {
 // itself (C x 256 B from L2), workgroup 0 also leaves them in the form later kernels read (mean / invstd for the backward
 // pass, running statistics, dgamma / dbeta).  The per-element arithmetic is that of bn_apply_kernel / bn_bwd_apply_kernel.
 
-// grid: few, fat workgroups - each one pays the C-channel prologue, so at least 16 float4 per thread
-static int acc_grid(long n4) {
-  long b = (n4 + 256 * 16 - 1) / (256 * 16);
-  if (b > 1024) b = 1024;
+// grid: every workgroup pays the prologue (32 C bytes of accumulator words from L2 per 256 threads, one round trip, a few fp64
+// operations, two barriers), so at least 4 float4 per thread - and at most ONE round of 8 resident workgroups per CU
+// (<= 64 registers), whose prologues overlap each other's streaming
+static int acc_grid(long n4, int per_cu = 8) {
+  long b = (n4 + 256 * 4 - 1) / (256 * 4);
+  if (b > 256 * per_cu) b = 256 * per_cu;
   if (b < 1) b = 1;
   return (int)b;
 }
 
-// y = act((z - mean) * (invstd * gamma) + beta (+ residual)); LDS: [3][C] floats
-__global__ __launch_bounds__(256) void bn_apply_acc_kernel(const float* __restrict__ z, BnAccFwd a, const float* __restrict__ gamma,
-                                                           const float* __restrict__ beta, const float* __restrict__ res,
-                                                           int relu, float* __restrict__ y, long total, int C) {
-  extern __shared__ float tab[];
+// y = act((z - mean) * (invstd * gamma) + beta (+ residual)); LDS: [4][C] accumulator words | [3][C] floats
+__global__ __launch_bounds__(256, 8) void bn_apply_acc_kernel(const float* __restrict__ z, BnAccFwd a,
+                                                              const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                              const float* __restrict__ res, int relu, float* __restrict__ y,
+                                                              long total, int C) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+  long long* wsum = reinterpret_cast<long long*>(lds_raw);
+  float* tab = reinterpret_cast<float*>(lds_raw + (size_t)BNACC_WORDS * C * sizeof(long long));
+  const long n4 = total >> 2;
+  const long step = (long)gridDim.x * 256;
+  // the first elements are on their way from HBM while the statistics are decoded
+  long i = (long)blockIdx.x * 256 + threadIdx.x;
+  f32x4 v0 = (f32x4){0.f, 0.f, 0.f, 0.f}, v1 = v0, r0 = v0, r1 = v0;
+  auto fetch = [&](long j) {
+    if (j < n4) {
+      v0 = reinterpret_cast<const f32x4*>(z)[j];
+      if (res) r0 = reinterpret_cast<const f32x4*>(res)[j];
+    }
+    if (j + step < n4) {
+      v1 = reinterpret_cast<const f32x4*>(z)[j + step];
+      if (res) r1 = reinterpret_cast<const f32x4*>(res)[j + step];
+    }
+  };
+  fetch(i);
+  bnacc_gather_lds(a.acc, C, wsum);
   for (int c = threadIdx.x; c < C; c += 256) {
-    const BnFwdStat st = bnacc_fwd_stat(a.acc, C, c, a.rows, a.eps);
+    double s1, s2;
+    bnacc_read_lds(wsum, C, c, &s1, &s2);
+    const BnFwdStat st = bnacc_fwd_stat_sums(s1, s2, a.rows, a.eps);
     tab[c] = st.mean;
     tab[C + c] = st.invstd * gamma[c];
     tab[2 * C + c] = beta[c];
@@ -676,29 +700,30 @@ __global__ __launch_bounds__(256) void bn_apply_acc_kernel(const float* __restri
     }
   }
   __syncthreads();
-  const long n4 = total >> 2;
-  const long step = (long)gridDim.x * 256;
   const int dc = (int)((step * 4) % C);
-  int c = (int)((((long)blockIdx.x * 256 + threadIdx.x) * 4) % C) - dc;
-  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += step) {
-    c += dc;
-    if (c >= C) c -= C;
-    const f32x4 v = reinterpret_cast<const f32x4*>(z)[i];
-    const f32x4 mu = *reinterpret_cast<const f32x4*>(tab + c);
-    const f32x4 sc = *reinterpret_cast<const f32x4*>(tab + C + c);
-    const f32x4 be = *reinterpret_cast<const f32x4*>(tab + 2 * C + c);
+  int c = (int)((i * 4) % C) - dc;
+  auto one = [&](long j, int cc, f32x4 v, f32x4 r) {
+    const f32x4 mu = *reinterpret_cast<const f32x4*>(tab + cc);
+    const f32x4 sc = *reinterpret_cast<const f32x4*>(tab + C + cc);
+    const f32x4 be = *reinterpret_cast<const f32x4*>(tab + 2 * C + cc);
     f32x4 o;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) o[j] = (v[j] - mu[j]) * sc[j] + be[j];
-    if (res) {
-      const f32x4 r = reinterpret_cast<const f32x4*>(res)[i];
-      o += r;
-    }
+    for (int j4 = 0; j4 < 4; ++j4) o[j4] = (v[j4] - mu[j4]) * sc[j4] + be[j4];
+    if (res) o += r;
     if (relu) {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) o[j] = fmaxf(o[j], 0.f);
+      for (int j4 = 0; j4 < 4; ++j4) o[j4] = fmaxf(o[j4], 0.f);
     }
-    reinterpret_cast<f32x4*>(y)[i] = o;
+    reinterpret_cast<f32x4*>(y)[j] = o;
+  };
+  for (; i < n4; i += 2 * step) {       // two elements per trip: their loads are in flight together
+    c += dc;
+    if (c >= C) c -= C;
+    one(i, c, v0, r0);
+    c += dc;
+    if (c >= C) c -= C;
+    if (i + step < n4) one(i + step, c, v1, r1);
+    fetch(i + 2 * step);
   }
 }
 
@@ -725,8 +750,8 @@ extern "C" int buctd_bn_apply_acc(const float* z, const buctd_bn_acc_in* st, con
   if (rc) return rc;
   BUCTD_CHECK_ARG(st->rows == rows, "buctd_bn_apply_acc: the statistics cover %ld rows, the tensor has %ld", st->rows, rows);
   const long total = rows * C;
-  hipLaunchKernelGGL(bn_apply_acc_kernel, dim3(acc_grid(total / 4)), dim3(256), (size_t)3 * C * sizeof(float), (hipStream_t)stream,
-                     z, acc_in(st), gamma, beta, residual, relu, y, total, C);
+  hipLaunchKernelGGL(bn_apply_acc_kernel, dim3(acc_grid(total / 4)), dim3(256), (size_t)(BNACC_WORDS * 8 + 3 * 4) * C,
+                     (hipStream_t)stream, z, acc_in(st), gamma, beta, residual, relu, y, total, C);
   BUCTD_CHECK_LAUNCH("buctd_bn_apply_acc");
   return BUCTD_OK;
 }
@@ -793,24 +818,51 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_acc_kernel(const float* __r
       s1 += sm[0][k * c4n + tc];
       s2 += sm[1][k * c4n + tc];
     }
-#pragma unroll
-    for (int j = 0; j < 4; ++j) bnacc_add(acc, C, blockIdx.x, tc * 4 + j, (double)s1[j], (double)s2[j]);
+    sm[0][tc] = s1;
+    sm[1][tc] = s2;
   }
+  __syncthreads();
+  // lane = channel: one atomic instruction covers a contiguous run of words (bn_acc.h)
+  const unsigned shard = bnacc_shard();
+  for (int c = threadIdx.x; c < C; c += 256)
+    bnacc_add(acc, C, shard, c, (double)reinterpret_cast<const float*>(&sm[0][0])[c], (double)reinterpret_cast<const float*>(&sm[1][0])[c]);
 }
 
-// dz = gamma * invstd * (g - s1 / M - zhat * s2 / M); dres = g.  LDS: [6][C] floats (mean, invstd, gamma, beta, s1, s2)
-__global__ __launch_bounds__(256) void bn_bwd_apply_acc_kernel(const float* __restrict__ dy, const float* __restrict__ y,
-                                                               const float* __restrict__ z, const float* __restrict__ mean,
-                                                               const float* __restrict__ invstd,
-                                                               const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                               const long long* __restrict__ acc, int relu, long total, int C,
-                                                               float inv_rows, float* __restrict__ dz, float* __restrict__ dres,
-                                                               float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                                               int accumulate) {
-  extern __shared__ float tab[];
+// dz = gamma * invstd * (g - s1 / M - zhat * s2 / M); dres = g.  LDS: [4][C] accumulator words | [6][C] floats (mean, invstd,
+// gamma, beta, s1, s2)
+__global__ __launch_bounds__(256, 6) void bn_bwd_apply_acc_kernel(const float* __restrict__ dy, const float* __restrict__ y,
+                                                                  const float* __restrict__ z, const float* __restrict__ mean,
+                                                                  const float* __restrict__ invstd,
+                                                                  const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                  const long long* __restrict__ acc, int relu, long total, int C,
+                                                                  float inv_rows, float* __restrict__ dz, float* __restrict__ dres,
+                                                                  float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                                  int accumulate) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+  long long* wsum = reinterpret_cast<long long*>(lds_raw);
+  float* tab = reinterpret_cast<float*>(lds_raw + (size_t)BNACC_WORDS * C * sizeof(long long));
+  const long n4 = total >> 2;
+  const long step = (long)gridDim.x * 256;
+  const bool ld_y = relu && y;
+  long i = (long)blockIdx.x * 256 + threadIdx.x;
+  f32x4 g0 = (f32x4){0.f, 0.f, 0.f, 0.f}, g1 = g0, z0 = g0, z1 = g0, y0 = g0, y1 = g0;
+  auto fetch = [&](long j) {
+    if (j < n4) {
+      g0 = reinterpret_cast<const f32x4*>(dy)[j];
+      z0 = reinterpret_cast<const f32x4*>(z)[j];
+      if (ld_y) y0 = reinterpret_cast<const f32x4*>(y)[j];
+    }
+    if (j + step < n4) {
+      g1 = reinterpret_cast<const f32x4*>(dy)[j + step];
+      z1 = reinterpret_cast<const f32x4*>(z)[j + step];
+      if (ld_y) y1 = reinterpret_cast<const f32x4*>(y)[j + step];
+    }
+  };
+  fetch(i);       // in flight while the sums are decoded
+  bnacc_gather_lds(acc, C, wsum);
   for (int c = threadIdx.x; c < C; c += 256) {
     double s1, s2;
-    bnacc_read(acc, C, c, &s1, &s2);
+    bnacc_read_lds(wsum, C, c, &s1, &s2);
     tab[c] = mean[c];
     tab[C + c] = invstd[c];
     tab[2 * C + c] = gamma[c];
@@ -823,43 +875,44 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_acc_kernel(const float* __re
     }
   }
   __syncthreads();
-  const long n4 = total >> 2;
-  const long step = (long)gridDim.x * 256;
   const int dc = (int)((step * 4) % C);
-  int c = (int)((((long)blockIdx.x * 256 + threadIdx.x) * 4) % C) - dc;
-  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += step) {
-    c += dc;
-    if (c >= C) c -= C;
-    f32x4 g = reinterpret_cast<const f32x4*>(dy)[i];
-    const f32x4 zz = reinterpret_cast<const f32x4*>(z)[i];
-    const f32x4 mu = *reinterpret_cast<const f32x4*>(tab + c);
-    const f32x4 is = *reinterpret_cast<const f32x4*>(tab + C + c);
-    const f32x4 ga = *reinterpret_cast<const f32x4*>(tab + 2 * C + c);
+  int c = (int)((i * 4) % C) - dc;
+  auto one = [&](long j, int cc, f32x4 g, f32x4 zz, f32x4 yy) {
+    const f32x4 mu = *reinterpret_cast<const f32x4*>(tab + cc);
+    const f32x4 is = *reinterpret_cast<const f32x4*>(tab + C + cc);
+    const f32x4 ga = *reinterpret_cast<const f32x4*>(tab + 2 * C + cc);
     if (relu) {
-      f32x4 yy;
-      if (y) yy = reinterpret_cast<const f32x4*>(y)[i];
-      else {
-        const f32x4 be = *reinterpret_cast<const f32x4*>(tab + 3 * C + c);
+      if (!y) {
+        const f32x4 be = *reinterpret_cast<const f32x4*>(tab + 3 * C + cc);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const float sc = is[j] * ga[j];
-          yy[j] = (zz[j] - mu[j]) * sc + be[j];
+        for (int j4 = 0; j4 < 4; ++j4) {
+          const float sc = is[j4] * ga[j4];
+          yy[j4] = (zz[j4] - mu[j4]) * sc + be[j4];
         }
       }
 #pragma unroll
-      for (int j = 0; j < 4; ++j)
-        if (!(yy[j] > 0.f)) g[j] = 0.f;
+      for (int j4 = 0; j4 < 4; ++j4)
+        if (!(yy[j4] > 0.f)) g[j4] = 0.f;
     }
-    const f32x4 s1 = *reinterpret_cast<const f32x4*>(tab + 4 * C + c);
-    const f32x4 s2 = *reinterpret_cast<const f32x4*>(tab + 5 * C + c);
+    const f32x4 s1 = *reinterpret_cast<const f32x4*>(tab + 4 * C + cc);
+    const f32x4 s2 = *reinterpret_cast<const f32x4*>(tab + 5 * C + cc);
     f32x4 o;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const float zh = (zz[j] - mu[j]) * is[j];
-      o[j] = ga[j] * is[j] * (g[j] - s1[j] * inv_rows - zh * s2[j] * inv_rows);
+    for (int j4 = 0; j4 < 4; ++j4) {
+      const float zh = (zz[j4] - mu[j4]) * is[j4];
+      o[j4] = ga[j4] * is[j4] * (g[j4] - s1[j4] * inv_rows - zh * s2[j4] * inv_rows);
     }
-    reinterpret_cast<f32x4*>(dz)[i] = o;
-    if (dres) reinterpret_cast<f32x4*>(dres)[i] = g;
+    reinterpret_cast<f32x4*>(dz)[j] = o;
+    if (dres) reinterpret_cast<f32x4*>(dres)[j] = g;
+  };
+  for (; i < n4; i += 2 * step) {       // two elements per trip: their loads are in flight together
+    c += dc;
+    if (c >= C) c -= C;
+    one(i, c, g0, z0, y0);
+    c += dc;
+    if (c >= C) c -= C;
+    if (i + step < n4) one(i + step, c, g1, z1, y1);
+    fetch(i + 2 * step);
   }
 }
 
@@ -882,7 +935,7 @@ extern "C" int buctd_bn_bwd_acc(const float* dy, const float* y, const float* z,
     BUCTD_CHECK_LAUNCH("buctd_bn_bwd_acc(reduce)");
   }
   const long total = rows * C;
-  hipLaunchKernelGGL(bn_bwd_apply_acc_kernel, dim3(acc_grid(total / 4)), dim3(256), (size_t)6 * C * sizeof(float), st, dy, y, z,
+  hipLaunchKernelGGL(bn_bwd_apply_acc_kernel, dim3(acc_grid(total / 4, 6)), dim3(256), (size_t)(BNACC_WORDS * 8 + 6 * 4) * C, st, dy, y, z,
                      mean, invstd, gamma, beta, (const long long*)acc, relu, total, C, 1.0f / (float)rows, dz, dres, dgamma, dbeta,
                      accumulate);
   BUCTD_CHECK_LAUNCH("buctd_bn_bwd_acc(apply)");

@@ -19,10 +19,10 @@
 // rms ~1e-5.
 //
 // Contention: every workgroup of a launch adds into the same few words at the same time; one word takes ~20 ns per atomic
-// (scratch/ubench/atomic_fanin.hip: 506 workgroups x 96 words = +10 us on one copy, +0.6 us on 8 copies).  BNACC_SHARDS
-// copies, selected by the workgroup index, are summed (exactly) by the consumer.
+// (scratch/ubench/atomic_fanin.hip: 506 workgroups x 96 words = +10 us on one copy, +0.6 us on 8 copies, one per XCD).
+// BNACC_SHARDS copies, selected by the XCD a workgroup runs on, are summed (exactly) by the consumer.
 //
-// Layout: long long acc[BNACC_SHARDS][C][4] = {s1 lo, s1 hi, s2 lo, s2 hi}; must be zero before the producer launch
+// Layout: long long acc[BNACC_SHARDS][4][C], word kinds {s1 lo, s1 hi, s2 lo, s2 hi}; must be zero before the producer launch
 // (the host hands out slices of a zeroed pool, ops.py: _AccPool).
 #pragma once
 #include "common.h"
@@ -32,24 +32,37 @@
 
 __host__ __device__ static inline size_t bnacc_bytes(int C) { return (size_t)BNACC_SHARDS * C * BNACC_WORDS * sizeof(long long); }
 
-// one sum into the pair of limbs at w (w[0] lo, w[1] hi)
-__device__ __forceinline__ void bnacc_add1(long long* w, double v) {
+// one sum into its pair of limbs (lo at w_lo, hi at w_hi)
+__device__ __forceinline__ void bnacc_add1(long long* w_lo, long long* w_hi, double v) {
   if (!(fabs(v) < 0x1p46)) {        // out of range or NaN: poison
-    __hip_atomic_fetch_max(w + 1, (long long)1 << 61, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_fetch_max(w_hi, (long long)1 << 61, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     return;
   }
   const double h = trunc(v);
   const long long ih = (long long)h;
   const long long il = (long long)rint((v - h) * 0x1p48);     // v - h is exact, |.| < 1
-  if (il) __hip_atomic_fetch_add(w, il, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  if (ih) __hip_atomic_fetch_add(w + 1, ih, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (il) __hip_atomic_fetch_add(w_lo, il, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (ih) __hip_atomic_fetch_add(w_hi, ih, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// workgroup `shard_id` (any integer: its low bits pick the copy) adds the pair (s1, s2) of channel c
-__device__ __forceinline__ void bnacc_add(long long* acc, int C, unsigned shard_id, int c, double s1, double s2) {
-  long long* w = acc + ((size_t)(shard_id % BNACC_SHARDS) * C + c) * BNACC_WORDS;
-  bnacc_add1(w, s1);
-  bnacc_add1(w + 2, s2);
+// The copy a workgroup adds into: the XCD it runs on.  Atomics of ONE XCD on a word are served at that XCD's L2 rate; words
+// that workgroups of different XCDs hit at the same time are serialised across the fabric (measured in the train step: shards
+// picked by tile index cost 14-24 us per convolution launch, by XCD nothing measurable).  Any choice is correct - the
+// consumer sums all copies exactly - only the speed depends on it.
+__device__ __forceinline__ unsigned bnacc_shard() {
+  unsigned x;
+  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(x));
+  return x & (BNACC_SHARDS - 1);
+}
+
+// this workgroup adds the pair (s1, s2) of channel c.  Call it with CONSECUTIVE lanes on consecutive channels: the words of
+// one kind are contiguous over the channels, so a wavefront's atomic instruction is a few cache-line requests (the L2 serves
+// atomic requests to one line one after the other, ~10 ns each: with a lane's four words side by side every lane was its own
+// request - 192 requests per workgroup of the BatchNorm-backward reduction, +20 us on a 25 us kernel).
+__device__ __forceinline__ void bnacc_add(long long* acc, int C, unsigned shard, int c, double s1, double s2) {
+  long long* w = acc + (size_t)shard * BNACC_WORDS * C + c;
+  bnacc_add1(w, w + C, s1);
+  bnacc_add1(w + 2 * C, w + 3 * C, s2);
 }
 
 __device__ __forceinline__ double bnacc_decode(long long lo, long long hi) {
@@ -59,26 +72,51 @@ __device__ __forceinline__ double bnacc_decode(long long lo, long long hi) {
 
 // the two sums of channel c
 __device__ __forceinline__ void bnacc_read(const long long* __restrict__ acc, int C, int c, double* s1, double* s2) {
-  typedef long long ll2 __attribute__((ext_vector_type(2)));
-  ll2 a = {0, 0}, b = {0, 0};
+  long long w[BNACC_WORDS] = {0, 0, 0, 0};
   bool bad = false;
 #pragma unroll
   for (int sh = 0; sh < BNACC_SHARDS; ++sh) {
-    const ll2* p = reinterpret_cast<const ll2*>(acc + ((size_t)sh * C + c) * BNACC_WORDS);
-    const ll2 u = p[0], v = p[1];
-    bad |= u.y >= ((long long)1 << 60) || v.y >= ((long long)1 << 60);
-    a += u;
-    b += v;
+    const long long* p = acc + (size_t)sh * BNACC_WORDS * C + c;
+    long long u[BNACC_WORDS];
+#pragma unroll
+    for (int k = 0; k < BNACC_WORDS; ++k) u[k] = p[(size_t)k * C];
+    bad |= u[1] >= ((long long)1 << 60) || u[3] >= ((long long)1 << 60);
+#pragma unroll
+    for (int k = 0; k < BNACC_WORDS; ++k) w[k] += u[k];
   }
-  *s1 = bad ? __builtin_nan("") : bnacc_decode(a.x, a.y);
-  *s2 = bad ? __builtin_nan("") : bnacc_decode(b.x, b.y);
+  *s1 = bad ? __builtin_nan("") : bnacc_decode(w[0], w[1]);
+  *s2 = bad ? __builtin_nan("") : bnacc_decode(w[2], w[3]);
+}
+
+struct BnFwdStat { float mean, invstd; double mu, m2; };
+
+// The same for a whole workgroup: all 256 threads fetch the BNACC_SHARDS * 4 * C words (coalesced 8-byte loads, a handful per
+// thread instead of 32 in the threads of C channels) and add them - exactly - into wsum[4][C] in LDS.  Ends with a barrier;
+// bnacc_read_lds then decodes a channel.  (A poisoned copy keeps the sum above the poison threshold: the other copies are
+// below 2^59 in magnitude each.)
+__device__ __forceinline__ void bnacc_gather_lds(const long long* __restrict__ acc, int C, long long* wsum) {
+  const int n = BNACC_WORDS * C;
+  for (int k = threadIdx.x; k < n; k += 256) wsum[k] = 0;
+  __syncthreads();
+  for (int k = threadIdx.x; k < n; k += 256) {
+    long long v[BNACC_SHARDS];
+#pragma unroll
+    for (int sh = 0; sh < BNACC_SHARDS; ++sh) v[sh] = acc[(size_t)sh * n + k];
+    long long t = 0;
+#pragma unroll
+    for (int sh = 0; sh < BNACC_SHARDS; ++sh) t += v[sh];
+    wsum[k] = t;
+  }
+  __syncthreads();
+}
+__device__ __forceinline__ void bnacc_read_lds(const long long* wsum, int C, int c, double* s1, double* s2) {
+  *s1 = bnacc_decode(wsum[c], wsum[C + c]);
+  *s2 = bnacc_decode(wsum[2 * C + c], wsum[3 * C + c]);
 }
 
 // forward statistics of channel c from (sum z, sum z^2) over `rows` values: the arithmetic of bn_finalize_kernel
-struct BnFwdStat { float mean, invstd; double mu, m2; };
-__device__ __forceinline__ BnFwdStat bnacc_fwd_stat(const long long* __restrict__ acc, int C, int c, double rows, float eps) {
-  double s1, s2;
-  bnacc_read(acc, C, c, &s1, &s2);
+__device__ __forceinline__ BnFwdStat bnacc_fwd_stat_sums(double s1, double s2, double rows, float eps);
+__device__ __forceinline__ BnFwdStat bnacc_fwd_stat_sums(double s1, double s2, double rows, float eps) {
   BnFwdStat r;
   r.mu = s1 / rows;
   double m2 = s2 - s1 * r.mu;
@@ -88,6 +126,12 @@ __device__ __forceinline__ BnFwdStat bnacc_fwd_stat(const long long* __restrict_
   r.mean = (float)r.mu;
   r.invstd = (float)(1.0 / sqrt(var + (double)eps));
   return r;
+}
+
+__device__ __forceinline__ BnFwdStat bnacc_fwd_stat(const long long* __restrict__ acc, int C, int c, double rows, float eps) {
+  double s1, s2;
+  bnacc_read(acc, C, c, &s1, &s2);
+  return bnacc_fwd_stat_sums(s1, s2, rows, eps);
 }
 
 // running statistics, as bn_finalize_kernel updates them (unbiased variance)

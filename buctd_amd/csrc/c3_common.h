@@ -230,7 +230,7 @@ __device__ __forceinline__ void c3_epilogue(const C3Args& p, f32x4 (&acc)[MF][NF
           a1 += v.x;
           a2 += v.y;
         }
-        bnacc_add(p.stats_acc, p.Co, (unsigned)(bx + by), n0 + t, a1, a2);
+        bnacc_add(p.stats_acc, p.Co, bnacc_shard(), n0 + t, a1, a2);
       }
     }
   }
@@ -372,7 +372,7 @@ __device__ __forceinline__ void c3_epilogue(const C3Args& p, f32x4 (&acc)[MF][NF
           a1 += v.x;
           a2 += v.y;
         }
-        bnacc_add(p.bs_acc, p.Co, (unsigned)(bx + by), n0 + t, a1, a2);
+        bnacc_add(p.bs_acc, p.Co, bnacc_shard(), n0 + t, a1, a2);
       }
     }
   }
