@@ -44,6 +44,33 @@ class BnAccIn(C.Structure):            # mirrors buctd_bn_acc_in
                 ("running_var", C.c_void_p)]
 
 
+class C3Conv(C.Structure):             # mirrors buctd_c3_conv
+    _fields_ = ([(n, C.c_int) for n in ("N", "H", "W", "Ci", "Co")] +
+                [(n, C.c_void_p) for n in ("x", "wprep", "residual")] + [("relu", C.c_int)] +
+                [(n, C.c_void_p) for n in ("y", "stats_acc")] + [("in_bn", C.POINTER(BnAccIn))] +
+                [(n, C.c_void_p) for n in ("in_gamma", "in_beta")] + [("in_relu", C.c_int)] +
+                [(n, C.c_void_p) for n in ("bn_z", "bn_y", "bn_mean", "bn_invstd", "bn_gamma", "bn_beta", "bn_acc")])
+
+
+class BnApplyItem(C.Structure):        # mirrors buctd_bn_apply_item
+    _fields_ = [("z", C.c_void_p), ("st", BnAccIn), ("gamma", C.c_void_p), ("beta", C.c_void_p), ("residual", C.c_void_p),
+                ("relu", C.c_int), ("y", C.c_void_p), ("rows", C.c_long), ("C", C.c_int)]
+
+
+class BnBwdItem(C.Structure):          # mirrors buctd_bn_bwd_item
+    _fields_ = ([(n, C.c_void_p) for n in ("dy", "y", "z", "mean", "invstd", "gamma", "beta")] +
+                [("relu", C.c_int), ("rows", C.c_long), ("C", C.c_int)] +
+                [(n, C.c_void_p) for n in ("dz", "dres", "dgamma", "dbeta")] +
+                [("accumulate", C.c_int), ("acc", C.c_void_p), ("acc_ready", C.c_int)])
+
+
+class Wg3Conv(C.Structure):            # mirrors buctd_wg3_conv
+    _fields_ = ([(n, C.c_int) for n in ("N", "H", "W", "Ci", "Co")] +
+                [(n, C.c_void_p) for n in ("x", "dy", "dw")] + [("accumulate", C.c_int)] +
+                [(n, C.c_void_p) for n in ("x_mean", "x_invstd", "x_gamma", "x_beta")] + [("x_relu", C.c_int)] +
+                [("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t)])
+
+
 class MatmulDesc(C.Structure):
     _fields_ = [
         ("batch", C.c_int), ("M", C.c_int), ("N", C.c_int), ("K", C.c_int),
@@ -112,6 +139,13 @@ SIGNATURES = {
     "buctd_conv3x3_bf16x6_acc": (_I, [_I] * 5 + [_P, _P, _P, _I, _P, _P, C.POINTER(BnAccIn), _P, _P, _I, _P]),
     "buctd_conv3x3_bf16x6_bnstat_acc": (_I, [_I] * 5 + [_P] * 12),
     "buctd_gconv_x6_fwd_acc": (_I, [_I] * 6 + [_P] * 6),
+    "buctd_conv3x3_bf16x6_group": (_I, [_I, C.POINTER(C3Conv), _P]),
+    "buctd_bn_apply_acc_group": (_I, [_I, C.POINTER(BnApplyItem), _P]),
+    "buctd_bn_bwd_acc_group": (_I, [_I, C.POINTER(BnBwdItem), _P]),
+    "buctd_conv3x3_wgrad_bf16x6_group_workspace": (_SZ, [_I] * 6),
+    "buctd_conv3x3_wgrad_bf16x6_group": (_I, [_I, C.POINTER(Wg3Conv), _P]),
+    "buctd_basic_branches_fwd_train": (_I, [_I, _I, C.POINTER(BasicBlockDesc), _P]),
+    "buctd_basic_branches_bwd": (_I, [_I, _I, C.POINTER(BasicBlockDesc), C.POINTER(BasicBlockGrads), _P, _P]),
     "buctd_basic_block_fwd_train": (_I, [C.POINTER(BasicBlockDesc), _P]),
     "buctd_basic_block_bwd": (_I, [C.POINTER(BasicBlockDesc), C.POINTER(BasicBlockGrads), _P, _P]),
     "buctd_basic_chain_fwd_train": (_I, [_I, C.POINTER(BasicBlockDesc), _P]),

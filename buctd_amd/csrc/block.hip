@@ -5,6 +5,7 @@
 // which made HRNet-W32 at 256x192 host-bound).  Same kernels, same order, same streams: results are bit-identical.
 #include "common.h"
 #include "../../include/buctd_hip.h"
+#include <string.h>
 
 #define BLK_TRY(call)      \
   do {                     \
@@ -125,6 +126,182 @@ extern "C" int buctd_basic_chain_bwd(int n, const buctd_basic_block* blocks, con
     BLK_TRY(block_bwd_impl(blocks + k, grads + k, chain ? blocks + k - 1 : nullptr, chain ? grads + k - 1 : nullptr, ready, stream,
                            side_stream));
     ready = chain;
+  }
+  return BUCTD_OK;
+}
+
+// ---- the branches of a HighResolutionModule (pose_hrnet.py:177-185, 247-249) ---------------------------------------------
+// nb independent chains of n BasicBlocks each (blocks[b * n + k] = block k of branch b), advanced TOGETHER: the k-th
+// convolutions of all branches are one launch (buctd_conv3x3_bf16x6_group: their tiles form one grid of several de-phased
+// rounds instead of nb phase-locked single rounds on nb streams), and so are the BatchNorm applies, the BatchNorm backwards
+// and the weight gradients.  3 launches per block step forward, 8 backward - whatever the number of branches.
+// Forward and data gradients are bit-identical to the per-branch chains; the weight gradients use the group split
+// (buctd_conv3x3_wgrad_bf16x6_group: fixed order, fp32-class).
+#define BR_MAX 4
+
+static void acc_in_of(const buctd_basic_block& b, int second, buctd_bn_acc_in* st) {
+  const long rows = (long)b.N * b.H * b.W;
+  const int C = b.C;
+  st->acc = second ? (char*)b.acc + buctd_bn_acc_bytes(C) : b.acc;
+  st->rows = rows;
+  st->eps = second ? b.eps2 : b.eps1;
+  st->momentum = second ? b.momentum2 : b.momentum1;
+  st->mean_out = b.stat + (second ? 2 * C : 0);
+  st->invstd_out = b.stat + (second ? 3 * C : C);
+  st->running_mean = second ? b.running_mean2 : b.running_mean1;
+  st->running_var = second ? b.running_var2 : b.running_var1;
+}
+
+extern "C" int buctd_basic_branches_fwd_train(int nb, int n, const buctd_basic_block* blocks, void* stream) {
+  BUCTD_CHECK_ARG(nb > 0 && nb <= BR_MAX && n > 0 && blocks, "buctd_basic_branches_fwd_train: 1..%d branches", BR_MAX);
+  for (int i = 0; i < nb * n; ++i)
+    BUCTD_CHECK_ARG(blocks[i].x && blocks[i].w1_fwd && blocks[i].w2_fwd && blocks[i].z1 && blocks[i].z2 && blocks[i].y &&
+                        blocks[i].acc && blocks[i].stat,
+                    "buctd_basic_branches_fwd_train: null pointer in block %d", i);
+  for (int k = 0; k < n; ++k) {
+    buctd_c3_conv cv[BR_MAX];
+    buctd_bn_acc_in st1[BR_MAX];
+    buctd_bn_apply_item ap[BR_MAX];
+    memset(cv, 0, sizeof(cv));
+    for (int b = 0; b < nb; ++b) {
+      const buctd_basic_block& B = blocks[b * n + k];
+      buctd_c3_conv& c = cv[b];
+      c.N = B.N; c.H = B.H; c.W = B.W; c.Ci = c.Co = B.C;
+      c.x = B.x; c.wprep = B.w1_fwd; c.y = B.z1; c.stats_acc = B.acc;
+    }
+    BLK_TRY(buctd_conv3x3_bf16x6_group(nb, cv, stream));
+    for (int b = 0; b < nb; ++b) {
+      const buctd_basic_block& B = blocks[b * n + k];
+      buctd_c3_conv& c = cv[b];
+      acc_in_of(B, 0, &st1[b]);
+      c.x = B.z1; c.wprep = B.w2_fwd; c.y = B.z2; c.stats_acc = (char*)B.acc + buctd_bn_acc_bytes(B.C);
+      c.in_bn = &st1[b]; c.in_gamma = B.gamma1; c.in_beta = B.beta1; c.in_relu = 1;
+    }
+    BLK_TRY(buctd_conv3x3_bf16x6_group(nb, cv, stream));
+    for (int b = 0; b < nb; ++b) {
+      const buctd_basic_block& B = blocks[b * n + k];
+      buctd_bn_apply_item& a = ap[b];
+      a.z = B.z2;
+      acc_in_of(B, 1, &a.st);
+      a.gamma = B.gamma2; a.beta = B.beta2; a.residual = B.x; a.relu = 1; a.y = B.y;
+      a.rows = (long)B.N * B.H * B.W; a.C = B.C;
+    }
+    BLK_TRY(buctd_bn_apply_acc_group(nb, ap, stream));
+  }
+  return BUCTD_OK;
+}
+
+extern "C" int buctd_basic_branches_bwd(int nb, int n, const buctd_basic_block* blocks, const buctd_basic_block_grads* grads,
+                                        void* stream, void* side_stream) {
+  BUCTD_CHECK_ARG(nb > 0 && nb <= BR_MAX && n > 0 && blocks && grads, "buctd_basic_branches_bwd: 1..%d branches", BR_MAX);
+  for (int i = 0; i < nb * n; ++i) {
+    const buctd_basic_block& b = blocks[i];
+    const buctd_basic_block_grads& g = grads[i];
+    BUCTD_CHECK_ARG(b.x && b.w1_bwd && b.w2_bwd && b.z1 && b.z2 && b.y && b.stat && g.dy && g.dres && g.dy1 && g.dw1 && g.dw2 &&
+                        g.bn_acc && g.wg_ws && g.dz2 && g.dz1,
+                    "buctd_basic_branches_bwd: null pointer in block %d", i);
+  }
+  hipStream_t main_s = (hipStream_t)stream, side_s = side_stream ? (hipStream_t)side_stream : main_s;
+  static thread_local hipEvent_t evs[16] = {nullptr};
+  int devid = 0;
+  if (side_s != main_s && (hipGetDevice(&devid) != hipSuccess || devid < 0 || devid >= 16)) {
+    buctd_set_error("buctd_basic_branches_bwd: cannot identify the current device");
+    return BUCTD_ELAUNCH;
+  }
+  hipEvent_t& ev = evs[devid];
+  auto fork = [&]() -> int {
+    if (side_s == main_s) return BUCTD_OK;
+    if (!ev && hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) {
+      buctd_set_error("buctd_basic_branches_bwd: hipEventCreate failed");
+      return BUCTD_ELAUNCH;
+    }
+    if (hipEventRecord(ev, main_s) != hipSuccess || hipStreamWaitEvent(side_s, ev, 0) != hipSuccess) {
+      buctd_set_error("buctd_basic_branches_bwd: stream fork failed");
+      return BUCTD_ELAUNCH;
+    }
+    return BUCTD_OK;
+  };
+  bool ready[BR_MAX] = {false, false, false, false};     // block k's bn2 sums were formed by block k + 1's conv1 data gradient
+  for (int k = n - 1; k >= 0; --k) {
+    buctd_bn_bwd_item bi[BR_MAX];
+    buctd_wg3_conv wg[BR_MAX];
+    buctd_c3_conv cv[BR_MAX];
+    bool chain[BR_MAX];
+    for (int b = 0; b < nb; ++b) {
+      const buctd_basic_block& B = blocks[b * n + k];
+      const buctd_basic_block_grads& G = grads[b * n + k];
+      const int C = B.C;
+      chain[b] = false;
+      if (k > 0) {
+        const buctd_basic_block& Bp = blocks[b * n + k - 1];
+        const buctd_basic_block_grads& Gp = grads[b * n + k - 1];
+        chain[b] = G.dx && G.dx == Gp.dy && Gp.bn_acc && Bp.y == B.x && Bp.N == B.N && Bp.H == B.H && Bp.W == B.W && Bp.C == C;
+      }
+      // conv2 / bn2 (+ skip): dres = masked upstream gradient
+      bi[b] = buctd_bn_bwd_item{G.dy, B.y, B.z2, B.stat + 2 * C, B.stat + 3 * C, B.gamma2, nullptr, 1, (long)B.N * B.H * B.W, C,
+                                G.dz2, G.dres, G.dgamma2, G.dbeta2, G.acc_bn2, (char*)G.bn_acc + buctd_bn_acc_bytes(C),
+                                ready[b] ? 1 : 0};
+    }
+    BLK_TRY(buctd_bn_bwd_acc_group(nb, bi, stream));
+    BLK_TRY(fork());
+    for (int b = 0; b < nb; ++b) {
+      const buctd_basic_block& B = blocks[b * n + k];
+      const buctd_basic_block_grads& G = grads[b * n + k];
+      const int C = B.C;
+      wg[b] = buctd_wg3_conv{B.N, B.H, B.W, C, C, B.z1, G.dz2, G.dw2, G.acc_w2, B.stat, B.stat + C, B.gamma1, B.beta1, 1,
+                             G.wg_ws, G.wg_ws_bytes};
+    }
+    BLK_TRY(buctd_conv3x3_wgrad_bf16x6_group(nb, wg, side_s));
+    // conv2's data gradients dy1, and with them the sums of bn1's backward (ReLU mask rebuilt from z1)
+    memset(cv, 0, sizeof(cv));
+    for (int b = 0; b < nb; ++b) {
+      const buctd_basic_block& B = blocks[b * n + k];
+      const buctd_basic_block_grads& G = grads[b * n + k];
+      const int C = B.C;
+      buctd_c3_conv& c = cv[b];
+      c.N = B.N; c.H = B.H; c.W = B.W; c.Ci = c.Co = C;
+      c.x = G.dz2; c.wprep = B.w2_bwd; c.y = G.dy1;
+      c.bn_z = B.z1; c.bn_mean = B.stat; c.bn_invstd = B.stat + C; c.bn_gamma = B.gamma1; c.bn_beta = B.beta1; c.bn_acc = G.bn_acc;
+    }
+    BLK_TRY(buctd_conv3x3_bf16x6_group(nb, cv, stream));
+    for (int b = 0; b < nb; ++b) {
+      const buctd_basic_block& B = blocks[b * n + k];
+      const buctd_basic_block_grads& G = grads[b * n + k];
+      const int C = B.C;
+      bi[b] = buctd_bn_bwd_item{G.dy1, nullptr, B.z1, B.stat, B.stat + C, B.gamma1, B.beta1, 1, (long)B.N * B.H * B.W, C,
+                                G.dz1, nullptr, G.dgamma1, G.dbeta1, G.acc_bn1, G.bn_acc, 1};
+    }
+    BLK_TRY(buctd_bn_bwd_acc_group(nb, bi, stream));
+    BLK_TRY(fork());
+    for (int b = 0; b < nb; ++b) {
+      const buctd_basic_block& B = blocks[b * n + k];
+      const buctd_basic_block_grads& G = grads[b * n + k];
+      const int C = B.C;
+      wg[b] = buctd_wg3_conv{B.N, B.H, B.W, C, C, B.x, G.dz1, G.dw1, G.acc_w1, nullptr, nullptr, nullptr, nullptr, 0,
+                             G.wg_ws, G.wg_ws_bytes};
+    }
+    BLK_TRY(buctd_conv3x3_wgrad_bf16x6_group(nb, wg, side_s));
+    // conv1's data gradients; the skip gradient joins in the epilogue; inside a chain the output is the upstream gradient of
+    // the block in front, whose bn2 sums are formed on the way out
+    int m = 0;
+    memset(cv, 0, sizeof(cv));
+    for (int b = 0; b < nb; ++b) {
+      const buctd_basic_block& B = blocks[b * n + k];
+      const buctd_basic_block_grads& G = grads[b * n + k];
+      const int C = B.C;
+      ready[b] = chain[b];
+      if (!G.dx) continue;
+      buctd_c3_conv& c = cv[m++];
+      c.N = B.N; c.H = B.H; c.W = B.W; c.Ci = c.Co = C;
+      c.x = G.dz1; c.wprep = B.w1_bwd; c.residual = G.dres; c.y = G.dx;
+      if (chain[b]) {
+        const buctd_basic_block& Bp = blocks[b * n + k - 1];
+        const buctd_basic_block_grads& Gp = grads[b * n + k - 1];
+        c.bn_z = Bp.z2; c.bn_y = Bp.y; c.bn_mean = Bp.stat + 2 * C; c.bn_invstd = Bp.stat + 3 * C; c.bn_gamma = Bp.gamma2;
+        c.bn_acc = (char*)Gp.bn_acc + buctd_bn_acc_bytes(C);
+      }
+    }
+    if (m) BLK_TRY(buctd_conv3x3_bf16x6_group(m, cv, stream));
   }
   return BUCTD_OK;
 }

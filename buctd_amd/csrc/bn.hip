@@ -662,17 +662,30 @@ static int acc_grid(long n4, int per_cu = 8) {
 }
 
 // y = act((z - mean) * (invstd * gamma) + beta (+ residual)); LDS: [4][C] accumulator words | [3][C] floats
-__global__ __launch_bounds__(256, 8) void bn_apply_acc_kernel(const float* __restrict__ z, BnAccFwd a,
-                                                              const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                              const float* __restrict__ res, int relu, float* __restrict__ y,
-                                                              long total, int C) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+// One tensor = one BnApplyArgs; workgroup `bid` of `nblk` (a whole launch, or this tensor's share of a group launch).
+struct BnApplyArgs {
+  const float* z;
+  BnAccFwd a;
+  const float* gamma;
+  const float* beta;
+  const float* res;
+  int relu;
+  float* y;
+  long total;
+  int C;
+};
+__device__ __forceinline__ void bn_apply_acc_body(const BnApplyArgs& p, unsigned bid, unsigned nblk, unsigned char* lds_raw) {
+  const float* __restrict__ z = p.z;
+  const float* __restrict__ res = p.res;
+  float* __restrict__ y = p.y;
+  const BnAccFwd& a = p.a;
+  const int C = p.C, relu = p.relu;
   long long* wsum = reinterpret_cast<long long*>(lds_raw);
   float* tab = reinterpret_cast<float*>(lds_raw + (size_t)BNACC_WORDS * C * sizeof(long long));
-  const long n4 = total >> 2;
-  const long step = (long)gridDim.x * 256;
+  const long n4 = p.total >> 2;
+  const long step = (long)nblk * 256;
   // the first elements are on their way from HBM while the statistics are decoded
-  long i = (long)blockIdx.x * 256 + threadIdx.x;
+  long i = (long)bid * 256 + threadIdx.x;
   f32x4 v0 = (f32x4){0.f, 0.f, 0.f, 0.f}, v1 = v0, r0 = v0, r1 = v0;
   auto fetch = [&](long j) {
     if (j < n4) {
@@ -691,9 +704,9 @@ __global__ __launch_bounds__(256, 8) void bn_apply_acc_kernel(const float* __res
     bnacc_read_lds(wsum, C, c, &s1, &s2);
     const BnFwdStat st = bnacc_fwd_stat_sums(s1, s2, a.rows, a.eps);
     tab[c] = st.mean;
-    tab[C + c] = st.invstd * gamma[c];
-    tab[2 * C + c] = beta[c];
-    if (blockIdx.x == 0) {
+    tab[C + c] = st.invstd * p.gamma[c];
+    tab[2 * C + c] = p.beta[c];
+    if (bid == 0) {
       a.mean_out[c] = st.mean;
       a.invstd_out[c] = st.invstd;
       if (a.rmean) bnacc_running(st, a.rows, a.momentum, a.rmean, a.rvar, c);
@@ -726,6 +739,36 @@ __global__ __launch_bounds__(256, 8) void bn_apply_acc_kernel(const float* __res
     fetch(i + 2 * step);
   }
 }
+__global__ __launch_bounds__(256, 8) void bn_apply_acc_kernel(BnApplyArgs p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+  bn_apply_acc_body(p, blockIdx.x, gridDim.x, lds_raw);
+}
+
+// Several tensors in one launch (the branches of a HighResolutionModule): workgroups [first[k], first[k + 1]) work on tensor
+// k exactly as its own launch of that many workgroups would.  The descriptor is read in place from the kernel-argument
+// segment (scalar loads at a computed offset).
+#define BNG_MAX 4
+template <class A>
+struct BnGroup {
+  A s[BNG_MAX];
+  int n;
+  unsigned first[BNG_MAX + 1];
+};
+template <class A>
+__device__ __forceinline__ int bn_group_find(const BnGroup<A>& g, unsigned* bid, unsigned* nblk) {
+  int k = 0;
+  while (k + 1 < g.n && blockIdx.x >= g.first[k + 1]) ++k;
+  *bid = blockIdx.x - g.first[k];
+  *nblk = g.first[k + 1] - g.first[k];
+  return k;
+}
+__global__ __launch_bounds__(256, 8) void bn_apply_acc_group_kernel(BnGroup<BnApplyArgs> g_) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+  const BnGroup<BnApplyArgs>& g = *(const BnGroup<BnApplyArgs>*)__builtin_amdgcn_kernarg_segment_ptr();
+  unsigned bid, nblk;
+  const int k = bn_group_find(g, &bid, &nblk);
+  bn_apply_acc_body(g.s[k], bid, nblk, lds_raw);
+}
 
 extern "C" size_t buctd_bn_acc_bytes(int C) { return C > 0 ? bnacc_bytes(C) : 0; }
 
@@ -750,24 +793,75 @@ extern "C" int buctd_bn_apply_acc(const float* z, const buctd_bn_acc_in* st, con
   if (rc) return rc;
   BUCTD_CHECK_ARG(st->rows == rows, "buctd_bn_apply_acc: the statistics cover %ld rows, the tensor has %ld", st->rows, rows);
   const long total = rows * C;
+  const BnApplyArgs a{z, acc_in(st), gamma, beta, residual, relu, y, total, C};
   hipLaunchKernelGGL(bn_apply_acc_kernel, dim3(acc_grid(total / 4)), dim3(256), (size_t)(BNACC_WORDS * 8 + 3 * 4) * C,
-                     (hipStream_t)stream, z, acc_in(st), gamma, beta, residual, relu, y, total, C);
+                     (hipStream_t)stream, a);
   BUCTD_CHECK_LAUNCH("buctd_bn_apply_acc");
   return BUCTD_OK;
 }
 
+extern "C" int buctd_bn_apply_acc_group(int n, const buctd_bn_apply_item* items, void* stream) {
+  BUCTD_CHECK_ARG(n > 0 && n <= BNG_MAX && items, "buctd_bn_apply_acc_group: 1..%d tensors", BNG_MAX);
+  BnGroup<BnApplyArgs> g;
+  g.n = n;
+  g.first[0] = 0;
+  size_t lds = 0;
+  for (int k = 0; k < n; ++k) {
+    const buctd_bn_apply_item& it = items[k];
+    BUCTD_CHECK_ARG(it.z && it.gamma && it.beta && it.y && it.rows > 0 && it.C > 0 && it.C % 4 == 0 && it.C <= 4096,
+                    "buctd_bn_apply_acc_group: bad argument (C must be a multiple of 4, <= 4096)");
+    const int rc = acc_in_check(&it.st, "buctd_bn_apply_acc_group");
+    if (rc) return rc;
+    BUCTD_CHECK_ARG(it.st.rows == it.rows, "buctd_bn_apply_acc_group: the statistics cover %ld rows, the tensor has %ld",
+                    it.st.rows, it.rows);
+    const long total = it.rows * it.C;
+    g.s[k] = BnApplyArgs{it.z, acc_in(&it.st), it.gamma, it.beta, it.residual, it.relu, it.y, total, it.C};
+    g.first[k + 1] = g.first[k] + (unsigned)acc_grid(total / 4);
+    const size_t l = (size_t)(BNACC_WORDS * 8 + 3 * 4) * it.C;
+    if (l > lds) lds = l;
+  }
+  for (int k = n; k < BNG_MAX; ++k) g.first[k + 1] = g.first[n];
+  hipLaunchKernelGGL(bn_apply_acc_group_kernel, dim3(g.first[n]), dim3(256), lds, (hipStream_t)stream, g);
+  BUCTD_CHECK_LAUNCH("buctd_bn_apply_acc_group");
+  return BUCTD_OK;
+}
+
 // backward reduction into an accumulator: bn_bwd_reduce2_kernel with one exact integer addition per workgroup, channel and sum
-__global__ __launch_bounds__(256) void bn_bwd_reduce_acc_kernel(const float* __restrict__ dy, const float* __restrict__ y,
-                                                                const float* __restrict__ z, const float* __restrict__ mean,
-                                                                const float* __restrict__ invstd,
-                                                                const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                                int relu, long rows, int C, long rows_per_block,
-                                                                long long* __restrict__ acc) {
-  __shared__ f32x4 sm[2][256];
+struct BnBwdArgs {        // one BatchNorm backward (reduction and apply kernels)
+  const float* dy;
+  const float* y;
+  const float* z;
+  const float* mean;
+  const float* invstd;
+  const float* gamma;
+  const float* beta;
+  long long* acc;
+  int relu;
+  long rows;
+  int C;
+  long rows_per_block;     // reduction
+  float inv_rows;          // apply ...
+  float* dz;
+  float* dres;
+  float* dgamma;
+  float* dbeta;
+  int accumulate;
+};
+__device__ __forceinline__ void bn_bwd_reduce_acc_body(const BnBwdArgs& p, unsigned bid, f32x4 (&sm)[2][256]) {
+  const float* __restrict__ dy = p.dy;
+  const float* __restrict__ y = p.y;
+  const float* __restrict__ z = p.z;
+  const float* __restrict__ mean = p.mean;
+  const float* __restrict__ invstd = p.invstd;
+  const float* __restrict__ gamma = p.gamma;
+  const float* __restrict__ beta = p.beta;
+  long long* __restrict__ acc = p.acc;
+  const int relu = p.relu, C = p.C;
+  const long rows = p.rows, rows_per_block = p.rows_per_block;
   const int c4n = C >> 2;                 // C % 4 == 0, C / 4 <= 256
   const int rl = 256 / c4n;
   const int tc = threadIdx.x % c4n, tr = threadIdx.x / c4n;
-  const long r0 = (long)blockIdx.x * rows_per_block;
+  const long r0 = (long)bid * rows_per_block;
   long r1 = r0 + rows_per_block;
   if (r1 > rows) r1 = rows;
   f32x4 s1 = (f32x4){0.f, 0.f, 0.f, 0.f}, s2 = s1;
@@ -827,24 +921,42 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_acc_kernel(const float* __r
   for (int c = threadIdx.x; c < C; c += 256)
     bnacc_add(acc, C, shard, c, (double)reinterpret_cast<const float*>(&sm[0][0])[c], (double)reinterpret_cast<const float*>(&sm[1][0])[c]);
 }
+__global__ __launch_bounds__(256) void bn_bwd_reduce_acc_kernel(BnBwdArgs p) {
+  __shared__ f32x4 sm[2][256];
+  bn_bwd_reduce_acc_body(p, blockIdx.x, sm);
+}
+__global__ __launch_bounds__(256) void bn_bwd_reduce_acc_group_kernel(BnGroup<BnBwdArgs> g_) {
+  __shared__ f32x4 sm[2][256];
+  const BnGroup<BnBwdArgs>& g = *(const BnGroup<BnBwdArgs>*)__builtin_amdgcn_kernarg_segment_ptr();
+  unsigned bid, nblk;
+  const int k = bn_group_find(g, &bid, &nblk);
+  bn_bwd_reduce_acc_body(g.s[k], bid, sm);
+}
 
 // dz = gamma * invstd * (g - s1 / M - zhat * s2 / M); dres = g.  LDS: [4][C] accumulator words | [6][C] floats (mean, invstd,
 // gamma, beta, s1, s2)
-__global__ __launch_bounds__(256, 6) void bn_bwd_apply_acc_kernel(const float* __restrict__ dy, const float* __restrict__ y,
-                                                                  const float* __restrict__ z, const float* __restrict__ mean,
-                                                                  const float* __restrict__ invstd,
-                                                                  const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                                  const long long* __restrict__ acc, int relu, long total, int C,
-                                                                  float inv_rows, float* __restrict__ dz, float* __restrict__ dres,
-                                                                  float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                                                  int accumulate) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+__device__ __forceinline__ void bn_bwd_apply_acc_body(const BnBwdArgs& p, unsigned bid, unsigned nblk, unsigned char* lds_raw) {
+  const float* __restrict__ dy = p.dy;
+  const float* __restrict__ y = p.y;
+  const float* __restrict__ z = p.z;
+  const float* __restrict__ mean = p.mean;
+  const float* __restrict__ invstd = p.invstd;
+  const float* __restrict__ gamma = p.gamma;
+  const float* __restrict__ beta = p.beta;
+  const long long* __restrict__ acc = p.acc;
+  float* __restrict__ dz = p.dz;
+  float* __restrict__ dres = p.dres;
+  float* __restrict__ dgamma = p.dgamma;
+  float* __restrict__ dbeta = p.dbeta;
+  const int relu = p.relu, C = p.C, accumulate = p.accumulate;
+  const long total = p.rows * C;
+  const float inv_rows = p.inv_rows;
   long long* wsum = reinterpret_cast<long long*>(lds_raw);
   float* tab = reinterpret_cast<float*>(lds_raw + (size_t)BNACC_WORDS * C * sizeof(long long));
   const long n4 = total >> 2;
-  const long step = (long)gridDim.x * 256;
+  const long step = (long)nblk * 256;
   const bool ld_y = relu && y;
-  long i = (long)blockIdx.x * 256 + threadIdx.x;
+  long i = (long)bid * 256 + threadIdx.x;
   f32x4 g0 = (f32x4){0.f, 0.f, 0.f, 0.f}, g1 = g0, z0 = g0, z1 = g0, y0 = g0, y1 = g0;
   auto fetch = [&](long j) {
     if (j < n4) {
@@ -869,7 +981,7 @@ __global__ __launch_bounds__(256, 6) void bn_bwd_apply_acc_kernel(const float* _
     tab[3 * C + c] = (relu && !y) ? beta[c] : 0.f;
     tab[4 * C + c] = (float)s1;
     tab[5 * C + c] = (float)s2;
-    if (blockIdx.x == 0) {
+    if (bid == 0) {
       if (dbeta) dbeta[c] = accumulate ? dbeta[c] + (float)s1 : (float)s1;
       if (dgamma) dgamma[c] = accumulate ? dgamma[c] + (float)s2 : (float)s2;
     }
@@ -915,29 +1027,84 @@ __global__ __launch_bounds__(256, 6) void bn_bwd_apply_acc_kernel(const float* _
     fetch(i + 2 * step);
   }
 }
+__global__ __launch_bounds__(256, 6) void bn_bwd_apply_acc_kernel(BnBwdArgs p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+  bn_bwd_apply_acc_body(p, blockIdx.x, gridDim.x, lds_raw);
+}
+__global__ __launch_bounds__(256, 6) void bn_bwd_apply_acc_group_kernel(BnGroup<BnBwdArgs> g_) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+  const BnGroup<BnBwdArgs>& g = *(const BnGroup<BnBwdArgs>*)__builtin_amdgcn_kernarg_segment_ptr();
+  unsigned bid, nblk;
+  const int k = bn_group_find(g, &bid, &nblk);
+  bn_bwd_apply_acc_body(g.s[k], bid, nblk, lds_raw);
+}
 
 /* buctd_bn_bwd on an accumulator (buctd_bn_acc_bytes(C), zero on entry unless acc_ready): acc_ready = 0 runs the
  * streaming reduction into it first; acc_ready = 1: the data gradient that produced dy already did
  * (buctd_conv3x3_bf16x6_bnstat_acc).  No finalize launch: the apply kernel decodes the sums itself and its first workgroup
  * writes dgamma / dbeta. */
+static int bn_bwd_acc_fill(const buctd_bn_bwd_item& it, const char* who, BnBwdArgs& a, long* nb) {
+  BUCTD_CHECK_ARG(it.dy && it.z && it.mean && it.invstd && it.gamma && it.dz && it.acc && it.rows > 0 && it.C > 0 && it.C % 4 == 0 &&
+                      it.C / 4 <= 256,
+                  "%s: bad argument (C must be a multiple of 4, <= 1024)", who);
+  BUCTD_CHECK_ARG(!it.relu || it.y || it.beta, "%s: relu backward needs the forward output, or beta to rebuild its sign", who);
+  a.dy = it.dy; a.y = it.y; a.z = it.z; a.mean = it.mean; a.invstd = it.invstd; a.gamma = it.gamma; a.beta = it.beta;
+  a.acc = (long long*)it.acc; a.relu = it.relu; a.rows = it.rows; a.C = it.C;
+  *nb = bwd2_blocks(it.rows, &a.rows_per_block);
+  a.inv_rows = 1.0f / (float)it.rows;
+  a.dz = it.dz; a.dres = it.dres; a.dgamma = it.dgamma; a.dbeta = it.dbeta; a.accumulate = it.accumulate;
+  return BUCTD_OK;
+}
+
 extern "C" int buctd_bn_bwd_acc(const float* dy, const float* y, const float* z, const float* mean, const float* invstd,
                                 const float* gamma, const float* beta, int relu, long rows, int C, float* dz, float* dres,
                                 float* dgamma, float* dbeta, int accumulate, void* acc, int acc_ready, void* stream) {
-  BUCTD_CHECK_ARG(dy && z && mean && invstd && gamma && dz && acc && rows > 0 && C > 0 && C % 4 == 0 && C / 4 <= 256,
-                  "buctd_bn_bwd_acc: bad argument (C must be a multiple of 4, <= 1024)");
-  BUCTD_CHECK_ARG(!relu || y || beta, "buctd_bn_bwd_acc: relu backward needs the forward output, or beta to rebuild its sign");
+  const buctd_bn_bwd_item it{dy, y, z, mean, invstd, gamma, beta, relu, rows, C, dz, dres, dgamma, dbeta, accumulate, acc, acc_ready};
+  BnBwdArgs a;
+  long nb;
+  const int rc = bn_bwd_acc_fill(it, "buctd_bn_bwd_acc", a, &nb);
+  if (rc) return rc;
   hipStream_t st = (hipStream_t)stream;
   if (!acc_ready) {
-    long rpb;
-    const long nb = bwd2_blocks(rows, &rpb);
-    hipLaunchKernelGGL(bn_bwd_reduce_acc_kernel, dim3((unsigned)nb), dim3(256), 0, st, dy, y, z, mean, invstd, gamma, beta, relu,
-                       rows, C, rpb, (long long*)acc);
+    hipLaunchKernelGGL(bn_bwd_reduce_acc_kernel, dim3((unsigned)nb), dim3(256), 0, st, a);
     BUCTD_CHECK_LAUNCH("buctd_bn_bwd_acc(reduce)");
   }
   const long total = rows * C;
-  hipLaunchKernelGGL(bn_bwd_apply_acc_kernel, dim3(acc_grid(total / 4, 6)), dim3(256), (size_t)(BNACC_WORDS * 8 + 6 * 4) * C, st, dy, y, z,
-                     mean, invstd, gamma, beta, (const long long*)acc, relu, total, C, 1.0f / (float)rows, dz, dres, dgamma, dbeta,
-                     accumulate);
+  hipLaunchKernelGGL(bn_bwd_apply_acc_kernel, dim3(acc_grid(total / 4, 6)), dim3(256), (size_t)(BNACC_WORDS * 8 + 6 * 4) * C, st, a);
   BUCTD_CHECK_LAUNCH("buctd_bn_bwd_acc(apply)");
+  return BUCTD_OK;
+}
+
+/* n BatchNorm backwards in one launch each for the reductions that are still needed (items with acc_ready = 0) and the
+ * applies: the branches of a HighResolutionModule.  Every tensor is processed exactly as by buctd_bn_bwd_acc. */
+extern "C" int buctd_bn_bwd_acc_group(int n, const buctd_bn_bwd_item* items, void* stream) {
+  BUCTD_CHECK_ARG(n > 0 && n <= BNG_MAX && items, "buctd_bn_bwd_acc_group: 1..%d tensors", BNG_MAX);
+  BnGroup<BnBwdArgs> ga, gr;
+  ga.n = n; gr.n = 0;
+  ga.first[0] = gr.first[0] = 0;
+  size_t lds = 0;
+  for (int k = 0; k < n; ++k) {
+    long nb;
+    const int rc = bn_bwd_acc_fill(items[k], "buctd_bn_bwd_acc_group", ga.s[k], &nb);
+    if (rc) return rc;
+    const long total = items[k].rows * items[k].C;
+    ga.first[k + 1] = ga.first[k] + (unsigned)acc_grid(total / 4, 6);
+    const size_t l = (size_t)(BNACC_WORDS * 8 + 6 * 4) * items[k].C;
+    if (l > lds) lds = l;
+    if (!items[k].acc_ready) {
+      gr.s[gr.n] = ga.s[k];
+      gr.first[gr.n + 1] = gr.first[gr.n] + (unsigned)nb;
+      ++gr.n;
+    }
+  }
+  for (int k = n; k < BNG_MAX; ++k) ga.first[k + 1] = ga.first[n];
+  for (int k = gr.n; k < BNG_MAX; ++k) gr.first[k + 1] = gr.first[gr.n];
+  hipStream_t st = (hipStream_t)stream;
+  if (gr.n) {
+    hipLaunchKernelGGL(bn_bwd_reduce_acc_group_kernel, dim3(gr.first[gr.n]), dim3(256), 0, st, gr);
+    BUCTD_CHECK_LAUNCH("buctd_bn_bwd_acc_group(reduce)");
+  }
+  hipLaunchKernelGGL(bn_bwd_apply_acc_group_kernel, dim3(ga.first[n]), dim3(256), lds, st, ga);
+  BUCTD_CHECK_LAUNCH("buctd_bn_bwd_acc_group(apply)");
   return BUCTD_OK;
 }

@@ -389,8 +389,14 @@ __device__ __forceinline__ void c3x6_tile(const C3Args& p, unsigned char* smem, 
         __builtin_amdgcn_sched_barrier(0);
         bf16x8 (&ac)[3] = a[i % (AD + 1)];
 #define X6_MMA(qa, qb) acc[mf][nf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ac[qa], bc[qb][nf], acc[mf][nf], 0, 0, 0);
+#ifdef C3_MMA_INTERLEAVE
+#define X6_ROW(qa, qb) _Pragma("unroll") for (int nf = 0; nf < NF; ++nf) { X6_MMA(qa, qb) }
+        X6_ROW(2, 0) X6_ROW(0, 2) X6_ROW(1, 1) X6_ROW(1, 0) X6_ROW(0, 1) X6_ROW(0, 0)
+#undef X6_ROW
+#else
 #pragma unroll
         for (int nf = 0; nf < NF; ++nf) { X6_MMA(2, 0) X6_MMA(0, 2) X6_MMA(1, 1) X6_MMA(1, 0) X6_MMA(0, 1) X6_MMA(0, 0) }
+#endif
 #undef X6_MMA
         __builtin_amdgcn_sched_barrier(0);
       }
@@ -485,6 +491,78 @@ __global__ __launch_bounds__(256, WPS) void conv3x3_x6_kernel(C3Args p) {
     }
   }
   c3x6_tile<MF, NF, WM, WN, DBUF, BPF_>(p, smem, bx, by);
+}
+
+// ---- several convolutions in ONE launch (the branches of a HighResolutionModule, pose_hrnet.py:177-185) -----------------
+// A HighResolutionModule runs 2-4 independent branches whose k-th convolutions cost the same FLOPs on maps of different
+// size.  As separate launches each of them is ONE round of workgroups on the 512 slots of the chip: all of them load their
+// first chunk, multiply, and write their tile at the same time, so prologue and epilogue are exposed chip-wide and launches
+// of other streams only get slots when the round retires - all at once.  Here the tiles of all branches form one grid:
+// the dispatcher hands a new tile to a CU slot as soon as one retires, rounds de-phase, one workgroup's epilogue runs under
+// its neighbour's main loop, and the tail of the grid is made of the cheapest tiles (convolutions ordered by tile cost).
+// Every tile is computed by c3x6_tile with the argument block and the tile shape of ITS convolution - the arithmetic (and
+// the accumulation order of every output and of the statistics) is that of the single launches: bit-identical results.
+#define C3G_MAX 4
+struct C3Group {
+  C3Args conv[C3G_MAX];
+  int nconv;
+  int tiles[C3G_MAX];      // workgroup tiles of convolution c
+  int gx[C3G_MAX];         // ... position tiles
+  int gy[C3G_MAX];         // ... column tiles
+  int variant[C3G_MAX];    // index into the variant list of the kernel family
+};
+
+// FAM 0: 48-channel multiples (NF = 3; HRNet-W48), FAM 1: 32-channel multiples (NF = 2 / 4; HRNet-W32)
+template <int FAM>
+__global__ __launch_bounds__(256, 2) void conv3x3_x6_group_kernel(C3Group g_) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  // the descriptor is read where it lies - in the kernel-argument segment (constant memory, scalar loads at a computed
+  // offset): indexing the by-value copy with the convolution id made the compiler spill the whole block to scratch
+  const C3Group& g = *(const C3Group*)__builtin_amdgcn_kernarg_segment_ptr();
+  // workgroup -> (convolution, tile): hardware workgroup ids round-robin over the 8 XCDs; every XCD walks, convolution after
+  // convolution, a contiguous eighth of that convolution's tile sequence (its L2 keeps the halo rows of neighbouring tiles)
+  const unsigned lin = blockIdx.x, xcd = lin & 7;
+  unsigned idx = lin >> 3;
+  int c = -1;
+  unsigned L = 0;
+  for (int k = 0; k < g.nconv; ++k) {
+    const unsigned total = (unsigned)g.tiles[k], per = total >> 3, rem = total & 7;
+    const unsigned mine = per + (xcd < rem ? 1u : 0u);
+    if (idx < mine) {
+      L = xcd < rem ? xcd * (per + 1) + idx : rem * (per + 1) + (xcd - rem) * per + idx;
+      c = k;
+      break;
+    }
+    idx -= mine;
+  }
+  if (c < 0) return;
+  const C3Args& p = g.conv[c];
+  int bx, by;
+  if (p.col_major) {
+    by = (int)(L / (unsigned)g.gx[c]);
+    bx = (int)(L - (unsigned)by * g.gx[c]);
+  } else {
+    bx = (int)(L / (unsigned)g.gy[c]);
+    by = (int)(L - (unsigned)bx * g.gy[c]);
+  }
+  const int v = g.variant[c];
+  if constexpr (FAM == 0) {
+    switch (v) {
+      case 0: c3x6_tile<7, 3, 4, 1, false, false>(p, smem, bx, by); break;
+      case 1: c3x6_tile<4, 3, 2, 2, true, true>(p, smem, bx, by); break;
+      case 2: c3x6_tile<2, 2, 4, 1, true, true>(p, smem, bx, by); break;
+      default: c3x6_tile<4, 3, 4, 1, true, true>(p, smem, bx, by); break;
+    }
+  } else {
+    switch (v) {
+      case 0: c3x6_tile<4, 2, 4, 1, true, true>(p, smem, bx, by); break;
+      case 1: c3x6_tile<1, 4, 4, 1, true, true>(p, smem, bx, by); break;
+      case 2: c3x6_tile<2, 2, 4, 1, true, true>(p, smem, bx, by); break;
+      case 3: c3x6_tile<1, 2, 4, 1, true, true>(p, smem, bx, by); break;
+      case 4: c3x6_tile<2, 4, 4, 1, true, true>(p, smem, bx, by); break;
+      default: c3x6_tile<2, 4, 2, 2, true, true>(p, smem, bx, by); break;
+    }
+  }
 }
 
 // ------------------------------------------------------------------------------------- weight preparation ----
@@ -597,7 +675,9 @@ struct C3Plan { int MF, NF, WM, WN, BM, BN, na, lean; size_t lds; };
 
 static int c3_steps(int Kc, int np) { return np == 3 ? (Kc / 16) * 5 : (Kc / CK) * 9 + ((Kc % CK) ? 5 : 0); }
 
-static bool c3_plan(int np, int N, int H, int W, int Ci, int Co, C3Plan* pl) {
+// group: the convolution shares its launch with others (buctd_conv3x3_bf16x6_group) - the grid-filling heuristics of a
+// single launch do not apply, the tile with the best sustained rate is taken
+static bool c3_plan(int np, int N, int H, int W, int Ci, int Co, C3Plan* pl, int group = 0) {
   if (N <= 0 || H <= 0 || W <= 0 || Ci <= 0 || Co <= 0 || Ci % 16 != 0 || Co % 16 != 0 || c3_row_width(W) > MAX_SW) return false;
   const int rowb = np == 3 ? Geo<3>::ROWB : Geo<2>::ROWB, blds = np == 3 ? Geo<3>::BLDS : Geo<2>::BLDS;
   const long P = (long)N * (H + 1) * c3_row_width(W) + c3_row_width(W);
@@ -627,7 +707,9 @@ static bool c3_plan(int np, int N, int H, int W, int Ci, int Co, C3Plan* pl) {
   }
   bool single = false;
   pl->lean = 0;
-  if (np == 3 && nf == 3 && wn == 1 && Co == bn) {
+  if (group && np == 3 && Co % 96 == 0) { nf = 3; wn = 2; wm = 2; bn = 96; mf = 4; }
+  else if (group && np == 3 && Co % 48 == 0) { nf = 3; wn = 1; wm = 4; bn = 48; mf = 4; }
+  else if (np == 3 && nf == 3 && wn == 1 && Co == bn) {
     // 512-position tiles in ONE round of workgroups (2 resident per CU = 512 slots) instead of 1.75 rounds of
     // 256-position tiles: the 48-channel branch at N*H*W >= ~115k positions (single A buffer: 64.5 KB at W = 72)
     const long b8 = (P + 511) / 512;
@@ -766,18 +848,17 @@ struct C3BwdStat { const float* z; const float* y; const float* mean; const floa
 // accumulator forms (bn_acc.h): the launch's own forward statistics, and the input BatchNorm's statistics decoded in the prologue
 struct C3Acc { long long* stats_acc; const buctd_bn_acc_in* in; };
 
-static int c3_run(int np, int N, int H, int W, int Ci, int Co, const float* x, const void* wprep, const float* bias,
-                  const float* scale, const float* shift, const float* residual, int relu, float* y,
-                  float* stats_partials, int* stats_counts, void* stream, const C3InBn* in_bn = nullptr,
-                  const C3BwdStat* bst = nullptr, const C3Acc* accs = nullptr) {
-  C3Plan pl;
+// builds the argument block and the tile plan of one convolution (no launch)
+static int c3_fill(int np, int N, int H, int W, int Ci, int Co, const float* x, const void* wprep, const float* bias,
+                   const float* scale, const float* shift, const float* residual, int relu, float* y,
+                   float* stats_partials, int* stats_counts, const C3InBn* in_bn, const C3BwdStat* bst, const C3Acc* accs,
+                   C3Args& a, C3Plan& pl, int group = 0) {
   BUCTD_CHECK_ARG(x && wprep && y, "buctd_conv3x3 (split bf16): null tensor pointer");
-  BUCTD_CHECK_ARG(c3_np_ok(np) && c3_plan(np, N, H, W, Ci, Co, &pl),
+  BUCTD_CHECK_ARG(c3_np_ok(np) && c3_plan(np, N, H, W, Ci, Co, &pl, group),
                   "buctd_conv3x3 (split bf16): unsupported shape N%d H%d W%d Ci%d Co%d", N, H, W, Ci, Co);
   BUCTD_CHECK_ARG((scale == nullptr) == (shift == nullptr), "buctd_conv3x3 (split bf16): scale and shift go together");
   BUCTD_CHECK_ARG((stats_partials == nullptr) == (stats_counts == nullptr),
                   "buctd_conv3x3 (split bf16): stats partials and counts go together");
-  C3Args a;
   a.x = x; a.wp = (const unsigned char*)wprep; a.out = y; a.bias = bias; a.scale = scale; a.shift = shift;
   a.res = residual; a.stats = stats_partials; a.counts = stats_counts;
   a.N = N; a.H = H; a.W = W; a.Ci = Ci; a.Co = Co;
@@ -825,6 +906,18 @@ static int c3_run(int np, int N, int H, int W, int Ci, int Co, const float* x, c
 #endif
   magic_u32((unsigned)a.IB, &a.ib_mul, &a.ib_sh);
   magic_u32((unsigned)a.SW, &a.sw_mul, &a.sw_sh);
+  return BUCTD_OK;
+}
+
+static int c3_run(int np, int N, int H, int W, int Ci, int Co, const float* x, const void* wprep, const float* bias,
+                  const float* scale, const float* shift, const float* residual, int relu, float* y,
+                  float* stats_partials, int* stats_counts, void* stream, const C3InBn* in_bn = nullptr,
+                  const C3BwdStat* bst = nullptr, const C3Acc* accs = nullptr) {
+  C3Args a;
+  C3Plan pl;
+  const int rc = c3_fill(np, N, H, W, Ci, Co, x, wprep, bias, scale, shift, residual, relu, y, stats_partials, stats_counts,
+                         in_bn, bst, accs, a, pl);
+  if (rc) return rc;
   return np == 3 ? c3_dispatch<3>(a, pl, (hipStream_t)stream) : c3_dispatch<2>(a, pl, (hipStream_t)stream);
 }
 
@@ -912,4 +1005,99 @@ extern "C" int buctd_conv3x3_bf16x6_bnstat_acc(int N, int H, int W, int Ci, int 
   BUCTD_CHECK_ARG(bn_acc, "buctd_conv3x3_bf16x6_bnstat_acc: null accumulator");
   return c3_run(3, N, H, W, Ci, Co, x, wprep, nullptr, nullptr, nullptr, residual, 0, y, nullptr, nullptr, stream, nullptr,
                 &b);
+}
+
+/* Several 3x3 convolutions in ONE launch (include/buctd_hip.h: buctd_c3_conv): the tiles of all of them in one grid, each
+ * computed exactly as its own buctd_conv3x3_bf16x6_acc / _bnstat_acc launch would.  Shapes whose tile plans have no place in
+ * a group kernel are launched one after the other instead - the results are the same either way. */
+static int c3_group_variant(const C3Plan& pl, int* fam) {
+  struct V { int mf, nf, wm, wn; };
+  static const V f0[] = {{7, 3, 4, 1}, {4, 3, 2, 2}, {2, 2, 4, 1}, {4, 3, 4, 1}};
+  static const V f1[] = {{4, 2, 4, 1}, {1, 4, 4, 1}, {2, 2, 4, 1}, {1, 2, 4, 1}, {2, 4, 4, 1}, {2, 4, 2, 2}};
+  for (int f = 0; f < 2; ++f) {
+    if (*fam >= 0 && *fam != f) continue;
+    const V* l = f ? f1 : f0;
+    const int n = f ? 6 : 4;
+    for (int i = 0; i < n; ++i)
+      if (l[i].mf == pl.MF && l[i].nf == pl.NF && l[i].wm == pl.WM && l[i].wn == pl.WN) {
+        *fam = f;
+        return i;
+      }
+  }
+  return -1;
+}
+
+static int c3_group_plans(int n) {
+#ifdef BUCTD_TUNING
+  static const int env = getenv("BUCTD_C3_GROUP_PLAN") ? atoi(getenv("BUCTD_C3_GROUP_PLAN")) : -1;
+  if (env >= 0) return env;
+#endif
+  (void)n;
+  return 0;      // the single-launch plans: results bit-identical to the per-convolution launches (group plans: -4 % per launch)
+}
+
+extern "C" int buctd_conv3x3_bf16x6_group(int n, const buctd_c3_conv* convs, void* stream) {
+  BUCTD_CHECK_ARG(n > 0 && n <= C3G_MAX && convs, "buctd_conv3x3_bf16x6_group: 1..%d convolutions", C3G_MAX);
+  C3Group g;
+  C3Plan pl[C3G_MAX];
+  int order[C3G_MAX];
+  double cost[C3G_MAX];
+  for (int k = 0; k < n; ++k) {
+    const buctd_c3_conv& c = convs[k];
+    C3InBn ib{nullptr, nullptr, c.in_gamma, c.in_beta, c.in_relu};
+    C3BwdStat bs{c.bn_z, c.bn_y, c.bn_mean, c.bn_invstd, c.bn_gamma, c.bn_beta, nullptr, (long long*)c.bn_acc};
+    C3Acc ac{(long long*)c.stats_acc, c.in_bn};
+    BUCTD_CHECK_ARG(!c.in_bn || c.in_bn->acc, "buctd_conv3x3_bf16x6_group: in_bn without an accumulator");
+    const int rc = c3_fill(3, c.N, c.H, c.W, c.Ci, c.Co, c.x, c.wprep, nullptr, nullptr, nullptr, c.residual, c.relu, c.y,
+                           nullptr, nullptr, c.in_bn ? &ib : nullptr, c.bn_acc ? &bs : nullptr, &ac, g.conv[k], pl[k],
+                           c3_group_plans(n));
+    if (rc) return rc;
+    cost[k] = (double)pl[k].BM * pl[k].BN * c.Ci;
+    order[k] = k;
+  }
+  int fam = -1;
+  bool ok = n > 1;
+  int var[C3G_MAX];
+  for (int k = 0; k < n && ok; ++k) {
+    var[k] = c3_group_variant(pl[k], &fam);
+    ok = var[k] >= 0;
+  }
+  if (!ok) {
+    for (int k = 0; k < n; ++k) {
+      const int rc = c3_dispatch<3>(g.conv[k], pl[k], (hipStream_t)stream);
+      if (rc) return rc;
+    }
+    return BUCTD_OK;
+  }
+  // costliest tiles first: the grid ends with the cheap ones
+  for (int i = 1; i < n; ++i)
+    for (int j = i; j > 0 && cost[order[j]] > cost[order[j - 1]]; --j) { const int t = order[j]; order[j] = order[j - 1]; order[j - 1] = t; }
+  C3Group h;
+  h.nconv = n;
+  size_t lds = 0;
+  unsigned per_xcd = 0;
+  for (int i = 0; i < n; ++i) {
+    const int k = order[i];
+    h.conv[i] = g.conv[k];
+    h.gx[i] = ceil_div(h.conv[i].P, pl[k].BM);
+    h.gy[i] = h.conv[i].Co / pl[k].BN;
+    h.tiles[i] = h.gx[i] * h.gy[i];
+    h.variant[i] = var[k];
+    if (pl[k].lds > lds) lds = pl[k].lds;
+    per_xcd += ((unsigned)h.tiles[i] + 7) >> 3;
+  }
+  for (int i = n; i < C3G_MAX; ++i) h.tiles[i] = h.gx[i] = h.gy[i] = h.variant[i] = 0;
+  static bool attr_done[2] = {false, false};
+  void (*fn)(C3Group) = fam ? conv3x3_x6_group_kernel<1> : conv3x3_x6_group_kernel<0>;
+  if (!attr_done[fam]) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) {
+      buctd_set_error("buctd_conv3x3_bf16x6_group: cannot raise the dynamic LDS limit: %s", hipGetErrorString(e));
+      return BUCTD_ELAUNCH;
+    }
+    attr_done[fam] = true;
+  }
+  hipLaunchKernelGGL(fn, dim3(per_xcd * 8), dim3(256), lds, (hipStream_t)stream, h);
+  BUCTD_CHECK_LAUNCH("buctd_conv3x3_bf16x6_group");
+  return BUCTD_OK;
 }

@@ -23,9 +23,6 @@
 
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 
-#ifndef WG3_ABL
-#define WG3_ABL 0        // what-if builds only (scratch/build_alt.sh): 1 no slab stores, 2 no split / LDS stores, 4 no MFMAs, 8 no loads
-#endif
 #define WG_MAX_SW 75
 #define WG_PRO 96          // halo rows fetched per round of the first stage
 
@@ -99,8 +96,11 @@ __device__ __forceinline__ int ring_slot(int r, int ring) {     // r in [0, 2*ri
   return r - (r >= ring ? ring : 0);
 }
 
+// One workgroup's share of a weight gradient: chunk pair (bxc, byc) of ncx x ncy, position split z of nz.  The body of
+// conv3x3_wgrad_split_kernel (one convolution per launch) and of conv3x3_wgrad_group_kernel (the branches of a
+// HighResolutionModule in one launch).
 template <int NP, int CF>   // channel fragments (of 16) per chunk: 3 -> 48 channels, 2 -> 32
-__global__ __launch_bounds__(256, 2) void conv3x3_wgrad_split_kernel(WG3Args p) {
+__device__ __forceinline__ void wg3_tile(const WG3Args& p, unsigned char* smem, int bxc, int byc, int z, int ncx, int nz) {
   constexpr int KB = WGeo<NP>::KB;
   constexpr int CH = CF * 16;
   constexpr int LO = CH * 2;                 // byte stride between the pieces of a row
@@ -111,16 +111,14 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_split_kernel(WG3Args p) 
   constexpr int NFR = 9 * CF;                // n-fragments (tap, ci16)
   constexpr int NW = (NFR + 3) / 4;          // n-fragments per wave
 
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int R = KB + 2 * p.SW + 2;                   // rows of one stage = ring size
   unsigned char* Dt = smem;                          // dY tile [KB][RS]
   unsigned char* Xt = smem + (size_t)KB * RS;        // X  ring [R][RS]
 
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int t16 = lane & 15, g = lane >> 4;
-  const int co0 = blockIdx.x * CH, ci0 = blockIdx.y * CH;
+  const int co0 = bxc * CH, ci0 = byc * CH;
   // splits get q or q+1 stages (the first `split_rem` ones one more): no split-count rounding loss
-  const int z = blockIdx.z;
   const int k_begin = (z * p.split_q + (z < p.split_rem ? z : p.split_rem)) * KB;
   int k_end = k_begin + (p.split_q + (z < p.split_rem ? 1 : 0)) * KB;
   if (k_end > p.P) k_end = p.P;
@@ -240,11 +238,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_split_kernel(WG3Args p) 
   int rel_next = R;                          // first row (from k_begin - halo) of the stage after this one
   for (int k0 = k_begin; k0 < k_end; k0 += KB) {
     __syncthreads();                       // previous stage fully consumed
-    if (!(WG3_ABL & 2)) {
     store_d();
     store_x(slot_new);
-    }
-    if (k0 + KB < k_end && !(WG3_ABL & 8)) {                 // in flight during the MFMAs below
+    if (k0 + KB < k_end) {                 // in flight during the MFMAs below
       load_d(k0 + KB);
       load_x(rel_next);
     }
@@ -272,13 +268,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_split_kernel(WG3Args p) 
           bf16x8 b[NP];
 #pragma unroll
           for (int pc = 0; pc < NP; ++pc) b[pc] = tr_frag2(q0 + pc * LO, q1 + pc * LO);
-#if WG3_ABL & 4
-#define WG_MMA(qa, qb) _Pragma("unroll") for (int mf = 0; mf < CF; ++mf) asm volatile("" :: "v"(a[qa][mf]), "v"(b[qb]));
-#else
 #define WG_MMA(qa, qb)                                                                                      \
   _Pragma("unroll") for (int mf = 0; mf < CF; ++mf) acc[mf][j] =                                            \
       __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[qa][mf], b[qb], acc[mf][j], 0, 0, 0);
-#endif
           if constexpr (NP == 3) {
             WG_MMA(2, 0) WG_MMA(0, 2) WG_MMA(1, 1) WG_MMA(1, 0) WG_MMA(0, 1) WG_MMA(0, 0)
           } else {
@@ -296,35 +288,67 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_split_kernel(WG3Args p) 
   // instead of 84 scalar stores per lane into [co][tap][ci] rows; the reduction kernel sorts while it adds
   {
     const size_t slab4 = (size_t)4 * NW * CF * 64;
-    const size_t pair = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
-    f32x4* outp = reinterpret_cast<f32x4*>(p.part) + (pair * gridDim.z + blockIdx.z) * slab4;
+    const size_t pair = (size_t)byc * ncx + bxc;
+    f32x4* outp = reinterpret_cast<f32x4*>(p.part) + (pair * nz + z) * slab4;
 #pragma unroll
     for (int j = 0; j < NW; ++j)
 #pragma unroll
       for (int mf = 0; mf < CF; ++mf) {
-        if (WG3_ABL & 1) asm volatile("" :: "v"(acc[mf][j]));
-        else outp[((wave * NW + j) * CF + mf) * 64 + lane] = acc[mf][j];
+        outp[((wave * NW + j) * CF + mf) * 64 + lane] = acc[mf][j];
       }
   }
+}
+
+template <int NP, int CF>
+__global__ __launch_bounds__(256, 2) void conv3x3_wgrad_split_kernel(WG3Args p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  wg3_tile<NP, CF>(p, smem, blockIdx.x, blockIdx.y, blockIdx.z, gridDim.x, gridDim.z);
+}
+
+// Several weight gradients in ONE launch: workgroups [first[k], first[k + 1]) belong to convolution k.  Inside a convolution
+// the hardware's round-robin of workgroup ids over the 8 XCDs is undone so that every XCD walks a contiguous run of position
+// splits (neighbouring splits share their 2 * SW + 2 halo rows: they meet in that XCD's L2), chunk pairs fastest.
+#define WG3G_MAX 4
+struct WG3Group {
+  WG3Args conv[WG3G_MAX];
+  int n;
+  unsigned first[WG3G_MAX + 1];
+  int ncx[WG3G_MAX], ncy[WG3G_MAX], nsplit[WG3G_MAX];
+};
+template <int NP, int CF>
+__global__ __launch_bounds__(256, 2) void conv3x3_wgrad_group_kernel(WG3Group g_) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const WG3Group& g = *(const WG3Group*)__builtin_amdgcn_kernarg_segment_ptr();
+  int k = 0;
+  while (k + 1 < g.n && blockIdx.x >= g.first[k + 1]) ++k;
+  const unsigned lid = blockIdx.x - g.first[k], total = g.first[k + 1] - g.first[k];
+  const unsigned xcd = lid & 7, idx = lid >> 3, per = total >> 3, rem = total & 7;
+  const unsigned L = xcd < rem ? xcd * (per + 1) + idx : rem * (per + 1) + (xcd - rem) * per + idx;
+  const unsigned pairs = (unsigned)(g.ncx[k] * g.ncy[k]);
+  const unsigned z = L / pairs, pr = L - z * pairs;
+  const unsigned byc = pr / (unsigned)g.ncx[k], bxc = pr - byc * (unsigned)g.ncx[k];
+  wg3_tile<NP, CF>(g.conv[k], smem, (int)bxc, (int)byc, (int)z, g.ncx[k], g.nsplit[k]);
 }
 
 // slab reduction: thread = (element column, split lane); an element is one accumulator register quad (wave, j, mf, lane) =
 // rows co0 + mf*16 + g*4 + 0..3 of column (tap, ci0 + cf*16 + t16), nf = wave + 4 j = tap*CF + cf.  16 elements x 16 split
 // lanes per workgroup, four slab loads in flight per lane (the 512 slabs of the six-MFMA mode are 43 MB: at 8 split-lanes
 // this pass took 27 us), fixed summation order: deterministic.
+struct WG3Red { const float* part; float* out; int Ci, Co, nsplit, accumulate; };
 template <int CF>
-__global__ __launch_bounds__(256) void wg3_reduce_kernel(const float* __restrict__ part, float* __restrict__ out, int Ci,
-                                                         int Co, int nsplit, int accumulate) {
+__device__ __forceinline__ void wg3_reduce_body(const WG3Red& a, f32x4 (&sm)[16][16], int bx, int nbx, int pair) {
   constexpr int NFR = 9 * CF;
   constexpr int NW = (NFR + 3) / 4;
   constexpr int SLAB = 4 * NW * CF * 64;              // float4 per slab
-  __shared__ f32x4 sm[16][16];
+  const float* __restrict__ part = a.part;
+  float* __restrict__ out = a.out;
+  const int Ci = a.Ci, Co = a.Co, nsplit = a.nsplit, accumulate = a.accumulate;
   const int col = threadIdx.x & 15, zl = threadIdx.x >> 4;
-  const int pair = blockIdx.y;                          // pair = ci_chunk * (Co / CH) + co_chunk
+  // pair = ci_chunk * (Co / CH) + co_chunk
   const int nco = Co / (CF * 16);
   const int co0 = (pair % nco) * CF * 16, ci0 = (pair / nco) * CF * 16;
   const f32x4* base = reinterpret_cast<const f32x4*>(part) + (size_t)pair * nsplit * SLAB;
-  for (int e0 = blockIdx.x * 16; e0 < SLAB; e0 += gridDim.x * 16) {
+  for (int e0 = bx * 16; e0 < SLAB; e0 += nbx * 16) {
     const int e = e0 + col;
     f32x4 s0 = (f32x4){0.f, 0.f, 0.f, 0.f}, s1 = s0, s2 = s0, s3 = s0;
     if (e < SLAB) {
@@ -362,6 +386,24 @@ __global__ __launch_bounds__(256) void wg3_reduce_kernel(const float* __restrict
     __syncthreads();
   }
 }
+template <int CF>
+__global__ __launch_bounds__(256) void wg3_reduce_kernel(WG3Red a) {
+  __shared__ f32x4 sm[16][16];
+  wg3_reduce_body<CF>(a, sm, blockIdx.x, gridDim.x, blockIdx.y);
+}
+struct WG3RedGroup {
+  WG3Red r[WG3G_MAX];
+  int n;
+  unsigned first[WG3G_MAX + 1];     // in units of blockIdx.y (chunk pairs)
+};
+template <int CF>
+__global__ __launch_bounds__(256) void wg3_reduce_group_kernel(WG3RedGroup g_) {
+  __shared__ f32x4 sm[16][16];
+  const WG3RedGroup& g = *(const WG3RedGroup*)__builtin_amdgcn_kernarg_segment_ptr();
+  int k = 0;
+  while (k + 1 < g.n && blockIdx.y >= g.first[k + 1]) ++k;
+  wg3_reduce_body<CF>(g.r[k], sm, blockIdx.x, gridDim.x, (int)(blockIdx.y - g.first[k]));
+}
 
 // ---------------------------------------------------------------------------------------------- host ----
 struct WG3Plan { int CF, nsplit, q, rem; size_t lds; };
@@ -373,7 +415,7 @@ static void wg_magic(unsigned d, unsigned* mul, unsigned* sh) {
   *sh = l - 1;
 }
 
-static bool wg3_plan(int np, int N, int H, int W, int Ci, int Co, WG3Plan* pl) {
+static bool wg3_plan(int np, int N, int H, int W, int Ci, int Co, WG3Plan* pl, int target = 0) {
   if ((np != 2 && np != 3) || c3_row_width(W) > WG_MAX_SW || H < 1 || W < 2) return false;
   const int kb = np == 3 ? WGeo<3>::KB : WGeo<2>::KB;
   int cf;
@@ -393,7 +435,8 @@ static bool wg3_plan(int np, int N, int H, int W, int Ci, int Co, WG3Plan* pl) {
 #else
   constexpr int split_env = 0;
 #endif
-  long want = ((split_env > 0 ? split_env : (np == 3 ? 512 : 384)) + pairs - 1) / pairs;
+  // target > 0: the convolution shares its launch with others (wg3 group) and gets this many workgroups
+  long want = ((target > 0 ? target : split_env > 0 ? split_env : (np == 3 ? 512 : 384)) + pairs - 1) / pairs;
   const long stages = (P + kb - 1) / kb;
   if (want > stages) want = stages;
   if (want < 1) want = 1;
@@ -437,18 +480,17 @@ static int wg3_launch(const WG3Args& a, const WG3Plan& pl, hipStream_t st) {
 
 struct WG3InBn { const float* mean; const float* invstd; const float* gamma; const float* beta; int relu; };
 
-static int wg3_run(int np, int N, int H, int W, int Ci, int Co, const float* x, const float* dy, float* dw,
-                   int accumulate, void* workspace, size_t workspace_bytes, void* stream, const WG3InBn* x_bn = nullptr) {
-  WG3Plan pl;
+// argument block + plan of one weight gradient (no launch); target: see wg3_plan
+static int wg3_fill(int np, int N, int H, int W, int Ci, int Co, const float* x, const float* dy, float* dw, void* workspace,
+                    size_t workspace_bytes, const WG3InBn* x_bn, int target, WG3Args& a, WG3Plan& pl) {
   BUCTD_CHECK_ARG(x && dy && dw, "buctd_conv3x3_wgrad (split bf16): null tensor pointer");
-  BUCTD_CHECK_ARG(wg3_plan(np, N, H, W, Ci, Co, &pl),
+  BUCTD_CHECK_ARG(wg3_plan(np, N, H, W, Ci, Co, &pl, target),
                   "buctd_conv3x3_wgrad (split bf16): unsupported shape N%d H%d W%d Ci%d Co%d", N, H, W, Ci, Co);
   const size_t need = wg3_ws_bytes(pl, Ci, Co);
   if (!workspace || workspace_bytes < need) {
     buctd_set_error("buctd_conv3x3_wgrad (split bf16): workspace %zu bytes < required %zu", workspace_bytes, need);
     return BUCTD_EWORKSPACE;
   }
-  WG3Args a;
   a.x = x; a.dy = dy; a.part = (float*)workspace;
   a.N = N; a.H = H; a.W = W; a.Ci = Ci; a.Co = Co;
   a.SW = c3_row_width(W); a.IB = (H + 1) * a.SW;
@@ -467,24 +509,100 @@ static int wg3_run(int np, int N, int H, int W, int Ci, int Co, const float* x, 
   }
   wg_magic((unsigned)a.IB, &a.ib_mul, &a.ib_sh);
   wg_magic((unsigned)a.SW, &a.sw_mul, &a.sw_sh);
-  hipStream_t st = (hipStream_t)stream;
-  int rc;
-#ifdef WG3_WHATIF_SKIP_ALL      // what-if builds only (scratch/build_alt.sh): results are garbage, only the clock is read
   return BUCTD_OK;
-#endif
+}
+
+static int wg3_run(int np, int N, int H, int W, int Ci, int Co, const float* x, const float* dy, float* dw,
+                   int accumulate, void* workspace, size_t workspace_bytes, void* stream, const WG3InBn* x_bn = nullptr) {
+  WG3Plan pl;
+  WG3Args a;
+  int rc = wg3_fill(np, N, H, W, Ci, Co, x, dy, dw, workspace, workspace_bytes, x_bn, 0, a, pl);
+  if (rc) return rc;
+  hipStream_t st = (hipStream_t)stream;
   if (np == 3) rc = pl.CF == 3 ? wg3_launch<3, 3>(a, pl, st) : wg3_launch<3, 2>(a, pl, st);
   else rc = pl.CF == 3 ? wg3_launch<2, 3>(a, pl, st) : wg3_launch<2, 2>(a, pl, st);
   if (rc) return rc;
-#ifdef WG3_WHATIF_SKIP_REDUCE
-  return BUCTD_OK;
-#endif
   const int pairs = (Co / (pl.CF * 16)) * ((Ci + pl.CF * 16 - 1) / (pl.CF * 16));
   const dim3 rgrid(ceil_div((long)(wg3_slab_floats(pl.CF) / 4), 16), pairs);
+  const WG3Red ra{(const float*)workspace, dw, Ci, Co, pl.nsplit, accumulate};
   if (pl.CF == 3)
-    hipLaunchKernelGGL(wg3_reduce_kernel<3>, rgrid, dim3(256), 0, st, (const float*)workspace, dw, Ci, Co, pl.nsplit, accumulate);
+    hipLaunchKernelGGL(wg3_reduce_kernel<3>, rgrid, dim3(256), 0, st, ra);
   else
-    hipLaunchKernelGGL(wg3_reduce_kernel<2>, rgrid, dim3(256), 0, st, (const float*)workspace, dw, Ci, Co, pl.nsplit, accumulate);
+    hipLaunchKernelGGL(wg3_reduce_kernel<2>, rgrid, dim3(256), 0, st, ra);
   BUCTD_CHECK_LAUNCH("buctd_conv3x3_wgrad (split bf16, reduce)");
+  return BUCTD_OK;
+}
+
+// ---- the weight gradients of several convolutions in one launch (+ one launch for their slab reductions) ----------------
+// A convolution launched alone is cut into 512 position splits so that its ONE round of workgroups fills the chip; every
+// split pays the 2 * SW + 2 halo rows of its first stage and writes (and the reduction re-reads) an 84 KB slab.  n
+// convolutions in one grid fill the chip together: each gets WG3_GROUP_SLOTS / n workgroups, i.e. 1 / n of the halo and slab
+// traffic per convolution - and the launch is more than one round, so prologues and slab stores overlap other main loops.
+#ifndef WG3_GROUP_SLOTS
+#define WG3_GROUP_SLOTS 1024
+#endif
+static int wg3_group_target(int n) {
+#ifdef BUCTD_TUNING      // experiment builds only
+  static const int env = getenv("BUCTD_WG3_GROUP_SLOTS") ? atoi(getenv("BUCTD_WG3_GROUP_SLOTS")) : 0;
+  if (env > 0) return env / n;
+#endif
+  return WG3_GROUP_SLOTS / n;
+}
+
+extern "C" size_t buctd_conv3x3_wgrad_bf16x6_group_workspace(int n, int N, int H, int W, int Ci, int Co) {
+  WG3Plan pl;
+  if (n < 1 || n > WG3G_MAX || !wg3_plan(3, N, H, W, Ci, Co, &pl, n > 1 ? wg3_group_target(n) : 0)) return 0;
+  return wg3_ws_bytes(pl, Ci, Co);
+}
+
+extern "C" int buctd_conv3x3_wgrad_bf16x6_group(int n, const buctd_wg3_conv* convs, void* stream) {
+  BUCTD_CHECK_ARG(n > 0 && n <= WG3G_MAX && convs, "buctd_conv3x3_wgrad_bf16x6_group: 1..%d convolutions", WG3G_MAX);
+  if (n == 1) {
+    const buctd_wg3_conv& c = convs[0];
+    WG3InBn b{c.x_mean, c.x_invstd, c.x_gamma, c.x_beta, c.x_relu};
+    return wg3_run(3, c.N, c.H, c.W, c.Ci, c.Co, c.x, c.dy, c.dw, c.accumulate, c.workspace, c.workspace_bytes, stream, &b);
+  }
+  WG3Group g;
+  WG3RedGroup r;
+  WG3Plan pl[WG3G_MAX];
+  g.n = r.n = n;
+  g.first[0] = r.first[0] = 0;
+  size_t lds = 0;
+  const int target = wg3_group_target(n);
+  for (int k = 0; k < n; ++k) {
+    const buctd_wg3_conv& c = convs[k];
+    WG3InBn b{c.x_mean, c.x_invstd, c.x_gamma, c.x_beta, c.x_relu};
+    const int rc = wg3_fill(3, c.N, c.H, c.W, c.Ci, c.Co, c.x, c.dy, c.dw, c.workspace, c.workspace_bytes, &b, target, g.conv[k], pl[k]);
+    if (rc) return rc;
+    BUCTD_CHECK_ARG(pl[k].CF == pl[0].CF, "buctd_conv3x3_wgrad_bf16x6_group: the convolutions must share the chunk width (48 or 32 channels)");
+    const int ch = pl[k].CF * 16;
+    g.ncx[k] = c.Co / ch;
+    g.ncy[k] = (c.Ci + ch - 1) / ch;
+    g.nsplit[k] = pl[k].nsplit;
+    g.first[k + 1] = g.first[k] + (unsigned)(g.ncx[k] * g.ncy[k] * pl[k].nsplit);
+    r.r[k] = WG3Red{(const float*)c.workspace, c.dw, c.Ci, c.Co, pl[k].nsplit, c.accumulate};
+    r.first[k + 1] = r.first[k] + (unsigned)(g.ncx[k] * g.ncy[k]);
+    if (pl[k].lds > lds) lds = pl[k].lds;
+  }
+  for (int k = n; k < WG3G_MAX; ++k) { g.first[k + 1] = g.first[n]; r.first[k + 1] = r.first[n]; g.ncx[k] = g.ncy[k] = g.nsplit[k] = 0; }
+  hipStream_t st = (hipStream_t)stream;
+  static bool attr_done[2] = {false, false};
+  const int cf = pl[0].CF;
+  void (*fn)(WG3Group) = cf == 3 ? conv3x3_wgrad_group_kernel<3, 3> : conv3x3_wgrad_group_kernel<3, 2>;
+  if (!attr_done[cf - 2]) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) {
+      buctd_set_error("buctd_conv3x3_wgrad_bf16x6_group: cannot raise the dynamic LDS limit: %s", hipGetErrorString(e));
+      return BUCTD_ELAUNCH;
+    }
+    attr_done[cf - 2] = true;
+  }
+  hipLaunchKernelGGL(fn, dim3(g.first[n]), dim3(256), lds, st, g);
+  BUCTD_CHECK_LAUNCH("buctd_conv3x3_wgrad_bf16x6_group");
+  const dim3 rgrid(ceil_div((long)(wg3_slab_floats(cf) / 4), 16), r.first[n]);
+  if (cf == 3) hipLaunchKernelGGL(wg3_reduce_group_kernel<3>, rgrid, dim3(256), 0, st, r);
+  else hipLaunchKernelGGL(wg3_reduce_group_kernel<2>, rgrid, dim3(256), 0, st, r);
+  BUCTD_CHECK_LAUNCH("buctd_conv3x3_wgrad_bf16x6_group (reduce)");
   return BUCTD_OK;
 }
 

@@ -164,11 +164,46 @@ class HighResolutionModule(nn.Module):
     def get_num_inchannels(self):
         return self.num_inchannels
 
+    def _branches_grouped(self, x):
+        """All branches as ONE autograd node whose k-th convolutions share a launch (ops.BasicBranchesFn), or None when the
+        module does not qualify (eval mode, other block types, shapes without a native path)."""
+        nb = self.num_branches
+        if not (self.training and torch.is_grad_enabled() and all(type(br) is BlockChain and len(br) > 1 for br in self.branches)):
+            return None
+        chains = []
+        for br in self.branches:
+            if not all(type(m) is BasicBlock and m.downsample is None and m.stride == 1 and m.conv1.bias is None
+                       and m.conv2.bias is None and m.bn1.track_running_stats == m.bn2.track_running_stats
+                       == br[0].bn1.track_running_stats and m.bn1.training and m.bn2.training for m in br):
+                return None
+            chains.append([(m.conv1.weight, m.bn1, m.conv2.weight, m.bn2) for m in br])
+        xs = [x[i] for i in range(nb)]
+        if not ops.group_branches_ok(xs, chains):
+            return None
+        for chain in chains:
+            for (w1, _, w2, _) in chain:
+                nn._as_channels_last_(w1)
+                nn._as_channels_last_(w2)
+        parts = ops.group_branch_partition(nb)
+        if len(parts) == 1:
+            return list(ops.BasicBranchesFn.apply(chains[0][0][0], chains, *xs))
+        # several groups side by side on the branch streams: the streaming BatchNorm kernels of one group run under the
+        # convolutions of the other
+        outs = ops.fork_join([lambda p=p: ops.BasicBranchesFn.apply(chains[p[0]][0][0], [chains[i] for i in p], *[xs[i] for i in p])
+                              for p in parts], [[xs[i] for i in p] for p in parts])
+        ys = [None] * nb
+        for p, o in zip(parts, outs):
+            for i, y in zip(p, o):
+                ys[i] = y
+        return ys
+
     def forward(self, x):
         if self.num_branches == 1:
             return [self.branches[0](x[0])]
-        xs = ops.fork_join([lambda i=i: self.branches[i](x[i]) for i in range(self.num_branches)],
-                           [x[i] for i in range(self.num_branches)])
+        xs = self._branches_grouped(x)
+        if xs is None:
+            xs = ops.fork_join([lambda i=i: self.branches[i](x[i]) for i in range(self.num_branches)],
+                               [x[i] for i in range(self.num_branches)])
         rows = list(enumerate(self.fuse_layers))
         # every branch output feeds every fuse row: with gradients wanted, hand out aliases whose gradients are summed by one
         # n-ary add (ops.FanOut) instead of autograd's chain of two-operand adds

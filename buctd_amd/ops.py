@@ -1795,6 +1795,178 @@ class BasicChainFn(torch.autograd.Function):
         return (tmp[0, 4] if want_dx else None), None, None
 
 
+_GROUP_BRANCHES = {"on": True}
+
+
+def set_group_branches(on):
+    """HighResolutionModule branches as one autograd node with cross-branch group launches (BasicBranchesFn); off = one
+    BasicChainFn per branch on the branch streams (tests compare the two)."""
+    old = _GROUP_BRANCHES["on"]
+    _GROUP_BRANCHES["on"] = bool(on)
+    return old
+
+
+# 2: two group launch families side by side on two streams (branches {0, 1} | {2, 3}): C4 464.9 against 454.0 img/s with one
+# family and 462.5 with one chain per branch; C2 1170 against 1100 / 971 (one box, 20 steps)
+_GROUP_PARTS = {"n": 2}
+
+
+def set_group_parts(n):
+    old = _GROUP_PARTS["n"]
+    _GROUP_PARTS["n"] = int(n)
+    return old
+
+
+def group_branch_partition(nb):
+    """Branch indices per group launch family: one group of all branches, or two groups side by side on two streams."""
+    if _GROUP_PARTS["n"] <= 1 or nb < 3:
+        return [list(range(nb))]
+    if nb == 3:
+        return [[0], [1, 2]] if _GROUP_PARTS["n"] == 2 else [[0, 2], [1]]
+    return [[0, 1], [2, 3]] if _GROUP_PARTS["n"] == 2 else [[0, 3], [1, 2]]
+
+
+def group_branches_ok(xs, chains):
+    """True when the branches of a HighResolutionModule (activations xs[b], chains[b] = [(w1, bn1, w2, bn2), ...]) may run
+    as ONE native call per direction with cross-branch group launches."""
+    if not (_GROUP_BRANCHES["on"] and 1 <= len(xs) <= 4 and len({len(c) for c in chains}) == 1):
+        return False
+    cfs = set()
+    for x, chain in zip(xs, chains):
+        if not (x.is_cuda and x.dim() == 4 and native_chain_ok(tuple(x.shape)) and bn_in_fusable(tuple(x.shape), chain[0][0])):
+            return False
+        Cn = x.shape[-1]
+        cfs.add(3 if Cn % 48 == 0 else 2 if Cn % 32 == 0 else 0)
+    return len(cfs) == 1 and 0 not in cfs
+
+
+class BasicBranchesFn(torch.autograd.Function):
+    """The branches of a HighResolutionModule (pose_hrnet.py:177-185, 247-249) - nb chains of n residual BasicBlocks on maps of
+    different size - as ONE autograd node and one library call per direction (block.hip: buctd_basic_branches_*).  The k-th
+    convolutions of all branches are one launch (several de-phased rounds of workgroups instead of nb phase-locked rounds on
+    nb streams), so are the BatchNorm applies / backwards and the weight gradients.
+    chains[b] = [(w1, bn1, w2, bn2), ...]; w_first only makes autograd build the node when no input needs a gradient."""
+
+    @staticmethod
+    def forward(ctx, w_first, chains, *xs):
+        nb, n = len(xs), len(chains[0])
+        dev = xs[0].device
+        descs = (_C.BasicBlockDesc * (nb * n))()
+        acts, stats = [], []
+        for b, x in enumerate(xs):
+            N, H, W, Cn = x.shape
+            act = torch.empty((n, 3, N, H, W, Cn), dtype=torch.float32, device=dev)        # per block: z1 | z2 | y
+            stat = torch.empty((n, 4, Cn), dtype=torch.float32, device=dev)
+            acts.append(act)
+            stats.append(stat)
+            step = 4 * N * H * W * Cn
+            accb = acc_bytes(Cn)
+            abase, pbase, sbase = act.data_ptr(), AccRef(Cn, dev, 2 * n).ptr, stat.data_ptr()
+            xin = x.data_ptr()
+            for k, (w1, bn1, w2, bn2) in enumerate(chains[b]):
+                d = descs[b * n + k]
+                d.N, d.H, d.W, d.C = N, H, W, Cn
+                d.x = xin
+                d.w1_fwd = _conv3x3_prepared(w1, 0).data_ptr()
+                d.w2_fwd = _conv3x3_prepared(w2, 0).data_ptr()
+                d.gamma1, d.beta1 = bn1.weight.data_ptr(), bn1.bias.data_ptr()
+                d.gamma2, d.beta2 = bn2.weight.data_ptr(), bn2.bias.data_ptr()
+                if bn1.track_running_stats:
+                    d.running_mean1, d.running_var1 = bn1.running_mean.data_ptr(), bn1.running_var.data_ptr()
+                    d.running_mean2, d.running_var2 = bn2.running_mean.data_ptr(), bn2.running_var.data_ptr()
+                    bn1.count_batch() if hasattr(bn1, "count_batch") else bn1.num_batches_tracked.add_(1)
+                    bn2.count_batch() if hasattr(bn2, "count_batch") else bn2.num_batches_tracked.add_(1)
+                d.eps1, d.momentum1 = bn1.eps, 0.1 if bn1.momentum is None else bn1.momentum
+                d.eps2, d.momentum2 = bn2.eps, 0.1 if bn2.momentum is None else bn2.momentum
+                b0 = abase + 3 * step * k
+                d.z1, d.z2, d.y = b0, b0 + step, b0 + 2 * step
+                d.acc, d.stat = pbase + k * 2 * accb, sbase + k * 4 * Cn * 4
+                xin = d.y
+        check(lib().buctd_basic_branches_fwd_train(nb, n, descs, stream_ptr()), "basic_branches_fwd_train")
+        ctx.chains = chains
+        ctx.save_for_backward(*xs, *acts, *stats)
+        return tuple(act[n - 1, 2] for act in acts)
+
+    @staticmethod
+    def backward(ctx, *dys):
+        chains = ctx.chains
+        nb, n = len(chains), len(chains[0])
+        saved = ctx.saved_tensors
+        xs, acts, stats = saved[:nb], saved[nb:2 * nb], saved[2 * nb:]
+        dev = xs[0].device
+        descs = (_C.BasicBlockDesc * (nb * n))()
+        grads = (_C.BasicBlockGrads * (nb * n))()
+        main = torch.cuda.current_stream(dev)
+        use_side = _side["on"]
+        side = _side_stream(dev) if use_side else main
+        needs = []
+        for x in xs:
+            N, H, W, Cn = x.shape
+            needs.append(_memo(("wg3g", nb, N, H, W, Cn), lambda: (int(lib().buctd_conv3x3_wgrad_bf16x6_group_workspace(
+                nb, N, H, W, Cn, Cn)) + 255) & ~255))
+        wg_ws = workspace_on(side, sum(needs), dev)     # one slab area per branch: the branches share a launch
+        ws_ptr = wg_ws.data_ptr()
+        tmps, keep = [], []
+        for b, x in enumerate(xs):
+            N, H, W, Cn = x.shape
+            dy = dys[b]
+            dy = torch.zeros_like(x) if dy is None else _contig(dy)
+            keep.append(dy)
+            want_dx = ctx.needs_input_grad[2 + b]
+            tmp = torch.empty((n, 5, N, H, W, Cn), dtype=torch.float32, device=dev)   # per block: dz2 | dres | dy1 | dz1 | dx
+            tmps.append(tmp)
+            step = 4 * N * H * W * Cn
+            abase, sbase, tb = acts[b].data_ptr(), stats[b].data_ptr(), tmp.data_ptr()
+            accb = acc_bytes(Cn)
+            bn_acc = AccRef(Cn, dev, 2 * n).ptr
+            xin = x.data_ptr()
+            for k, (w1, bn1, w2, bn2) in enumerate(chains[b]):
+                d, g = descs[b * n + k], grads[b * n + k]
+                d.N, d.H, d.W, d.C = N, H, W, Cn
+                d.x = xin
+                d.w1_bwd = _conv3x3_prepared(w1, 1).data_ptr()
+                d.w2_bwd = _conv3x3_prepared(w2, 1).data_ptr()
+                d.gamma1, d.beta1 = bn1.weight.data_ptr(), bn1.bias.data_ptr()
+                d.gamma2, d.beta2 = bn2.weight.data_ptr(), bn2.bias.data_ptr()
+                b0 = abase + 3 * step * k
+                d.z1, d.z2, d.y = b0, b0 + step, b0 + 2 * step
+                d.stat = sbase + k * 4 * Cn * 4
+                xin = d.y
+                t0 = tb + 5 * step * k
+                g.dy = dy.data_ptr() if k == n - 1 else tb + 5 * step * (k + 1) + 4 * step      # the next block's dx
+                g.dz2, g.dres, g.dy1, g.dz1 = t0, t0 + step, t0 + 2 * step, t0 + 3 * step
+                g.dx = t0 + 4 * step if (k > 0 or want_dx) else 0
+                dg2, acc_g2 = grad_target(bn2.weight)
+                db2, acc_b2 = grad_target(bn2.bias)
+                dw2, acc_w2 = grad_target(w2)
+                dg1, acc_g1 = grad_target(bn1.weight)
+                db1, acc_b1 = grad_target(bn1.bias)
+                dw1, acc_w1 = grad_target(w1)
+                assert acc_g2 == acc_b2 and acc_g1 == acc_b1
+                weight_rsc(dw1)
+                weight_rsc(dw2)
+                g.dw1, g.dw2 = dw1.data_ptr(), dw2.data_ptr()
+                g.dgamma1, g.dbeta1, g.dgamma2, g.dbeta2 = dg1.data_ptr(), db1.data_ptr(), dg2.data_ptr(), db2.data_ptr()
+                g.acc_w1, g.acc_w2, g.acc_bn1, g.acc_bn2 = int(acc_w1), int(acc_w2), int(acc_g1), int(acc_g2)
+                g.bn_acc = bn_acc + k * 2 * accb
+                g.wg_ws, g.wg_ws_bytes = ws_ptr, needs[b]
+            ws_ptr += needs[b]
+        check(lib().buctd_basic_branches_bwd(nb, n, descs, grads, main.cuda_stream, side.cuda_stream if use_side else None),
+              "basic_branches_bwd")
+        if use_side:
+            for t in list(xs) + list(acts) + list(stats) + tmps + keep:
+                t.record_stream(side)
+            _queue_join()
+        elif _branch["on"]:
+            _queue_join()
+        for k in range(n - 1, -1, -1):
+            for b in range(nb):
+                w1, bn1, w2, bn2 = chains[b][k]
+                grad_done(bn2.weight, bn2.bias, w2)
+                grad_done(bn1.weight, bn1.bias, w1)
+        return (None, None) + tuple(tmps[b][0, 4] if ctx.needs_input_grad[2 + b] else None for b in range(nb))
+
+
 class Conv(torch.autograd.Function):
     """conv / Linear-as-1x1-conv with bias, optional fused residual + ReLU (no BatchNorm)."""
 

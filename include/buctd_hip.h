@@ -113,6 +113,27 @@ int buctd_conv3x3_bf16x6_bnstat_acc(int N, int H, int W, int Ci, int Co, const f
                                     const float* residual, float* y, const float* bn_z, const float* bn_y,
                                     const float* bn_mean, const float* bn_invstd, const float* bn_gamma, const float* bn_beta,
                                     void* bn_acc, void* stream);
+/* Several independent 3x3 convolutions in ONE launch - the k-th convolutions of the 2-4 branches of a HighResolutionModule
+ * (pose_hrnet.py:177-185), which cost the same FLOPs on maps of different size.  The tiles of all of them form one grid
+ * (costliest first), so the launch is several rounds of workgroups that de-phase instead of one phase-locked round per
+ * convolution.  Each entry is one buctd_conv3x3_bf16x6_acc call (forward: stats_acc / in_bn ...) or one
+ * buctd_conv3x3_bf16x6_bnstat_acc call (data gradient: bn_acc != NULL with bn_z ...; without bn_acc a plain data gradient);
+ * results are bit-identical to those calls.  n <= 4. */
+typedef struct {
+  int N, H, W, Ci, Co;
+  const float* x;
+  const void* wprep;
+  const float* residual;
+  int relu;
+  float* y;
+  void* stats_acc;                         /* forward statistics of y (NULL: none) */
+  const struct buctd_bn_acc_in_* in_bn;    /* input BatchNorm from the producer's accumulator (NULL: none) */
+  const float *in_gamma, *in_beta;
+  int in_relu;
+  const float *bn_z, *bn_y, *bn_mean, *bn_invstd, *bn_gamma, *bn_beta;   /* BatchNorm-backward by-product ... */
+  void* bn_acc;                                                          /* ... into this accumulator (NULL: none) */
+} buctd_c3_conv;
+int buctd_conv3x3_bf16x6_group(int n, const buctd_c3_conv* convs, void* stream);
 int buctd_conv3x3_bf16x3_supported(int N, int H, int W, int Ci, int Co);
 int buctd_conv3x3_bf16x3_stats_groups(int N, int H, int W, int Ci, int Co, int* ngroups, int* rows_per_group);
 size_t buctd_conv3x3_bf16x3_prep_bytes(int Ci, int Co, int flip);
@@ -144,6 +165,24 @@ int buctd_conv3x3_wgrad_bf16x6_bnin(int N, int H, int W, int Ci, int Co, const f
                                     int accumulate, const float* x_mean, const float* x_invstd, const float* x_gamma,
                                     const float* x_beta, int x_relu, void* workspace, size_t workspace_bytes,
                                     void* stream);
+/* The weight gradients of the k-th convolutions of the 2-4 branches of a HighResolutionModule (pose_hrnet.py:177-185) in ONE
+ * launch (+ one for their slab reductions).  Convolutions that share a launch fill the chip together, so each is cut into
+ * fewer position splits than it would be alone: less halo re-reading, fewer slabs (a different, still fixed, summation order
+ * than the single call: deterministic, fp32-class, not bit-identical to it).  Each item needs its OWN workspace of
+ * buctd_conv3x3_wgrad_bf16x6_group_workspace(n, ...) bytes (n = convolutions in the launch); x_mean != NULL: the BatchNorm
+ * (+ReLU) of the producer applied to x while it is staged, as in buctd_conv3x3_wgrad_bf16x6_bnin.  n <= 4. */
+typedef struct {
+  int N, H, W, Ci, Co;
+  const float *x, *dy;
+  float* dw;
+  int accumulate;
+  const float *x_mean, *x_invstd, *x_gamma, *x_beta;
+  int x_relu;
+  void* workspace;
+  size_t workspace_bytes;
+} buctd_wg3_conv;
+size_t buctd_conv3x3_wgrad_bf16x6_group_workspace(int n, int N, int H, int W, int Ci, int Co);
+int buctd_conv3x3_wgrad_bf16x6_group(int n, const buctd_wg3_conv* convs, void* stream);
 int buctd_conv3x3_wgrad_bf16x3_supported(int N, int H, int W, int Ci, int Co);
 size_t buctd_conv3x3_wgrad_bf16x3_workspace(int N, int H, int W, int Ci, int Co);
 int buctd_conv3x3_wgrad_bf16x3(int N, int H, int W, int Ci, int Co, const float* x, const float* dy, float* dw,
@@ -224,6 +263,29 @@ int buctd_bn_apply_acc(const float* z, const buctd_bn_acc_in* st, const float* g
 int buctd_bn_bwd_acc(const float* dy, const float* y, const float* z, const float* mean, const float* invstd,
                      const float* gamma, const float* beta, int relu, long rows, int C, float* dz, float* dres,
                      float* dgamma, float* dbeta, int accumulate, void* acc, int acc_ready, void* stream);
+/* The same for the 2-4 branch tensors of a HighResolutionModule (pose_hrnet.py:177-185) in ONE launch per kernel kind: every
+ * tensor is processed exactly as by its own buctd_bn_apply_acc / buctd_bn_bwd_acc call (bit-identical results).  n <= 4. */
+typedef struct {
+  const float* z;
+  buctd_bn_acc_in st;
+  const float *gamma, *beta, *residual;
+  int relu;
+  float* y;
+  long rows;
+  int C;
+} buctd_bn_apply_item;
+int buctd_bn_apply_acc_group(int n, const buctd_bn_apply_item* items, void* stream);
+typedef struct {
+  const float *dy, *y, *z, *mean, *invstd, *gamma, *beta;
+  int relu;
+  long rows;
+  int C;
+  float *dz, *dres, *dgamma, *dbeta;
+  int accumulate;
+  void* acc;
+  int acc_ready;
+} buctd_bn_bwd_item;
+int buctd_bn_bwd_acc_group(int n, const buctd_bn_bwd_item* items, void* stream);
 /* eval-mode helpers: scale = gamma/sqrt(var+eps), shift = beta - mean*scale */
 int buctd_bn_fold(const float* gamma, const float* beta, const float* running_mean, const float* running_var,
                   float eps, int C, float* scale, float* shift, void* stream);
@@ -404,6 +466,16 @@ int buctd_basic_block_bwd(const buctd_basic_block* b, const buctd_basic_block_gr
 int buctd_basic_chain_fwd_train(int n, const buctd_basic_block* blocks, void* stream);
 int buctd_basic_chain_bwd(int n, const buctd_basic_block* blocks, const buctd_basic_block_grads* grads, void* stream,
                           void* side_stream);
+
+/* The branches of a HighResolutionModule (pose_hrnet.py:177-185, 247-249): nb independent chains of n blocks each, advanced
+ * together - blocks[b * n + k] / grads[b * n + k] = block k of branch b, wired per branch as for buctd_basic_chain_*.  The
+ * k-th convolutions of all branches are ONE launch (buctd_conv3x3_bf16x6_group), so are their BatchNorm applies, BatchNorm
+ * backwards and weight gradients (buctd_conv3x3_wgrad_bf16x6_group on `side_stream`; each branch needs its own wg_ws of
+ * buctd_conv3x3_wgrad_bf16x6_group_workspace(nb, ...) bytes): 3 launches per block step forward, 8 backward, whatever nb.
+ * Activations, statistics and data gradients are bit-identical to nb buctd_basic_chain_* calls.  nb <= 4. */
+int buctd_basic_branches_fwd_train(int nb, int n, const buctd_basic_block* blocks, void* stream);
+int buctd_basic_branches_bwd(int nb, int n, const buctd_basic_block* blocks, const buctd_basic_block_grads* grads, void* stream,
+                             void* side_stream);
 
 /* ------------------------------------------------------------ bf16x6 GEMM --- */
 /* C = alpha * A * B (+ bias) in the bf16x6 arithmetic of the 3x3 convolutions (fp32 operands split exactly into three
