@@ -687,6 +687,9 @@ def conv_dgrad(dy, w, x_shape, stride=1, pad=0, bias=None, stats=False, residual
     return (dx, part, info) if stats else dx
 
 
+_GCONV_WGRAD = {"on": True}      # 1x1 / stride-2 weight gradients on the bf16x6 kernel (off: the exact-fp32 MFMA kernel; tests)
+
+
 def conv_wgrad(x, dy, w_like, stride=1, pad=0, out=None, accumulate=0, x_bn=None):
     """x_bn = (mean, invstd, gamma, beta, relu): like conv_fwd's in_bn, for the X operand of the weight gradient."""
     _f32(x, "conv wgrad x")
@@ -719,6 +722,16 @@ def conv_wgrad(x, dy, w_like, stride=1, pad=0, out=None, accumulate=0, x_bn=None
             return out
     if x_bn is not None:
         raise _C.BuctdHipError("conv_wgrad: x_bn needs the bf16x6 3x3 kernel (check bn_in_fusable first)")
+    kind = _gconv_kind(d) if mode == "bf16x6" and _GCONV_WGRAD["on"] else 0
+    if kind:
+        need = _memo(("gwg", kind, d.N, d.H, d.W, d.Ci, d.Co),
+                     lambda: (int(lib().buctd_gconv_wgrad_x6_workspace(kind, d.N, d.H, d.W, d.Ci, d.Co))
+                              if lib().buctd_gconv_wgrad_x6_supported(kind, d.N, d.H, d.W, d.Ci, d.Co) == 1 else -1))
+        if need >= 0:
+            ws = workspace(need, x.device)
+            check(lib().buctd_gconv_wgrad_x6(kind, d.N, d.H, d.W, d.Ci, d.Co, ptr(x), ptr(dy), ptr(out), int(accumulate), ptr(ws),
+                                             ws.numel(), stream_ptr()), "gconv_wgrad_x6")
+            return out
     need = lib().buctd_conv2d_wgrad_workspace(C.byref(d))
     ws = workspace(need, x.device)
     check(lib().buctd_conv2d_wgrad(C.byref(d), ptr(x), ptr(dy), ptr(out), int(accumulate), ptr(ws), ws.numel(),

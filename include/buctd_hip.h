@@ -428,6 +428,14 @@ int buctd_gconv_x6_fwd_acc(int kind, int N, int H, int W, int Ci, int Co, const 
                            float* y, void* stats_acc, void* stream);
 int buctd_gconv_x6_dgrad(int kind, int N, int H, int W, int Ci, int Co, const float* dy, const void* wprep,
                          const float* residual, float* dx, void* stream);
+/* Weight gradient of a 1x1 (kind 1) or stride-2 3x3 pad-1 (kind 2; H, W even) convolution Ci -> Co in the bf16x6 arithmetic
+ * (csrc/conv_gather_wgrad.hip): dw [Co][R][S][Ci] (+)= sum over output pixels dy (x) gathered x, x = [N][H][W][Ci], dy =
+ * [N][Ho][Wo][Co].  The autograd weight gradient of the fuse-layer / transition / Bottleneck convolutions
+ * (pose_hrnet.py:60-108, 187-245, 338-372); both channel counts must be multiples of 48, or both of 32. */
+int buctd_gconv_wgrad_x6_supported(int kind, int N, int H, int W, int Ci, int Co);
+size_t buctd_gconv_wgrad_x6_workspace(int kind, int N, int H, int W, int Ci, int Co);
+int buctd_gconv_wgrad_x6(int kind, int N, int H, int W, int Ci, int Co, const float* x, const float* dy, float* dw,
+                         int accumulate, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------- BasicBlock sequences --- */
 /* The kernel sequence of one residual BasicBlock in train mode (pose_hrnet.py:28-57: stride 1, C -> C, no downsample,

@@ -147,3 +147,49 @@ def test_prepared_images_follow_in_place_weight_updates(dev):
         ref += [y, ops.conv_dgrad(torch.ones_like(y), w2, tuple(x.shape), st, pad)]
     assert all(torch.equal(a, b) for a, b in zip(fresh, ref))
     assert not torch.equal(fresh[0], before[0])
+
+
+# (N, H, W, Ci, Co, k): the weight gradients of the same layers on the bf16x6 kernel (csrc/conv_gather_wgrad.hip)
+WG_SHAPES = [(2, 24, 18, 48, 96, 3), (2, 12, 10, 96, 192, 3), (3, 8, 6, 192, 384, 3), (2, 16, 12, 48, 48, 3), (2, 20, 14, 64, 64, 3),
+             (1, 6, 4, 256, 96, 3), (2, 4, 4, 48, 192, 3), (4, 96, 72, 48, 96, 3), (2, 24, 18, 64, 256, 1), (2, 24, 18, 256, 64, 1),
+             (3, 12, 9, 96, 48, 1), (2, 7, 5, 192, 96, 1), (2, 6, 5, 384, 192, 1), (1, 1, 2, 48, 48, 1), (2, 48, 36, 96, 48, 1),
+             (1, 5, 3, 32, 64, 1), (32, 24, 18, 192, 48, 1)]
+
+
+@pytest.mark.parametrize("shape", WG_SHAPES)
+def test_gconv_weight_gradient_vs_fp64(dev, shape):
+    """buctd_gconv_wgrad_x6 (every wave stages, splits and multiplies its own 32-pixel k-steps; partial slabs added in a fixed
+    order) against torch's fp64 conv2d_weight: <= 2e-6 of the largest element; accumulation into an existing gradient; run-to-run
+    bit-reproducible."""
+    from buctd_amd import ops, _C
+    N, H, W, Ci, Co, k = shape
+    stride, pad = (1, 0) if k == 1 else (2, 1)
+    kind = 1 if k == 1 else 2
+    assert _C.lib().buctd_gconv_wgrad_x6_supported(kind, N, H, W, Ci, Co) == 1
+    g = torch.Generator().manual_seed(sum(shape))
+    Ho, Wo = (H, W) if k == 1 else (H // 2, W // 2)
+    x = torch.randn(N, H, W, Ci, generator=g).to(dev)
+    dy = torch.randn(N, Ho, Wo, Co, generator=g).to(dev)
+    w_like = torch.empty(Co, Ci, k, k, device=dev).contiguous(memory_format=torch.channels_last)
+    dw = ops.conv_wgrad(x, dy, w_like, stride, pad)
+    dw2 = ops.conv_wgrad(x, dy, w_like, stride, pad)
+    base = torch.randn(Co, Ci, k, k, generator=g).to(dev).contiguous(memory_format=torch.channels_last)
+    acc = base.clone(memory_format=torch.preserve_format)
+    ops.conv_wgrad(x, dy, w_like, stride, pad, out=acc, accumulate=1)
+    torch.cuda.synchronize()
+    ref = torch.nn.grad.conv2d_weight(x.double().permute(0, 3, 1, 2).cpu(), (Co, Ci, k, k), dy.double().permute(0, 3, 1, 2).cpu(),
+                                      stride=stride, padding=pad)
+    sc = ref.abs().max().item()
+    assert torch.equal(dw, dw2), "not run-to-run reproducible"
+    assert (dw.cpu().double() - ref).abs().max().item() <= TOL * sc
+    assert (acc.cpu().double() - base.cpu().double() - ref).abs().max().item() <= 2 * TOL * max(sc, base.abs().max().item())
+
+
+def test_gconv_weight_gradient_dispatch(dev):
+    """channel counts without a bf16x6 tile (not multiples of 32 or 48) and odd stride-2 inputs stay on the exact-fp32 kernel"""
+    from buctd_amd import _C
+    lib = _C.lib()
+    assert lib.buctd_gconv_wgrad_x6_supported(1, 2, 8, 8, 48, 16) == 0
+    assert lib.buctd_gconv_wgrad_x6_supported(2, 2, 9, 8, 48, 48) == 0
+    assert lib.buctd_gconv_wgrad_x6_supported(2, 2, 8, 8, 64, 256) == 1
+    assert lib.buctd_gconv_wgrad_x6_supported(3, 2, 8, 8, 48, 48) == 0
