@@ -39,7 +39,7 @@ def _profile_json(name):
         return None
 
 
-def coam_w48_cfg(batch):
+def coam_w48_cfg(batch, colored=True):
     from buctd_amd.config import cfg as base, hrnet_extra
     c = base.clone()
     c.defrost()
@@ -53,7 +53,7 @@ def coam_w48_cfg(batch):
     c.MODEL.CONDITIONAL_TOPDOWN = True
     c.MODEL.EXTRA = hrnet_extra(48, use_attention=True)
     c.DATASET.DATASET = "crowdpose"
-    c.DATASET.COLORED = True
+    c.DATASET.COLORED = bool(colored)
     c.TRAIN.BATCH_SIZE_PER_GPU = batch
     c.TRAIN.LR = 0.002
     c.freeze()
@@ -118,6 +118,9 @@ def synthetic_batch(cfg, batch, device, seed):
                                 [1] * batch, seed, device=device)
     cond_j = syn[:, :, :2].float().contiguous()
     colors = torch.tensor((CROWDPOSE_COLORS * 2)[:k], dtype=torch.float32, device=device)
+    if not cfg.DATASET.COLORED:
+        # mono condition (north_star's literal "4-channel crops"; pose_hrnet_coam.py:750-757): one white heat-map channel
+        colors = torch.ones(k, 1, dtype=torch.float32, device=device)
     cond = ops.cond_render(cond_j, colors, h, w)
     x = torch.cat([rgb, cond], 1).contiguous()
     joints3 = torch.cat([gt, torch.zeros(batch, k, 1)], 2).to(device).contiguous()
@@ -237,8 +240,9 @@ def roofline_entry(math, batch, kind, in_step, solo, traffic, shape=(48, 96, 72)
     def frac(us):
         return round((mfma_us if bound == "mfma" else hbm_us) / us, 4) if us else None
 
-    tf = flops / t_head / 1e6
-    gbps = bytes_ / t_head / 1e3
+    t_ach = kernel_us if kernel_us else t_head      # `achieved` / `frac` follow the in-step kernel duration where it is known
+    tf = flops / t_ach / 1e6
+    gbps = bytes_ / t_ach / 1e3
     if shape != (48, 96, 72):
         kernel = kernel.split("<")[0] + "<...>"
     return {"kernel": f"{kernel}: 3x3 {cw}->{cw} @{hh}x{ww} N={n} (HRNet branch 0), {names[kind]}",
@@ -246,8 +250,12 @@ def roofline_entry(math, batch, kind, in_step, solo, traffic, shape=(48, 96, 72)
             "achieved": round(tf, 2) if bound == "mfma" else round(gbps, 1),
             "peak": round(peak, 1) if bound == "mfma" else PEAK_HBM_GBPS,
             "unit": "TFLOP/s" if bound == "mfma" else "GB/s",
-            "frac": frac(t_head),
+            # frac = the reproducible one: the kernel's own duration inside the step (committed rocprofv3 trace); without a trace
+            # for this configuration, the live event bracket
+            "frac": frac(kernel_us) if kernel_us else frac(t_head),
+            "frac_source": "frac_in_step_kernel" if kernel_us else "frac_event_bracket",
             "avg_kernel_us_in_step": kernel_us, "frac_in_step_kernel": frac(kernel_us),
+            "frac_event_bracket": frac(t_head),
             "traffic": traffic, "traffic_unit": "HBM bytes/launch (PMC, standalone launches)" if traffic else None,
             "sources": sources,
             "algorithmic_flops": flops, "algorithmic_bytes": bytes_,
@@ -256,7 +264,7 @@ def roofline_entry(math, batch, kind, in_step, solo, traffic, shape=(48, 96, 72)
             "frac_solo": frac(solo[0]),
             "hbm_gbps": round(gbps, 1), "hbm_frac": round(gbps / PEAK_HBM_GBPS, 4),
             "roof_times_us": {"mfma": round(mfma_us, 2), "hbm": round(hbm_us, 2)},
-            "timing": "HIP events on the launching stream around each launch. avg_launch_us / frac: every launch of this "
+            "timing": "HIP events on the launching stream around each launch. avg_launch_us / frac_event_bracket: every launch of this "
                       "shape inside the step (event to event: the step keeps 4 streams busy, so it contains the co-runners' "
                       "share of the GPU and the time the launch queues behind them); avg_kernel_us_in_step / "
                       "frac_in_step_kernel: the kernel's own duration inside the step, from the committed rocprofv3 "
@@ -442,9 +450,9 @@ def bench_infer_c5(args, rank, world, device):
         flops = 4.0 * args.batch * T * T * d
         bytes_ = 4.0 * args.batch * T * d * 4          # q, k, v read + o written once
         tf = flops / us / 1e6
-        x6 = args.conv_math == "bf16x6" and os.environ.get("BUCTD_MHA_X6", "1") != "0"
+        x6 = args.conv_math == "bf16x6" and ops._MHA_X6
         peak = PEAK_BF16_MFMA_TFLOPS / 6 if x6 else PEAK_FP32_MFMA_TFLOPS
-        pre = x6 and os.environ.get("BUCTD_MHA_PRESPLIT", "1") != "0"
+        pre = x6 and ops._MHA_PRESPLIT
         kname = ("mha_kv_split_kernel + mha_fwd_x6q_kernel" if pre else "mha_fwd_x6_kernel") if x6 else "mha_fwd_kernel"
         out["roofline"] = {"kernel": f"{kname}<7>: fused self-attention forward, "
                                      f"T={T} d={d} N={args.batch} (TransPose encoder layer)", "bound": "mfma",
@@ -503,11 +511,14 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=32, help="images per GPU (scripts: 32, W48 YAML: 24)")
-    ap.add_argument("--conv-math", default=os.environ.get("BUCTD_CONV_MATH", "bf16x6"),
+    ap.add_argument("--conv-math", default="bf16x6",
                     choices=["fp32", "bf16x6", "bf16x3"],
                     help="how the 3x3/s1 convs (fwd, dgrad, wgrad) are computed: bf16x6 (default) = fp32-class, exact "
                          "3-way bf16 split, 6 MFMAs per product; fp32 = v_mfma_f32_16x16x4_f32; bf16x3 = optional "
                          "reduced precision (~2^-16 per product) - not a headline mode")
+    ap.add_argument("--condition", default="colored", choices=["colored", "mono"],
+                    help="train_c4 only: colored = the CrowdPose recipe (6-channel input, the headline); mono = one white "
+                         "condition channel (4-channel input, north_star's literal variant)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timer", action="store_true")
     args = ap.parse_args()
@@ -535,6 +546,14 @@ def main():
         return
     make_cfg, module, metric, describe, rshape = TRAIN_WORKLOADS[args.workload]
     cfg = make_cfg(args.batch)
+    n_in = 6
+    if args.condition == "mono":
+        # north_star's literal "synthetic 384x288 4-channel crops": RGB + one mono condition heat map (pose_hrnet_coam.py:750-757)
+        if args.workload != "train_c4":
+            raise SystemExit("--condition mono is a variant of train_c4 (the preNet recipes stack a colored condition)")
+        cfg = coam_w48_cfg(args.batch, colored=False)
+        describe = describe.replace("colored condition", "mono condition (4-channel input)")
+        n_in = 4
     torch.manual_seed(1234)
     ops.manual_seed(1234 + rank)
     net = getattr(models, module).get_pose_net(cfg, is_train=True).to(device)
@@ -663,8 +682,10 @@ def main():
             "config": {"workload": describe + " full train step: fwd + JointsMSE + bwd + grad all-reduce + Adam + arg-max "
                                               "accuracy decode",
                        "global_batch": global_batch, "batch_per_gpu": args.batch,
-                       "input": f"N x 6 x {cfg.MODEL.IMAGE_SIZE[1]} x {cfg.MODEL.IMAGE_SIZE[0]} fp32",
+                       "input": f"N x {n_in} x {cfg.MODEL.IMAGE_SIZE[1]} x {cfg.MODEL.IMAGE_SIZE[0]} fp32",
                        "params": sum(p.numel() for p in net.parameters()), "parallelism": f"dp{world}",
+                       # HIP streams of this rank: main + branch / weight-gradient streams (+ communication under --gpus N)
+                       "hip_streams": 1 + len(ops.compute_streams(device)) + (1 if world > 1 else 0),
                        "conv_math": args.conv_math, "loss": round(losses.avg, 6)},
         }
         if comm_ms is not None:
@@ -679,21 +700,27 @@ def main():
             n = a[1] + b[1]
             return ((a[0] * a[1] + b[0] * b[1]) / n, n) if n else (None, 0)
 
-        # this round's measurements of the committed build (scratch/r04_profiles.sh), quoted with their file and date
-        quoted = args.conv_math == "bf16x6" and args.batch == 32 and rshape == (48, 96, 72) and args.workload == "train_c4"
-        pmc = _profile_json("r04_pmc_traffic.json") if quoted else None
-        trace = _profile_json("r04_in_step_kernel_us.json") if quoted else None
+        # this round's measurements of the committed build (scratch/r05_profiles.sh), quoted with their file and date: HBM traffic
+        # from the PMC passes (C4 shape only), the kernels' durations INSIDE the step from the kernel trace of this very command -
+        # a census by kernel name AND grid, so that the figure belongs to the roofline shape and to no other launch of the kernel
+        tag = {"train_c4": "c4", "train_c3": "c3", "train_c2": "c2"}[args.workload]
+        quoted = args.conv_math == "bf16x6" and args.batch == 32 and args.condition == "colored"
+        pmc = _profile_json("r05_pmc_traffic.json") if quoted and rshape == (48, 96, 72) else None
+        trace = _profile_json(f"r05_in_step_kernel_us_{tag}.json") if quoted else None
+        cw_, hh_, ww_ = rshape
+        P_ = args.batch * (hh_ + 1) * (ww_ + 1) + ww_ + 1             # zero-padded flattened positions (conv3x3.hip)
+        single = {"fwd": ("conv3x3_x6_kernel<7, 3, 4, 1", f"{((P_ + 447) // 448) * 256},1,1") if cw_ == 48 else
+                         ("conv3x3_x6_kernel<4, 2, 4, 1", f"{((P_ + 255) // 256) * 256},1,1"),
+                  "wgrad": ("conv3x3_wgrad_split_kernel<3, %d>" % (3 if cw_ == 48 else 2), "256,1,512"),
+                  "reduce": ("wg3_reduce_kernel<%d>" % (3 if cw_ == 48 else 2), None)}
 
-        def kernel_us(*subs):      # calls-weighted duration of the kernels whose name contains any of `subs`, summed per launch
+        def grid_us(name, grid):      # average duration of the launches of `name` with this grid (None: any grid of that name)
             if not trace:
                 return None
-            tot = 0.0
-            for sub in subs:
-                rows = [v for k, v in trace["kernels"].items() if sub in k]
-                if not rows:
-                    return None
-                tot += sum(v["ms_per_step"] for v in rows) / sum(v["calls_per_step"] for v in rows) * 1e3
-            return round(tot, 1)
+            rows = [v for k, v in trace["by_grid"].items() if name in k and (grid is None or k.endswith("|" + grid))]
+            if not rows:
+                return None
+            return sum(v["ms_per_step"] for v in rows) / sum(v["calls_per_step"] for v in rows) * 1e3
 
         def src(kind):
             out_ = {}
@@ -706,14 +733,35 @@ def main():
         fwd_traffic = None
         if pmc:
             fwd_traffic = round((pmc["fwd"]["bytes"] + pmc["dgrad"]["bytes"]) / 2)
+        k_fwd = grid_us(*single["fwd"])
+        k_wg, k_red = grid_us(*single["wgrad"]), grid_us(*single["reduce"])
+        if k_red is not None and trace:
+            # the slab reduction of the roofline shape: its launches follow the weight-gradient launches of that grid one to one
+            red_rows = {k: v for k, v in trace["by_grid"].items() if single["reduce"][0] in k}
+            wg_calls = sum(v["calls_per_step"] for k, v in trace["by_grid"].items()
+                           if single["wgrad"][0] in k and k.endswith("|" + single["wgrad"][1]))
+            best = min(red_rows.values(), key=lambda v: abs(v["calls_per_step"] - wg_calls)) if red_rows else None
+            k_red = best["avg_us"] if best else k_red
         main = roofline_entry(args.conv_math, args.batch, "fwd", merge(in_step["fwd"], in_step["dgrad"]),
                               merge(solo["fwd"], solo["dgrad"]), fwd_traffic, rshape,
-                              kernel_us("conv3x3_x6_kernel<7, 3, 4, 1"), src("fwd"))
+                              round(k_fwd, 1) if k_fwd else None, src("fwd"))
         wg = roofline_entry(args.conv_math, args.batch, "wgrad", in_step["wgrad"], solo["wgrad"],
                             pmc["wgrad"]["bytes"] if pmc else None, rshape,
-                            kernel_us("conv3x3_wgrad_split_kernel<3, 3>", "wg3_reduce_kernel"), src("wgrad"))
-        # `roofline` = the dominant kernel of the step by time (the weight gradient: 214 launches, kernel + slab reduction);
-        # the forward / data-gradient launches of the same shape ride beside it
+                            round(k_wg + k_red, 1) if (k_wg and k_red) else None, src("wgrad"))
+        # `roofline` = the dominant kernel of the step by time (the 3x3 weight gradient: kernel + slab reduction); the forward /
+        # data-gradient launches of the same shape ride beside it.  Most weight gradients of the step run as GROUP launches
+        # (two branch convolutions of equal FLOPs per launch): their aggregate rate is reported next to the single launches.
+        if wg is not None and trace:
+            g_us = grid_us("conv3x3_wgrad_group_kernel", None)
+            gr_us = grid_us("wg3_reduce_group_kernel", None)
+            if g_us and gr_us:
+                flops2 = 2 * wg["algorithmic_flops"]
+                peak = PEAK_BF16_MFMA_TFLOPS / MFMAS_PER_PRODUCT.get(args.conv_math, 6)
+                wg["group_launches"] = {
+                    "kernel": "conv3x3_wgrad_group_kernel + wg3_reduce_group_kernel: two branch convolutions of one "
+                              "HighResolutionModule layer-step per launch (equal FLOPs, 2 x the roofline launch)",
+                    "avg_kernel_us_in_step": round(g_us + gr_us, 1),
+                    "frac_in_step_kernel": round(flops2 / ((g_us + gr_us) * 1e6) / peak, 4)}
         if wg is not None:
             out["roofline"] = wg
         if main is not None:

@@ -18,12 +18,7 @@
 
 #define MHA_BQ 128
 #define MHA_BK 64
-#ifndef MHA_ABL
-#define MHA_ABL 0      // what-if switches of mha_fwd_x6q_kernel (scratch/mha_abl.sh; never set in the product build)
-#endif
-#ifndef MHA_VPM
 #define MHA_VPM 2      // soft-max VALU instructions slotted behind each MFMA of the next tile's logits (mha_fwd_x6q_kernel)
-#endif
 
 template <int DF>   // d / 16
 __global__ __launch_bounds__(512, 1) void mha_fwd_kernel(const float* __restrict__ q, const float* __restrict__ k,
@@ -728,7 +723,6 @@ __global__ __launch_bounds__(512, 1) void mha_fwd_x6q_kernel(const float* __rest
       mbf16x8 aa[3];
 #pragma unroll
       for (int qp = 0; qp < 3; ++qp) {
-        if (MHA_ABL & 2) { aa[qp] = qq[1][kk][qp]; continue; }
         aa[qp] = *reinterpret_cast<const mbf16x8*>(krow + koff[kk] + qp * LO);
         if (32 * kk + 8 * g >= D) {
 #pragma unroll
@@ -748,24 +742,12 @@ __global__ __launch_bounds__(512, 1) void mha_fwd_x6q_kernel(const float* __rest
         }
         aa[0] = __builtin_bit_cast(mbf16x8, a0);
       }
-      if (!(MHA_ABL & 32)) {
-        mha_mma6(sn[0][f], aa, qq[0][kk]);
-        mha_mma6(sn[1][f], aa, qq[1][kk]);
-      } else {
-        sn[0][f][0] += (float)aa[0][0];
-        sn[1][f][1] += (float)aa[1][1] + (float)aa[2][2];
-      }
+      mha_mma6(sn[0][f], aa, qq[0][kk]);
+      mha_mma6(sn[1][f], aa, qq[1][kk]);
 #pragma unroll
       for (int pr = 0; pr < 8; ++pr) {
         if ((pr * SL) / 8 != i) continue;
         const int w = pr >> 2, fb = (pr >> 1) & 1, r0 = (pr & 1) * 2;
-        if (MHA_ABL & 1) {
-#pragma unroll
-          for (int qp = 0; qp < 3; ++qp)
-            ppu[w][qp][2 * fb + (pr & 1)] = __float_as_uint(st[w][fb][r0]) ^ (__float_as_uint(st[w][fb][r0 + 1]) >> (qp + 1));
-          lrun[w] += st[w][fb][r0];
-          continue;
-        }
         float ra = __builtin_amdgcn_exp2f(st[w][fb][r0] - mrun[w]);
         float rb = __builtin_amdgcn_exp2f(st[w][fb][r0 + 1] - mrun[w]);
         lrun[w] += ra;
@@ -791,27 +773,21 @@ __global__ __launch_bounds__(512, 1) void mha_fwd_x6q_kernel(const float* __rest
         pp[w][qp] = __builtin_bit_cast(mbf16x8, r);
       }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // V(j) has landed
-    if (!(MHA_ABL & 16)) __syncthreads();                  // ... for everyone, and nobody reads K(j + 1) any more
-    if (!(MHA_ABL & 8) && j + 2 < ntile) dma_tile(kimg, (j + 2) * BK, kt);
+    __syncthreads();                                       // ... for everyone, and nobody reads K(j + 1) any more
+    if (j + 2 < ntile) dma_tile(kimg, (j + 2) * BK, kt);
     const unsigned char* vbase = vt + tr_off;
 #pragma unroll
     for (int n = 0; n < DF; ++n) {
       mbf16x8 bb[3];
 #pragma unroll
       for (int qp = 0; qp < 3; ++qp)
-        bb[qp] = (MHA_ABL & 4) ? qq[0][n & (NK - 1)][qp]
-                               : mha_tr_pair(vbase + n * 32 + qp * LO, vbase + n * 32 + qp * LO + 16 * RS);
-      if (!(MHA_ABL & 64)) {
-        mha_mma6(o[0][n], pp[0], bb);
-        mha_mma6(o[1][n], pp[1], bb);
-      } else {
-        o[0][n][0] += (float)bb[0][0] + (float)pp[0][0][0] + (float)pp[0][1][1] + (float)pp[0][2][2];
-        o[1][n][1] += (float)bb[1][1] + (float)bb[2][2] + (float)pp[1][0][0] + (float)pp[1][1][1] + (float)pp[1][2][2];
-      }
+        bb[qp] = mha_tr_pair(vbase + n * 32 + qp * LO, vbase + n * 32 + qp * LO + 16 * RS);
+      mha_mma6(o[0][n], pp[0], bb);
+      mha_mma6(o[1][n], pp[1], bb);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // K(j + 2) has landed
-    if (!(MHA_ABL & 16)) __syncthreads();                  // ... for everyone, and nobody reads V(j) any more
-    if (!(MHA_ABL & 8) && j + 1 < ntile) dma_tile(vimg, (j + 1) * BK, vt);
+    __syncthreads();                                       // ... for everyone, and nobody reads V(j) any more
+    if (j + 1 < ntile) dma_tile(vimg, (j + 1) * BK, vt);
 #pragma unroll
     for (int w = 0; w < 2; ++w)
 #pragma unroll
@@ -872,20 +848,11 @@ extern "C" int buctd_mha_fwd_supported(int T, int d) {
 template <int DF>
 static int mha_launch(int B, int T, const float* q, const float* k, const float* v, int ldqk, int ldv, float scale,
                       float* out, float* lse, int x6, hipStream_t st) {
-  static bool attr_done[2] = {false, false};     // idempotent attribute call: a race at first use only repeats it
+  static unsigned char attr_done[2][BUCTD_MAX_DEVICES] = {{0}};
   void (*fn)(const float*, const float*, const float*, int, int, int, float, float*, float*) =
       x6 ? mha_fwd_x6_kernel<DF> : mha_fwd_kernel<DF>;
   const size_t lds = x6 ? mha_x6_lds(DF * 16) : mha_lds(DF * 16);
-  bool& attr_set = attr_done[x6 ? 1 : 0];
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       160 * 1024);
-    if (e != hipSuccess) {
-      buctd_set_error("buctd_mha_fwd: cannot raise the dynamic LDS limit: %s", hipGetErrorString(e));
-      return BUCTD_ELAUNCH;
-    }
-    attr_set = true;
-  }
+  if (const int rc = buctd_raise_lds_limit(reinterpret_cast<const void*>(fn), 160 * 1024, attr_done[x6 ? 1 : 0], "buctd_mha_fwd")) return rc;
   hipLaunchKernelGGL(fn, dim3(T / MHA_BQ, B), dim3(512), lds, st, q, k, v, T, ldqk, ldv, scale, out, lse);
   BUCTD_CHECK_LAUNCH("buctd_mha_fwd");
   return BUCTD_OK;
@@ -928,26 +895,15 @@ extern "C" size_t buctd_mha_fwd_bf16x6_workspace(int B, int T, int d) {
 template <int DF>
 static int mha_launch_p(int B, int T, const float* q, const unsigned char* k6, const unsigned char* v6, int ldq, float scale,
                         float* out, float* lse, hipStream_t st) {
-  static bool attr_set[2] = {false, false};      // idempotent attribute call: a race at first use only repeats it
-#ifdef BUCTD_TUNING      // experiment builds only: BUCTD_MHA_Q16=1 runs the 16-query kernel for comparison
-  static const bool wide = []() { const char* e = getenv("BUCTD_MHA_Q16"); return !(e && e[0] == '1'); }();
-#else
+  static unsigned char attr_done[2][BUCTD_MAX_DEVICES] = {{0}};
   constexpr bool wide = true;
-#endif
   // wide (default): 32 queries per wavefront, keys split over the two wave quartets, 32-key tiles; BUCTD_MHA_Q16=1 keeps the
   // 16-query kernel (bit-identical to buctd_mha_fwd_bf16x6) for comparison
   void (*fn)(const float*, const unsigned char*, const unsigned char*, int, int, int, float, float*, float*) =
       wide ? mha_fwd_x6q_kernel<DF> : mha_fwd_x6p_kernel<DF>;
   const size_t lds = wide ? (size_t)4 * 32 * mha_x6_rs_c(DF * 16) : mha_x6_lds(DF * 16);
-  if (!attr_set[wide]) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       160 * 1024);
-    if (e != hipSuccess) {
-      buctd_set_error("buctd_mha_fwd_bf16x6_ws: cannot raise the dynamic LDS limit: %s", hipGetErrorString(e));
-      return BUCTD_ELAUNCH;
-    }
-    attr_set[wide] = true;
-  }
+  if (const int rc = buctd_raise_lds_limit(reinterpret_cast<const void*>(fn), 160 * 1024, attr_done[wide ? 1 : 0], "buctd_mha_fwd_bf16x6_ws"))
+    return rc;
   hipLaunchKernelGGL(fn, dim3((unsigned)(B * (T / MHA_BQ))), dim3(512), lds, st, q, k6, v6, B, T, ldq, scale,
                      out, lse);
   BUCTD_CHECK_LAUNCH("buctd_mha_fwd_bf16x6_ws");
@@ -984,10 +940,3 @@ extern "C" int buctd_mha_fwd_bf16x6_ws(int B, int T, int d, const float* q, cons
   return BUCTD_EINVAL;
 }
 
-#if MHA_ABL || defined(MHA_ABL_BUILD)
-extern "C" __attribute__((visibility("default"))) int abl_mha(int B, int T, int d, const float* q, const float* k, const float* v,
-                                                              int ldqk, int ldv, float scale, float* out, void* workspace,
-                                                              size_t workspace_bytes, void* stream) {
-  return buctd_mha_fwd_bf16x6_ws(B, T, d, q, k, v, ldqk, ldv, scale, out, nullptr, workspace, workspace_bytes, stream);
-}
-#endif

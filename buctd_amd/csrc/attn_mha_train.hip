@@ -350,22 +350,15 @@ extern "C" int buctd_mha_train_supported(int T, int d) {
 }
 
 template <typename F>
-static int mt_attr(F fn, bool* done, const char* who) {
-  if (*done) return BUCTD_OK;
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  if (e != hipSuccess) {
-    buctd_set_error("%s: cannot raise the dynamic LDS limit: %s", who, hipGetErrorString(e));
-    return BUCTD_ELAUNCH;
-  }
-  *done = true;
-  return BUCTD_OK;
+static int mt_attr(F fn, unsigned char (&done)[BUCTD_MAX_DEVICES], const char* who) {
+  return buctd_raise_lds_limit(reinterpret_cast<const void*>(fn), 160 * 1024, done, who);
 }
 
 template <int DF>
 static int mt_fwd_launch(int B, int T, const float* q, const float* k, const float* v, int ldqk, int ldv, float scale,
                          float p_drop, uint64_t seed, float* out, float* lse, hipStream_t st) {
-  static bool done = false;      // idempotent attribute call: a race at first use only repeats it
-  const int rc = mt_attr(mha_fwd_train_kernel<DF>, &done, "buctd_mha_fwd_train");
+  static unsigned char done[BUCTD_MAX_DEVICES] = {0};
+  const int rc = mt_attr(mha_fwd_train_kernel<DF>, done, "buctd_mha_fwd_train");
   if (rc) return rc;
   hipLaunchKernelGGL(mha_fwd_train_kernel<DF>, dim3(T / MT_BO, B), dim3(512), mt_fwd_lds(DF * 16), st, q, k, v, T, ldqk, ldv,
                      scale, p_drop, seed, out, lse);
@@ -375,10 +368,10 @@ static int mt_fwd_launch(int B, int T, const float* q, const float* k, const flo
 
 template <int DF>
 static int mt_bwd_launch(int B, const MhaBwdArgs& a, hipStream_t st) {
-  static bool done[2] = {false, false};
-  int rc = mt_attr(mha_bwd_kernel<DF, false>, &done[0], "buctd_mha_bwd");
+  static unsigned char done[2][BUCTD_MAX_DEVICES] = {{0}};
+  int rc = mt_attr(mha_bwd_kernel<DF, false>, done[0], "buctd_mha_bwd");
   if (rc) return rc;
-  rc = mt_attr(mha_bwd_kernel<DF, true>, &done[1], "buctd_mha_bwd");
+  rc = mt_attr(mha_bwd_kernel<DF, true>, done[1], "buctd_mha_bwd");
   if (rc) return rc;
   hipLaunchKernelGGL((mha_bwd_kernel<DF, true>), dim3(a.T / MT_BO, B), dim3(512), mt_bwd_lds(DF * 16), st, a);
   BUCTD_CHECK_LAUNCH("buctd_mha_bwd (dK, dV)");

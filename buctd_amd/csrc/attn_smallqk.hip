@@ -884,9 +884,6 @@ extern "C" int buctd_attn_smallqk_fwd(int B, int T, int R4, int C, const float* 
   BUCTD_CHECK_ARG(q && k && v && out && m && linv && B > 0, "buctd_attn_smallqk_fwd: null argument");
   BUCTD_CHECK_ARG(attn_shape_ok(T, R4, C), "buctd_attn_smallqk_fwd: unsupported T=%d R4=%d C=%d", T, R4, C);
   BUCTD_CHECK_ARG(p_drop >= 0.f && p_drop < 1.f && (long)B * T < 2147483647L, "buctd_attn_smallqk_fwd: bad p_drop / size");
-#ifdef WHATIF_SKIP_ATTN     // what-if builds only (scratch/build_alt.sh)
-  return BUCTD_OK;
-#endif
   AttnArgs a = attn_args(T, C, scale, p_drop, seed);
   a.q = q; a.k = k; a.v = v; a.m = m; a.linv = linv; a.out = out; a.b3 = attn_split_mode(bf16x3, C);
   if (!(a.b3 && R4 <= 8)) {            // the bf16x3 forward kernel computes the soft-max statistics on the fly
@@ -902,9 +899,6 @@ extern "C" int buctd_attn_smallqk_bwd(int B, int T, int R4, int C, const float* 
                                       const float* o, const float* dout, const float* m, const float* linv,
                                       float scale, float p_drop, uint64_t seed, int bf16x3, float* dq, float* dk,
                                       float* dv, float* dvec_workspace, void* stream) {
-#ifdef WHATIF_SKIP_ATTN
-  return BUCTD_OK;
-#endif
   BUCTD_CHECK_ARG(q && k && v && o && dout && m && linv && dq && dk && dv && dvec_workspace && B > 0,
                   "buctd_attn_smallqk_bwd: null argument");
   BUCTD_CHECK_ARG(attn_shape_ok(T, R4, C), "buctd_attn_smallqk_bwd: unsupported T=%d R4=%d C=%d", T, R4, C);

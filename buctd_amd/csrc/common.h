@@ -31,6 +31,26 @@ void buctd_set_error(const char* fmt, ...);
     }                                                                              \
   } while (0)
 
+// Raises the dynamic-LDS limit of kernel `fn` to `bytes` once per DEVICE: the attribute belongs to the device's copy of the
+// kernel, so a process-wide flag would leave a second GPU of the same process at the 64 KB default.  `done` is the caller's
+// static flag array (one per kernel); a race at first use only repeats the idempotent call.
+#define BUCTD_MAX_DEVICES 16
+static inline int buctd_raise_lds_limit(const void* fn, int bytes, unsigned char (&done)[BUCTD_MAX_DEVICES], const char* who) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= BUCTD_MAX_DEVICES) {
+    buctd_set_error("%s: cannot identify the current device", who);
+    return BUCTD_ELAUNCH;
+  }
+  if (done[dev]) return BUCTD_OK;
+  const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  if (e != hipSuccess) {
+    buctd_set_error("%s: cannot raise the dynamic LDS limit: %s", who, hipGetErrorString(e));
+    return BUCTD_ELAUNCH;
+  }
+  done[dev] = 1;
+  return BUCTD_OK;
+}
+
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 static inline int ceil_div(long a, long b) { return (int)((a + b - 1) / b); }

@@ -1127,12 +1127,7 @@ static bool dgrad_thin_s2_ok(const buctd_conv_desc* d) {
 }
 
 static bool fwd_thin_ok(const buctd_conv_desc* d) {
-#ifdef BUCTD_TUNING      // experiment builds only: BUCTD_FWD_THIN=0 routes back to the implicit-GEMM kernel
-  static const bool off = getenv("BUCTD_FWD_THIN") && atoi(getenv("BUCTD_FWD_THIN")) == 0;
-#else
-  constexpr bool off = false;
-#endif
-  return !off && d->stride == 1 && d->R == 7 && d->S == 7 && d->pad == 3 && d->Co <= 4 && d->Ci <= 64 && d->Ho == d->H &&
+  return d->stride == 1 && d->R == 7 && d->S == 7 && d->pad == 3 && d->Co <= 4 && d->Ci <= 64 && d->Ho == d->H &&
          d->Wo == d->W && (long)d->N * d->H * d->W >= 4096;
 }
 
@@ -1182,6 +1177,11 @@ extern "C" int buctd_conv2d_fwd(const buctd_conv_desc* d, const float* x, const 
     BUCTD_CHECK_LAUNCH("buctd_conv2d_fwd(thin)");
     return BUCTD_OK;
   }
+  // buctd_conv2d_stats_groups reports the thin kernel's grouping for these shapes whatever the epilogue: statistics together
+  // with an epilogue the thin kernel does not have would send the launch to the implicit-GEMM kernel, whose (more) groups
+  // overrun the caller's partials buffer
+  BUCTD_CHECK_ARG(!(fwd_thin_in_ok(d) && stats_partials && (scale || residual || relu)),
+                  "buctd_conv2d_fwd: statistics of a thin-input convolution cannot be combined with scale / residual / relu");
   if (fwd_thin_in_ok(d) && !scale && !residual && !relu) {      // 3 -> 64 3x3 of the preNet: lane = output channel
     ThinInArgs ta;
     ta.x = x; ta.w = w; ta.bias = bias; ta.y = y; ta.part = stats_partials;
@@ -1390,10 +1390,6 @@ __global__ __launch_bounds__(256) void conv_wgrad_thin_kernel(ThinArgs p) {
 }
 
 static bool wgrad_thin_ok(const buctd_conv_desc* d) {
-#ifdef BUCTD_TUNING      // experiment builds only
-  static const bool off = getenv("BUCTD_WGRAD_THIN") && atoi(getenv("BUCTD_WGRAD_THIN")) == 0;
-  if (off) return false;
-#endif
   const int thin = d->Ci < d->Co ? d->Ci : d->Co, wide = d->Ci < d->Co ? d->Co : d->Ci;
   // 3x3 with the thin side on x (3 -> 64): the implicit-GEMM kernel is faster there (0.8 against 1.2 ms at 384x288)
   if (d->R == 3 && d->Co > d->Ci) return false;
@@ -1598,9 +1594,6 @@ extern "C" int buctd_conv2d_wgrad(const buctd_conv_desc* d, const float* x, cons
   int rc = check_desc(d, "buctd_conv2d_wgrad");
   if (rc) return rc;
   BUCTD_CHECK_ARG(x && dy && dw, "buctd_conv2d_wgrad: null tensor pointer");
-#ifdef WHATIF_SKIP_CONV_WGRAD     // what-if builds only (scratch/build_alt.sh): results are garbage, only the clock is read
-  return BUCTD_OK;
-#endif
   int bm, bn, ns, pps;
   wgrad_plan(d, &bm, &bn, &ns, &pps);
   const bool thin = wgrad_thin_ok(d);
@@ -1620,15 +1613,10 @@ extern "C" int buctd_conv2d_wgrad(const buctd_conv_desc* d, const float* x, cons
     ta.N = d->N; ta.H = d->H; ta.W = d->W; ta.Co = d->Co;
     thin_rows_geo(d, &ta.strips, &ta.segs, &ta.rows_per_seg);
     const size_t lds = ((size_t)TR_RING * TR_XW * 64 + 2 * TR_W * 4) * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) {
-      if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_thin_rows_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              (int)lds) != hipSuccess) {
-        buctd_set_error("buctd_conv2d_wgrad(thin rows): cannot raise the dynamic LDS limit");
-        return BUCTD_ELAUNCH;
-      }
-      attr_set = true;
-    }
+    static unsigned char attr_done[BUCTD_MAX_DEVICES] = {0};
+    if (const int rc = buctd_raise_lds_limit(reinterpret_cast<const void*>(conv_wgrad_thin_rows_kernel), (int)lds, attr_done,
+                                             "buctd_conv2d_wgrad(thin rows)"))
+      return rc;
     hipLaunchKernelGGL(conv_wgrad_thin_rows_kernel, dim3(ns), dim3(256), lds, (hipStream_t)stream, ta);
     BUCTD_CHECK_LAUNCH("buctd_conv2d_wgrad(thin rows)");
   } else

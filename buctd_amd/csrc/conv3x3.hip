@@ -217,17 +217,6 @@ __global__ __launch_bounds__(256, 2) void conv3x3_split_kernel(C3Args p) {
 //     With six MFMAs per product the fragment stream needs ~31 B/clk/CU of the 64 B/clk L1 - half of what the
 //     three-MFMA mode would need, which is why that mode keeps its LDS stage.
 // Two taps per K = 32 MFMA (lanes 0-31 feed tap 2s, lanes 32-63 tap 2s+1; the 10th half-step has zero weights).
-#ifndef C3_PRIO
-#define C3_PRIO 0
-#endif
-constexpr bool PRIO = C3_PRIO != 0;
-#ifdef C3_TRACE
-__device__ unsigned long long c3_trace_buf[8][64];
-__device__ unsigned long long c3_trace_wall[4096][2];   // wall clock (100 MHz) at start / end of every workgroup, dispatch order
-#define C3_TR(k) do { if (tr_on) c3_trace_buf[tr_slot][(k)] = clock64(); } while (0)
-#else
-#define C3_TR(k) do {} while (0)
-#endif
 // One output tile (bx, by) of a launch described by p: the body of conv3x3_x6_kernel (one tile per workgroup) and of
 // conv3x3_x6_group_kernel (a persistent workgroup walking a tile table over several convolutions).
 // smem = [DBUF ? 2 : 1][arows][ROWB] A buffers | [3][Ci] floats: the input-BatchNorm table (mean, invstd * gamma, beta)
@@ -250,12 +239,6 @@ __device__ __forceinline__ void c3x6_tile(const C3Args& p, unsigned char* smem, 
   const int halo = p.SW + 1;
   const int c4 = (t % CPR) * 4, prow = t / CPR;
 
-
-#ifdef C3_TRACE
-  const int tr_stride = (gridDim.x + 7) / 8;
-  const bool tr_on = t == 0 && by == 0 && bx % tr_stride == 0;
-  const int tr_slot = bx / tr_stride;
-#endif
   // global element offset (channel 0) of every staged row of this thread; -1 zero row, -2 beyond the tile
   int goff[PA];
 #pragma unroll
@@ -348,13 +331,10 @@ __device__ __forceinline__ void c3x6_tile(const C3Args& p, unsigned char* smem, 
     for (int i = 0; i < AD; ++i) read_a(abase, i, a[i]);
 #pragma unroll
     for (int s = 0; s < 5; ++s) {
-      if (ch == 1) C3_TR(50 + s);
       if (DBUF && s == 2 && ch + 1 < nchunks) {    // next chunk: registers -> pieces -> the other A buffer
         // done while the fewest registers are live (no B prefetch in flight, no A fragments): the split needs ~60
-        if (ch == 1) C3_TR(56);
         store_a(smem + ((ch + 1) & 1) * abytes, (ch + 1) * 16);
         __builtin_amdgcn_sched_barrier(0);
-        if (ch == 1) C3_TR(57);
       }
       if constexpr (BPF) {
 #pragma unroll
@@ -376,7 +356,6 @@ __device__ __forceinline__ void c3x6_tile(const C3Args& p, unsigned char* smem, 
         __builtin_amdgcn_sched_barrier(0);
         load_a((ch + 2) * 16);
         __builtin_amdgcn_sched_barrier(0);
-        if (ch == 1) C3_TR(58);
       }
       // A fragments travel AD 16-row fragments ahead of their MFMAs through a ring of AD + 1 register sets, across the
       // step boundaries of the chunk (flat index i = s * MF + mf): with eight waves reading, a ds_read_b128 triple takes
@@ -389,14 +368,8 @@ __device__ __forceinline__ void c3x6_tile(const C3Args& p, unsigned char* smem, 
         __builtin_amdgcn_sched_barrier(0);
         bf16x8 (&ac)[3] = a[i % (AD + 1)];
 #define X6_MMA(qa, qb) acc[mf][nf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ac[qa], bc[qb][nf], acc[mf][nf], 0, 0, 0);
-#ifdef C3_MMA_INTERLEAVE
-#define X6_ROW(qa, qb) _Pragma("unroll") for (int nf = 0; nf < NF; ++nf) { X6_MMA(qa, qb) }
-        X6_ROW(2, 0) X6_ROW(0, 2) X6_ROW(1, 1) X6_ROW(1, 0) X6_ROW(0, 1) X6_ROW(0, 0)
-#undef X6_ROW
-#else
 #pragma unroll
         for (int nf = 0; nf < NF; ++nf) { X6_MMA(2, 0) X6_MMA(0, 2) X6_MMA(1, 1) X6_MMA(1, 0) X6_MMA(0, 1) X6_MMA(0, 0) }
-#endif
 #undef X6_MMA
         __builtin_amdgcn_sched_barrier(0);
       }
@@ -405,12 +378,6 @@ __device__ __forceinline__ void c3x6_tile(const C3Args& p, unsigned char* smem, 
     }
   };
 
-  C3_TR(0);
-#ifdef C3_TRACE
-  if (tr_on) c3_trace_buf[tr_slot][62] = wall_clock64();
-  const unsigned tr_lin = blockIdx.y * gridDim.x + blockIdx.x;
-  if (t == 0 && tr_lin < 4096) c3_trace_wall[tr_lin][0] = wall_clock64();
-#endif
   load_a(0);
   if constexpr (BPF) load_b(0, bn);
   if constexpr (BPF2) load_b(last_step > 0 ? 1 : 0, bn2);
@@ -442,31 +409,15 @@ __device__ __forceinline__ void c3x6_tile(const C3Args& p, unsigned char* smem, 
   store_a(smem, 0);
   if (nchunks > 1) load_a(16);
   __syncthreads();
-  C3_TR(1);
   for (int ch = 0; ch < nchunks; ++ch) {
     if (!DBUF && ch > 0) {   // single buffer (the largest position tiles): restage between two barriers
       store_a(smem, ch * 16);
       if (ch + 1 < nchunks) load_a((ch + 1) * 16);
       __syncthreads();
     }
-    if (ch < 24) C3_TR(2 + 2 * ch);
-    if (PRIO) {
-      // the two workgroups of a CU are not served alike: the instruction arbiter favours the older wave, so the first
-      // workgroup finishes a third ahead and the second runs its last chunks alone at half the throughput (cycle stamps:
-      // lifetimes 35 / 47 us).  Priority by progress quartile - whoever is behind wins - keeps them level.
-      switch (4 * ch / nchunks) {
-        case 0: __builtin_amdgcn_s_setprio(3); break;
-        case 1: __builtin_amdgcn_s_setprio(2); break;
-        case 2: __builtin_amdgcn_s_setprio(1); break;
-        default: __builtin_amdgcn_s_setprio(0); break;
-      }
-    }
     run_chunk(ch);
-    if (ch < 24) C3_TR(3 + 2 * ch);
     __syncthreads();       // DBUF: chunk ch+1 is complete in its buffer; nobody reads this chunk's buffer any more
   }
-  C3_TR(60);
-  if (PRIO) __builtin_amdgcn_s_setprio(0);
   c3_epilogue<MF, NF, WM, WN>(p, acc, smem, bx, by, p0, n0);
 }
 
@@ -669,15 +620,13 @@ __global__ __launch_bounds__(256) void conv3x3_prep3_kernel(const float* __restr
 }
 
 // ---------------------------------------------------------------------------------------------- host ----
-struct C3Plan { int MF, NF, WM, WN, BM, BN, na, lean; size_t lds; };
+struct C3Plan { int MF, NF, WM, WN, BM, BN, na; size_t lds; };
 
 // magic for unsigned division of n < 2^31 by d (2 <= d < 2^31): q = mulhi(n, mul) >> sh
 
 static int c3_steps(int Kc, int np) { return np == 3 ? (Kc / 16) * 5 : (Kc / CK) * 9 + ((Kc % CK) ? 5 : 0); }
 
-// group: the convolution shares its launch with others (buctd_conv3x3_bf16x6_group) - the grid-filling heuristics of a
-// single launch do not apply, the tile with the best sustained rate is taken
-static bool c3_plan(int np, int N, int H, int W, int Ci, int Co, C3Plan* pl, int group = 0) {
+static bool c3_plan(int np, int N, int H, int W, int Ci, int Co, C3Plan* pl) {
   if (N <= 0 || H <= 0 || W <= 0 || Ci <= 0 || Co <= 0 || Ci % 16 != 0 || Co % 16 != 0 || c3_row_width(W) > MAX_SW) return false;
   const int rowb = np == 3 ? Geo<3>::ROWB : Geo<2>::ROWB, blds = np == 3 ? Geo<3>::BLDS : Geo<2>::BLDS;
   const long P = (long)N * (H + 1) * c3_row_width(W) + c3_row_width(W);
@@ -706,10 +655,7 @@ static bool c3_plan(int np, int N, int H, int W, int Ci, int Co, C3Plan* pl, int
     if (blocks >= (np == 3 ? 224 : 320)) { mf = cand[i]; break; }   // (238 for the 192-channel 24x18 maps at N = 32)
   }
   bool single = false;
-  pl->lean = 0;
-  if (group && np == 3 && Co % 96 == 0) { nf = 3; wn = 2; wm = 2; bn = 96; mf = 4; }
-  else if (group && np == 3 && Co % 48 == 0) { nf = 3; wn = 1; wm = 4; bn = 48; mf = 4; }
-  else if (np == 3 && nf == 3 && wn == 1 && Co == bn) {
+  if (np == 3 && nf == 3 && wn == 1 && Co == bn) {
     // 512-position tiles in ONE round of workgroups (2 resident per CU = 512 slots) instead of 1.75 rounds of
     // 256-position tiles: the 48-channel branch at N*H*W >= ~115k positions (single A buffer: 64.5 KB at W = 72)
     const long b8 = (P + 511) / 512;
@@ -720,25 +666,13 @@ static bool c3_plan(int np, int N, int H, int W, int Ci, int Co, C3Plan* pl, int
       // where 512-position tiles leave 63 slots empty (N = 32 @ 96x72: 449 -> 512 workgroups)
       if ((P + 447) / 448 <= 512) mf = 7;
     }
-#ifdef BUCTD_TUNING      // experiment builds only (scratch/build_trace_lib.sh): 3 lean workgroups per CU instead
-    static const int lean_env = getenv("BUCTD_C3_LEAN") ? atoi(getenv("BUCTD_C3_LEAN")) : 0;
-    if (lean_env && mf == 8) { mf = 4; pl->lean = 1; }
-#endif
   }
-#ifdef BUCTD_TUNING      // experiment builds only: BUCTD_C3_FORCE="mf,nf,wn" (scratch/sweep_c3_plan.py)
-  if (const char* f = getenv("BUCTD_C3_FORCE")) {
-    int fm = 0, fn = 0, fw = 0;
-    if (np == 3 && sscanf(f, "%d,%d,%d", &fm, &fn, &fw) == 3 && (fw == 1 || fw == 2) && Co % (fn * 16 * fw) == 0) {
-      mf = fm; nf = fn; wn = fw; wm = 4 / wn; bn = wn * nf * 16; single = mf >= 7; pl->lean = 0;
-    }
-  }
-#endif
   pl->MF = mf; pl->NF = nf; pl->WM = wm; pl->WN = wn; pl->BM = wm * mf * 16; pl->BN = bn;
   pl->na = (pl->BM + 2 * c3_row_width(W) + 2 + 31) / 32;
   size_t stage = (size_t)4 * (mf >= 2 ? 2 : 1) * 16 * (nf * 16 + 4) * 4 + 4 * 128 * 4;   // epilogue staging + row offsets
   if (np == 3 && stage < (size_t)C3_EPI_LDS) stage = C3_EPI_LDS;      // ... the bs reduction scratch and the accumulator exchange
   if (np == 3) {            // two A buffers (one for the 512-position tiles), no B stage; behind them the input-BatchNorm table
-    const int nb = (single || pl->lean) ? 1 : 2;
+    const int nb = single ? 1 : 2;
     while ((size_t)nb * pl->na * 32 * rowb < stage) ++pl->na;
     pl->lds = (size_t)nb * pl->na * 32 * rowb + (size_t)3 * Ci * sizeof(float);
   } else {
@@ -752,27 +686,16 @@ static bool c3_np_ok(int np) { return np == 2 || np == 3; }
 
 template <int NP, int MF, int NF, int WM, int WN>
 static int c3_launch(const C3Args& a, const C3Plan& pl, hipStream_t st) {
-  static bool attr_done[3] = {false, false, false};   // idempotent attribute call: a race at first use only repeats it
+  static unsigned char attr_done[3][BUCTD_MAX_DEVICES] = {{0}};
   void (*fn)(C3Args);
   int variant = 0;
   if constexpr (NP == 3) {
     if (MF >= 7) fn = conv3x3_x6_kernel<MF, NF, WM, WN, false, false, 2>;
-#ifdef BUCTD_TUNING
-    else if (pl.lean) { fn = conv3x3_x6_kernel<MF, NF, WM, WN, false, false, 3>; variant = 1; }
-#endif
     else { fn = conv3x3_x6_kernel<MF, NF, WM, WN, true, true, 2>; variant = 2; }
   }
   else fn = conv3x3_split_kernel<NP, (MF > 4 ? 4 : MF), NF, WM, WN>;
-  bool& attr_set = attr_done[variant];
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       160 * 1024);
-    if (e != hipSuccess) {
-      buctd_set_error("conv3x3 (split bf16): cannot raise the dynamic LDS limit: %s", hipGetErrorString(e));
-      return BUCTD_ELAUNCH;
-    }
-    attr_set = true;
-  }
+  if (const int rc = buctd_raise_lds_limit(reinterpret_cast<const void*>(fn), 160 * 1024, attr_done[variant], "conv3x3 (split bf16)"))
+    return rc;
   dim3 grid(ceil_div(a.P, pl.BM), a.Co / pl.BN);
   hipLaunchKernelGGL(fn, grid, dim3(256), pl.lds, st, a);
   BUCTD_CHECK_LAUNCH("buctd_conv3x3 (split bf16)");
@@ -792,15 +715,6 @@ static int c3_dispatch(const C3Args& a, const C3Plan& pl, hipStream_t st) {
   buctd_set_error("conv3x3 (split bf16): no kernel for MF=%d NF=%d WN=%d", pl.MF, pl.NF, pl.WN);
   return BUCTD_EINVAL;
 }
-
-#ifdef C3_TRACE
-extern "C" int buctd_debug_c3_wall(unsigned long long* host_out) {
-  return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(c3_trace_wall), sizeof(unsigned long long) * 4096 * 2);
-}
-extern "C" int buctd_debug_c3_trace(unsigned long long* host_out) {
-  return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(c3_trace_buf), sizeof(unsigned long long) * 8 * 64);
-}
-#endif
 
 static int c3_supported(int np, int N, int H, int W, int Ci, int Co) {
   C3Plan pl;
@@ -852,9 +766,9 @@ struct C3Acc { long long* stats_acc; const buctd_bn_acc_in* in; };
 static int c3_fill(int np, int N, int H, int W, int Ci, int Co, const float* x, const void* wprep, const float* bias,
                    const float* scale, const float* shift, const float* residual, int relu, float* y,
                    float* stats_partials, int* stats_counts, const C3InBn* in_bn, const C3BwdStat* bst, const C3Acc* accs,
-                   C3Args& a, C3Plan& pl, int group = 0) {
+                   C3Args& a, C3Plan& pl) {
   BUCTD_CHECK_ARG(x && wprep && y, "buctd_conv3x3 (split bf16): null tensor pointer");
-  BUCTD_CHECK_ARG(c3_np_ok(np) && c3_plan(np, N, H, W, Ci, Co, &pl, group),
+  BUCTD_CHECK_ARG(c3_np_ok(np) && c3_plan(np, N, H, W, Ci, Co, &pl),
                   "buctd_conv3x3 (split bf16): unsupported shape N%d H%d W%d Ci%d Co%d", N, H, W, Ci, Co);
   BUCTD_CHECK_ARG((scale == nullptr) == (shift == nullptr), "buctd_conv3x3 (split bf16): scale and shift go together");
   BUCTD_CHECK_ARG((stats_partials == nullptr) == (stats_counts == nullptr),
@@ -901,9 +815,6 @@ static int c3_fill(int np, int N, int H, int W, int Ci, int Co, const float* x, 
     a.bs_beta = bst->beta; a.bs_part = bst->part; a.bs_acc = bst->acc;
   }
   a.col_major = (np == 3 && Co / pl.BN >= 2 && (size_t)c3_steps(Ci, 3) * Co * Geo<3>::BROW > ((size_t)3 << 20)) ? 1 : 0;
-#ifdef BUCTD_TUNING
-  if (const char* f = getenv("BUCTD_C3_COLMAJOR")) a.col_major = np == 3 && atoi(f) != 0;
-#endif
   magic_u32((unsigned)a.IB, &a.ib_mul, &a.ib_sh);
   magic_u32((unsigned)a.SW, &a.sw_mul, &a.sw_sh);
   return BUCTD_OK;
@@ -1027,15 +938,6 @@ static int c3_group_variant(const C3Plan& pl, int* fam) {
   return -1;
 }
 
-static int c3_group_plans(int n) {
-#ifdef BUCTD_TUNING
-  static const int env = getenv("BUCTD_C3_GROUP_PLAN") ? atoi(getenv("BUCTD_C3_GROUP_PLAN")) : -1;
-  if (env >= 0) return env;
-#endif
-  (void)n;
-  return 0;      // the single-launch plans: results bit-identical to the per-convolution launches (group plans: -4 % per launch)
-}
-
 extern "C" int buctd_conv3x3_bf16x6_group(int n, const buctd_c3_conv* convs, void* stream) {
   BUCTD_CHECK_ARG(n > 0 && n <= C3G_MAX && convs, "buctd_conv3x3_bf16x6_group: 1..%d convolutions", C3G_MAX);
   C3Group g;
@@ -1049,8 +951,7 @@ extern "C" int buctd_conv3x3_bf16x6_group(int n, const buctd_c3_conv* convs, voi
     C3Acc ac{(long long*)c.stats_acc, c.in_bn};
     BUCTD_CHECK_ARG(!c.in_bn || c.in_bn->acc, "buctd_conv3x3_bf16x6_group: in_bn without an accumulator");
     const int rc = c3_fill(3, c.N, c.H, c.W, c.Ci, c.Co, c.x, c.wprep, nullptr, nullptr, nullptr, c.residual, c.relu, c.y,
-                           nullptr, nullptr, c.in_bn ? &ib : nullptr, c.bn_acc ? &bs : nullptr, &ac, g.conv[k], pl[k],
-                           c3_group_plans(n));
+                           nullptr, nullptr, c.in_bn ? &ib : nullptr, c.bn_acc ? &bs : nullptr, &ac, g.conv[k], pl[k]);
     if (rc) return rc;
     cost[k] = (double)pl[k].BM * pl[k].BN * c.Ci;
     order[k] = k;
@@ -1087,16 +988,10 @@ extern "C" int buctd_conv3x3_bf16x6_group(int n, const buctd_c3_conv* convs, voi
     per_xcd += ((unsigned)h.tiles[i] + 7) >> 3;
   }
   for (int i = n; i < C3G_MAX; ++i) h.tiles[i] = h.gx[i] = h.gy[i] = h.variant[i] = 0;
-  static bool attr_done[2] = {false, false};
+  static unsigned char attr_done[2][BUCTD_MAX_DEVICES] = {{0}};
   void (*fn)(C3Group) = fam ? conv3x3_x6_group_kernel<1> : conv3x3_x6_group_kernel<0>;
-  if (!attr_done[fam]) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (e != hipSuccess) {
-      buctd_set_error("buctd_conv3x3_bf16x6_group: cannot raise the dynamic LDS limit: %s", hipGetErrorString(e));
-      return BUCTD_ELAUNCH;
-    }
-    attr_done[fam] = true;
-  }
+  if (const int rc = buctd_raise_lds_limit(reinterpret_cast<const void*>(fn), 160 * 1024, attr_done[fam], "buctd_conv3x3_bf16x6_group"))
+    return rc;
   hipLaunchKernelGGL(fn, dim3(per_xcd * 8), dim3(256), lds, (hipStream_t)stream, h);
   BUCTD_CHECK_LAUNCH("buctd_conv3x3_bf16x6_group");
   return BUCTD_OK;

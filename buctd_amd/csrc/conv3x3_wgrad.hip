@@ -430,13 +430,8 @@ static bool wg3_plan(int np, int N, int H, int W, int Ci, int Co, WG3Plan* pl, i
   const long pairs = (long)(Co / ch) * ((Ci + ch - 1) / ch);
   // two resident workgroups per CU (512 in all) when one (co, ci) chunk pair exists; fewer splits per pair otherwise
   // (partial-slab traffic grows with the split).  Splits take q or q + 1 stages, so no rounding loss.
-#ifdef BUCTD_TUNING      // experiment builds only
-  static const int split_env = getenv("BUCTD_WG3_SPLIT") ? atoi(getenv("BUCTD_WG3_SPLIT")) : 0;
-#else
-  constexpr int split_env = 0;
-#endif
   // target > 0: the convolution shares its launch with others (wg3 group) and gets this many workgroups
-  long want = ((target > 0 ? target : split_env > 0 ? split_env : (np == 3 ? 512 : 384)) + pairs - 1) / pairs;
+  long want = ((target > 0 ? target : (np == 3 ? 512 : 384)) + pairs - 1) / pairs;
   const long stages = (P + kb - 1) / kb;
   if (want > stages) want = stages;
   if (want < 1) want = 1;
@@ -460,18 +455,11 @@ static size_t wg3_ws_bytes(const WG3Plan& pl, int Ci, int Co) {
 
 template <int NP, int CF>
 static int wg3_launch(const WG3Args& a, const WG3Plan& pl, hipStream_t st) {
-  static bool attr_set = false;     // idempotent attribute call: a race at first use only repeats it
+  static unsigned char attr_done[BUCTD_MAX_DEVICES] = {0};
   auto fn = conv3x3_wgrad_split_kernel<NP, CF>;
   const dim3 block(256);
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       160 * 1024);
-    if (e != hipSuccess) {
-      buctd_set_error("conv3x3_wgrad (split bf16): cannot raise the dynamic LDS limit: %s", hipGetErrorString(e));
-      return BUCTD_ELAUNCH;
-    }
-    attr_set = true;
-  }
+  if (const int rc = buctd_raise_lds_limit(reinterpret_cast<const void*>(fn), 160 * 1024, attr_done, "conv3x3_wgrad (split bf16)"))
+    return rc;
   dim3 grid(a.Co / (CF * 16), (a.Ci + CF * 16 - 1) / (CF * 16), pl.nsplit);
   hipLaunchKernelGGL(fn, grid, block, pl.lds, st, a);
   BUCTD_CHECK_LAUNCH("buctd_conv3x3_wgrad (split bf16)");
@@ -538,16 +526,8 @@ static int wg3_run(int np, int N, int H, int W, int Ci, int Co, const float* x, 
 // split pays the 2 * SW + 2 halo rows of its first stage and writes (and the reduction re-reads) an 84 KB slab.  n
 // convolutions in one grid fill the chip together: each gets WG3_GROUP_SLOTS / n workgroups, i.e. 1 / n of the halo and slab
 // traffic per convolution - and the launch is more than one round, so prologues and slab stores overlap other main loops.
-#ifndef WG3_GROUP_SLOTS
-#define WG3_GROUP_SLOTS 1024
-#endif
-static int wg3_group_target(int n) {
-#ifdef BUCTD_TUNING      // experiment builds only
-  static const int env = getenv("BUCTD_WG3_GROUP_SLOTS") ? atoi(getenv("BUCTD_WG3_GROUP_SLOTS")) : 0;
-  if (env > 0) return env / n;
-#endif
-  return WG3_GROUP_SLOTS / n;
-}
+#define WG3_GROUP_SLOTS 1024      // 512 / 768 / 1536 / 2048 measured within 3 % of each other (scratch/time_group_wgrad.py)
+static int wg3_group_target(int n) { return WG3_GROUP_SLOTS / n; }
 
 extern "C" size_t buctd_conv3x3_wgrad_bf16x6_group_workspace(int n, int N, int H, int W, int Ci, int Co) {
   WG3Plan pl;
@@ -586,17 +566,11 @@ extern "C" int buctd_conv3x3_wgrad_bf16x6_group(int n, const buctd_wg3_conv* con
   }
   for (int k = n; k < WG3G_MAX; ++k) { g.first[k + 1] = g.first[n]; r.first[k + 1] = r.first[n]; g.ncx[k] = g.ncy[k] = g.nsplit[k] = 0; }
   hipStream_t st = (hipStream_t)stream;
-  static bool attr_done[2] = {false, false};
+  static unsigned char attr_done[2][BUCTD_MAX_DEVICES] = {{0}};
   const int cf = pl[0].CF;
   void (*fn)(WG3Group) = cf == 3 ? conv3x3_wgrad_group_kernel<3, 3> : conv3x3_wgrad_group_kernel<3, 2>;
-  if (!attr_done[cf - 2]) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (e != hipSuccess) {
-      buctd_set_error("buctd_conv3x3_wgrad_bf16x6_group: cannot raise the dynamic LDS limit: %s", hipGetErrorString(e));
-      return BUCTD_ELAUNCH;
-    }
-    attr_done[cf - 2] = true;
-  }
+  if (const int rc = buctd_raise_lds_limit(reinterpret_cast<const void*>(fn), 160 * 1024, attr_done[cf - 2], "buctd_conv3x3_wgrad_bf16x6_group"))
+    return rc;
   hipLaunchKernelGGL(fn, dim3(g.first[n]), dim3(256), lds, st, g);
   BUCTD_CHECK_LAUNCH("buctd_conv3x3_wgrad_bf16x6_group");
   const dim3 rgrid(ceil_div((long)(wg3_slab_floats(cf) / 4), 16), r.first[n]);

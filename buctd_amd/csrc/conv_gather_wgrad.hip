@@ -299,16 +299,9 @@ extern "C" size_t buctd_gconv_wgrad_x6_workspace(int kind, int N, int H, int W, 
 
 template <int CF, int TPG>
 static int gw_launch(const GwArgs& a, const GwPlan& pl, float* dw, int accumulate, hipStream_t st) {
-  static bool attr_set = false;     // idempotent attribute call: a race at first use only repeats it
+  static unsigned char attr_done[BUCTD_MAX_DEVICES] = {0};
   auto fn = gconv_wgrad_x6_kernel<CF, TPG>;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (e != hipSuccess) {
-      buctd_set_error("buctd_gconv_wgrad_x6: cannot raise the dynamic LDS limit: %s", hipGetErrorString(e));
-      return BUCTD_ELAUNCH;
-    }
-    attr_set = true;
-  }
+  if (const int rc = buctd_raise_lds_limit(reinterpret_cast<const void*>(fn), 160 * 1024, attr_done, "buctd_gconv_wgrad_x6")) return rc;
   const int ch = CF * 16;
   hipLaunchKernelGGL(fn, dim3(a.Co / ch, a.Ci / ch, pl.nsplit * pl.ntg), dim3(256), pl.lds, st, a);
   BUCTD_CHECK_LAUNCH("buctd_gconv_wgrad_x6");

@@ -26,9 +26,6 @@
 #include <string.h>
 
 #define GC_MAXT 9
-#ifndef GC_ABL
-#define GC_ABL 0      // what-if switches (scratch/gc_abl.sh): 1 no weight loads, 2 no gathers, 4 no LDS stores, 8 no barriers, 16 no MFMAs
-#endif
 
 struct GcClass {
   int ntaps, nhs, nsteps;            // taps, half-steps = ntaps * (SC / 16), steps = ceil(nhs / 2)
@@ -132,7 +129,6 @@ __global__ __launch_bounds__(256, 2) void gconv_x6_kernel(GcArgs p) {
     }
   };
   auto load_b = [&](int st, bf16x8 (&dst)[3][NF]) {
-    if ((GC_ABL & 1) && st > 1) return;
     const unsigned char* wp = wbase + (size_t)st * wstep;
 #pragma unroll
     for (int q = 0; q < 3; ++q)
@@ -186,19 +182,16 @@ __global__ __launch_bounds__(256, 2) void gconv_x6_kernel(GcArgs p) {
 #define GC_MMA(qa, qb) acc[mf][nf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ac[qa], bc[qb][nf], acc[mf][nf], 0, 0, 0);
 #pragma unroll
       for (int nf = 0; nf < NF; ++nf) {
-        if (GC_ABL & 16) { acc[mf][nf][0] += (float)ac[0][0] + (float)ac[1][1] + (float)ac[2][2] + (float)bc[0][nf][0] + (float)bc[1][nf][1] + (float)bc[2][nf][2]; continue; }
         GC_MMA(2, 0) GC_MMA(0, 2) GC_MMA(1, 1) GC_MMA(1, 0) GC_MMA(0, 1) GC_MMA(0, 0)
       }
 #undef GC_MMA
       // a quarter of the next stage's split + store behind each fragment's MFMAs
-      if (!(GC_ABL & 4) || st < 1) {
-        if (mf < 2 * QA && mf < MF) {
-          const int h = mf / QA, q = mf % QA;
-          const bool ok = (aok[1 - SET] >> (h * QA + q)) & 1u;
-          const f32x4 v = areg[1 - SET][h][q];
-          split_store_pk<3, PST>(smem + (size_t)(1 - SET) * ABUF + ((size_t)h * BM + arow + RSTEP * q) * ROWB, c4 * 4,
-                              (f32x4){ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f});
-        }
+      if (mf < 2 * QA && mf < MF) {
+        const int h = mf / QA, q = mf % QA;
+        const bool ok = (aok[1 - SET] >> (h * QA + q)) & 1u;
+        const f32x4 v = areg[1 - SET][h][q];
+        split_store_pk<3, PST>(smem + (size_t)(1 - SET) * ABUF + ((size_t)h * BM + arow + RSTEP * q) * ROWB, c4 * 4,
+                            (f32x4){ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f});
       }
       __builtin_amdgcn_sched_barrier(0);
     }
@@ -212,7 +205,7 @@ __global__ __launch_bounds__(256, 2) void gconv_x6_kernel(GcArgs p) {
                             (f32x4){ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f});
       }
     }
-    if (!PRIV && !(GC_ABL & 8)) __syncthreads();        // stage st + 1 is complete, stage st is read
+    if (!PRIV) __syncthreads();        // stage st + 1 is complete, stage st is read
   };
 
   load_a(0, areg[0], aok[0]);
@@ -491,9 +484,6 @@ static int gc_run(int kind, int dir, int N, int H, int W, int Ci, int Co, const 
 extern "C" int buctd_gconv_x6_fwd(int kind, int N, int H, int W, int Ci, int Co, const float* x, const void* wprep,
                                   const float* bias, const float* scale, const float* shift, const float* residual, int relu,
                                   float* y, float* stats_partials, int* stats_counts, void* stream) {
-#ifdef WHATIF_SKIP_GCONV     // what-if builds only
-  return BUCTD_OK;
-#endif
   return gc_run(kind, 0, N, H, W, Ci, Co, x, wprep, bias, scale, shift, residual, relu, y, stats_partials, stats_counts, stream,
                 "buctd_gconv_x6_fwd");
 }
@@ -508,9 +498,6 @@ extern "C" int buctd_gconv_x6_fwd_acc(int kind, int N, int H, int W, int Ci, int
 
 extern "C" int buctd_gconv_x6_dgrad(int kind, int N, int H, int W, int Ci, int Co, const float* dy, const void* wprep,
                                     const float* residual, float* dx, void* stream) {
-#ifdef WHATIF_SKIP_GCONV
-  return BUCTD_OK;
-#endif
   return gc_run(kind, 1, N, H, W, Ci, Co, dy, wprep, nullptr, nullptr, nullptr, residual, 0, dx, nullptr, nullptr, stream,
                 "buctd_gconv_x6_dgrad");
 }

@@ -263,24 +263,13 @@ extern "C" int buctd_x6_gemm(int M, int N, int K, const void* a_image, const voi
   BUCTD_CHECK_ARG(a_image && b_image && C && M > 0 && N > 0 && K > 0, "buctd_x6_gemm: bad argument");
   BUCTD_CHECK_ARG(bias_axis == 0 || bias_axis == 1, "buctd_x6_gemm: bias_axis must be 0 (per column) or 1 (per row)");
   if (Nc <= 0) Nc = N;
-  static bool attr_done = false;   // idempotent attribute call: a race at first use only repeats it
-  if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(x6_gemm_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, 2 * GX_ABUF);
-    if (e != hipSuccess) {
-      buctd_set_error("buctd_x6_gemm: cannot raise the dynamic LDS limit: %s", hipGetErrorString(e));
-      return BUCTD_ELAUNCH;
-    }
-    attr_done = true;
-  }
+  static unsigned char attr_done[BUCTD_MAX_DEVICES] = {0};
+  if (const int rc = buctd_raise_lds_limit(reinterpret_cast<const void*>(x6_gemm_kernel), 2 * GX_ABUF, attr_done, "buctd_x6_gemm")) return rc;
   GxArgs p;
   p.a = (const unsigned char*)a_image; p.b = (const unsigned char*)b_image; p.c = C; p.bias = bias;
   p.M = M; p.N = N; p.KB = pad_to(K, GX_KPAD) / 32; p.ldc = ldc; p.gsc = gsc; p.Nc = Nc; p.alpha = alpha;
   p.bias_axis = bias_axis;
   p.row_major = (size_t)pad_to(M, GX_BM) > (size_t)pad_to(N, GX_BN) ? 1 : 0;     // image bytes ~ V x Kpad
-#ifdef BUCTD_TUNING      // experiment builds only
-  if (const char* f = getenv("BUCTD_GX_ROWMAJOR")) p.row_major = atoi(f) != 0;
-#endif
   dim3 grid(pad_to(M, GX_BM) / GX_BM, pad_to(N, GX_BN) / GX_BN);
   hipLaunchKernelGGL(x6_gemm_kernel, grid, dim3(512), 2 * GX_ABUF, (hipStream_t)stream, p);
   BUCTD_CHECK_LAUNCH("buctd_x6_gemm");

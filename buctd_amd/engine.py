@@ -345,6 +345,10 @@ class DataParallel(torch.nn.Module):
                     # must not queue behind the four compute streams' workgroups (it would start when they drain, i.e.
                     # exposed); what it takes away from them is its channel count (RCCL's default: <= 32 CUs of 256)
                     self._comm_stream = torch.cuda.Stream(priority=-1)
+                    # HIP stream budget: the default runtime serves FOUR hardware queues and any fifth stream costs 25-32 %
+                    # (DESIGN.md 3.12, 6).  With the communication stream the compute side gets main + ONE branch stream
+                    # (the two group-launch families of a HighResolutionModule, the fuse rows) + the weight-gradient stream.
+                    ops.set_branch_max(1)
                     ops.set_grad_ready_callback(self._grad_ready)
         return self.flat
 
@@ -372,11 +376,19 @@ class DataParallel(torch.nn.Module):
             # the stream the backward pass is entered on: autograd replays nodes of the main path here
             self._entry_stream = torch.cuda.current_stream(self.flat.flat.device)
 
+    MAX_HIP_STREAMS = 4      # main + branch + weight-gradient + communication (the hardware queues of the default runtime)
+
+    def _check_stream_budget(self, device):
+        n = 1 + len(ops.compute_streams(device)) + (1 if self._comm_stream is not None else 0)
+        assert n <= self.MAX_HIP_STREAMS, (f"{n} HIP streams on {device} (main + {len(ops.compute_streams(device))} compute + "
+                                           "communication): more than four hardware queues cost 25-32 % (DESIGN.md 6)")
+
     def _launch(self, i):
         s, e, _ = self.buckets.buckets[i]
         view = self.flat.grad[s:e]
         self._launched[i] = True
         if self._comm_stream is not None:
+            self._check_stream_budget(view.device)
             # one event per stream that wrote into this bucket, recorded now: stream order makes it cover the
             # bucket's kernels on that stream (and nothing of streams that did not contribute)
             streams = dict(self._streams[i])

@@ -36,7 +36,7 @@ class BasicBlock(nn.Module):
 
     def forward(self, x):
         if (self.training and self.downsample is None and self.stride == 1 and x.is_cuda and torch.is_grad_enabled()
-                and self.conv1.bias is None and self.conv2.bias is None):
+                and self.conv1.bias is None and self.conv2.bias is None and self.bn1.training and self.bn2.training):
             nn._as_channels_last_(self.conv1.weight)
             nn._as_channels_last_(self.conv2.weight)
             return ops.BasicBlockFn.apply(x, self.conv1.weight, self.bn1, self.conv2.weight, self.bn2)
@@ -61,7 +61,11 @@ class Bottleneck(nn.Module):
         self.stride = stride
 
     def forward(self, x):
+        # the one-node path runs every inner BatchNorm in train mode: a BatchNorm put in eval on its own (frozen statistics
+        # while the block trains) takes the layer-by-layer path, which honours bn.training per layer
+        bns = (self.bn1, self.bn2, self.bn3) + (() if self.downsample is None or len(self.downsample) < 2 else (self.downsample[1],))
         if (self.training and x.is_cuda and torch.is_grad_enabled() and ops.fused_bottleneck_on()
+                and all(b.training for b in bns)
                 and (self.downsample is None or type(self.downsample) is nn.ConvBN and not self.downsample._relu)):
             for c in (self.conv1, self.conv2, self.conv3) + (() if self.downsample is None else (self.downsample[0],)):
                 nn._as_channels_last_(c.weight)
@@ -79,8 +83,8 @@ class BlockChain(nn.Chain):
     def forward(self, x):
         if (len(self) > 1 and self.training and x.is_cuda and torch.is_grad_enabled() and ops.native_chain_ok(tuple(x.shape))
                 and all(type(m) is BasicBlock and m.downsample is None and m.stride == 1 and m.conv1.bias is None
-                        and m.conv2.bias is None and m.bn1.track_running_stats == m.bn2.track_running_stats
-                        == self[0].bn1.track_running_stats for m in self)
+                        and m.conv2.bias is None and m.bn1.training and m.bn2.training
+                        and m.bn1.track_running_stats == m.bn2.track_running_stats == self[0].bn1.track_running_stats for m in self)
                 and ops.bn_in_fusable(tuple(x.shape), self[0].conv1.weight)):
             blocks = []
             for m in self:
@@ -293,7 +297,7 @@ class HRNetTrunk(nn.Module):
             heads = [trans[i] if isinstance(trans[i], nn.ConvBN) else trans[i][0] if isinstance(trans[i], nn.Chain) else None
                      for i in range(n)]
             if (self.training and prev.is_cuda and torch.is_grad_enabled() and ops.fused_bottleneck_on() and n > 1
-                    and all(type(h) is nn.ConvBN for h in heads)):
+                    and all(type(h) is nn.ConvBN and h[1].training for h in heads)):
                 # every new branch starts with a conv + BN + ReLU on the same tensor: one autograd node (ops.ForkConvBnFn)
                 for h in heads:
                     nn._as_channels_last_(h[0].weight)

@@ -20,6 +20,15 @@ import torch
 from . import _C
 from ._C import ConvDesc, MatmulDesc, check, lib, ptr, stream_ptr
 
+# Engine switches and their product defaults.  The product reads NO environment variable for them: experiments (scratch/ A/B
+# scripts) set BUCTD_TUNING=1, and only then buctd_amd/_tuning.py is imported and overrides entries from BUCTD_<NAME>.
+_SW = {"CONV_MATH": "bf16x6", "PREP_BATCH": "1", "GCONV_X6": "1", "GCONV_MASK": "15", "NATIVE_BLOCK": "1", "FUSED_BOTTLENECK": "1",
+       "FUSE_BN_IN": "1", "FC_O_X6": "1", "MHA_X6": "1", "MHA_PRESPLIT": "1", "ATTN_X6": "1", "WGRAD_STREAM": "1", "WGRAD_STREAMS": "1",
+       "WGRAD_PRIO": "-1", "BRANCH_STREAMS": "1", "BRANCH_MAX": "2", "BRANCH_PRIO": "0"}
+if os.environ.get("BUCTD_TUNING") == "1":
+    from . import _tuning
+    _tuning.override(_SW)
+
 # --------------------------------------------------------------------------------------
 # workspace + RNG seed bookkeeping
 # --------------------------------------------------------------------------------------
@@ -45,17 +54,20 @@ def workspace_on(stream, nbytes, device):
     buf = _workspaces.get(key)
     if buf is None or buf.numel() < nbytes:
         # growth (rare: the first step visits increasingly large shapes): the old buffer may still be written by kernels
-        # queued on `stream`, and it was allocated under whatever stream was current - keep it alive instead of handing its
-        # block back to that stream's pool, where the next torch.empty could reuse it under the running kernel
+        # queued on `stream`, and it was allocated under whatever stream was current - it is kept alive until an event
+        # recorded on `stream` here has passed (checked at the next growth), then handed back to the allocator
+        _retired_workspaces[:] = [(b, ev) for b, ev in _retired_workspaces if not ev.query()]
         if buf is not None:
-            _retired_workspaces.append(buf)
+            ev = torch.cuda.Event()
+            ev.record(stream)
+            _retired_workspaces.append((buf, ev))
         buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
         buf.record_stream(stream)
         _workspaces[key] = buf
     return buf
 
 
-_retired_workspaces = []
+_retired_workspaces = []     # (buffer, event on the stream that may still use it)
 
 
 # --------------------------------------------------------------------------------------
@@ -260,7 +272,7 @@ def _memo(key, fn):
 
 
 _CONV_MATH_MODES = ("fp32", "bf16x6", "bf16x3")
-_conv_math = {"mode": os.environ.get("BUCTD_CONV_MATH", "bf16x6")}
+_conv_math = {"mode": _SW["CONV_MATH"]}
 
 
 def set_conv_math(mode):
@@ -303,7 +315,7 @@ _weights_epoch = {"n": 0}
 # After an optimizer step every prepared filter image of the model is rebuilt by ONE launch on the stream of the step
 # (refresh_prepared, called by FusedAdam) instead of ~430 small launches in front of the convolutions that need them:
 # off the critical path of the next forward / backward, 430 launches less per step.  BUCTD_PREP_BATCH=0: lazy refresh.
-_PREP_BATCH = os.environ.get("BUCTD_PREP_BATCH", "1") == "1"
+_PREP_BATCH = _SW["PREP_BATCH"] == "1"
 _prep_registry = {"weights": [], "table": None, "table_key": None, "event": None, "stream": None, "waited": set()}
 
 
@@ -493,8 +505,8 @@ def _conv3x3_bf16x3(x, w, flip, cin, cout, bias, scale, shift, residual, relu, s
 
 
 # ---- gathered bf16x6 convolutions (csrc/conv_gather_x6.hip): 1x1 and stride-2 3x3, forward + data gradient ----------------
-_GCONV_X6 = os.environ.get("BUCTD_GCONV_X6", "1") != "0"
-_GCONV_MASK = int(os.environ.get("BUCTD_GCONV_MASK", "15"))     # experiments: bit 0/1 = 1x1 forward / data gradient, 2/3 = stride-2 3x3
+_GCONV_X6 = _SW["GCONV_X6"] != "0"
+_GCONV_MASK = int(_SW["GCONV_MASK"])     # experiments: bit 0/1 = 1x1 forward / data gradient, 2/3 = stride-2 3x3
 
 
 def _gconv_kind(d):
@@ -568,8 +580,8 @@ def _gconv_fwd(x, w, d, bias, scale, shift, residual, relu, stats):
     return (y, part, info) if stats else y
 
 
-_NATIVE_BLOCK = os.environ.get("BUCTD_NATIVE_BLOCK", "1") == "1"
-_FUSED_BOTTLENECK = {"on": os.environ.get("BUCTD_FUSED_BOTTLENECK", "1") == "1"}
+_NATIVE_BLOCK = _SW["NATIVE_BLOCK"] == "1"
+_FUSED_BOTTLENECK = {"on": _SW["FUSED_BOTTLENECK"] == "1"}
 
 
 def fused_bottleneck_on():
@@ -582,11 +594,11 @@ def set_fused_bottleneck(on):
     _FUSED_BOTTLENECK["on"] = bool(on)
     return old
 # experiment switches, read ONCE at import (the hot path consults module constants, never the environment)
-_FUSE_BN_IN = os.environ.get("BUCTD_FUSE_BN_IN", "1") == "1"
-_FC_O_X6 = os.environ.get("BUCTD_FC_O_X6", "1") != "0"
-_MHA_X6 = os.environ.get("BUCTD_MHA_X6", "1") != "0"
-_MHA_PRESPLIT = os.environ.get("BUCTD_MHA_PRESPLIT", "1") != "0"
-_ATTN_X6 = os.environ.get("BUCTD_ATTN_X6", "1") != "0"
+_FUSE_BN_IN = _SW["FUSE_BN_IN"] == "1"
+_FC_O_X6 = _SW["FC_O_X6"] != "0"
+_MHA_X6 = _SW["MHA_X6"] != "0"
+_MHA_PRESPLIT = _SW["MHA_PRESPLIT"] != "0"
+_ATTN_X6 = _SW["ATTN_X6"] != "0"
 # optional veto: callable(x_shape) -> True sends a BasicBlock through the step-by-step path (bench.py brackets every launch
 # of its roofline shape with HIP events, which it can only do from the host mirror)
 native_block_veto = {"fn": None}
@@ -742,15 +754,15 @@ def conv_wgrad(x, dy, w_like, stride=1, pad=0, out=None, accumulate=0, x_bn=None
 # Weight gradients are off the critical path of the backward pass (nothing downstream of dgrad needs them), so they
 # run on a second HIP stream and fill the CUs that the latency-bound BN / dgrad chain leaves idle.  The join is queued
 # as an autograd end-of-backward callback, so param.grad is complete on the caller's stream when backward() returns.
-_side = {"on": os.environ.get("BUCTD_WGRAD_STREAM", "1") == "1", "streams": {}, "joined": True, "rr": 0,
-         "n": max(1, int(os.environ.get("BUCTD_WGRAD_STREAMS", "1")))}   # more than one measured slower (L2 contention)
+_side = {"on": _SW["WGRAD_STREAM"] == "1", "streams": {}, "joined": True, "rr": 0,
+         "n": max(1, int(_SW["WGRAD_STREAMS"]))}   # more than one measured slower (L2 contention)
 
 
 # The weight-gradient stream runs at HIGH HIP priority: the critical path of the backward pass runs along it for half of the
 # time (profiles/r04_critical_path.txt: 12.9 ms of weight gradients + 3.5 ms of their slab reductions on the chain), so its
 # kernels should get free workgroup slots before the main stream's: 454.0 -> 457.2 img/s (interleaved A/B on one box, round
 # 4; the branch streams at high priority cost 1 %).
-_SIDE_PRIO = int(os.environ.get("BUCTD_WGRAD_PRIO", "-1"))
+_SIDE_PRIO = int(_SW["WGRAD_PRIO"])
 
 
 def _side_stream(device):
@@ -785,12 +797,28 @@ def wait_side_stream(stream=None):
 # enqueued on separate HIP streams: the low-resolution branches are launch/latency bound and hide under the
 # bandwidth-bound high-resolution one.  Autograd replays every backward node on the stream of its forward op, so the
 # backward pass inherits the same concurrency.
-_branch = {"on": os.environ.get("BUCTD_BRANCH_STREAMS", "1") == "1", "streams": {}}
+_branch = {"on": _SW["BRANCH_STREAMS"] == "1", "streams": {}}
 
 
 # main + 2 branch streams + the weight-gradient stream = the 4 HIP hardware queues: no two streams share a queue by
 # accident (HRNet branches 2 and 3, the cheapest, share the last stream): 453 -> 468 img/s
-_BRANCH_MAX = int(os.environ.get("BUCTD_BRANCH_MAX", "2"))
+_BRANCH_MAX = int(_SW["BRANCH_MAX"])
+
+
+def set_branch_max(n):
+    """Cap on the number of branch streams (besides the main stream).  The default runtime serves four hardware queues and any
+    fifth HIP stream costs 25-32 %: engine.DataParallel lowers the cap to 1 when it adds its communication
+    stream (main + 1 branch + weight-gradient + communication = 4).  Returns the previous cap."""
+    global _BRANCH_MAX
+    old, _BRANCH_MAX = _BRANCH_MAX, max(0, int(n))
+    return old
+
+
+def compute_streams(device):
+    """The HIP streams this module owns on `device` (branch + weight-gradient streams created so far)."""
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    return ([st for (d, _), st in _branch["streams"].items() if d == idx] +
+            [st for (d, _), st in _side["streams"].items() if d == idx])
 
 
 def _branch_stream(device, i):
@@ -798,7 +826,7 @@ def _branch_stream(device, i):
     key = (device.index, i)
     st = _branch["streams"].get(key)
     if st is None:
-        st = torch.cuda.Stream(device=device, priority=int(os.environ.get("BUCTD_BRANCH_PRIO", "0")))
+        st = torch.cuda.Stream(device=device, priority=int(_SW["BRANCH_PRIO"]))
         _branch["streams"][key] = st
     return st
 

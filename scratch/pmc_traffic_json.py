@@ -1,6 +1,6 @@
 """HBM traffic per launch of the roofline kernels from the FETCH_SIZE / WRITE_SIZE passes of scratch/pmc_run.sh, and their
 in-step kernel durations from a rocprofv3 kernel trace of bench.py -> the two small JSON files bench.py quotes:
-    python scratch/pmc_traffic_json.py <gpurun_out dir with pmc_<tag>{fwd,dgrad,wg}> <kernel_trace_stats.txt> <out dir> <date>"""
+    python scratch/pmc_traffic_json.py <gpurun_out dir with pmc_r5{fwd,dg,wg}> <unused> <out dir> <date>"""
 import csv, glob, json, os, re, sys
 from collections import defaultdict
 base, stats_txt, outdir, date = sys.argv[1:5]
@@ -15,8 +15,8 @@ def kb(dirn, counter):
 
 res = {"date": date, "unit": "HBM bytes per launch = 2 x FETCH_SIZE + WRITE_SIZE (KB counters; gfx950: FETCH_SIZE counts 64 B per "
                              "128-B request of a wide coalesced read, MI355X_MICROARCH.md), standalone launches at N = 32, 48->48 @96x72",
-       "source": "profiles/r04_pmc_conv3x3.txt (scratch/pmc_run.sh, one rocprofv3 --pmc pass per counter group)"}
-for kind, tag in (("fwd", "r4fwd"), ("dgrad", "r4dg"), ("wgrad", "r4wg")):
+       "source": "profiles/r05_pmc_conv3x3.txt (scratch/pmc_run.sh, one rocprofv3 --pmc pass per counter group)"}
+for kind, tag in (("fwd", "r5fwd"), ("dgrad", "r5dg"), ("wgrad", "r5wg")):
     d = os.path.join(base, "pmc_" + tag)
     f, w = kb(d, "FETCH_SIZE"), kb(d, "WRITE_SIZE")
     tot, detail = 0.0, {}
@@ -27,12 +27,5 @@ for kind, tag in (("fwd", "r4fwd"), ("dgrad", "r4dg"), ("wgrad", "r4wg")):
             if "prep" not in k:
                 tot += b
     res[kind] = {"bytes": round(tot), "kernels": detail}
-json.dump(res, open(os.path.join(outdir, "r04_pmc_traffic.json"), "w"), indent=1)
-us = {}
-for line in open(stats_txt):
-    m = re.match(r"(.+?)\s+([\d.]+)\s+([\d.]+)\s+([\d.]+)\s+([\d.]+)%", line)
-    if m:
-        us[m.group(1).strip()[:70]] = {"calls_per_step": float(m.group(2)), "ms_per_step": float(m.group(3)), "avg_us": float(m.group(4))}
-json.dump({"date": date, "source": "profiles/r04_kernel_trace_stats_bench.txt (rocprofv3 --kernel-trace of python bench.py --steps 10 "
-           "--warmup 3 --no-cpu-baseline --no-kernel-timer)", "kernels": us}, open(os.path.join(outdir, "r04_in_step_kernel_us.json"), "w"), indent=1)
+json.dump(res, open(os.path.join(outdir, "pmc_traffic.json"), "w"), indent=1)
 print(json.dumps({k: res[k]["bytes"] for k in ("fwd", "dgrad", "wgrad")}))

@@ -1,7 +1,7 @@
 # kernel census of the train step with every stream serialised (kernel durations ~ solo): gpurun_out/<tag>/serial_stats.txt
 cd $GRAFT_REPO_ROOT
 tag=${1:-ser}; W=${2:-train_c4}; O=$GRAFT_REPO_ROOT/gpurun_out/$tag; mkdir -p $O
-export BUCTD_WGRAD_STREAM=0 BUCTD_BRANCH_STREAMS=0
+export BUCTD_TUNING=1 BUCTD_WGRAD_STREAM=0 BUCTD_BRANCH_STREAMS=0
 timeout 200 python bench.py --workload $W --steps 20 --warmup 5 --no-cpu-baseline --no-kernel-timer 2>/dev/null | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('serialised streams:', d['value'], d['ms_per_step'])" > $O/serial_bench.txt
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/trs_$tag

@@ -8,8 +8,22 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 
+def pytest_addoption(parser):
+    parser.addoption("--runslow", action="store_true", default=False, help="also run the tests marked slow (speed reports)")
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a ROCm device (run on the MI355X box with -m gpu)")
+    config.addinivalue_line("markers", "slow: speed reports without a pass / fail bar; skipped unless --runslow is given")
+
+
+def pytest_collection_modifyitems(config, items):
+    if config.getoption("--runslow"):
+        return
+    skip = pytest.mark.skip(reason="speed report: run with --runslow")
+    for item in items:
+        if "slow" in item.keywords:
+            item.add_marker(skip)
 
 
 @pytest.fixture(scope="session")

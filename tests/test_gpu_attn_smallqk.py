@@ -188,6 +188,7 @@ def test_position_attention_module_uses_fused_path(dev):
         assert _e(a, b) <= 5e-5, f"{name}: fused vs materialised rel err {_e(a, b):.2e}"
 
 
+@pytest.mark.slow
 def test_smallqk_speed_report(dev):
     """Not a pass/fail bar: prints fused vs materialised timings at the CoAM-W48 size, batch 32."""
     from buctd_amd import ops

@@ -154,6 +154,7 @@ def test_networks_in_bf16x3_mode(dev, name):
         ops.set_conv_math(old)
 
 
+@pytest.mark.slow
 def test_conv3x3_speed_report(dev):
     """Not a pass/fail bar: prints the stage-4 branch-0 conv timing in every math mode (HIP events)."""
     from buctd_amd import ops

@@ -192,6 +192,12 @@ def _check_bucket_rows(out):
     assert sorted(r["bucket"] for r in rows) == list(range(len(rows)))
     assert all(r["end_ms"] >= r["start_ms"] >= 0 for r in rows)
     assert all(rows[i]["start_ms"] <= rows[i + 1]["start_ms"] + 1e-3 for i in range(len(rows) - 1))
+    # overlap: a bucket's exchange is launched from the backward callbacks as soon as its last gradient kernel is enqueued, so
+    # every bucket but the last (the stem's parameters, final when the backward pass is) starts INSIDE the backward pass
+    assert all(r["start_ms"] < b["backward_ms"] for r in rows[:-1]), (b["backward_ms"], [r["start_ms"] for r in rows])
+    assert rows[0]["start_ms"] < 0.75 * b["backward_ms"]
+    # HIP stream budget under --gpus N: main + one branch stream + weight-gradient stream + communication stream
+    assert out["config"].get("hip_streams", 4) <= 4
     assert abs(sum(r["mb"] for r in rows) * 2 ** 20 - 4 * out["config"]["params"]) <= 0.02 * 4 * out["config"]["params"] + 2 ** 20
 
 
