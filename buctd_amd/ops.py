@@ -1858,8 +1858,19 @@ def set_group_parts(n):
     return old
 
 
+_GROUP_PARTITION = {}      # branches -> explicit partition (experiments: ops.set_group_partition)
+
+
+def set_group_partition(nb, parts):
+    """Explicit assignment of the branches of an nb-branch module to group-launch families, e.g. (3, [[0, 1], [2]])."""
+    assert sorted(i for p in parts for i in p) == list(range(nb))
+    _GROUP_PARTITION[nb] = [list(p) for p in parts]
+
+
 def group_branch_partition(nb):
     """Branch indices per group launch family: one group of all branches, or two groups side by side on two streams."""
+    if nb in _GROUP_PARTITION:
+        return _GROUP_PARTITION[nb]
     if _GROUP_PARTS["n"] <= 1 or nb < 3:
         return [list(range(nb))]
     if nb == 3:

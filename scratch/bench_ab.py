@@ -11,6 +11,8 @@ for tok in sys.argv[1].split(","):
         ops.set_group_parts(int(tok[6:]))
     elif tok == "nofuse":
         ops.conv_bn_group_ok = lambda xs, layers: False
+    elif tok.startswith("p3=") or tok.startswith("p4=") or tok.startswith("p2="):       # e.g. p3=01-2  p4=012-3
+        ops.set_group_partition(int(tok[1]), [[int(c) for c in part] for part in tok[3:].split("-")])
     elif tok == "nogwg":
         ops._GCONV_WGRAD["on"] = False
     elif tok == "nobranch":
