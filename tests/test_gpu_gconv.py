@@ -153,7 +153,7 @@ def test_prepared_images_follow_in_place_weight_updates(dev):
 WG_SHAPES = [(2, 24, 18, 48, 96, 3), (2, 12, 10, 96, 192, 3), (3, 8, 6, 192, 384, 3), (2, 16, 12, 48, 48, 3), (2, 20, 14, 64, 64, 3),
              (1, 6, 4, 256, 96, 3), (2, 4, 4, 48, 192, 3), (4, 96, 72, 48, 96, 3), (2, 24, 18, 64, 256, 1), (2, 24, 18, 256, 64, 1),
              (3, 12, 9, 96, 48, 1), (2, 7, 5, 192, 96, 1), (2, 6, 5, 384, 192, 1), (1, 1, 2, 48, 48, 1), (2, 48, 36, 96, 48, 1),
-             (1, 5, 3, 32, 64, 1), (32, 24, 18, 192, 48, 1)]
+             (1, 5, 3, 32, 64, 1), (32, 24, 18, 192, 48, 1), (16, 64, 64, 64, 128, 1), (17, 64, 62, 256, 64, 1)]
 
 
 @pytest.mark.parametrize("shape", WG_SHAPES)
