@@ -179,6 +179,15 @@ def test_train_step_matches_reference(dev, name):
             others.append((float(np.median(eh)), float(np.median(ec)), max(eh), max(ec)))
         print(f"{name}: recipe input misses the bars (median hip {med_h:.2e} / cpu32 {med_c:.2e}, worst hip {worst:.2e} at "
               f"{worst_k} / cpu32 {worst_ref:.2e}); two other inputs: {others}")
+        # where the error ORIGINATES: walking the parameters in backward order (last registered = closest to the loss), the
+        # first tensor beyond the bar names the layer behind which a unit flipped; everything between it and the loss must be
+        # clean - an error that is already in the head's gradient is not a flip inside the trunk
+        order = list(reversed(list(zip(kept_all, e_hip, e_cpu))))
+        onset = next((i for i, (_, eh_, ec_) in enumerate(order) if eh_ > max(3 * ec_, 1e-3)), None)
+        if onset is not None:
+            print(f"{name}: first tensor in backward order beyond the bar: {order[onset][0]} ({order[onset][1]:.2e}); "
+                  f"{onset} tensors between it and the loss are clean")
+            assert onset > 0, f"{name}: the gradient of the last layer ({order[0][0]}) is already off by {order[0][1]:.2e}"
         assert all(bars(*o) for o in others), \
             (f"{name}: grad error vs fp64 beyond the bars on the recipe input (median hip {med_h:.2e} / cpu32 {med_c:.2e}, worst "
              f"hip {worst:.2e} at {worst_k} / cpu32 {worst_ref:.2e}) AND on other inputs {others}: not a flipped ReLU")
@@ -213,6 +222,9 @@ def _grad_errors(m, omodel, xin, tgt, wt, dev):
         eh.append((params[k].grad.detach().cpu().double() - ref).norm().item() / den)
         ec.append((g32[k].double() - ref).norm().item() / den)
         keys.append(k)
+    order = list(reversed(list(zip(keys, eh, ec))))      # backward order: last registered parameter = closest to the loss
+    onset = next((i for i, (_, a, b) in enumerate(order) if a > max(3 * b, 1e-3)), None)
+    _grad_errors.onset = None if onset is None else (onset, order[onset][0], order[onset][1], order[0][0])
     return float(np.median(eh)), float(np.median(ec)), max(eh), max(ec), keys[int(np.argmax(eh))]
 
 
@@ -236,6 +248,13 @@ def test_train_step_at_the_original_seed_differs_by_a_relu_flip_only(dev, name):
     print(f"{name} @ seed 1234: median hip {mh:.2e} / cpu32 {mc:.2e}, worst hip {wh:.2e} at {wk} / cpu32 {wc:.2e}")
     if bars(mh, mc, wh, wc):
         return
+    # where the error originates (first tensor beyond the bar in backward order): a flip sits INSIDE the trunk, so the tensors
+    # between it and the loss - at least the head - are clean
+    on = _grad_errors.onset
+    if on is not None:
+        print(f"{name} @ seed 1234: first tensor in backward order beyond the bar: {on[1]} ({on[2]:.2e}); {on[0]} tensors between it "
+              f"and the loss are clean")
+        assert on[0] > 0, f"{name} @ seed 1234: the gradient of the last layer ({on[3]}) is already off"
     others = []
     for alt in (1, 2):
         ga = torch.Generator().manual_seed(9100 + alt)
