@@ -956,12 +956,17 @@ extern "C" int buctd_conv3x3_bf16x6_group(int n, const buctd_c3_conv* convs, voi
     cost[k] = (double)pl[k].BM * pl[k].BN * c.Ci;
     order[k] = k;
   }
+  // the kernel family that holds the tile shapes of ALL members (128 x 32 tiles exist in both families)
   int fam = -1;
-  bool ok = n > 1;
+  bool ok = false;
   int var[C3G_MAX];
-  for (int k = 0; k < n && ok; ++k) {
-    var[k] = c3_group_variant(pl[k], &fam);
-    ok = var[k] >= 0;
+  for (int f = 0; f < 2 && !ok && n > 1; ++f) {
+    ok = true;
+    for (int k = 0; k < n && ok; ++k) {
+      fam = f;
+      var[k] = c3_group_variant(pl[k], &fam);
+      ok = var[k] >= 0;
+    }
   }
   if (!ok) {
     for (int k = 0; k < n; ++k) {
