@@ -305,3 +305,25 @@ extern "C" int buctd_basic_branches_bwd(int nb, int n, const buctd_basic_block* 
   }
   return BUCTD_OK;
 }
+
+/* `to` waits for everything enqueued on `from` so far (event record + stream wait through one cached event per host thread
+ * and device): the fork in front of a weight gradient launched on the side stream. */
+extern "C" int buctd_stream_fork(void* from, void* to) {
+  if (from == to) return BUCTD_OK;
+  static thread_local hipEvent_t evs[16] = {nullptr};
+  int devid = 0;
+  if (hipGetDevice(&devid) != hipSuccess || devid < 0 || devid >= 16) {
+    buctd_set_error("buctd_stream_fork: cannot identify the current device");
+    return BUCTD_ELAUNCH;
+  }
+  hipEvent_t& ev = evs[devid];
+  if (!ev && hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) {
+    buctd_set_error("buctd_stream_fork: hipEventCreate failed");
+    return BUCTD_ELAUNCH;
+  }
+  if (hipEventRecord(ev, (hipStream_t)from) != hipSuccess || hipStreamWaitEvent((hipStream_t)to, ev, 0) != hipSuccess) {
+    buctd_set_error("buctd_stream_fork: stream fork failed");
+    return BUCTD_ELAUNCH;
+  }
+  return BUCTD_OK;
+}

@@ -702,8 +702,16 @@ def conv_dgrad(dy, w, x_shape, stride=1, pad=0, bias=None, stats=False, residual
 _GCONV_WGRAD = {"on": True}      # 1x1 / stride-2 weight gradients on the bf16x6 kernel (off: the exact-fp32 MFMA kernel; tests)
 
 
-def conv_wgrad(x, dy, w_like, stride=1, pad=0, out=None, accumulate=0, x_bn=None):
-    """x_bn = (mean, invstd, gamma, beta, relu): like conv_fwd's in_bn, for the X operand of the weight gradient."""
+def conv_wgrad(x, dy, w_like, stride=1, pad=0, out=None, accumulate=0, x_bn=None, stream=None):
+    """x_bn = (mean, invstd, gamma, beta, relu): like conv_fwd's in_bn, for the X operand of the weight gradient.
+    stream: a torch.cuda.Stream to launch on WITHOUT making it current (entering a stream context costs ~15 us of host time
+    per call - more than the launch); None = the current stream."""
+    if stream is None:
+        workspace_ = workspace
+        stream_ptr_ = stream_ptr
+    else:
+        workspace_ = lambda nbytes, device: workspace_on(stream, nbytes, device)
+        stream_ptr_ = lambda: stream.cuda_stream
     _f32(x, "conv wgrad x")
     _f32(dy, "conv wgrad dy")
     d = conv_desc(x.shape, _wshape(w_like), stride, pad)
@@ -719,18 +727,18 @@ def conv_wgrad(x, dy, w_like, stride=1, pad=0, out=None, accumulate=0, x_bn=None
                               if getattr(lib(), "buctd_conv3x3_wgrad_" + mode + "_supported")(d.N, d.H, d.W, d.Ci, d.Co) == 1
                               else -1))
         if need >= 0:
-            ws = workspace(need, x.device)
+            ws = workspace_(need, x.device)
             if x_bn is not None:
                 if mode != "bf16x6":
                     raise _C.BuctdHipError("conv_wgrad: x_bn needs the bf16x6 kernel")
                 mean, invstd, gamma, beta, x_relu = x_bn
                 check(lib().buctd_conv3x3_wgrad_bf16x6_bnin(d.N, d.H, d.W, d.Ci, d.Co, ptr(x), ptr(dy), ptr(out),
                                                             int(accumulate), ptr(mean), ptr(invstd), ptr(gamma), ptr(beta),
-                                                            int(bool(x_relu)), ptr(ws), ws.numel(), stream_ptr()),
+                                                            int(bool(x_relu)), ptr(ws), ws.numel(), stream_ptr_()),
                       "conv3x3_wgrad_bf16x6_bnin")
                 return out
             check(fn(d.N, d.H, d.W, d.Ci, d.Co, ptr(x), ptr(dy), ptr(out), int(accumulate), ptr(ws), ws.numel(),
-                     stream_ptr()), "conv3x3_wgrad (split bf16)")
+                     stream_ptr_()), "conv3x3_wgrad (split bf16)")
             return out
     if x_bn is not None:
         raise _C.BuctdHipError("conv_wgrad: x_bn needs the bf16x6 3x3 kernel (check bn_in_fusable first)")
@@ -740,14 +748,14 @@ def conv_wgrad(x, dy, w_like, stride=1, pad=0, out=None, accumulate=0, x_bn=None
                      lambda: (int(lib().buctd_gconv_wgrad_x6_workspace(kind, d.N, d.H, d.W, d.Ci, d.Co))
                               if lib().buctd_gconv_wgrad_x6_supported(kind, d.N, d.H, d.W, d.Ci, d.Co) == 1 else -1))
         if need >= 0:
-            ws = workspace(need, x.device)
+            ws = workspace_(need, x.device)
             check(lib().buctd_gconv_wgrad_x6(kind, d.N, d.H, d.W, d.Ci, d.Co, ptr(x), ptr(dy), ptr(out), int(accumulate), ptr(ws),
-                                             ws.numel(), stream_ptr()), "gconv_wgrad_x6")
+                                             ws.numel(), stream_ptr_()), "gconv_wgrad_x6")
             return out
     need = lib().buctd_conv2d_wgrad_workspace(C.byref(d))
-    ws = workspace(need, x.device)
+    ws = workspace_(need, x.device)
     check(lib().buctd_conv2d_wgrad(C.byref(d), ptr(x), ptr(dy), ptr(out), int(accumulate), ptr(ws), ws.numel(),
-                                   stream_ptr()), "conv2d_wgrad")
+                                   stream_ptr_()), "conv2d_wgrad")
     return out
 
 
@@ -903,11 +911,11 @@ def conv_wgrad_async(x, dy, w_like, stride, pad, out, accumulate, x_bn=None):
         if x.is_cuda and _branch["on"]:
             _queue_join()     # parameter gradients may be written on branch streams: still join them at the end
         return conv_wgrad(x, dy, w_like, stride, pad, out=out, accumulate=accumulate, x_bn=x_bn)
-    main = torch.cuda.current_stream(x.device)
     side = _side_stream(x.device)
-    side.wait_stream(main)
-    with torch.cuda.stream(side):
-        conv_wgrad(x, dy, w_like, stride, pad, out=out, accumulate=accumulate, x_bn=x_bn)
+    # fork: the side stream waits for what the current stream has enqueued so far (one cached event in the library: creating
+    # an Event object and entering a stream context per call cost ~25 us of host time - the step of HRNet-W32 is host-bound)
+    check(lib().buctd_stream_fork(stream_ptr(), side.cuda_stream), "stream_fork")
+    conv_wgrad(x, dy, w_like, stride, pad, out=out, accumulate=accumulate, x_bn=x_bn, stream=side)
     x.record_stream(side)
     dy.record_stream(side)
     if x_bn is not None:

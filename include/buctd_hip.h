@@ -485,6 +485,10 @@ int buctd_basic_branches_fwd_train(int nb, int n, const buctd_basic_block* block
 int buctd_basic_branches_bwd(int nb, int n, const buctd_basic_block* blocks, const buctd_basic_block_grads* grads, void* stream,
                              void* side_stream);
 
+/* Stream `to` waits for everything enqueued on stream `from` so far (one cached event per host thread and device): the fork in
+ * front of work launched on a second stream, e.g. a weight gradient beside the data-gradient chain. */
+int buctd_stream_fork(void* from, void* to);
+
 /* ------------------------------------------------------------ bf16x6 GEMM --- */
 /* C = alpha * A * B (+ bias) in the bf16x6 arithmetic of the 3x3 convolutions (fp32 operands split exactly into three
  * bf16 pieces, six bf16 MFMAs per product, fp32 accumulate) for the large plain GEMMs of the path - fc_o =
