@@ -145,11 +145,12 @@ class KernelTimer:
         return (d.R == 3 and d.stride == 1 and d.pad == 1 and d.Ci == c and d.Co == c and d.H == h and d.W == w
                 and d.N == self.batch)
 
-    def timed(self, kind, fn):
+    def timed(self, kind, fn, stream=None):
+        """events on the stream the kernel is launched on: the current one, or the explicit stream of a weight gradient"""
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
+        e0.record(stream) if stream is not None else e0.record()
         out = fn()
-        e1.record()
+        e1.record(stream) if stream is not None else e1.record()
         self.pairs[kind].append((e0, e1))
         return out
 
@@ -188,7 +189,7 @@ def install_timer(timer):
         if timer.enabled:
             d = ops.conv_desc(x.shape, ops._wshape(w_like), stride, pad)
             if timer.match(d):
-                return timer.timed("wgrad", lambda: raw_wgrad(x, dy, w_like, stride, pad, **kw))
+                return timer.timed("wgrad", lambda: raw_wgrad(x, dy, w_like, stride, pad, **kw), kw.get("stream"))
         return raw_wgrad(x, dy, w_like, stride, pad, **kw)
 
     ops.conv_fwd, ops.conv_dgrad, ops.conv_wgrad = conv_fwd, conv_dgrad, conv_wgrad
