@@ -823,9 +823,10 @@ def set_branch_max(n):
 
 
 def compute_streams(device):
-    """The HIP streams this module owns on `device` (branch + weight-gradient streams created so far)."""
+    """The HIP streams this module launches on besides the current one on `device` (branch + weight-gradient streams)."""
     idx = device.index if device.index is not None else torch.cuda.current_device()
-    return ([st for (d, _), st in _branch["streams"].items() if d == idx] +
+    # branch streams above the current cap were created before it was lowered and are no longer handed out
+    return ([st for (d, i), st in _branch["streams"].items() if d == idx and i <= _BRANCH_MAX] +
             [st for (d, _), st in _side["streams"].items() if d == idx])
 
 
