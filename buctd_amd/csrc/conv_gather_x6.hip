@@ -420,6 +420,202 @@ static int gc_launch(const GcArgs& a, int tiles, int ncol, hipStream_t st) {
   return BUCTD_OK;
 }
 
+// ---- 1x1 convolutions on large maps: a row-streaming kernel ------------------------------------------------------------------
+// The 1x1 convolutions of layer1 (64 <-> 256 channels at 1/4 resolution: pose_hrnet.py:60-98) move 283 MB for 7 GFLOP - they are
+// HBM-side (35 us), and the tiled kernel above spends its time in per-tile prologues and epilogues (K = 64: two steps per tile;
+// 100-115 us).  Here a wavefront streams 32-row blocks of the [rows][Ci] input:
+//   * its A fragments come STRAIGHT from global memory in MFMA layout (lane (i16, g) of a K = 32 step needs channels 8 g .. 8 g + 7
+//     of row i16: 32 contiguous bytes), are split into the three bf16 pieces in registers - no LDS round trip for the input, every
+//     element is read and split exactly once per launch whatever the number of output columns;
+//   * the whole prepared filter image ([step][Co][32 h | 32 m | 32 l], <= 104 KB, rows padded to 208 B: conflict-free
+//     ds_read_b128) sits in LDS for the lifetime of the persistent workgroup (8 waves, one workgroup per CU);
+//   * all Co / 16 column fragments of a block are accumulated in registers (two 16-row fragments x Co / 16 <= 128 registers);
+//     the next K-step's A loads travel under the current one's MFMAs;
+//   * epilogue per block: bias, BatchNorm statistics as per-lane column sums (folded over the workgroup at the end into the
+//     integer accumulator of bn_acc.h); the tile leaves through a per-wave LDS staging slice, 16 rows x 64 columns at a time,
+//     so that the stores and the residual reads are 16-byte pieces of contiguous runs (scalar accesses in accumulator
+//     layout: 143 / 495 us for the data gradients with a residual instead of 60 / 120).
+struct R1Args {
+  const float* x;            // [rows][Ci]
+  const unsigned char* wp;   // gathered-kernel image of the direction: [Ci / 32 steps][Co][192 B]
+  const float* bias;
+  const float* res;          // [rows][Co] or null
+  float* out;                // [rows][Co]
+  long long* stats_acc;      // or null
+  long rows;
+  int Ci, Co, nblocks;       // nblocks = ceil(rows / 32)
+};
+
+#define R1_WROW 208          // LDS stride of an image row (192 B + 16: lanes i16 = 0..15 land in 16 distinct 16-byte bank groups)
+#define R1_LD 68             // staging row stride in floats (64 columns + 4)
+#define R1_STG (16 * R1_LD * 4)      // staging bytes per wave
+
+template <int NFT>           // column fragments: Co / 16
+__global__ __launch_bounds__(512, 1) void conv1x1_rows_x6_kernel(R1Args p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int t = threadIdx.x, lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int i16 = lane & 15, g = lane >> 4;
+  const int KS = p.Ci / 32, Co = p.Co;
+  // the filter image -> LDS (16-byte pieces; 12 per row)
+  {
+    const int pieces = KS * Co * 12;
+    for (int i = t; i < pieces; i += 512) {
+      const int row = i / 12, pc = i - row * 12;
+      *reinterpret_cast<f32x4*>(smem + (size_t)row * R1_WROW + pc * 16) =
+          *reinterpret_cast<const f32x4*>(p.wp + (size_t)row * 192 + pc * 16);
+    }
+  }
+  __syncthreads();
+  const unsigned char* bl = smem + (size_t)i16 * R1_WROW + g * 16;      // this lane's slot inside a 16-row group of the image
+  float* stg = reinterpret_cast<float*>(smem + (size_t)KS * Co * R1_WROW + (size_t)wave * R1_STG);
+
+  float s1[NFT], s2[NFT];
+#pragma unroll
+  for (int nf = 0; nf < NFT; ++nf) s1[nf] = s2[nf] = 0.f;
+
+  const int nwaves = gridDim.x * 8;
+  int blk = blockIdx.x * 8 + wave;
+  // A of (block, k-step): rows r0 + mf * 16 + i16, channels 32 s + 8 g .. + 7
+  f32x4 an[2][2];
+  auto load_a = [&](int b, int sIdx) {
+#pragma unroll
+    for (int mf = 0; mf < 2; ++mf) {
+      long row = (long)b * 32 + mf * 16 + i16;
+      if (row >= p.rows) row = 0;                    // clamped: the values are not stored
+      const float* src = p.x + row * p.Ci + sIdx * 32 + g * 8;
+      an[mf][0] = *reinterpret_cast<const f32x4*>(src);
+      an[mf][1] = *reinterpret_cast<const f32x4*>(src + 4);
+    }
+  };
+  if (blk < p.nblocks) load_a(blk, 0);
+  for (; blk < p.nblocks; blk += nwaves) {
+    f32x4 acc[2][NFT];
+#pragma unroll
+    for (int mf = 0; mf < 2; ++mf)
+#pragma unroll
+      for (int nf = 0; nf < NFT; ++nf) acc[mf][nf] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int sIdx = 0; sIdx < KS; ++sIdx) {
+      // this step's A: fp32 -> three bf16 pieces (exact residuals), then the next step's loads go out
+      bf16x8 a[3][2];
+#pragma unroll
+      for (int mf = 0; mf < 2; ++mf) {
+        c3_f32x2 v[4] = {{an[mf][0].x, an[mf][0].y}, {an[mf][0].z, an[mf][0].w}, {an[mf][1].x, an[mf][1].y}, {an[mf][1].z, an[mf][1].w}};
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+          unsigned w[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            w[j] = __builtin_bit_cast(unsigned, __builtin_convertvector(v[j], c3_bf16x2));
+            if (q < 2) v[j] -= (c3_f32x2){__uint_as_float(w[j] << 16), __uint_as_float(w[j] & 0xffff0000u)};
+          }
+          typedef unsigned r1_u32x4 __attribute__((ext_vector_type(4)));
+          a[q][mf] = __builtin_bit_cast(bf16x8, (r1_u32x4){w[0], w[1], w[2], w[3]});
+        }
+      }
+      if (sIdx + 1 < KS) load_a(blk, sIdx + 1);
+      else if (blk + nwaves < p.nblocks) load_a(blk + nwaves, 0);
+      const unsigned char* bs = bl + (size_t)sIdx * Co * R1_WROW;
+#pragma unroll
+      for (int nf = 0; nf < NFT; ++nf) {
+        bf16x8 b[3];
+#pragma unroll
+        for (int q = 0; q < 3; ++q) b[q] = *reinterpret_cast<const bf16x8*>(bs + (size_t)nf * 16 * R1_WROW + q * 64);
+#define R1_MMA(qa, qb)                                                                                      \
+  _Pragma("unroll") for (int mf = 0; mf < 2; ++mf) acc[mf][nf] =                                            \
+      __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[qa][mf], b[qb], acc[mf][nf], 0, 0, 0);
+        R1_MMA(2, 0) R1_MMA(0, 2) R1_MMA(1, 1) R1_MMA(1, 0) R1_MMA(0, 1) R1_MMA(0, 0)
+#undef R1_MMA
+      }
+    }
+    // epilogue: accumulator (mf, nf, rg) = row blk * 32 + mf * 16 + g * 4 + rg, column nf * 16 + i16.  Statistics from the
+    // registers; the tile leaves through this wave's LDS staging slice, 16 rows x 64 columns at a time, so that every lane
+    // stores (and reads the residual as) 16-byte pieces of contiguous runs
+#pragma unroll
+    for (int mf = 0; mf < 2; ++mf) {
+#pragma unroll
+      for (int cg = 0; cg < NFT / 4; ++cg) {
+#pragma unroll
+        for (int nl = 0; nl < 4; ++nl) {
+          const int nf = cg * 4 + nl;
+          const float bv = p.bias ? p.bias[nf * 16 + i16] : 0.f;
+#pragma unroll
+          for (int rg = 0; rg < 4; ++rg) {
+            const float v = acc[mf][nf][rg] + bv;
+            stg[(g * 4 + rg) * R1_LD + nl * 16 + i16] = v;
+            if ((long)blk * 32 + mf * 16 + g * 4 + rg < p.rows) {
+              s1[nf] += v;
+              s2[nf] += v * v;
+            }
+          }
+        }
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int item = lane + 64 * k, row = item >> 4, c4 = item & 15;
+          const long grow = (long)blk * 32 + mf * 16 + row;
+          f32x4 v = *reinterpret_cast<const f32x4*>(stg + row * R1_LD + c4 * 4);
+          if (grow < p.rows) {
+            const long o = grow * Co + cg * 64 + c4 * 4;
+            if (p.res) v += *reinterpret_cast<const f32x4*>(p.res + o);
+            *reinterpret_cast<f32x4*>(p.out + o) = v;
+          }
+        }
+        __builtin_amdgcn_wave_barrier();
+      }
+    }
+  }
+  if (p.stats_acc) {
+    // lanes -> columns (the four row groups of a fragment), waves -> workgroup (fixed order), one exact integer addition per
+    // channel and sum (bn_acc.h); the exchange reuses the image area (nobody reads it any more)
+    __syncthreads();
+    double2* exch = reinterpret_cast<double2*>(smem);       // [8 waves][Co]
+#pragma unroll
+    for (int nf = 0; nf < NFT; ++nf) {
+      float a1 = s1[nf], a2 = s2[nf];
+      a1 += __shfl_xor(a1, 16, 64); a1 += __shfl_xor(a1, 32, 64);
+      a2 += __shfl_xor(a2, 16, 64); a2 += __shfl_xor(a2, 32, 64);
+      if (g == 0) exch[wave * Co + nf * 16 + i16] = make_double2((double)a1, (double)a2);
+    }
+    __syncthreads();
+    for (int c = t; c < Co; c += 512) {
+      double a1 = 0.0, a2 = 0.0;
+#pragma unroll
+      for (int w = 0; w < 8; ++w) {
+        const double2 v = exch[w * Co + c];
+        a1 += v.x;
+        a2 += v.y;
+      }
+      bnacc_add(p.stats_acc, Co, bnacc_shard(), c, a1, a2);
+    }
+  }
+}
+
+// shapes the row-streaming kernel takes: 1x1, whole 32-channel steps, 4 / 8 / 16 column fragments, the image (+ the statistics
+// exchange) within one CU's LDS, and enough rows to give every wave of the persistent grid a few blocks
+static bool r1_ok(int kind, long rows, int cin, int cout) {
+  if (kind != 1 || cin % 32 || (cout != 64 && cout != 128 && cout != 256)) return false;
+  const size_t lds = (size_t)(cin / 32) * cout * R1_WROW + (size_t)8 * R1_STG;
+  return lds <= 150 * 1024 && (size_t)8 * cout * 16 <= (size_t)(cin / 32) * cout * R1_WROW && rows >= 65536;
+}
+
+static int r1_run(long rows, int cin, int cout, const float* x, const void* wprep, const float* bias, const float* residual, float* out,
+                  long long* stats_acc, hipStream_t st, const char* who) {
+  R1Args a;
+  a.x = x; a.wp = (const unsigned char*)wprep; a.bias = bias; a.res = residual; a.out = out; a.stats_acc = stats_acc;
+  a.rows = rows; a.Ci = cin; a.Co = cout; a.nblocks = (int)((rows + 31) / 32);
+  const size_t lds = (size_t)(cin / 32) * cout * R1_WROW + (size_t)8 * R1_STG;
+  static unsigned char done[3][BUCTD_MAX_DEVICES] = {{0}};
+  void (*fn)(R1Args) = cout == 64 ? conv1x1_rows_x6_kernel<4> : cout == 128 ? conv1x1_rows_x6_kernel<8> : conv1x1_rows_x6_kernel<16>;
+  if (const int rc = buctd_raise_lds_limit(reinterpret_cast<const void*>(fn), 160 * 1024, done[cout == 64 ? 0 : cout == 128 ? 1 : 2], who))
+    return rc;
+  int grid = 256;
+  if (grid * 8 > a.nblocks) grid = (a.nblocks + 7) / 8;
+  hipLaunchKernelGGL(fn, dim3(grid), dim3(512), lds, st, a);
+  BUCTD_CHECK_LAUNCH(who);
+  return BUCTD_OK;
+}
+
 static int gc_run(int kind, int dir, int N, int H, int W, int Ci, int Co, const float* src, const void* wprep, const float* bias,
                   const float* scale, const float* shift, const float* residual, int relu, float* out, float* stats_partials,
                   int* stats_counts, void* stream, const char* who, long long* stats_acc = nullptr) {
@@ -430,6 +626,8 @@ static int gc_run(int kind, int dir, int N, int H, int W, int Ci, int Co, const 
   BUCTD_CHECK_ARG((scale == nullptr) == (shift == nullptr), "%s: scale and shift go together", who);
   BUCTD_CHECK_ARG((stats_partials == nullptr) == (stats_counts == nullptr), "%s: stats partials and counts go together", who);
   BUCTD_CHECK_ARG(!(dir && stats_partials), "%s: no statistics on the data gradient", who);
+  if (!scale && !relu && !stats_partials && r1_ok(kind, (long)N * H * W, SC, nout))
+    return r1_run((long)N * H * W, SC, nout, src, wprep, bias, residual, out, stats_acc, (hipStream_t)stream, who);
   GcPlan pl;
   gc_plan(nout, (long)N * (Hg + 1) * (Wg + 2) + Wg + 2, &pl);
   GcArgs a;

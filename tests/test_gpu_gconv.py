@@ -24,7 +24,10 @@ def nchw(t):
 SHAPES = [(2, 24, 18, 48, 96, 3, 2, 1), (2, 12, 10, 96, 192, 3, 2, 1), (3, 8, 6, 192, 384, 3, 2, 1), (2, 16, 12, 48, 48, 3, 2, 1),
           (2, 20, 14, 64, 64, 3, 2, 1), (1, 6, 4, 256, 96, 3, 2, 1), (2, 2, 2, 48, 192, 3, 2, 1), (4, 96, 72, 48, 96, 3, 2, 1),
           (2, 24, 18, 64, 256, 1, 1, 0), (2, 24, 18, 256, 64, 1, 1, 0), (3, 12, 9, 96, 48, 1, 1, 0), (2, 7, 5, 192, 96, 1, 1, 0),
-          (2, 6, 5, 384, 192, 1, 1, 0), (1, 1, 1, 48, 48, 1, 1, 0), (2, 48, 36, 96, 48, 1, 1, 0)]
+          (2, 6, 5, 384, 192, 1, 1, 0), (1, 1, 1, 48, 48, 1, 1, 0), (2, 48, 36, 96, 48, 1, 1, 0),
+          # >= 65536 rows with 64 / 128 / 256 output channels: the row-streaming 1x1 kernel (conv1x1_rows_x6_kernel), incl. a
+          # ragged last 32-row block
+          (16, 64, 64, 64, 256, 1, 1, 0), (17, 64, 62, 256, 64, 1, 1, 0), (8, 96, 96, 128, 128, 1, 1, 0), (16, 65, 65, 64, 64, 1, 1, 0)]
 
 
 @pytest.mark.parametrize("shape", SHAPES)
@@ -193,3 +196,31 @@ def test_gconv_weight_gradient_dispatch(dev):
     assert lib.buctd_gconv_wgrad_x6_supported(2, 2, 9, 8, 48, 48) == 0
     assert lib.buctd_gconv_wgrad_x6_supported(2, 2, 8, 8, 64, 256) == 1
     assert lib.buctd_gconv_wgrad_x6_supported(3, 2, 8, 8, 48, 48) == 0
+
+
+@pytest.mark.parametrize("shape", [(16, 64, 65, 64, 256), (9, 96, 80, 256, 64)])
+def test_rows_kernel_statistics_accumulator(dev, shape):
+    """conv1x1_rows_x6_kernel (1x1 convolutions on >= 65536 rows): the BatchNorm statistics it adds to the accumulator, through
+    the consumer that decodes them (bn_apply_acc), against an fp64 BatchNorm of the fp64 convolution; ragged last row block."""
+    import torch.nn as tnn
+    from buctd_amd import ops
+    N, H, W, Ci, Co = shape
+    g = torch.Generator().manual_seed(sum(shape))
+    x = torch.randn(N, H, W, Ci, generator=g).to(dev) + 0.3
+    w = (torch.randn(Co, Ci, 1, 1, generator=g) / math.sqrt(Ci)).contiguous(memory_format=torch.channels_last).to(dev)
+    bn = tnn.BatchNorm2d(Co).to(dev).train()
+    with torch.no_grad():
+        bn.weight.uniform_(0.5, 1.5); bn.bias.normal_(0, 0.3)
+    z, acc, info = ops.conv_fwd(x, w, None, 1, 0, stats="acc")
+    assert info[0] == "acc"
+    rows = N * H * W
+    bnin = ops.BnAccInput(acc, rows, bn, True, relu=False)
+    y = ops.bn_apply_acc(z, bnin, None, False)
+    torch.cuda.synchronize()
+    zr = F.conv2d(x.double().permute(0, 3, 1, 2).cpu(), w.double().cpu())
+    yr = F.batch_norm(zr, None, None, bn.weight.double().cpu(), bn.bias.double().cpu(), True, 0.1, bn.eps).permute(0, 2, 3, 1)
+    assert (z.cpu().double() - zr.permute(0, 2, 3, 1)).abs().max().item() <= TOL * zr.abs().max().item()
+    assert (y.cpu().double() - yr).abs().max().item() <= 2e-5 * max(1.0, yr.abs().max().item())
+    zz = zr.permute(0, 2, 3, 1).reshape(rows, Co)
+    assert (bnin.mean.cpu().double() - zz.mean(0)).abs().max().item() <= 1e-6
+    assert (bn.running_var.cpu().double() - (0.9 + 0.1 * zz.var(0, unbiased=True))).abs().max().item() <= 1e-5
