@@ -2,11 +2,6 @@
 cd $GRAFT_REPO_ROOT
 O=$GRAFT_REPO_ROOT/gpurun_out/r05; mkdir -p $O
 D=$(date +%F)
-for w in train_c4 train_c3 train_c2 infer_c5; do
-  extra=""; [ $w = train_c4 ] || extra="--no-cpu-baseline"
-  timeout 600 python bench.py --workload $w --steps 20 --warmup 5 $extra 2>/dev/null | tail -1 > $O/bench_line_$w.json
-done
-timeout 300 python bench.py --condition mono --steps 20 --warmup 5 --no-cpu-baseline 2>/dev/null | tail -1 > $O/bench_line_train_c4_mono.json
 BATCH=32 timeout 200 python scratch/cpu_split.py 2>/dev/null | grep batch > $O/host_split.txt
 BATCH=2 timeout 200 python scratch/cpu_split.py 2>/dev/null | grep batch >> $O/host_split.txt
 cd /tmp && export TMPDIR=/tmp
@@ -24,6 +19,13 @@ for t in c4:train_c4 c3:train_c3 c2:train_c2; do
   fi
 done
 cd $GRAFT_REPO_ROOT
+# the bench lines quote the census of THIS tree: the in-step JSONs first, then the lines
+for tag in c4 c3 c2; do [ -f $O/in_step_kernel_us_$tag.json ] && cp $O/in_step_kernel_us_$tag.json profiles/r05_in_step_kernel_us_$tag.json; done
+for w in train_c4 train_c3 train_c2 infer_c5; do
+  extra=""; [ $w = train_c4 ] || extra="--no-cpu-baseline"
+  timeout 600 python bench.py --workload $w --steps 20 --warmup 5 $extra 2>/dev/null | tail -1 > $O/bench_line_$w.json
+done
+timeout 300 python bench.py --condition mono --steps 20 --warmup 5 --no-cpu-baseline 2>/dev/null | tail -1 > $O/bench_line_train_c4_mono.json
 bash scratch/pmc_run.sh r5fwd bf16x6 fwd > /dev/null 2>&1; python scratch/pmc_summary.py gpurun_out/pmc_r5fwd conv3x3 > $O/pmc_fwd.txt 2>&1
 bash scratch/pmc_run.sh r5wg bf16x6 wgrad > /dev/null 2>&1; python scratch/pmc_summary.py gpurun_out/pmc_r5wg "" > $O/pmc_wgrad.txt 2>&1
 bash scratch/pmc_run.sh r5dg bf16x6 dgrad > /dev/null 2>&1; python scratch/pmc_summary.py gpurun_out/pmc_r5dg conv3x3 > $O/pmc_dgrad.txt 2>&1
