@@ -365,6 +365,19 @@ def transpose_a6_cfg(batch):
     return c
 
 
+def emit(out, rank, world, in_group=False):
+    """rank 0's ONE JSON line as the LAST line of the job's stdout.  RCCL writes a banner ("Librccl path : ...") through C stdio;
+    on a pipe it stays in every rank's buffer until the process exits - behind the JSON line.  So: every rank flushes its C and
+    Python buffers, the ranks meet, then rank 0 prints."""
+    import ctypes
+    ctypes.CDLL(None).fflush(None)
+    sys.stdout.flush()
+    if world > 1 or in_group:
+        dist.barrier()
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+
+
 def bench_infer_c5(args, rank, world, device):
     """BASELINE config C5: BUCTD-TransPose-H-A6 256x192, 3x iterative-refinement inference, persons/s:
     one step = three chained passes, each forward -> device arg-max decode -> colored condition re-rendered from the
@@ -430,6 +443,7 @@ def bench_infer_c5(args, rank, world, device):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     if rank != 0:
+        emit(None, rank, world)
         return
     persons = args.batch * world * args.steps
     out = {"metric": "persons/sec (3x iterative-refinement inference) BUCTD-TransPose-H-A6 256x192",
@@ -468,7 +482,7 @@ def bench_infer_c5(args, rank, world, device):
                            "note": ("bf16x6: dense bf16 MFMA peak 2500 TFLOP/s / 6 MFMAs per fp32 product = 416.7 TFLOP/s-"
                                     "equivalent" if x6 else "exact fp32 MFMA (v_mfma_f32_16x16x4_f32, 157.3 TFLOP/s peak)") +
                                    " binds: 4 T^2 d FLOP against 4 T d floats of HBM traffic per image"}
-    print(json.dumps(out), flush=True)
+    emit(out, rank, world)
 
 
 def self_launch(n):
@@ -520,6 +534,10 @@ def main():
     ap.add_argument("--condition", default="colored", choices=["colored", "mono"],
                     help="train_c4 only: colored = the CrowdPose recipe (6-channel input, the headline); mono = one white "
                          "condition channel (4-channel input, north_star's literal variant)")
+    ap.add_argument("--one-rank-exchange", action="store_true",
+                    help="--gpus 1 only: initialise an RCCL process group of ONE rank and run the whole gradient exchange "
+                         "(buckets, communication stream, collectives, 1 branch stream) - the per-GPU cost of the data-parallel "
+                         "machinery without a second GPU; not the headline configuration")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timer", action="store_true")
     args = ap.parse_args()
@@ -558,7 +576,15 @@ def main():
     torch.manual_seed(1234)
     ops.manual_seed(1234 + rank)
     net = getattr(models, module).get_pose_net(cfg, is_train=True).to(device)
-    model = engine.DataParallel(net)
+    if args.one_rank_exchange:
+        if world != 1:
+            raise SystemExit("--one-rank-exchange is a --gpus 1 measurement")
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29547")
+        engine.reserve_streams(device, data_parallel=True)     # what engine.init_distributed does under --gpus N
+        dist.init_process_group(backend="nccl", rank=0, world_size=1)
+        describe += " [one-rank RCCL exchange on]"
+    model = engine.DataParallel(net, exchange_in_world_of_one=args.one_rank_exchange)
     optimizer = engine.get_optimizer(cfg, model)
     if world == 1:
         model.flatten()
@@ -609,7 +635,7 @@ def main():
         in_step = {k: timer.mean_us(k) for k in ("fwd", "dgrad", "wgrad")}
     # exposed gradient-exchange time per step (N > 1): a pass with the device drained in front of and behind the exchange
     comm_ms = None
-    if world > 1:
+    if world > 1 or args.one_rank_exchange:
         ts = []
         raw_sync = model.sync_gradients
 
@@ -668,6 +694,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
+    out = None
     if rank == 0:
         global_batch = args.batch * world
         value = global_batch * args.steps / dt
@@ -686,7 +713,7 @@ def main():
                        "input": f"N x {n_in} x {cfg.MODEL.IMAGE_SIZE[1]} x {cfg.MODEL.IMAGE_SIZE[0]} fp32",
                        "params": sum(p.numel() for p in net.parameters()), "parallelism": f"dp{world}",
                        # HIP streams of this rank: main + branch / weight-gradient streams (+ communication under --gpus N)
-                       "hip_streams": 1 + len(ops.compute_streams(device)) + (1 if world > 1 else 0),
+                       "hip_streams": 1 + len(ops.compute_streams(device)) + (1 if world > 1 or args.one_rank_exchange else 0),
                        "conv_math": args.conv_math, "loss": round(losses.avg, 6)},
         }
         if comm_ms is not None:
@@ -769,8 +796,8 @@ def main():
             out["roofline_fwd_dgrad"] = main
         if world == 1 and not args.no_cpu_baseline and args.workload == "train_c4":
             out["cpu_baseline"] = cpu_baseline()
-        print(json.dumps(out), flush=True)
-    if world > 1:
+    emit(out, rank, world, in_group=args.one_rank_exchange)
+    if world > 1 or args.one_rank_exchange:
         dist.barrier()
         dist.destroy_process_group()
 

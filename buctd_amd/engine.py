@@ -311,12 +311,16 @@ class DataParallel(torch.nn.Module):
 
     Without an initialised process group (single GPU) it is a transparent wrapper."""
 
-    def __init__(self, module, device_ids=None, bucket_bytes=48 << 20, overlap=True):
+    def __init__(self, module, device_ids=None, bucket_bytes=48 << 20, overlap=True, exchange_in_world_of_one=False):
         super().__init__()
         self.module = module
         self.flat = None
         self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
         self.rank = dist.get_rank() if self.world > 1 else 0
+        # exchange_in_world_of_one: run the whole gradient exchange (buckets, communication stream, collectives) in an
+        # initialised process group of ONE rank too - the sum over one rank is the identity, so the step must equal the
+        # plain engine's bit for bit; the hardware test of the RCCL transport on a single-GPU box
+        self._exchange = self.world > 1 or (exchange_in_world_of_one and dist.is_available() and dist.is_initialized())
         self.bucket_bytes = bucket_bytes
         self.overlap = overlap
         self._handles = []
@@ -324,6 +328,7 @@ class DataParallel(torch.nn.Module):
         self._dirty = False
         self._entry_stream = None
         self._comm_stream = None
+        self._collective_in_stream = False
         # bench.py: set to a list to get one (bucket index, bytes, start event, end event) per bucket exchange on the
         # communication stream (timing events; None = off, the production setting)
         self.bucket_trace = None
@@ -336,7 +341,7 @@ class DataParallel(torch.nn.Module):
     def flatten(self):
         if self.flat is None:
             self.flat = FlatParams(self.module)
-            if self.world > 1:
+            if self._exchange:
                 dist.broadcast(self.flat.flat, src=0)
                 self.broadcast_buffers()
                 self.buckets = GradBuckets(self.flat, self.bucket_bytes)
@@ -344,7 +349,9 @@ class DataParallel(torch.nn.Module):
                     # the exchange runs at the HIGHEST stream priority: an RCCL kernel occupies a few CUs per channel and
                     # must not queue behind the four compute streams' workgroups (it would start when they drain, i.e.
                     # exposed); what it takes away from them is its channel count (RCCL's default: <= 32 CUs of 256)
-                    self._comm_stream = torch.cuda.Stream(priority=-1)
+                    dev = self.flat.flat.device
+                    self._comm_stream = _comm_streams.get(dev.index) or torch.cuda.Stream(device=dev, priority=-1)
+                    self._collective_in_stream = dist.get_backend() == "nccl"
                     # HIP stream budget: the default runtime serves FOUR hardware queues and any fifth stream costs 25-32 %
                     # (DESIGN.md 3.12, 6).  With the communication stream the compute side gets main + ONE branch stream
                     # (the two group-launch families of a HighResolutionModule, the fuse rows) + the weight-gradient stream.
@@ -354,12 +361,12 @@ class DataParallel(torch.nn.Module):
 
     def broadcast_buffers(self):
         """rank 0's BatchNorm running statistics win, like replica 0 under nn.DataParallel."""
-        if self.world > 1:
+        if self._exchange:
             for b in self.module.buffers():
                 dist.broadcast(b, src=0)
 
     def forward(self, *args, **kwargs):
-        if self.world > 1 and self.flat is not None:
+        if self._exchange and self.flat is not None:
             self._start_step()
         return self.module(*args, **kwargs)
 
@@ -402,9 +409,17 @@ class DataParallel(torch.nn.Module):
                 if self.bucket_trace is not None:
                     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                     e0.record(self._comm_stream)
-                self._handles.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, async_op=True))
+                if self._collective_in_stream:
+                    # RCCL: a collective issued with async_op=False is enqueued on the CURRENT stream - the communication
+                    # stream - and returns at once.  async_op=True would run it on the process group's own internal stream
+                    # behind an event: a FIFTH HIP stream, i.e. the 25 % cliff of DESIGN.md 6 (measured with a one-rank
+                    # group: 470 -> 351 images/s).  sync_gradients joins the communication stream, no handles needed.
+                    dist.all_reduce(view, op=dist.ReduceOp.SUM, async_op=False)
+                else:
+                    self._handles.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, async_op=True))
                 if self.bucket_trace is not None:
-                    self._handles[-1].wait()          # stream-side wait only: orders e1 behind the collective
+                    if not self._collective_in_stream:
+                        self._handles[-1].wait()      # stream-side wait only: orders e1 behind the collective
                     e1.record(self._comm_stream)
                     self.bucket_trace.append((i, 4 * (e - s), e0, e1))
         else:
@@ -437,7 +452,7 @@ class DataParallel(torch.nn.Module):
     def sync_gradients(self):
         """Finish the all-reduce of every bucket; returns the scale that turns the summed gradient into the
         gradient of the global-batch mean loss (what nn.DataParallel computes)."""
-        if self.world == 1:
+        if not self._exchange:
             return 1.0
         if not self._pending:
             self._start_step()
@@ -484,6 +499,37 @@ def get_optimizer(cfg, model):
     return None       # the reference returns None for any other name (utils.py:259, 274)
 
 
+_comm_streams = {}      # device index -> the communication stream reserved by reserve_streams
+
+
+def reserve_streams(device, data_parallel):
+    """Create AND use the HIP streams of the engine on `device` before anything else creates streams there - in particular
+    before the RCCL communicator, which opens internal streams of its own.  The runtime binds a stream to one of its four
+    hardware queues when the stream is first used; the first four get a queue each, later ones share - and two busy streams
+    on one queue serialise (a wait of one blocks the kernels of the other).  Measured on one MI355X with a one-rank RCCL
+    group: process group first, engine streams later = 352-357 images/s; engine streams first = 479 (the plain engine: 470-479).
+    data_parallel: reserve main + ONE branch stream + weight-gradient stream + communication stream (and cap the branch
+    streams at one); otherwise main + the branch streams + the weight-gradient stream."""
+    if device.type != "cuda":
+        return
+    streams = []
+    if data_parallel:
+        ops.set_branch_max(1)
+        if device.index not in _comm_streams:
+            _comm_streams[device.index] = torch.cuda.Stream(device=device, priority=-1)
+    streams += ops.reserve_compute_streams(device)
+    if data_parallel:
+        streams.append(_comm_streams[device.index])
+    probe = torch.zeros(64, device=device)
+    main = torch.cuda.current_stream(device)
+    for st in streams:
+        st.wait_stream(main)
+        with torch.cuda.stream(st):
+            probe.add_(1.0)
+        main.wait_stream(st)
+    torch.cuda.synchronize(device)
+
+
 def init_distributed():
     """One process per GPU (torchrun env: RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*). Returns (rank, world, device)."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -499,6 +545,7 @@ def init_distributed():
         device = torch.device("cpu")
         backend = "gloo"
     if world > 1 and not dist.is_initialized():
+        reserve_streams(device, data_parallel=True)     # before RCCL opens its own streams
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         dist.init_process_group(backend=backend, rank=rank, world_size=world)

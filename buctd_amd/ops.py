@@ -830,6 +830,21 @@ def compute_streams(device):
             [st for (d, _), st in _side["streams"].items() if d == idx])
 
 
+def reserve_compute_streams(device):
+    """Create the branch streams (up to the cap) and the weight-gradient stream(s) of `device` now; returns them.  See
+    engine.reserve_streams: streams are bound to hardware queues in the order of their first use."""
+    out = []
+    if _branch["on"]:
+        out += [_branch_stream(device, i) for i in range(1, _BRANCH_MAX + 1)]
+    if _side["on"]:
+        for rr in range(_side["n"]):
+            key = (device.index, rr)
+            if key not in _side["streams"]:
+                _side["streams"][key] = torch.cuda.Stream(device=device, priority=_SIDE_PRIO)
+            out.append(_side["streams"][key])
+    return out
+
+
 def _branch_stream(device, i):
     i = min(i, _BRANCH_MAX)     # branches beyond the cap share the last branch stream
     key = (device.index, i)

@@ -16,13 +16,22 @@ from oracle import recipes  # noqa: E402
 
 def main():
     rank, world, dev = engine.init_distributed()
+    one_rank_rccl = os.environ.get("BUCTD_DDP_MODE") == "rccl1"
+    if one_rank_rccl:
+        # a process group of ONE rank over the production backend ("nccl" = RCCL): the exchange machinery runs for real
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29541")
+        engine.reserve_streams(dev, data_parallel=True)      # as engine.init_distributed does in front of a real group
+        dist.init_process_group(backend="nccl", rank=0, world_size=1)
     ops.set_conv_math(os.environ.get("BUCTD_CONV_MATH", "fp32"))
     cfg, omodel, x, joints = recipes.build("coam_w16_96x64_colored")
     net = getattr(models, cfg.MODEL.NAME).get_pose_net(cfg, is_train=True)
     net.load_state_dict(omodel.state_dict(), strict=True)
     net = net.to(dev).train()
     recipes.set_dropout(net, 0.0)
-    model = engine.DataParallel(net, bucket_bytes=1 << 16)   # many small buckets: exercises the overlap machinery
+    model = engine.DataParallel(net, bucket_bytes=1 << 16,   # many small buckets: exercises the overlap machinery
+                                exchange_in_world_of_one=one_rank_rccl)
     opt = engine.get_optimizer(cfg, model)
     tgt, wt = recipes.make_targets(cfg, joints, 77)
     crit = JointsMSELoss(True)
@@ -50,6 +59,8 @@ def main():
         return
     xd, td, wd = x.to(dev), tgt.to(dev), wt.to(dev)
     losses = []
+    if one_rank_rccl:
+        model.bucket_trace = []
     for _ in range(2):
         loss = crit(model(xd), td, wd)
         opt.zero_grad()
@@ -58,6 +69,13 @@ def main():
         losses.append(loss.item())
     torch.cuda.synchronize()
     flat = model.flat.flat.detach().cpu().numpy()
+    if one_rank_rccl:
+        import torch.distributed as dist
+        assert model._comm_stream is not None and len(model.bucket_trace) >= 2 * len(model.buckets.buckets) > 2
+        np.savez(sys.argv[1], flat=flat, losses=np.array(losses), world=world, exchanges=len(model.bucket_trace),
+                 hip_streams=1 + len(ops.compute_streams(dev)) + 1)
+        dist.destroy_process_group()
+        return
     if rank == 0:
         np.savez(sys.argv[1], flat=flat, losses=np.array(losses), world=world)
     if world > 1:

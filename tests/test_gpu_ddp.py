@@ -105,6 +105,24 @@ def test_two_ranks_over_rccl_when_two_devices_are_visible(tmp_path):
     assert np.array_equal(a["losses"], b["losses"]) and np.array_equal(a["flat"], b["flat"])
 
 
+def test_one_rank_over_rccl_equals_the_plain_engine(tmp_path):
+    """The production transport on a single-GPU box: a process group of ONE rank over backend "nccl" (RCCL), with
+    DataParallel(exchange_in_world_of_one=True) - flat-parameter broadcast, bucketed all-reduces launched from the backward
+    callbacks on the high-priority communication stream, the stream budget assertion, FusedAdam's gradient sync.  The sum over one
+    rank is the identity and the scale is 1, so parameters and losses must equal the plain one-process run bit for bit."""
+    one, two = str(tmp_path / "one.npz"), str(tmp_path / "rccl1.npz")
+    r = subprocess.run([sys.executable, WORKER, one], env=_env(BUCTD_CONV_MATH="bf16x6"), capture_output=True, text=True,
+                       timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    r = subprocess.run([sys.executable, WORKER, two],
+                       env=_env(BUCTD_CONV_MATH="bf16x6", BUCTD_DDP_MODE="rccl1", HSA_ENABLE_IPC_MODE_LEGACY="0"),
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    a, b = np.load(one), np.load(two)
+    assert int(b["exchanges"]) > 2 and int(b["hip_streams"]) <= 4
+    assert np.array_equal(a["losses"], b["losses"]) and np.array_equal(a["flat"], b["flat"])
+
+
 def test_validate_is_sharded_over_ranks(tmp_path):
     """core.function.validate under a two-rank launch (both ranks on GPU 0, gloo): every rank runs half of the batches,
     rank 0's evaluate() sees the complete, correctly ordered tables - identical to a one-process run."""
