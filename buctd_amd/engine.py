@@ -345,13 +345,13 @@ class DataParallel(torch.nn.Module):
                 dist.broadcast(self.flat.flat, src=0)
                 self.broadcast_buffers()
                 self.buckets = GradBuckets(self.flat, self.bucket_bytes)
+                self._collective_in_stream = self.flat.flat.is_cuda and dist.get_backend() == "nccl"
                 if self.overlap and self.flat.flat.is_cuda:
                     # the exchange runs at the HIGHEST stream priority: an RCCL kernel occupies a few CUs per channel and
                     # must not queue behind the four compute streams' workgroups (it would start when they drain, i.e.
                     # exposed); what it takes away from them is its channel count (RCCL's default: <= 32 CUs of 256)
                     dev = self.flat.flat.device
                     self._comm_stream = _comm_streams.get(dev.index) or torch.cuda.Stream(device=dev, priority=-1)
-                    self._collective_in_stream = dist.get_backend() == "nccl"
                     # HIP stream budget: the default runtime serves FOUR hardware queues and any fifth stream costs 25-32 %
                     # (DESIGN.md 3.12, 6).  With the communication stream the compute side gets main + ONE branch stream
                     # (the two group-launch families of a HighResolutionModule, the fuse rows) + the weight-gradient stream.
@@ -425,7 +425,10 @@ class DataParallel(torch.nn.Module):
         else:
             if view.is_cuda:
                 ops.wait_side_stream()
-            self._handles.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, async_op=True))
+            if self._collective_in_stream:
+                dist.all_reduce(view, op=dist.ReduceOp.SUM, async_op=False)     # in the current stream, as above
+            else:
+                self._handles.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, async_op=True))
 
     def _grad_ready(self, p):
         """Called by the backward ops right after the kernels writing p.grad were enqueued (on the current stream
