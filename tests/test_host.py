@@ -93,7 +93,7 @@ def test_flat_params_arena_keeps_layout_and_values():
     assert flat.grad_is_arena(w) and float(flat.grad[s:e].sum()) == w.numel()
 
 
-def _dp_worker(rank, world, port, q):
+def _dp_worker(rank, world, port, q, one_rank=False):
     import torch.distributed as dist
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     sys.path.insert(0, ROOT)
@@ -101,7 +101,12 @@ def _dp_worker(rank, world, port, q):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     torch.manual_seed(100 + rank)                  # replicas start different: rank 0 must win
     net = torch.nn.Sequential(bnn.Conv2d(4, 8, 3, 1, 1), bnn.BatchNorm2d(8), bnn.Linear(6, 3))
-    dp = engine.DataParallel(net, bucket_bytes=64, overlap=False)
+    if one_rank:
+        assert engine.reserve_streams(torch.device("cpu"), data_parallel=True) is None
+        plain = engine.DataParallel(torch.nn.Sequential(bnn.Linear(6, 3)))
+        assert not plain._exchange and plain.sync_gradients() == 1.0          # a group of one is ignored by default
+    dp = engine.DataParallel(net, bucket_bytes=64, overlap=False, exchange_in_world_of_one=one_rank)
+    assert dp._exchange
     flat = dp.flatten()
     ref = flat.flat.clone()
     gathered = [torch.empty_like(ref) for _ in range(world)]
@@ -140,6 +145,21 @@ def test_data_parallel_gloo_world2():
         assert same, "parameters were not broadcast from rank 0"
         assert nb >= 2, "expected several gradient buckets"
         assert scale == 0.5 and vals == {1.5}, (vals, scale)   # (1 + 2) / 2: mean over the two replicas
+
+
+def test_exchange_in_a_world_of_one_and_stream_reservation_on_cpu():
+    """DataParallel(exchange_in_world_of_one=True): a process group of ONE rank (gloo here, RCCL in test_gpu_ddp.py) runs the
+    whole exchange - buckets, collectives, scale 1/1 - and leaves the gradients as they were; without the flag the same
+    group is ignored.  engine.reserve_streams is a no-op on a CPU device."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_dp_worker, args=(0, 1, 29650 + (os.getpid() + 7) % 200, q, True))
+    p.start()
+    rank, same, rm, nb, vals, scale = q.get(timeout=120)
+    p.join(timeout=60)
+    assert p.exitcode == 0
+    assert same and nb >= 2 and scale == 1.0 and vals == {1.0}, (nb, vals, scale)
 
 
 def test_host_mirror_numpy_paths_match_reference_golden():
