@@ -770,6 +770,8 @@ __global__ __launch_bounds__(256, 8) void bn_apply_acc_group_kernel(BnGroup<BnAp
   bn_apply_acc_body(g.s[k], bid, nblk, lds_raw);
 }
 
+// 44 bytes of dynamic LDS per channel (four 8-byte accumulator words + mean, scale, shift): 3720 channels fill a CU's 160 KB
+#define BN_APPLY_ACC_MAXC 3720
 extern "C" size_t buctd_bn_acc_bytes(int C) { return C > 0 ? bnacc_bytes(C) : 0; }
 
 static int acc_in_check(const buctd_bn_acc_in* st, const char* who) {
@@ -787,13 +789,18 @@ static BnAccFwd acc_in(const buctd_bn_acc_in* st) {
 
 extern "C" int buctd_bn_apply_acc(const float* z, const buctd_bn_acc_in* st, const float* gamma, const float* beta,
                                   const float* residual, int relu, float* y, long rows, int C, void* stream) {
-  BUCTD_CHECK_ARG(z && gamma && beta && y && rows > 0 && C > 0 && C % 4 == 0 && C <= 4096,
-                  "buctd_bn_apply_acc: bad argument (C must be a multiple of 4, <= 4096)");
+  BUCTD_CHECK_ARG(z && gamma && beta && y && rows > 0 && C > 0 && C % 4 == 0 && C <= BN_APPLY_ACC_MAXC,
+                  "buctd_bn_apply_acc: bad argument (C must be a multiple of 4, <= %d)", BN_APPLY_ACC_MAXC);
   const int rc = acc_in_check(st, "buctd_bn_apply_acc");
   if (rc) return rc;
   BUCTD_CHECK_ARG(st->rows == rows, "buctd_bn_apply_acc: the statistics cover %ld rows, the tensor has %ld", st->rows, rows);
   const long total = rows * C;
   const BnApplyArgs a{z, acc_in(st), gamma, beta, residual, relu, y, total, C};
+  if ((size_t)(BNACC_WORDS * 8 + 3 * 4) * C > 64 * 1024) {       // 44 bytes of LDS per channel: beyond 1489 channels above the default limit
+    static unsigned char attr_done[BUCTD_MAX_DEVICES] = {0};
+    if (const int rc2 = buctd_raise_lds_limit(reinterpret_cast<const void*>(bn_apply_acc_kernel), 160 * 1024, attr_done, "buctd_bn_apply_acc"))
+      return rc2;
+  }
   hipLaunchKernelGGL(bn_apply_acc_kernel, dim3(acc_grid(total / 4)), dim3(256), (size_t)(BNACC_WORDS * 8 + 3 * 4) * C,
                      (hipStream_t)stream, a);
   BUCTD_CHECK_LAUNCH("buctd_bn_apply_acc");
@@ -808,8 +815,8 @@ extern "C" int buctd_bn_apply_acc_group(int n, const buctd_bn_apply_item* items,
   size_t lds = 0;
   for (int k = 0; k < n; ++k) {
     const buctd_bn_apply_item& it = items[k];
-    BUCTD_CHECK_ARG(it.z && it.gamma && it.beta && it.y && it.rows > 0 && it.C > 0 && it.C % 4 == 0 && it.C <= 4096,
-                    "buctd_bn_apply_acc_group: bad argument (C must be a multiple of 4, <= 4096)");
+    BUCTD_CHECK_ARG(it.z && it.gamma && it.beta && it.y && it.rows > 0 && it.C > 0 && it.C % 4 == 0 && it.C <= BN_APPLY_ACC_MAXC,
+                    "buctd_bn_apply_acc_group: bad argument (C must be a multiple of 4, <= %d)", BN_APPLY_ACC_MAXC);
     const int rc = acc_in_check(&it.st, "buctd_bn_apply_acc_group");
     if (rc) return rc;
     BUCTD_CHECK_ARG(it.st.rows == it.rows, "buctd_bn_apply_acc_group: the statistics cover %ld rows, the tensor has %ld",
@@ -821,6 +828,12 @@ extern "C" int buctd_bn_apply_acc_group(int n, const buctd_bn_apply_item* items,
     if (l > lds) lds = l;
   }
   for (int k = n; k < BNG_MAX; ++k) g.first[k + 1] = g.first[n];
+  if (lds > 64 * 1024) {
+    static unsigned char attr_done[BUCTD_MAX_DEVICES] = {0};
+    if (const int rc2 = buctd_raise_lds_limit(reinterpret_cast<const void*>(bn_apply_acc_group_kernel), 160 * 1024, attr_done,
+                                              "buctd_bn_apply_acc_group"))
+      return rc2;
+  }
   hipLaunchKernelGGL(bn_apply_acc_group_kernel, dim3(g.first[n]), dim3(256), lds, (hipStream_t)stream, g);
   BUCTD_CHECK_LAUNCH("buctd_bn_apply_acc_group");
   return BUCTD_OK;

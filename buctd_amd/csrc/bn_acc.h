@@ -92,20 +92,25 @@ struct BnFwdStat { float mean, invstd; double mu, m2; };
 
 // The same for a whole workgroup: all 256 threads fetch the BNACC_SHARDS * 4 * C words (coalesced 8-byte loads, a handful per
 // thread instead of 32 in the threads of C channels) and add them - exactly - into wsum[4][C] in LDS.  Ends with a barrier;
-// bnacc_read_lds then decodes a channel.  (A poisoned copy keeps the sum above the poison threshold: the other copies are
-// below 2^59 in magnitude each.)
+// bnacc_read_lds then decodes a channel.  Every copy is checked for the poison mark BEFORE it is added: a diverged
+// activation poisons the copies of several XCDs at once, and 4 x 2^61 wraps to a negative (8 x 2^61 to zero) sum that would
+// decode as a finite number.  A poisoned word is stored as the saturated mark 2^61 (hi words only carry the mark, so a lo
+// word never trips the check).
 __device__ __forceinline__ void bnacc_gather_lds(const long long* __restrict__ acc, int C, long long* wsum) {
   const int n = BNACC_WORDS * C;
-  for (int k = threadIdx.x; k < n; k += 256) wsum[k] = 0;
-  __syncthreads();
   for (int k = threadIdx.x; k < n; k += 256) {
     long long v[BNACC_SHARDS];
 #pragma unroll
     for (int sh = 0; sh < BNACC_SHARDS; ++sh) v[sh] = acc[(size_t)sh * n + k];
+    const bool is_hi = ((k / C) & 1) != 0;          // word kinds {s1 lo, s1 hi, s2 lo, s2 hi}
     long long t = 0;
+    bool bad = false;
 #pragma unroll
-    for (int sh = 0; sh < BNACC_SHARDS; ++sh) t += v[sh];
-    wsum[k] = t;
+    for (int sh = 0; sh < BNACC_SHARDS; ++sh) {
+      bad |= is_hi && v[sh] >= ((long long)1 << 60);
+      t += v[sh];
+    }
+    wsum[k] = bad ? ((long long)1 << 61) : t;
   }
   __syncthreads();
 }

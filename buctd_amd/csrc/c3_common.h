@@ -78,6 +78,17 @@ struct C3Args {
   BnAccFwd in_acc;
 };
 
+// several convolutions in ONE launch (conv3x3.hip: conv3x3_x6_group_kernel; conv3x3_lean.hip: the train-mode kernels)
+#define C3G_MAX 4
+struct C3Group {
+  C3Args conv[C3G_MAX];
+  int nconv;
+  int tiles[C3G_MAX];      // workgroup tiles of convolution c
+  int gx[C3G_MAX];         // ... position tiles
+  int gy[C3G_MAX];         // ... column tiles
+  int variant[C3G_MAX];    // index into the variant list of the kernel family
+};
+
 // LDS the epilogue needs at the front of `smem`: row staging + row offsets (<= 19.5 KB), the lane reduction of the
 // BatchNorm-backward by-product (<= 24 KB, reuses the staging area), and behind them the cross-wave exchange of the
 // accumulator paths (WM * BN <= 256 pairs of doubles)

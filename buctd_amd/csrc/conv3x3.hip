@@ -31,6 +31,10 @@
 #include "c3_common.h"
 #include <string.h>
 
+// conv3x3_lean.hip: the train-mode option sets as template arguments (c3_lean.h)
+enum { C3M_IN_BN = 1, C3M_STATS = 2, C3M_RES = 4, C3M_BS_REBUILD = 8, C3M_BS_Y = 16 };
+int c3_lean_launch(const C3Group& h, int fam, int mode, unsigned grid, size_t lds, hipStream_t st);
+
 template <int NP, int MF, int NF, int WM, int WN>
 __global__ __launch_bounds__(256, 2) void conv3x3_split_kernel(C3Args p) {
   using G = Geo<NP>;
@@ -453,15 +457,7 @@ __global__ __launch_bounds__(256, WPS) void conv3x3_x6_kernel(C3Args p) {
 // its neighbour's main loop, and the tail of the grid is made of the cheapest tiles (convolutions ordered by tile cost).
 // Every tile is computed by c3x6_tile with the argument block and the tile shape of ITS convolution - the arithmetic (and
 // the accumulation order of every output and of the statistics) is that of the single launches: bit-identical results.
-#define C3G_MAX 4
-struct C3Group {
-  C3Args conv[C3G_MAX];
-  int nconv;
-  int tiles[C3G_MAX];      // workgroup tiles of convolution c
-  int gx[C3G_MAX];         // ... position tiles
-  int gy[C3G_MAX];         // ... column tiles
-  int variant[C3G_MAX];    // index into the variant list of the kernel family
-};
+// (C3Group: c3_common.h)
 
 // FAM 0: 48-channel multiples (NF = 3; HRNet-W48), FAM 1: 32-channel multiples (NF = 2 / 4; HRNet-W32)
 template <int FAM>
@@ -820,6 +816,95 @@ static int c3_fill(int np, int N, int H, int W, int Ci, int Co, const float* x, 
   return BUCTD_OK;
 }
 
+// the train-mode option set of a launch (c3_lean.h), or -1: the general kernel
+static int c3_lean_mode(const C3Args& a) {
+  if (a.bias || a.scale || a.shift || a.relu || a.stats || a.counts || a.bs_part || a.omap || a.in_mean || a.in_invstd) return -1;
+  if (a.in_acc.acc && (!a.in_gamma || !a.in_beta)) return -1;
+  int m = 0;
+  if (a.in_acc.acc) m |= C3M_IN_BN;
+  if (a.stats_acc) m |= C3M_STATS;
+  if (a.res) m |= C3M_RES;
+  if (a.bs_acc) m |= a.bs_y ? C3M_BS_Y : C3M_BS_REBUILD;
+  switch (m) {
+    case C3M_STATS: case C3M_STATS | C3M_IN_BN: case C3M_BS_REBUILD: case C3M_RES | C3M_BS_Y: case C3M_RES: return m;
+    default: return -1;
+  }
+}
+
+static int c3_group_variant(const C3Plan& pl, int* fam) {
+  struct V { int mf, nf, wm, wn; };
+  static const V f0[] = {{7, 3, 4, 1}, {4, 3, 2, 2}, {2, 2, 4, 1}, {4, 3, 4, 1}};
+  static const V f1[] = {{4, 2, 4, 1}, {1, 4, 4, 1}, {2, 2, 4, 1}, {1, 2, 4, 1}, {2, 4, 4, 1}, {2, 4, 2, 2}};
+  for (int f = 0; f < 2; ++f) {
+    if (*fam >= 0 && *fam != f) continue;
+    const V* l = f ? f1 : f0;
+    const int n = f ? 6 : 4;
+    for (int i = 0; i < n; ++i)
+      if (l[i].mf == pl.MF && l[i].nf == pl.NF && l[i].wm == pl.WM && l[i].wn == pl.WN) {
+        *fam = f;
+        return i;
+      }
+  }
+  return -1;
+}
+
+// n convolutions (argument blocks a[], tile plans pl[]) as ONE launch: the train-mode kernel of their common option set, else
+// the general group kernel (n > 1 only).  *done = false: the tile shapes have no common kernel family - nothing was launched.
+static int c3_group_launch(int n, const C3Args* a, const C3Plan* pl, hipStream_t stream, bool* done) {
+  *done = false;
+  int order[C3G_MAX];
+  double cost[C3G_MAX];
+  int lean = c3_lean_mode(a[0]);
+  for (int k = 0; k < n; ++k) {
+    cost[k] = (double)pl[k].BM * pl[k].BN * a[k].Ci;
+    order[k] = k;
+    if (c3_lean_mode(a[k]) != lean) lean = -1;
+  }
+  if (n == 1 && lean < 0) return BUCTD_OK;
+  // the kernel family that holds the tile shapes of ALL members (128 x 32 tiles exist in both families)
+  int fam = -1;
+  bool ok = false;
+  int var[C3G_MAX];
+  for (int f = 0; f < 2 && !ok; ++f) {
+    ok = true;
+    for (int k = 0; k < n && ok; ++k) {
+      fam = f;
+      var[k] = c3_group_variant(pl[k], &fam);
+      ok = var[k] >= 0;
+    }
+  }
+  if (!ok) return BUCTD_OK;
+  // costliest tiles first: the grid ends with the cheap ones
+  for (int i = 1; i < n; ++i)
+    for (int j = i; j > 0 && cost[order[j]] > cost[order[j - 1]]; --j) { const int t = order[j]; order[j] = order[j - 1]; order[j - 1] = t; }
+  C3Group h;
+  h.nconv = n;
+  size_t lds = 0;
+  unsigned per_xcd = 0;
+  for (int i = 0; i < n; ++i) {
+    const int k = order[i];
+    h.conv[i] = a[k];
+    h.gx[i] = ceil_div(h.conv[i].P, pl[k].BM);
+    h.gy[i] = h.conv[i].Co / pl[k].BN;
+    h.tiles[i] = h.gx[i] * h.gy[i];
+    h.variant[i] = var[k];
+    const size_t l = pl[k].lds + (lean >= 0 ? (size_t)4 * pl[k].BN * sizeof(float) : 0);   // + the epilogue table (c3_lean.h)
+    if (l > lds) lds = l;
+    per_xcd += ((unsigned)h.tiles[i] + 7) >> 3;
+  }
+  for (int i = n; i < C3G_MAX; ++i) h.tiles[i] = h.gx[i] = h.gy[i] = h.variant[i] = 0;
+  if (lds > 160 * 1024) return BUCTD_OK;
+  *done = true;
+  if (lean >= 0) return c3_lean_launch(h, fam, lean, per_xcd * 8, lds, stream);
+  static unsigned char attr_done[2][BUCTD_MAX_DEVICES] = {{0}};
+  void (*fn)(C3Group) = fam ? conv3x3_x6_group_kernel<1> : conv3x3_x6_group_kernel<0>;
+  if (const int rc = buctd_raise_lds_limit(reinterpret_cast<const void*>(fn), 160 * 1024, attr_done[fam], "buctd_conv3x3_bf16x6_group"))
+    return rc;
+  hipLaunchKernelGGL(fn, dim3(per_xcd * 8), dim3(256), lds, stream, h);
+  BUCTD_CHECK_LAUNCH("buctd_conv3x3_bf16x6_group");
+  return BUCTD_OK;
+}
+
 static int c3_run(int np, int N, int H, int W, int Ci, int Co, const float* x, const void* wprep, const float* bias,
                   const float* scale, const float* shift, const float* residual, int relu, float* y,
                   float* stats_partials, int* stats_counts, void* stream, const C3InBn* in_bn = nullptr,
@@ -829,6 +914,11 @@ static int c3_run(int np, int N, int H, int W, int Ci, int Co, const float* x, c
   const int rc = c3_fill(np, N, H, W, Ci, Co, x, wprep, bias, scale, shift, residual, relu, y, stats_partials, stats_counts,
                          in_bn, bst, accs, a, pl);
   if (rc) return rc;
+  if (np == 3 && c3_lean_mode(a) >= 0) {       // a train-mode option set: the specialised kernel, if the tile shape has one
+    bool done = false;
+    const int rc2 = c3_group_launch(1, &a, &pl, (hipStream_t)stream, &done);
+    if (rc2 || done) return rc2;
+  }
   return np == 3 ? c3_dispatch<3>(a, pl, (hipStream_t)stream) : c3_dispatch<2>(a, pl, (hipStream_t)stream);
 }
 
@@ -921,29 +1011,10 @@ extern "C" int buctd_conv3x3_bf16x6_bnstat_acc(int N, int H, int W, int Ci, int 
 /* Several 3x3 convolutions in ONE launch (include/buctd_hip.h: buctd_c3_conv): the tiles of all of them in one grid, each
  * computed exactly as its own buctd_conv3x3_bf16x6_acc / _bnstat_acc launch would.  Shapes whose tile plans have no place in
  * a group kernel are launched one after the other instead - the results are the same either way. */
-static int c3_group_variant(const C3Plan& pl, int* fam) {
-  struct V { int mf, nf, wm, wn; };
-  static const V f0[] = {{7, 3, 4, 1}, {4, 3, 2, 2}, {2, 2, 4, 1}, {4, 3, 4, 1}};
-  static const V f1[] = {{4, 2, 4, 1}, {1, 4, 4, 1}, {2, 2, 4, 1}, {1, 2, 4, 1}, {2, 4, 4, 1}, {2, 4, 2, 2}};
-  for (int f = 0; f < 2; ++f) {
-    if (*fam >= 0 && *fam != f) continue;
-    const V* l = f ? f1 : f0;
-    const int n = f ? 6 : 4;
-    for (int i = 0; i < n; ++i)
-      if (l[i].mf == pl.MF && l[i].nf == pl.NF && l[i].wm == pl.WM && l[i].wn == pl.WN) {
-        *fam = f;
-        return i;
-      }
-  }
-  return -1;
-}
-
 extern "C" int buctd_conv3x3_bf16x6_group(int n, const buctd_c3_conv* convs, void* stream) {
   BUCTD_CHECK_ARG(n > 0 && n <= C3G_MAX && convs, "buctd_conv3x3_bf16x6_group: 1..%d convolutions", C3G_MAX);
-  C3Group g;
+  C3Args a[C3G_MAX];
   C3Plan pl[C3G_MAX];
-  int order[C3G_MAX];
-  double cost[C3G_MAX];
   for (int k = 0; k < n; ++k) {
     const buctd_c3_conv& c = convs[k];
     C3InBn ib{nullptr, nullptr, c.in_gamma, c.in_beta, c.in_relu};
@@ -951,53 +1022,17 @@ extern "C" int buctd_conv3x3_bf16x6_group(int n, const buctd_c3_conv* convs, voi
     C3Acc ac{(long long*)c.stats_acc, c.in_bn};
     BUCTD_CHECK_ARG(!c.in_bn || c.in_bn->acc, "buctd_conv3x3_bf16x6_group: in_bn without an accumulator");
     const int rc = c3_fill(3, c.N, c.H, c.W, c.Ci, c.Co, c.x, c.wprep, nullptr, nullptr, nullptr, c.residual, c.relu, c.y,
-                           nullptr, nullptr, c.in_bn ? &ib : nullptr, c.bn_acc ? &bs : nullptr, &ac, g.conv[k], pl[k]);
+                           nullptr, nullptr, c.in_bn ? &ib : nullptr, c.bn_acc ? &bs : nullptr, &ac, a[k], pl[k]);
     if (rc) return rc;
-    cost[k] = (double)pl[k].BM * pl[k].BN * c.Ci;
-    order[k] = k;
   }
-  // the kernel family that holds the tile shapes of ALL members (128 x 32 tiles exist in both families)
-  int fam = -1;
-  bool ok = false;
-  int var[C3G_MAX];
-  for (int f = 0; f < 2 && !ok && n > 1; ++f) {
-    ok = true;
-    for (int k = 0; k < n && ok; ++k) {
-      fam = f;
-      var[k] = c3_group_variant(pl[k], &fam);
-      ok = var[k] >= 0;
-    }
+  bool done = false;
+  const int rc = c3_group_launch(n, a, pl, (hipStream_t)stream, &done);
+  if (rc || done) return rc;
+  for (int k = 0; k < n; ++k) {       // no common kernel: one launch per member (each may still take its train-mode kernel)
+    bool d1 = false;
+    int rc1 = c3_group_launch(1, a + k, pl + k, (hipStream_t)stream, &d1);
+    if (!rc1 && !d1) rc1 = c3_dispatch<3>(a[k], pl[k], (hipStream_t)stream);
+    if (rc1) return rc1;
   }
-  if (!ok) {
-    for (int k = 0; k < n; ++k) {
-      const int rc = c3_dispatch<3>(g.conv[k], pl[k], (hipStream_t)stream);
-      if (rc) return rc;
-    }
-    return BUCTD_OK;
-  }
-  // costliest tiles first: the grid ends with the cheap ones
-  for (int i = 1; i < n; ++i)
-    for (int j = i; j > 0 && cost[order[j]] > cost[order[j - 1]]; --j) { const int t = order[j]; order[j] = order[j - 1]; order[j - 1] = t; }
-  C3Group h;
-  h.nconv = n;
-  size_t lds = 0;
-  unsigned per_xcd = 0;
-  for (int i = 0; i < n; ++i) {
-    const int k = order[i];
-    h.conv[i] = g.conv[k];
-    h.gx[i] = ceil_div(h.conv[i].P, pl[k].BM);
-    h.gy[i] = h.conv[i].Co / pl[k].BN;
-    h.tiles[i] = h.gx[i] * h.gy[i];
-    h.variant[i] = var[k];
-    if (pl[k].lds > lds) lds = pl[k].lds;
-    per_xcd += ((unsigned)h.tiles[i] + 7) >> 3;
-  }
-  for (int i = n; i < C3G_MAX; ++i) h.tiles[i] = h.gx[i] = h.gy[i] = h.variant[i] = 0;
-  static unsigned char attr_done[2][BUCTD_MAX_DEVICES] = {{0}};
-  void (*fn)(C3Group) = fam ? conv3x3_x6_group_kernel<1> : conv3x3_x6_group_kernel<0>;
-  if (const int rc = buctd_raise_lds_limit(reinterpret_cast<const void*>(fn), 160 * 1024, attr_done[fam], "buctd_conv3x3_bf16x6_group"))
-    return rc;
-  hipLaunchKernelGGL(fn, dim3(per_xcd * 8), dim3(256), lds, (hipStream_t)stream, h);
-  BUCTD_CHECK_LAUNCH("buctd_conv3x3_bf16x6_group");
   return BUCTD_OK;
 }
