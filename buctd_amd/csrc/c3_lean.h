@@ -24,6 +24,22 @@
 
 enum { C3M_IN_BN = 1, C3M_STATS = 2, C3M_RES = 4, C3M_BS_REBUILD = 8, C3M_BS_Y = 16 };
 
+// Tensors are addressed through buffer descriptors (32-bit byte offsets, hardware bounds check): a pad row carries the offset
+// C3_OOB, its loads return zeros and its stores are dropped - no select, no branch, no 64-bit address arithmetic per row.
+// (Tensors of the train-mode kernels are below 2 GB: conv3x3.hip checks.)
+#define C3_OOB 0x80000000u
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t c3_rsrc(const void* ptr, unsigned bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(ptr), 0, bytes, 0x00020000);
+}
+__device__ __forceinline__ f32x4 c3_bload(__amdgpu_buffer_rsrc_t r, unsigned off) {
+  typedef unsigned u32x4_ __attribute__((ext_vector_type(4)));
+  return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0));
+}
+__device__ __forceinline__ void c3_bstore(__amdgpu_buffer_rsrc_t r, unsigned off, f32x4 v) {
+  typedef unsigned u32x4_ __attribute__((ext_vector_type(4)));
+  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_, v), r, off, 0, 0);
+}
+
 // LDS behind the A buffers: [3][Ci] floats input-BatchNorm table | [4][BN] floats epilogue table
 //   BS modes: mean, invstd, invstd * gamma, beta of the workgroup's BN output columns;  STATS: one pivot per wave and column
 static inline size_t c3l_tab_bytes(int Ci, int BN) { return (size_t)3 * Ci * 4 + (size_t)4 * BN * 4; }
@@ -59,23 +75,22 @@ __device__ __forceinline__ void c3l_epilogue(const C3Args& p, f32x4 (&acc)[MF][N
   int* rowoff = reinterpret_cast<int*>(smem) + 4 * 16 * LD + wave * 128;
   double2* exch = reinterpret_cast<double2*>(smem + C3_EPI_EXCH_OFF);
 
-  // element offset of output row r of this wave (-1: pad position)
+  // byte offset of output row r of this wave (C3_OOB: pad position)
+  const unsigned obytes = (unsigned)p.N * p.H * p.W * p.Co * 4u;
+  const __amdgpu_buffer_rsrc_t r_out = c3_rsrc(p.out, obytes);
   int cnt = 0;
 #pragma unroll
   for (int h = 0; h < RH; ++h) {
-    int myoff = -1;
+    unsigned myoff = C3_OOB;
     const int r = lane + 64 * h;
-    if (r < MR) {
-      const int pp = p0 + wave_m * MR + r;
-      if (pp < p.P) {
-        const int n = fast_div(pp, p.ib_mul, p.ib_sh);
-        const int rem = pp - n * p.IB;
-        const int yy = fast_div(rem, p.sw_mul, p.sw_sh), xx = rem - yy * p.SW;
-        if (n < p.N && yy >= 1 && xx >= 1 && xx <= p.W) myoff = ((n * p.H + yy - 1) * p.W + xx - 1) * p.Co;
-      }
-    }
-    if (STATS) cnt += __popcll(__ballot(myoff >= 0));
-    rowoff[r] = myoff;
+    const int pp = p0 + wave_m * MR + r;
+    const int n = fast_div(pp, p.ib_mul, p.ib_sh);
+    const int rem = pp - n * p.IB;
+    const int yy = fast_div(rem, p.sw_mul, p.sw_sh), xx = rem - yy * p.SW;
+    if ((r < MR) & (pp < p.P) & (n < p.N) & (yy >= 1) & (xx >= 1) & (xx <= p.W))
+      myoff = (unsigned)(((n * p.H + yy - 1) * p.W + xx - 1) * p.Co) * 4u;
+    if (STATS) cnt += __popcll(__ballot(myoff != C3_OOB));
+    if (r < MR) reinterpret_cast<unsigned*>(rowoff)[r] = myoff;
   }
   const int ncol0 = n0 + wave_n * NF * 16;
   float* piv = tab + wave * (NF * 16);                 // STATS: this wave's pivots
@@ -91,7 +106,7 @@ __device__ __forceinline__ void c3l_epilogue(const C3Args& p, f32x4 (&acc)[MF][N
   // a lane's items: item k = (row_k, quad c4_k) of every 16-row pass; everything that does not depend on the pass is formed
   // once: the staged piece, the row-offset slot, the output / side-tensor addresses up to the row offset
   const float* sp[NI];
-  const int* rp[NI];
+  const unsigned* rp[NI];
   int c4_k[NI];
 #pragma unroll
   for (int k = 0; k < NI; ++k) {
@@ -99,8 +114,9 @@ __device__ __forceinline__ void c3l_epilogue(const C3Args& p, f32x4 (&acc)[MF][N
     const int row = item / Q4;
     c4_k[k] = item - row * Q4;
     sp[k] = stg + row * LD + c4_k[k] * 4;
-    rp[k] = rowoff + row;
+    rp[k] = reinterpret_cast<const unsigned*>(rowoff) + row;
   }
+  const unsigned colb = (unsigned)ncol0 * 4u;          // byte offset of this wave's first column
   f32x4 s1[NACC], s2[NACC], pq[NACC];
 #pragma unroll
   for (int j = 0; j < NACC; ++j) {
@@ -108,15 +124,18 @@ __device__ __forceinline__ void c3l_epilogue(const C3Args& p, f32x4 (&acc)[MF][N
     if constexpr (STATS) pq[j] = *reinterpret_cast<const f32x4*>(piv + c4_k[j] * 4);
   }
   // tensors read beside the tile travel one pass ahead (c3_epilogue: a memory round trip per pass otherwise)
+  [[maybe_unused]] __amdgpu_buffer_rsrc_t r_res, r_z, r_y;
+  if constexpr (RES) r_res = c3_rsrc(p.res, obytes);
+  if constexpr (BS) r_z = c3_rsrc(p.bs_z, obytes);
+  if constexpr (BSY) r_y = c3_rsrc(p.bs_y, obytes);
   f32x4 pre_r[2][RES ? NI : 1], pre_z[2][BS ? NI : 1], pre_y[2][BSY ? NI : 1];
   auto issue = [&](int ps, int buf) {
 #pragma unroll
     for (int k = 0; k < NI; ++k) {
-      const int off = rp[k][ps * 16];
-      const int o = off >= 0 ? off + ncol0 + c4_k[k] * 4 : 0;      // pad rows: any valid address, the value is not used
-      if constexpr (RES) pre_r[buf][k] = *reinterpret_cast<const f32x4*>(p.res + o);
-      if constexpr (BS) pre_z[buf][k] = *reinterpret_cast<const f32x4*>(p.bs_z + o);
-      if constexpr (BSY) pre_y[buf][k] = *reinterpret_cast<const f32x4*>(p.bs_y + o);
+      const unsigned o = rp[k][ps * 16] + colb + c4_k[k] * 16;      // pad rows: out of range, the load returns zeros
+      if constexpr (RES) pre_r[buf][k] = c3_bload(r_res, o);
+      if constexpr (BS) pre_z[buf][k] = c3_bload(r_z, o);
+      if constexpr (BSY) pre_y[buf][k] = c3_bload(r_y, o);
     }
   };
   if constexpr (RES || BS) issue(0, 0);
@@ -131,17 +150,23 @@ __device__ __forceinline__ void c3l_epilogue(const C3Args& p, f32x4 (&acc)[MF][N
 #pragma unroll
       for (int rg = 0; rg < 4; ++rg) stg[(g * 4 + rg) * LD + nf * 16 + i16] = acc[ps][nf][rg];
     __builtin_amdgcn_wave_barrier();
+    // The items of a pass are ONE basic block (no branch around the store: a pad row's store is dropped by the bounds check,
+    // its sums add zeros): next to a workgroup that is streaming MFMAs every DEPENDENT instruction of this wave waits tens
+    // of cycles for its issue slot, so the pass must offer the scheduler independent work - the items side by side.
+    f32x4 v[NI];
+    unsigned off[NI];
 #pragma unroll
     for (int k = 0; k < NI; ++k) {
-      f32x4 v = *reinterpret_cast<const f32x4*>(sp[k]);
-      const int off = rp[k][ps * 16];
-      const bool ok = off >= 0;
-      if constexpr (RES) v += pre_r[ps & 1][k];
-      if (ok) *reinterpret_cast<f32x4*>(p.out + off + ncol0 + c4_k[k] * 4) = v;
-      // the sums are formed branch-free (pad rows add zeros): accumulators updated under a divergent branch made the compiler
-      // copy whole accumulator sets around every item
+      v[k] = *reinterpret_cast<const f32x4*>(sp[k]);
+      off[k] = rp[k][ps * 16];
+    }
+#pragma unroll
+    for (int k = 0; k < NI; ++k) {
+      const bool ok = off[k] != C3_OOB;
+      if constexpr (RES) v[k] += pre_r[ps & 1][k];
+      c3_bstore(r_out, off[k] + colb + c4_k[k] * 16, v[k]);
       if constexpr (STATS) {
-        f32x4 d = v - pq[k % NACC];
+        f32x4 d = v[k] - pq[k % NACC];
 #pragma unroll
         for (int j = 0; j < 4; ++j) d[j] = ok ? d[j] : 0.f;
         s1[k % NACC] += d;
@@ -164,18 +189,17 @@ __device__ __forceinline__ void c3l_epilogue(const C3Args& p, f32x4 (&acc)[MF][N
         }
         f32x4 gm;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) gm[j] = (ok && yy[j] > 0.f) ? v[j] : 0.f;
+        for (int j = 0; j < 4; ++j) gm[j] = (ok && yy[j] > 0.f) ? v[k][j] : 0.f;
         s1[k % NACC] += gm;
-        // pad rows: z was fetched from a valid dummy address; gm = 0 makes the term +0 (or -0): the sum is unchanged
-        // unless that dummy value is Inf / NaN - select the whole term
-        f32x4 tm = gm * (zz - mu) * is;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) tm[j] = ok ? tm[j] : 0.f;
+        f32x4 tm = gm * (zz - mu) * is;       // pad rows: gm = 0 and z = 0 (bounds check): the term is a zero
         s2[k % NACC] += tm;
       }
-      // keep an item's arithmetic with the item: left alone the optimiser sinks the sums of all passes behind the last
-      // store and carries every staged piece there in registers (up to 300 spilled in the backward modes)
-      if constexpr (STATS || BS) asm volatile("" : "+v"(s1[k % NACC]), "+v"(s2[k % NACC]));
+    }
+    // keep a pass's arithmetic with the pass: left alone the optimiser sinks the sums of all passes behind the last store
+    // and carries every staged piece there in registers (hundreds spilled in the backward modes)
+    if constexpr (STATS || BS) {
+#pragma unroll
+      for (int j = 0; j < NACC; ++j) asm volatile("" : "+v"(s1[j]), "+v"(s2[j]));
     }
   }
   if constexpr (STATS || BS) {
@@ -241,6 +265,97 @@ __device__ __forceinline__ void c3l_epilogue(const C3Args& p, f32x4 (&acc)[MF][N
   }
 }
 
+// ---- input staging ----------------------------------------------------------------------------------------------------------
+// A thread's share of one 16-channel chunk of a tile's input: row prow + 64 q (q < PA) of the BM + 2 SW + 2 staged rows, four
+// channels.  make(): the rows' byte offsets in x (C3_OOB for a pad position: the load returns zeros) and their LDS slots (rows
+// beyond the tile - last pass only - all go to the spare row arows - 1, which no fragment reads); load(): fp32 -> registers;
+// store(): (input BatchNorm,) split into three bf16 pieces, pieces -> LDS.
+// Passes [0, P0) exist for every row width, the rest come in pairs under a wave-uniform test.  A group is ONE basic block: the
+// split is a chain of dependent conversions and subtractions per value, and a wave whose SIMD partner streams MFMAs waits tens
+// of cycles per dependent issue (cycle stamps: the same ten passes take 2 k cycles beside an idle partner, 9-10 k beside a
+// multiplying one) - the passes must stand side by side for the scheduler to interleave them.
+template <int BM, bool IN_BN>
+struct C3Stager {
+  static constexpr int ROWB = Geo<3>::ROWB, PST = Geo<3>::PST, CPR = Geo<3>::CPR;
+  static constexpr int RPP = 256 / CPR;                                 // 64 rows staged per pass
+  static constexpr int PA = (BM + 2 * MAX_SW + 2 + RPP - 1) / RPP;
+  static constexpr int P0 = (BM + 2 * 3 + 2) / RPP < PA ? (BM + 2 * 3 + 2) / RPP : PA;
+  unsigned goff[PA], lrow[PA];
+  f32x4 areg[PA];
+  int arows, c4, prow;
+  __amdgpu_buffer_rsrc_t r_x;
+
+  __device__ __forceinline__ void init(const C3Args& p) {
+    const int t = threadIdx.x;
+    arows = p.na * 32;
+    c4 = (t % CPR) * 4;
+    prow = t / CPR;
+    r_x = c3_rsrc(p.x, (unsigned)p.N * p.H * p.W * p.Ci * 4u);
+#pragma unroll
+    for (int q = 0; q < PA; ++q) {
+      const int row = prow + RPP * q;
+      lrow[q] = (unsigned)(row < arows ? row : arows - 1) * ROWB + 2 * c4;
+    }
+  }
+  __device__ __forceinline__ void make(const C3Args& p, int p0) {
+    const int halo = p.SW + 1;
+#pragma unroll
+    for (int q = 0; q < PA; ++q) {
+      const int row = prow + RPP * q;
+      const int pp = p0 - halo + row;
+      const int n = fast_div(pp, p.ib_mul, p.ib_sh);
+      const int rem = pp - n * p.IB;
+      const int yy = fast_div(rem, p.sw_mul, p.sw_sh);
+      const int xx = rem - yy * p.SW;
+      // (bitwise: a short-circuit && would put every pass in its own basic blocks)
+      const bool real = (row < arows) & (pp >= 0) & (pp < p.P) & (n < p.N) & (yy >= 1) & (xx >= 1) & (xx <= p.W);
+      goff[q] = real ? (unsigned)(((n * p.H + yy - 1) * p.W + xx - 1) * p.Ci + c4) * 4u : C3_OOB;
+    }
+  }
+  __device__ __forceinline__ void load(int c0) {
+#pragma unroll
+    for (int q = 0; q < P0; ++q) areg[q] = c3_bload(r_x, goff[q] + (unsigned)c0 * 4u);
+#pragma unroll
+    for (int q0 = P0; q0 < PA; q0 += 2)
+      if (RPP * q0 < arows) {
+        areg[q0] = c3_bload(r_x, goff[q0] + (unsigned)c0 * 4u);
+        if (q0 + 1 < PA) areg[q0 + 1] = c3_bload(r_x, goff[q0 + 1] + (unsigned)c0 * 4u);
+      }
+  }
+  __device__ __forceinline__ void store_pass(const C3Args& p, unsigned char* At, int q, const f32x4& mu, const f32x4& sc,
+                                             const f32x4& be) {
+    f32x4 v = areg[q];
+    if constexpr (IN_BN) {
+      // the exact expression of bn_apply_kernel; zero padding stays zero: it pads the NORMALISED tensor
+      const bool real = goff[q] != C3_OOB;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float u = (v[j] - mu[j]) * sc[j] + be[j];
+        const float w = p.in_relu ? fmaxf(u, 0.f) : u;
+        v[j] = real ? w : 0.f;
+      }
+    }
+    split_store_pk<3, PST>(At + lrow[q], 0, v);
+  }
+  // bntab: [3][Ci] floats (mean, invstd * gamma, beta) of the input BatchNorm
+  __device__ __forceinline__ void store(const C3Args& p, unsigned char* At, int c0, const float* bntab) {
+    f32x4 mu = (f32x4){0.f, 0.f, 0.f, 0.f}, sc = mu, be = mu;
+    if constexpr (IN_BN) {
+      mu = *reinterpret_cast<const f32x4*>(bntab + c0 + c4);
+      sc = *reinterpret_cast<const f32x4*>(bntab + p.Ci + c0 + c4);
+      be = *reinterpret_cast<const f32x4*>(bntab + 2 * p.Ci + c0 + c4);
+    }
+#pragma unroll
+    for (int q = 0; q < P0; ++q) store_pass(p, At, q, mu, sc, be);
+#pragma unroll
+    for (int q0 = P0; q0 < PA; q0 += 2)
+      if (RPP * q0 < arows) {
+        store_pass(p, At, q0, mu, sc, be);
+        if (q0 + 1 < PA) store_pass(p, At, q0 + 1, mu, sc, be);       // (rows beyond the tile land in the spare row)
+      }
+  }
+};
+
 // ---- one output tile ---------------------------------------------------------------------------------------------------
 // c3x6_tile (conv3x3.hip) with the option set as a template argument, the packed split, and the epilogue above.
 // smem = [DBUF ? 2 : 1][arows][ROWB] A buffers | [3][Ci] input-BatchNorm table | [4][BN] epilogue table
@@ -265,51 +380,11 @@ __device__ __forceinline__ void c3l_tile(const C3Args& p, unsigned char* smem, i
   const int halo = p.SW + 1;
   const int c4 = (t % CPR) * 4, prow = t / CPR;
 
-  // global element offset (channel 0) of every staged row of this thread; -1 zero row, -2 beyond the tile
-  int goff[PA];
-#pragma unroll
-  for (int q = 0; q < PA; ++q) {
-    const int row = prow + RPP * q;
-    const int pp = p0 - halo + row;
-    int o = row < arows ? -1 : -2;
-    if (row < arows && pp >= 0 && pp < p.P) {
-      const int n = fast_div(pp, p.ib_mul, p.ib_sh);
-      const int rem = pp - n * p.IB;
-      const int yy = fast_div(rem, p.sw_mul, p.sw_sh);
-      const int xx = rem - yy * p.SW;
-      if (n < p.N && yy >= 1 && xx >= 1 && xx <= p.W) o = ((n * p.H + yy - 1) * p.W + xx - 1) * p.Ci;
-    }
-    goff[q] = o;
-  }
-  f32x4 areg[PA];
-  auto load_a = [&](int c0) {
-#pragma unroll
-    for (int q = 0; q < PA; ++q)
-      if (RPP * q < arows) areg[q] = *reinterpret_cast<const f32x4*>(p.x + (goff[q] >= 0 ? goff[q] + c0 + c4 : 0));
-  };
-  auto store_a = [&](unsigned char* At, int c0) {
-    f32x4 mu, sc, be;
-    if constexpr (IN_BN) {
-      mu = *reinterpret_cast<const f32x4*>(bntab + c0 + c4);
-      sc = *reinterpret_cast<const f32x4*>(bntab + p.Ci + c0 + c4);
-      be = *reinterpret_cast<const f32x4*>(bntab + 2 * p.Ci + c0 + c4);
-    }
-#pragma unroll
-    for (int q = 0; q < PA; ++q)
-      if (RPP * q < arows && goff[q] != -2) {
-        f32x4 v = areg[q];
-        if constexpr (IN_BN) {
-          // the exact expression of bn_apply_kernel; zero padding stays zero: it pads the NORMALISED tensor
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            v[j] = (v[j] - mu[j]) * sc[j] + be[j];
-            if (p.in_relu) v[j] = fmaxf(v[j], 0.f);
-          }
-        }
-        if (goff[q] < 0) v = (f32x4){0.f, 0.f, 0.f, 0.f};
-        split_store_pk<3, PST>(At + (size_t)(prow + RPP * q) * ROWB, c4, v);
-      }
-  };
+  C3Stager<BM, IN_BN> stg;
+  stg.init(p);
+  stg.make(p, p0);
+  auto load_a = [&](int c0) { stg.load(c0); };
+  auto store_a = [&](unsigned char* At, int c0) { stg.store(p, At, c0, bntab); };
 
   // B fragments of this lane: image [step][Co/16][3][64][16 B]
   const unsigned char* bptr = p.wp + ((size_t)(n0 / 16 + wave_n * NF) * 3) * 1024;   // scalar base

@@ -34,6 +34,14 @@
 // conv3x3_lean.hip: the train-mode option sets as template arguments (c3_lean.h)
 enum { C3M_IN_BN = 1, C3M_STATS = 2, C3M_RES = 4, C3M_BS_REBUILD = 8, C3M_BS_Y = 16 };
 int c3_lean_launch(const C3Group& h, int fam, int mode, unsigned grid, size_t lds, hipStream_t st);
+// conv3x3_pers.hip: the same option sets as a persistent grid of resident workgroups (c3_pers.h)
+int c3_pers_launch(const C3Group& h, int fam, int mode, unsigned grid, size_t lds, hipStream_t st);
+#define C3P_SLOTS 512      // resident workgroups of a persistent launch: two per CU
+static inline size_t c3p_lds_bytes(int na, int Ci, int BN) {       // c3_pers.h: two A buffers (each at least the epilogue's LDS) + tables
+  size_t b = (size_t)na * 32 * Geo<3>::ROWB;
+  if (b < (size_t)C3_EPI_LDS) b = C3_EPI_LDS;
+  return 2 * b + (size_t)3 * Ci * 4 + (size_t)4 * BN * 4;
+}
 
 template <int NP, int MF, int NF, int WM, int WN>
 __global__ __launch_bounds__(256, 2) void conv3x3_split_kernel(C3Args p) {
@@ -622,7 +630,8 @@ struct C3Plan { int MF, NF, WM, WN, BM, BN, na; size_t lds; };
 
 static int c3_steps(int Kc, int np) { return np == 3 ? (Kc / 16) * 5 : (Kc / CK) * 9 + ((Kc % CK) ? 5 : 0); }
 
-static bool c3_plan(int np, int N, int H, int W, int Ci, int Co, C3Plan* pl) {
+// pers: the plan of a persistent launch (c3_pers.h) - double-buffered tiles only
+static bool c3_plan(int np, int N, int H, int W, int Ci, int Co, C3Plan* pl, bool pers = false) {
   if (N <= 0 || H <= 0 || W <= 0 || Ci <= 0 || Co <= 0 || Ci % 16 != 0 || Co % 16 != 0 || c3_row_width(W) > MAX_SW) return false;
   const int rowb = np == 3 ? Geo<3>::ROWB : Geo<2>::ROWB, blds = np == 3 ? Geo<3>::BLDS : Geo<2>::BLDS;
   const long P = (long)N * (H + 1) * c3_row_width(W) + c3_row_width(W);
@@ -651,7 +660,7 @@ static bool c3_plan(int np, int N, int H, int W, int Ci, int Co, C3Plan* pl) {
     if (blocks >= (np == 3 ? 224 : 320)) { mf = cand[i]; break; }   // (238 for the 192-channel 24x18 maps at N = 32)
   }
   bool single = false;
-  if (np == 3 && nf == 3 && wn == 1 && Co == bn) {
+  if (np == 3 && nf == 3 && wn == 1 && Co == bn && !pers) {
     // 512-position tiles in ONE round of workgroups (2 resident per CU = 512 slots) instead of 1.75 rounds of
     // 256-position tiles: the 48-channel branch at N*H*W >= ~115k positions (single A buffer: 64.5 KB at W = 72)
     const long b8 = (P + 511) / 512;
@@ -664,7 +673,7 @@ static bool c3_plan(int np, int N, int H, int W, int Ci, int Co, C3Plan* pl) {
     }
   }
   pl->MF = mf; pl->NF = nf; pl->WM = wm; pl->WN = wn; pl->BM = wm * mf * 16; pl->BN = bn;
-  pl->na = (pl->BM + 2 * c3_row_width(W) + 2 + 31) / 32;
+  pl->na = (pl->BM + 2 * c3_row_width(W) + 3 + 31) / 32;      // the staged rows + one spare row (c3_lean.h: C3Stager)
   size_t stage = (size_t)4 * (mf >= 2 ? 2 : 1) * 16 * (nf * 16 + 4) * 4 + 4 * 128 * 4;   // epilogue staging + row offsets
   if (np == 3 && stage < (size_t)C3_EPI_LDS) stage = C3_EPI_LDS;      // ... the bs reduction scratch and the accumulator exchange
   if (np == 3) {            // two A buffers (one for the 512-position tiles), no B stage; behind them the input-BatchNorm table
@@ -818,6 +827,8 @@ static int c3_fill(int np, int N, int H, int W, int Ci, int Co, const float* x, 
 
 // the train-mode option set of a launch (c3_lean.h), or -1: the general kernel
 static int c3_lean_mode(const C3Args& a) {
+  // (tensors are addressed through buffer descriptors with 32-bit byte offsets, pad rows by an offset beyond 2 GB)
+  if ((long)a.N * a.H * a.W * (a.Ci > a.Co ? a.Ci : a.Co) * 4 >= 2147483648L) return -1;
   if (a.bias || a.scale || a.shift || a.relu || a.stats || a.counts || a.bs_part || a.omap || a.in_mean || a.in_invstd) return -1;
   if (a.in_acc.acc && (!a.in_gamma || !a.in_beta)) return -1;
   int m = 0;
@@ -848,6 +859,61 @@ static int c3_group_variant(const C3Plan& pl, int* fam) {
   return -1;
 }
 
+// The persistent form of a train-mode launch (c3_pers.h), taken when the tiles of the launch exceed the resident slots - and only
+// when switched on (buctd_conv3x3_bf16x6_persistent): measured 10-18 % SLOWER than the dispatcher-scheduled one-tile
+// workgroups on the HRNet-W48 shapes, it stays an opt-in for experiments.
+static int c3_persistent_on = 0;
+extern "C" int buctd_conv3x3_bf16x6_persistent(int on) {
+  const int was = c3_persistent_on;
+  if (on >= 0) c3_persistent_on = on ? 1 : 0;
+  return was;
+}
+static int c3_pers_try(int n, const C3Args* a, int lean, hipStream_t stream, bool* done) {
+  if (!c3_persistent_on) return BUCTD_OK;
+  C3Plan pp[C3G_MAX];
+  int order[C3G_MAX], var[C3G_MAX];
+  double cost[C3G_MAX];
+  long tiles = 0;
+  for (int k = 0; k < n; ++k) {
+    if (a[k].Ci < 32 || !c3_plan(3, a[k].N, a[k].H, a[k].W, a[k].Ci, a[k].Co, &pp[k], true)) return BUCTD_OK;
+    tiles += (long)ceil_div(a[k].P, pp[k].BM) * (a[k].Co / pp[k].BN);
+    cost[k] = (double)pp[k].BM * pp[k].BN * a[k].Ci;
+    order[k] = k;
+  }
+  if (tiles <= C3P_SLOTS) return BUCTD_OK;
+  int fam = -1;
+  bool ok = false;
+  for (int f = 0; f < 2 && !ok; ++f) {
+    ok = true;
+    for (int k = 0; k < n && ok; ++k) {
+      fam = f;
+      var[k] = c3_group_variant(pp[k], &fam);
+      ok = var[k] >= 0 && !(f == 0 && var[k] == 0);      // (the single-buffered 448-position tile has no persistent form)
+    }
+  }
+  if (!ok) return BUCTD_OK;
+  for (int i = 1; i < n; ++i)
+    for (int j = i; j > 0 && cost[order[j]] > cost[order[j - 1]]; --j) { const int t = order[j]; order[j] = order[j - 1]; order[j - 1] = t; }
+  C3Group h;
+  h.nconv = n;
+  size_t lds = 0;
+  for (int i = 0; i < n; ++i) {
+    const int k = order[i];
+    h.conv[i] = a[k];
+    h.conv[i].na = pp[k].na;
+    h.gx[i] = ceil_div(a[k].P, pp[k].BM);
+    h.gy[i] = a[k].Co / pp[k].BN;
+    h.tiles[i] = h.gx[i] * h.gy[i];
+    h.variant[i] = var[k];
+    const size_t l = c3p_lds_bytes(pp[k].na, a[k].Ci, pp[k].BN);
+    if (l > lds) lds = l;
+  }
+  for (int i = n; i < C3G_MAX; ++i) h.tiles[i] = h.gx[i] = h.gy[i] = h.variant[i] = 0;
+  if (lds > 160 * 1024) return BUCTD_OK;
+  *done = true;
+  return c3_pers_launch(h, fam, lean, C3P_SLOTS, lds, stream);
+}
+
 // n convolutions (argument blocks a[], tile plans pl[]) as ONE launch: the train-mode kernel of their common option set, else
 // the general group kernel (n > 1 only).  *done = false: the tile shapes have no common kernel family - nothing was launched.
 static int c3_group_launch(int n, const C3Args* a, const C3Plan* pl, hipStream_t stream, bool* done) {
@@ -861,6 +927,11 @@ static int c3_group_launch(int n, const C3Args* a, const C3Plan* pl, hipStream_t
     if (c3_lean_mode(a[k]) != lean) lean = -1;
   }
   if (n == 1 && lean < 0) return BUCTD_OK;
+  if (lean >= 0) {
+    // more than one round of workgroups: the persistent form (a slot walks its tiles as one software pipeline)
+    const int rc = c3_pers_try(n, a, lean, stream, done);
+    if (rc || *done) return rc;
+  }
   // the kernel family that holds the tile shapes of ALL members (128 x 32 tiles exist in both families)
   int fam = -1;
   bool ok = false;

@@ -99,6 +99,14 @@ __device__ __forceinline__ int ring_slot(int r, int ring) {     // r in [0, 2*ri
 // One workgroup's share of a weight gradient: chunk pair (bxc, byc) of ncx x ncy, position split z of nz.  The body of
 // conv3x3_wgrad_split_kernel (one convolution per launch) and of conv3x3_wgrad_group_kernel (the branches of a
 // HighResolutionModule in one launch).
+// Round 6: the staging code is straight-line (cycle stamps of the forward kernel: a wave whose SIMD partner streams MFMAs
+// waits tens of cycles per DEPENDENT instruction, so the passes of a stage must stand side by side in ONE basic block for the
+// scheduler to interleave them) - tensors are read through buffer descriptors (a pad position is an out-of-range offset: the
+// load returns zeros, no select and no branch per row), the pixel arithmetic is branch-free, the input BatchNorm comes from
+// an LDS table instead of four global loads per staged piece; in the main loop the wave id is a scalar (tap and channel
+// fragment of an n-fragment are SALU work) and the X fragment of the next n-fragment is read while the current one is
+// multiplied.
+#define WG_OOB 0x80000000u
 template <int NP, int CF>   // channel fragments (of 16) per chunk: 3 -> 48 channels, 2 -> 32
 __device__ __forceinline__ void wg3_tile(const WG3Args& p, unsigned char* smem, int bxc, int byc, int z, int ncx, int nz) {
   constexpr int KB = WGeo<NP>::KB;
@@ -110,12 +118,15 @@ __device__ __forceinline__ void wg3_tile(const WG3Args& p, unsigned char* smem, 
   constexpr int PP = (WG_PRO * C4 + 255) / 256;  // ... for one prologue round of WG_PRO rows
   constexpr int NFR = 9 * CF;                // n-fragments (tap, ci16)
   constexpr int NW = (NFR + 3) / 4;          // n-fragments per wave
+  constexpr bool WHOLE = KB * C4 == PD * 256;       // a stage is a whole number of passes of the workgroup (NP = 3: always)
 
   const int R = KB + 2 * p.SW + 2;                   // rows of one stage = ring size
   unsigned char* Dt = smem;                          // dY tile [KB][RS]
   unsigned char* Xt = smem + (size_t)KB * RS;        // X  ring [R][RS]
+  float* bntab = reinterpret_cast<float*>(Xt + (size_t)R * RS);     // [3][CH]: mean, invstd * gamma, beta of this ci chunk
 
-  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int t = threadIdx.x, lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
   const int t16 = lane & 15, g = lane >> 4;
   const int co0 = bxc * CH, ci0 = byc * CH;
   // splits get q or q+1 stages (the first `split_rem` ones one more): no split-count rounding loss
@@ -124,75 +135,72 @@ __device__ __forceinline__ void wg3_tile(const WG3Args& p, unsigned char* smem, 
   if (k_end > p.P) k_end = p.P;
   const int halo = p.SW + 1;
   const int ci_lim = p.Ci - ci0;             // input channels this chunk really has (< CH only in a ragged last chunk: zeros beyond)
+  const bool x_bn = p.x_mean != nullptr;
 
-  auto pos_offset = [&](int pp, int C) -> int {   // element offset of pixel pp in an [N][H][W][C] tensor, -1 = pad
-    if (pp < 0 || pp >= p.P) return -1;
+  const __amdgpu_buffer_rsrc_t r_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, (unsigned)p.N * p.H * p.W * p.Ci * 4u, 0x00020000);
+  const __amdgpu_buffer_rsrc_t r_d = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.dy), 0, (unsigned)p.N * p.H * p.W * p.Co * 4u, 0x00020000);
+  typedef unsigned wg_u32x4 __attribute__((ext_vector_type(4)));
+  auto bload = [&](__amdgpu_buffer_rsrc_t r, unsigned off) -> f32x4 {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0));
+  };
+  // byte offset of pixel pp (channel 0) in an [N][H][W][C] tensor, WG_OOB for a pad position (or `ok` false)
+  auto pos_offset = [&](int pp, int C, bool ok) -> unsigned {
     const int n = wg_fast_div(pp, p.ib_mul, p.ib_sh);
     const int rem = pp - n * p.IB;
     const int yy = wg_fast_div(rem, p.sw_mul, p.sw_sh);
     const int xx = rem - yy * p.SW;
-    if (n >= p.N || yy < 1 || xx < 1 || xx > p.W) return -1;
-    return ((n * p.H + yy - 1) * p.W + xx - 1) * C;
+    const bool real = ok & (pp >= 0) & (pp < p.P) & (n < p.N) & (yy >= 1) & (xx >= 1) & (xx <= p.W);
+    return real ? (unsigned)(((n * p.H + yy - 1) * p.W + xx - 1) * C) * 4u : WG_OOB;
   };
-
-  auto bn_in = [&](f32x4 v, int c) -> f32x4 {    // channels ci0 + c .. + 3 of a real pixel
-    if (!p.x_mean) return v;
-    const f32x4 mu = *reinterpret_cast<const f32x4*>(p.x_mean + ci0 + c);
-    const f32x4 is = *reinterpret_cast<const f32x4*>(p.x_invstd + ci0 + c);
-    const f32x4 ga = *reinterpret_cast<const f32x4*>(p.x_gamma + ci0 + c);
-    const f32x4 be = *reinterpret_cast<const f32x4*>(p.x_beta + ci0 + c);
+  // a thread's pieces of a stage: piece q = (row srow[q], channels sc4[q] .. + 3) of the KB rows
+  int srow[PD], sc4[PD];
+#pragma unroll
+  for (int q = 0; q < PD; ++q) {
+    const int idx = t + 256 * q;
+    srow[q] = idx / C4;
+    sc4[q] = (idx - srow[q] * C4) * 4;
+  }
+  auto bn_in = [&](f32x4 v, int c, bool real) -> f32x4 {    // channels ci0 + c .. + 3; zero padding stays zero
+    const f32x4 mu = *reinterpret_cast<const f32x4*>(bntab + c);
+    const f32x4 sc = *reinterpret_cast<const f32x4*>(bntab + CH + c);
+    const f32x4 be = *reinterpret_cast<const f32x4*>(bntab + 2 * CH + c);
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      v[j] = (v[j] - mu[j]) * (is[j] * ga[j]) + be[j];
-      if (p.x_relu) v[j] = fmaxf(v[j], 0.f);
+      const float u = (v[j] - mu[j]) * sc[j] + be[j];
+      const float w = p.x_relu ? fmaxf(u, 0.f) : u;
+      v[j] = real ? w : 0.f;
     }
     return v;
   };
 
   f32x4 dreg[PD], xreg[PD];
-  unsigned dmask = 0, xmask = 0;             // bit q: the row loaded in pass q is a real pixel (else zero row)
+  unsigned xoff[PD];                          // (the BatchNorm form needs to know which rows are padding)
   auto load_d = [&](int k0) {
-    dmask = 0;
 #pragma unroll
     for (int q = 0; q < PD; ++q) {
-      const int idx = t + 256 * q;
-      const int row = idx / C4, c4 = (idx - row * C4) * 4;
-      const int pp = k0 + row;
-      const int o = (row < KB && pp < k_end) ? pos_offset(pp, p.Co) : -1;
-      dmask |= (o >= 0 ? 1u : 0u) << q;
-      dreg[q] = *reinterpret_cast<const f32x4*>(p.dy + (o >= 0 ? o + co0 + c4 : 0));
+      const int pp = k0 + srow[q];
+      dreg[q] = bload(r_d, pos_offset(pp, p.Co, (WHOLE || srow[q] < KB) & (pp < k_end)) + (unsigned)(co0 + sc4[q]) * 4u);
     }
   };
   // X rows rel0 .. rel0 + KB - 1, counted from position k_begin - halo
   auto load_x = [&](int rel0) {
-    xmask = 0;
 #pragma unroll
     for (int q = 0; q < PD; ++q) {
-      const int idx = t + 256 * q;
-      const int row = idx / C4, c4 = (idx - row * C4) * 4;
-      const int o = (row < KB && c4 < ci_lim) ? pos_offset(k_begin - halo + rel0 + row, p.Ci) : -1;
-      xmask |= (o >= 0 ? 1u : 0u) << q;
-      xreg[q] = *reinterpret_cast<const f32x4*>(p.x + (o >= 0 ? o + ci0 + c4 : 0));
+      xoff[q] = pos_offset(k_begin - halo + rel0 + srow[q], p.Ci, (WHOLE || srow[q] < KB) & (sc4[q] < ci_lim));
+      xreg[q] = bload(r_x, xoff[q] + (unsigned)(ci0 + sc4[q]) * 4u);
     }
   };
   auto store_d = [&]() {
 #pragma unroll
-    for (int q = 0; q < PD; ++q) {
-      const int idx = t + 256 * q;
-      const int row = idx / C4, c4 = (idx - row * C4) * 4;
-      if (row < KB)
-        wg_split_store<NP, LO>(Dt + (size_t)row * RS, c4, ((dmask >> q) & 1u) ? dreg[q] : (f32x4){0.f, 0.f, 0.f, 0.f});
-    }
+    for (int q = 0; q < PD; ++q)
+      if (WHOLE || srow[q] < KB) wg_split_store<NP, LO>(Dt + (size_t)srow[q] * RS, sc4[q], dreg[q]);
   };
   auto store_x = [&](int slot0) {            // slot0: ring slot of the first of the KB rows (already reduced mod RING)
 #pragma unroll
-    for (int q = 0; q < PD; ++q) {
-      const int idx = t + 256 * q;
-      const int row = idx / C4, c4 = (idx - row * C4) * 4;
-      if (row < KB)
-        wg_split_store<NP, LO>(Xt + (size_t)ring_slot(slot0 + row, R) * RS, c4,
-                               ((xmask >> q) & 1u) ? bn_in(xreg[q], c4) : (f32x4){0.f, 0.f, 0.f, 0.f});
-    }
+    for (int q = 0; q < PD; ++q)
+      if (WHOLE || srow[q] < KB)
+        wg_split_store<NP, LO>(Xt + (size_t)ring_slot(slot0 + srow[q], R) * RS, sc4[q],
+                               x_bn ? bn_in(xreg[q], sc4[q], xoff[q] != WG_OOB) : xreg[q]);
   };
 
   f32x4 acc[CF][NW];
@@ -206,28 +214,35 @@ __device__ __forceinline__ void wg3_tile(const WG3Args& p, unsigned char* smem, 
   const int lane_row = g * 4 + (t16 >> 2), lane_col = (t16 & 3) * 8;
   const int lane_off = lane_row * RS + lane_col;
 
+  if (x_bn) {
+    for (int c = t; c < CH; c += 256) {
+      const bool in = c < ci_lim;
+      bntab[c] = in ? p.x_mean[ci0 + c] : 0.f;
+      bntab[CH + c] = in ? p.x_invstd[ci0 + c] * p.x_gamma[ci0 + c] : 0.f;
+      bntab[2 * CH + c] = in ? p.x_beta[ci0 + c] : 0.f;
+    }
+    __syncthreads();
+  }
   // first stage: the first R - KB rows (the halo) go in synchronously, WG_PRO rows per round with all loads of a
   // round in flight together; the last KB rows of the first stage travel through the steady-state registers
   if (k_begin < k_end) {
     const int pro = R - KB;                  // = 2*SW + 2 < R: slots 0 .. pro-1, no wrap
     for (int r0 = 0; r0 < pro; r0 += WG_PRO) {
       f32x4 preg[PP];
-      unsigned pmask = 0;
+      unsigned poff[PP];
 #pragma unroll
       for (int q = 0; q < PP; ++q) {
         const int idx = t + 256 * q;
         const int row = idx / C4, c4 = (idx - row * C4) * 4;
-        const int o = (row < WG_PRO && r0 + row < pro && c4 < ci_lim) ? pos_offset(k_begin - halo + r0 + row, p.Ci) : -1;
-        pmask |= (o >= 0 ? 1u : 0u) << q;
-        preg[q] = *reinterpret_cast<const f32x4*>(p.x + (o >= 0 ? o + ci0 + c4 : 0));
+        poff[q] = pos_offset(k_begin - halo + r0 + row, p.Ci, (row < WG_PRO) & (r0 + row < pro) & (c4 < ci_lim));
+        preg[q] = bload(r_x, poff[q] + (unsigned)(ci0 + c4) * 4u);
       }
 #pragma unroll
       for (int q = 0; q < PP; ++q) {
         const int idx = t + 256 * q;
         const int row = idx / C4, c4 = (idx - row * C4) * 4;
         if (row < WG_PRO && r0 + row < pro)
-          wg_split_store<NP, LO>(Xt + (size_t)(r0 + row) * RS, c4,
-                                 ((pmask >> q) & 1u) ? bn_in(preg[q], c4) : (f32x4){0.f, 0.f, 0.f, 0.f});
+          wg_split_store<NP, LO>(Xt + (size_t)(r0 + row) * RS, c4, x_bn ? bn_in(preg[q], c4, poff[q] != WG_OOB) : preg[q]);
       }
     }
     load_d(k_begin);
@@ -236,6 +251,7 @@ __device__ __forceinline__ void wg3_tile(const WG3Args& p, unsigned char* smem, 
   int slot_new = R - KB;                     // ring slot receiving the first of the KB rows held in xreg
   int slot_base = 0;                         // ring slot of position (k0 - halo), tap shift 0
   int rel_next = R;                          // first row (from k_begin - halo) of the stage after this one
+  const bool has_last = wave + 4 * (NW - 1) < NFR;     // (27 n-fragments on four waves: 7 + 7 + 7 + 6)
   for (int k0 = k_begin; k0 < k_end; k0 += KB) {
     __syncthreads();                       // previous stage fully consumed
     store_d();
@@ -247,6 +263,21 @@ __device__ __forceinline__ void wg3_tile(const WG3Args& p, unsigned char* smem, 
     slot_new = ring_slot(slot_new + KB, R);
     rel_next += KB;
     __syncthreads();
+    // X fragment of n-fragment j in k-step ks: tap and channel fragment are scalars (the wave id is), only the ring slot of
+    // the lane's row is vector work; read one n-fragment ahead of its MFMAs, across the k-step boundary
+    const int rb = slot_base + lane_row;
+    bf16x8 b[2][NP];
+    auto read_b = [&](int ks, int j, bf16x8 (&dst)[NP]) {
+      const int nf = wave + 4 * j;
+      const int tap = nf / CF, cf = nf - tap * CF;
+      const int shift = (tap / 3) * p.SW + tap % 3 + ks * 32;      // X row of position k + shift(tap) (the ring starts at -halo)
+      const int r0 = ring_slot(rb + shift, R), r1 = ring_slot(r0 + 16, R);
+      const unsigned char* q0 = Xt + (__umul24(r0, RS) + lane_col + cf * 32);     // 32-bit LDS offsets
+      const unsigned char* q1 = Xt + (__umul24(r1, RS) + lane_col + cf * 32);
+#pragma unroll
+      for (int pc = 0; pc < NP; ++pc) dst[pc] = tr_frag2(q0 + pc * LO, q1 + pc * LO);
+    };
+    read_b(0, 0, b[0]);
 #pragma unroll
     for (int ks = 0; ks < KB / 32; ++ks) {
       bf16x8 a[NP][CF];
@@ -258,19 +289,17 @@ __device__ __forceinline__ void wg3_tile(const WG3Args& p, unsigned char* smem, 
       }
 #pragma unroll
       for (int j = 0; j < NW; ++j) {
-        const int nf = wave + 4 * j;         // (tap, ci16) fragment of this wave
-        if (nf < NFR) {
-          const int tap = nf / CF, cf = nf - tap * CF;
-          const int shift = (tap / 3) * p.SW + tap % 3;      // X row of position k + shift(tap) (the ring starts at -halo)
-          const int r0 = ring_slot(slot_base + lane_row + ks * 32 + shift, R), r1 = ring_slot(r0 + 16, R);
-          const unsigned char* q0 = Xt + (__umul24(r0, RS) + lane_col + cf * 32);     // 32-bit LDS offsets: the 64-bit
-          const unsigned char* q1 = Xt + (__umul24(r1, RS) + lane_col + cf * 32);     // form cost two v_mad_u64_u32 per fragment
-          bf16x8 b[NP];
-#pragma unroll
-          for (int pc = 0; pc < NP; ++pc) b[pc] = tr_frag2(q0 + pc * LO, q1 + pc * LO);
+        const int i = ks * NW + j;                         // flat index over the stage's n-fragments of this wave
+        const bool more = i + 1 < (KB / 32) * NW;
+        if (more) {
+          const int jn = j + 1 < NW ? j + 1 : 0, ksn = j + 1 < NW ? ks : ks + 1;
+          if (jn < NW - 1 || has_last) read_b(ksn, jn, b[(i + 1) & 1]);
+        }
+        if (j < NW - 1 || has_last) {
+          bf16x8 (&bb)[NP] = b[i & 1];
 #define WG_MMA(qa, qb)                                                                                      \
   _Pragma("unroll") for (int mf = 0; mf < CF; ++mf) acc[mf][j] =                                            \
-      __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[qa][mf], b[qb], acc[mf][j], 0, 0, 0);
+      __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[qa][mf], bb[qb], acc[mf][j], 0, 0, 0);
           if constexpr (NP == 3) {
             WG_MMA(2, 0) WG_MMA(0, 2) WG_MMA(1, 1) WG_MMA(1, 0) WG_MMA(0, 1) WG_MMA(0, 0)
           } else {
@@ -441,7 +470,7 @@ static bool wg3_plan(int np, int N, int H, int W, int Ci, int Co, WG3Plan* pl, i
   pl->rem = (int)(stages % want);
   int rs = ch * 2 * np;
   if (rs % 64 != 32) rs += 32;
-  pl->lds = (size_t)(2 * kb + 2 * c3_row_width(W) + 2) * rs;      // dY tile (KB rows) + X ring (KB + 2*SW + 2 rows)
+  pl->lds = (size_t)(2 * kb + 2 * c3_row_width(W) + 2) * rs + (size_t)3 * ch * sizeof(float);   // dY tile (KB rows) + X ring (KB + 2*SW + 2 rows) + input-BatchNorm table
   return pl->lds <= 160 * 1024;
 }
 

@@ -24,7 +24,7 @@ from ._C import ConvDesc, MatmulDesc, check, lib, ptr, stream_ptr
 # scripts) set BUCTD_TUNING=1, and only then buctd_amd/_tuning.py is imported and overrides entries from BUCTD_<NAME>.
 _SW = {"CONV_MATH": "bf16x6", "PREP_BATCH": "1", "GCONV_X6": "1", "GCONV_MASK": "15", "NATIVE_BLOCK": "1", "FUSED_BOTTLENECK": "1",
        "FUSE_BN_IN": "1", "FC_O_X6": "1", "MHA_X6": "1", "MHA_PRESPLIT": "1", "ATTN_X6": "1", "WGRAD_STREAM": "1", "WGRAD_STREAMS": "1",
-       "WGRAD_PRIO": "-1", "BRANCH_STREAMS": "1", "BRANCH_MAX": "2", "BRANCH_PRIO": "0"}
+       "WGRAD_PRIO": "-1", "BRANCH_STREAMS": "1", "BRANCH_MAX": "2", "BRANCH_PRIO": "0", "C3_PERSISTENT": "0"}
 if os.environ.get("BUCTD_TUNING") == "1":
     from . import _tuning
     _tuning.override(_SW)
@@ -581,6 +581,8 @@ def _gconv_fwd(x, w, d, bias, scale, shift, residual, relu, stats):
 
 
 _NATIVE_BLOCK = _SW["NATIVE_BLOCK"] == "1"
+if _SW["C3_PERSISTENT"] == "1":      # experiments: the persistent form of the train-mode 3x3 launches (include/buctd_hip.h)
+    lib().buctd_conv3x3_bf16x6_persistent(1)
 _FUSED_BOTTLENECK = {"on": _SW["FUSED_BOTTLENECK"] == "1"}
 
 

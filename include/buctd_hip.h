@@ -134,6 +134,13 @@ typedef struct {
   void* bn_acc;                                                          /* ... into this accumulator (NULL: none) */
 } buctd_c3_conv;
 int buctd_conv3x3_bf16x6_group(int n, const buctd_c3_conv* convs, void* stream);
+/* Train-mode launches (the option sets of block.hip: statistics accumulator, input BatchNorm from an accumulator, skip
+ * gradient, BatchNorm-backward sums) run kernels specialised on the option set (csrc/conv3x3_lean.hip).  Their PERSISTENT
+ * form (csrc/conv3x3_pers.hip: a grid of resident workgroups, each walking its share of the tiles as one software pipeline
+ * across tile boundaries) is an opt-in: bit-identical results, measured slower than the dispatcher-scheduled launches on
+ * HRNet-W48.  on = 1 / 0 switches it, on < 0 only queries; returns the previous setting.  Process-wide; call
+ * it before launching from several threads. */
+int buctd_conv3x3_bf16x6_persistent(int on);
 int buctd_conv3x3_bf16x3_supported(int N, int H, int W, int Ci, int Co);
 int buctd_conv3x3_bf16x3_stats_groups(int N, int H, int W, int Ci, int Co, int* ngroups, int* rows_per_group);
 size_t buctd_conv3x3_bf16x3_prep_bytes(int Ci, int Co, int flip);

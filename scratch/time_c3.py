@@ -49,10 +49,41 @@ def run(which, stats, reps=60, warm=120):
     return a.elapsed_time(b) / reps * 1e3
 
 
+def check(which):
+    """train-mode launch vs the general kernel: outputs bit for bit, accumulators vs fp64 sums of the output"""
+    for c in ctx:
+        for a_ in c["acc"]:
+            a_.zero_()
+    group(which, False)
+    torch.cuda.synchronize()
+    ref = {}
+    seen = {}
+    for i in which:
+        j = seen.get(i, 0)
+        seen[i] = j + 1
+        ref[(i, j)] = ctx[i]["y"][j].clone()
+        ctx[i]["y"][j].zero_()
+    group(which, True)
+    torch.cuda.synchronize()
+    msg = []
+    for (i, j), r in ref.items():
+        y = ctx[i]["y"][j]
+        Cn = ctx[i]["C"]
+        w = ctx[i]["acc"][j].view(8, 4, Cn).sum(0).double()
+        s1 = w[1] + w[0] * 2.0 ** -48
+        s2 = w[3] + w[2] * 2.0 ** -48
+        yd = y.double().reshape(-1, Cn)
+        e1 = ((s1 - yd.sum(0)).abs() / yd.abs().sum(0)).max().item()
+        e2 = ((s2 - (yd * yd).sum(0)).abs() / (yd * yd).sum(0)).max().item()
+        msg.append(f"{i}.{j}: out equal {torch.equal(y, r)} s1 {e1:.1e} s2 {e2:.1e}")
+    print("   check " + "; ".join(msg), flush=True)
+
+
 sets = [[0], [0, 1], [2, 3], [0, 0], [0, 0, 0, 0], [1], [1, 1, 1, 1], [1, 2], [0, 1, 2, 3]]
 if len(sys.argv) > 3:
     sets = [[int(ch) for ch in a] for a in sys.argv[3:]]
 for which in sets:
+    check(which)
     flops = sum(2.0 * N * ctx[i]["H"] * ctx[i]["W"] * ctx[i]["C"] ** 2 * 9 for i in which)
     t1, t0 = run(which, True), run(which, False)
     print(f"members {which}: train-mode kernel {t1:7.1f} us = {flops / t1 / 1e6 / 416.7:.3f} of the bf16x6 roof | "
