@@ -39,6 +39,48 @@ def _profile_json(name):
         return None
 
 
+def _box_probe_start():
+    """rocm-smi as a child process: shader / memory clock, socket power, temperatures - of the box this line was measured on"""
+    import shutil
+    import subprocess
+    exe = shutil.which("rocm-smi") or "/opt/rocm/bin/rocm-smi"
+    try:
+        return subprocess.Popen([exe, "-d", "0", "--showclocks", "--showpower", "--showtemp", "--json"], stdout=subprocess.PIPE,
+                                stderr=subprocess.DEVNULL, text=True)
+    except OSError:
+        return None
+
+
+def _box_probe_collect(proc):
+    if proc is None:
+        return None
+    try:
+        out, _ = proc.communicate(timeout=20)
+        card = next(iter(json.loads(out).values()))
+    except Exception:      # noqa: BLE001 - a diagnostic, never a reason to lose the bench line
+        return None
+    keep = {}
+    for k, v in card.items():
+        kl = k.lower()
+        if any(w in kl for w in ("sclk", "mclk", "power", "temperature")) and "voltage" not in kl:
+            keep[k] = v
+    return keep or None
+
+
+def _serialised_census(tag):
+    """kernel time per step with every stream serialised, from the committed census of this round (scratch/serial_census.sh)"""
+    name = "r06_kernel_trace_stats_serialised_streams.txt" if tag == "c4" else f"r06_kernel_trace_stats_serialised_streams_{tag}.txt"
+    try:
+        import re
+        txt = open(os.path.join(ROOT, "profiles", name)).read()
+        m = re.search(r"kernel time ([0-9.]+) ms per step", txt)
+        b = re.search(r"serialised streams: ([0-9.]+) ([0-9.]+)", txt)
+        return {"kernel_ms_per_step": float(m.group(1)) if m else None, "ms_per_step": float(b.group(2)) if b else None,
+                "source": "profiles/" + name}
+    except OSError:
+        return None
+
+
 def coam_w48_cfg(batch, colored=True):
     from buctd_amd.config import cfg as base, hrnet_extra
     c = base.clone()
@@ -272,6 +314,174 @@ def roofline_entry(math, batch, kind, in_step, solo, traffic, shape=(48, 96, 72)
                       "trace of this command (sources); avg_launch_us_solo / frac_solo: 60 launches of the same kernel "
                       "alone on the GPU right after the timed steps and 150 warm-up rounds (settled clock)",
             "note": f"binding roof = {bound}: {unit_note}; HBM roof 8 TB/s on {bytes_ / 1e6:.1f} MB/launch"}
+
+
+def _c3conv_array(batch, shapes, tensors, stats):
+    from buctd_amd import _C
+    arr = (_C.C3Conv * len(shapes))()
+    for d, (cw, hh, ww), t in zip(arr, shapes, tensors):
+        d.N, d.H, d.W, d.Ci, d.Co = batch, hh, ww, cw, cw
+        d.x, d.wprep, d.y = t["x"].data_ptr(), t["w"].data_ptr(), t["y"].data_ptr()
+        d.stats_acc = t["acc"].data_ptr() if stats else None
+    return arr
+
+
+def group_launch_probe(batch, rshape, device):
+    """The DOMINANT launch of the step alone on the GPU: the two-member group launch of the forward / data-gradient 3x3
+    convolutions (branches 0 and 1 of a HighResolutionModule: C @ HxW and 2C @ H/2xW/2, equal FLOPs) with the BatchNorm
+    statistics accumulators, and the matching weight-gradient group launch (kernel + slab reduction) - 60 launches each after a
+    warm-up, HIP events on the launching stream.  Also asks the library for the grid of the forward launch, by which the
+    committed kernel trace is searched for the same launch INSIDE the step."""
+    from buctd_amd import _C, ops
+    lib = _C.lib()
+    cw, hh, ww = rshape
+    shapes = [(cw, hh, ww), (2 * cw, hh // 2, ww // 2)]
+    main = torch.cuda.current_stream()
+    ts = []
+    for (c_, h_, w_) in shapes:
+        wt = (torch.randn(c_, c_, 3, 3, device=device) * 0.05).contiguous(memory_format=torch.channels_last)
+        ts.append({"x": torch.randn(batch, h_, w_, c_, device=device), "y": torch.empty(batch, h_, w_, c_, device=device),
+                   "dw": torch.empty(c_, 3, 3, c_, device=device), "w": ops._conv3x3_prepared(wt, 0),
+                   "acc": torch.zeros(int(lib.buctd_bn_acc_bytes(c_)) // 8, dtype=torch.int64, device=device)})
+    arr = _c3conv_array(batch, shapes, ts, True)
+    wgs = int(lib.buctd_conv3x3_bf16x6_group_workgroups(2, arr))
+    wg = (_C.Wg3Conv * 2)()
+    wss = []
+    for it, (c_, h_, w_), t in zip(wg, shapes, ts):
+        ws = torch.empty(int(lib.buctd_conv3x3_wgrad_bf16x6_group_workspace(2, batch, h_, w_, c_, c_)), dtype=torch.uint8, device=device)
+        wss.append(ws)
+        it.N, it.H, it.W, it.Ci, it.Co = batch, h_, w_, c_, c_
+        it.x, it.dy, it.dw, it.accumulate = t["x"].data_ptr(), t["y"].data_ptr(), t["dw"].data_ptr(), 0
+        it.workspace, it.workspace_bytes = ws.data_ptr(), ws.numel()
+
+    def timed(fn, reps=60, warm=120):
+        for _ in range(warm):
+            fn()
+        torch.cuda.synchronize()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record(main)
+        for _ in range(reps):
+            fn()
+        b.record(main)
+        b.synchronize()
+        return a.elapsed_time(b) / reps * 1e3
+
+    fwd_us = timed(lambda: _C.check(lib.buctd_conv3x3_bf16x6_group(2, arr, main.cuda_stream), "group"))
+    wg_us = timed(lambda: _C.check(lib.buctd_conv3x3_wgrad_bf16x6_group(2, wg, main.cuda_stream), "wgrad group"))
+    return {"fwd_us": fwd_us, "wgrad_us": wg_us, "fwd_workgroups": wgs, "shapes": shapes, "launches": 60}
+
+
+def roofline_objects(args, rshape, tag, in_step, solo, grp):
+    """`roofline` = the dominant kernel of the step by time: conv3x3_x6_lean_kernel, the forward / data-gradient launches of the
+    3x3 BasicBlock convolutions (29 % of the kernel time of a step; most of them two-member GROUP launches, the entry's
+    launch); `roofline_wgrad` = the weight-gradient group launch of the same two convolutions (kernel + slab reduction);
+    `roofline_single` = the single-convolution launches of the roofline shape (event-bracketed inside the step, as before).
+    Durations INSIDE the step and the PMC traffic come from this round's committed profiles of this command (file + date
+    quoted; null when absent or when the configuration differs from the profiled one); solo durations are measured live."""
+    cw, hh, ww = rshape
+    quoted = args.conv_math == "bf16x6" and args.batch == 32 and args.condition == "colored"
+    trace = _profile_json(f"r06_in_step_kernel_us_{tag}.json") if quoted else None
+    pmc = _profile_json("r06_pmc_traffic.json") if quoted and rshape == (48, 96, 72) else None
+    k6 = MFMAS_PER_PRODUCT.get(args.conv_math, 6)
+    peak = PEAK_FP32_MFMA_TFLOPS if args.conv_math == "fp32" else PEAK_BF16_MFMA_TFLOPS / k6
+    n = args.batch
+    flops1 = 2.0 * n * hh * ww * cw * cw * 9                      # one convolution (every HRNet branch costs the same)
+    bytes1 = lambda c_, h_, w_: 4.0 * (2 * n * c_ * h_ * w_) + 4.0 * 9 * c_ * c_      # x in, y out (or x, dy in), filter
+
+    def grid_us(name, grid):
+        if not trace:
+            return None
+        rows = [v for k, v in trace["by_grid"].items() if name in k and (grid is None or k.endswith("|" + grid))]
+        if not rows:
+            return None
+        return sum(v["ms_per_step"] for v in rows) / sum(v["calls_per_step"] for v in rows) * 1e3
+
+    def obj(kernel, what, flops, bytes_, us_step, us_solo, launches, traffic, extra=None):
+        mfma_us, hbm_us = flops / (peak * 1e6), bytes_ / (PEAK_HBM_GBPS * 1e3)
+        bound = "mfma" if mfma_us >= hbm_us else "hbm"
+        roof = mfma_us if bound == "mfma" else hbm_us
+        t = us_step or us_solo
+        if not t:
+            return None
+        o = {"kernel": kernel, "launch": what, "bound": bound,
+             "achieved": round(flops / t / 1e6, 2) if bound == "mfma" else round(bytes_ / t / 1e3, 1),
+             "peak": round(peak, 1) if bound == "mfma" else PEAK_HBM_GBPS, "unit": "TFLOP/s" if bound == "mfma" else "GB/s",
+             "frac": round(roof / t, 4), "frac_source": "avg_kernel_us_in_step" if us_step else "avg_launch_us_solo",
+             "avg_kernel_us_in_step": round(us_step, 1) if us_step else None,
+             "frac_in_step_kernel": round(roof / us_step, 4) if us_step else None,
+             "avg_launch_us_solo": round(us_solo, 1) if us_solo else None, "frac_solo": round(roof / us_solo, 4) if us_solo else None,
+             "launches_timed_solo": launches,
+             "traffic": traffic, "traffic_unit": "HBM bytes per launch (PMC: 2 x FETCH_SIZE + WRITE_SIZE, gfx950 correction)" if traffic else None,
+             "algorithmic_flops": flops, "algorithmic_bytes": bytes_,
+             "roof_times_us": {"mfma": round(mfma_us, 2), "hbm": round(hbm_us, 2)},
+             "hbm_gbps": round(bytes_ / t / 1e3, 1), "hbm_frac": round(bytes_ / t / 1e3 / PEAK_HBM_GBPS, 4),
+             "sources": ({"avg_kernel_us_in_step": f"{trace['source']}, {trace['date']}"} if trace and us_step else {}) |
+                        ({"traffic": f"{pmc['source']}, {pmc['date']}"} if pmc and traffic else {}),
+             "note": (f"binding roof = {bound}: dense bf16 MFMA peak 2500 TFLOP/s / {k6} MFMAs per fp32 product = {peak:.1f} "
+                      f"TFLOP/s-equivalent; HBM roof 8 TB/s on {bytes_ / 1e6:.1f} MB/launch.  frac = in-step kernel duration "
+                      "from the committed rocprofv3 trace of this command where available, else the live solo launch; the chip "
+                      "clocks ~1.8-1.9 GHz under a pure MFMA stream (the kernel with everything but its MFMAs removed reaches "
+                      "0.75 of this nominal roof)")}
+        if extra:
+            o.update(extra)
+        return o
+
+    res = {}
+    if args.conv_math != "bf16x6":
+        # the other math modes keep the single-launch entries only
+        def merge(a, b):
+            m = a[1] + b[1]
+            return ((a[0] * a[1] + b[0] * b[1]) / m, m) if m else (None, 0)
+        main = roofline_entry(args.conv_math, args.batch, "fwd", merge(in_step["fwd"], in_step["dgrad"]),
+                              merge(solo["fwd"], solo["dgrad"]), None, rshape, None, None)
+        wg = roofline_entry(args.conv_math, args.batch, "wgrad", in_step["wgrad"], solo["wgrad"], None, rshape, None, None)
+        if main is not None:
+            res["roofline"] = main
+        if wg is not None:
+            res["roofline_wgrad"] = wg
+        return res
+    fam = 0 if cw == 48 else 1
+    shapes = [(cw, hh, ww), (2 * cw, hh // 2, ww // 2)]
+    b2 = sum(bytes1(*sh) for sh in shapes)
+    g_grid = f"{grp['fwd_workgroups'] * 256},1,1" if grp and grp.get("fwd_workgroups") else None
+    us_g = grid_us(f"conv3x3_x6_lean_kernel<{fam},", g_grid) if g_grid else None
+    res["roofline"] = obj(
+        f"conv3x3_x6_lean_kernel<{fam}, option set> (csrc/conv3x3_lean.hip): train-mode 3x3 bf16x6 convolution, forward and data gradient",
+        f"group launch of two BasicBlock convolutions of one HighResolutionModule layer-step: {cw}->{cw} @{hh}x{ww} + "
+        f"{2 * cw}->{2 * cw} @{hh // 2}x{ww // 2}, N={n}, with the BatchNorm accumulator epilogue; grid {g_grid}",
+        2 * flops1, b2, us_g, grp["fwd_us"] if grp else None, grp["launches"] if grp else 0,
+        round(pmc["fwd_group"]["bytes"]) if pmc and "fwd_group" in pmc else None,
+        {"all_launches_in_step": ({"calls_per_step": round(sum(v["calls_per_step"] for k, v in trace["by_grid"].items() if "conv3x3_x6_lean_kernel" in k), 1),
+                                   "ms_per_step": round(sum(v["ms_per_step"] for k, v in trace["by_grid"].items() if "conv3x3_x6_lean_kernel" in k), 3)}
+                                  if trace else None)})
+    us_wg = grid_us("conv3x3_wgrad_group_kernel", "262144,1,1")
+    us_red = grid_us("wg3_reduce_group_kernel", None)
+    if trace and us_red:
+        # the slab reduction that follows the two-member weight-gradient launches: five chunk pairs (1 + 4)
+        us_red = grid_us("wg3_reduce_group_kernel", "86016,5,1") or us_red
+    res["roofline_wgrad"] = obj(
+        f"conv3x3_wgrad_group_kernel<3, {3 if cw == 48 else 2}> + wg3_reduce_group_kernel (csrc/conv3x3_wgrad.hip)",
+        f"weight gradients of the same two convolutions in one launch + their slab reduction, N={n}",
+        2 * flops1, b2, (us_wg + us_red) if (us_wg and us_red) else None, grp["wgrad_us"] if grp else None,
+        grp["launches"] if grp else 0, round(pmc["wgrad_group"]["bytes"]) if pmc and "wgrad_group" in pmc else None)
+
+    def merge(a, b):
+        m = a[1] + b[1]
+        return ((a[0] * a[1] + b[0] * b[1]) / m, m) if m else (None, 0)
+    P_ = n * (hh + 1) * (ww + 1) + ww + 1
+    s_grid = f"{((((P_ + 447) // 448) + 7) // 8) * 8 * 256},1,1" if cw == 48 else None
+    us_s = grid_us(f"conv3x3_x6_lean_kernel<{fam},", s_grid) if s_grid else None
+    single = roofline_entry(args.conv_math, args.batch, "fwd", merge(in_step["fwd"], in_step["dgrad"]),
+                            merge(solo["fwd"], solo["dgrad"]), round((pmc["fwd"]["bytes"] + pmc["dgrad"]["bytes"]) / 2) if pmc and "fwd" in pmc else None,
+                            rshape, round(us_s, 1) if us_s else None,
+                            {"avg_kernel_us_in_step": f"{trace['source']}, {trace['date']}"} if trace and us_s else None)
+    if single is not None:
+        single["kernel"] = (f"conv3x3_x6_lean_kernel<{fam}, option set>, single-convolution launches: 3x3 {cw}->{cw} @{hh}x{ww} N={n} "
+                            "(HRNet branch 0; 448-position tiles, one round of 506 workgroups)")
+        res["roofline_single"] = single
+    for k in [k for k, v in res.items() if v is None]:
+        del res[k]
+    return res
 
 
 def _host_cores(cap=32):
@@ -613,12 +823,22 @@ def main():
     for _ in range(args.warmup):
         step()
     fence()
-    # the timed region runs the engine exactly as shipped: no per-launch events, no step-by-step blocks
+    # the timed region runs the engine exactly as shipped: no per-launch events, no step-by-step blocks.  ONE event per step
+    # on the main stream (read after the fence) gives the spread of the steps; the clock / power probe is a child process
+    # started in the middle of the region (it reads the SMU while the GPU is under THIS load) and collected afterwards.
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
+    probe = None
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for k in range(args.steps):
+        marks[k].record()
+        if k == args.steps // 2 and rank == 0:
+            probe = _box_probe_start()
         step()
+    marks[args.steps].record()
     fence()
     dt = time.perf_counter() - t0
+    step_ms = sorted(marks[k].elapsed_time(marks[k + 1]) for k in range(args.steps))
+    box = _box_probe_collect(probe) if rank == 0 else None
     # separate short pass for the in-step kernel durations: HIP events on the launching stream around the launches of the
     # roofline shape (every 4th BasicBlock of that shape goes through the step-by-step path so that its launches can be
     # bracketed); not part of `value`
@@ -672,6 +892,7 @@ def main():
         backward_ms = round(bw0.elapsed_time(bw1), 2)
         model.bucket_trace = None
     solo = {k: (None, 0) for k in in_step}
+    grp = None
     if not args.no_kernel_timer and rank == 0:
         # the same kernels alone on the GPU: 60 launches each (after 150 warm-up rounds) on a stage-4-branch-0 sized activation with one of the
         # model's own 48 -> 48 filters (forward with the BN-statistics epilogue, as in the step)
@@ -688,6 +909,8 @@ def main():
         torch.cuda.synchronize()
         timer.enabled = False
         solo = {k: timer.mean_us(k) for k in ("fwd", "dgrad", "wgrad")}
+        if args.conv_math == "bf16x6":
+            grp = group_launch_probe(args.batch, rshape, device)
     state["pending"].resolve(losses, acc)
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=device)
@@ -715,6 +938,10 @@ def main():
                        # HIP streams of this rank: main + branch / weight-gradient streams (+ communication under --gpus N)
                        "hip_streams": 1 + len(ops.compute_streams(device)) + (1 if world > 1 or args.one_rank_exchange else 0),
                        "conv_math": args.conv_math, "loss": round(losses.avg, 6)},
+            # is a slow line a slow box or a slow build?  the spread of the timed steps (GPU time between one event per step
+            # on the main stream) and what the SMU reported in the middle of the timed region
+            "step_ms": {"min": round(step_ms[0], 3), "median": round(step_ms[len(step_ms) // 2], 3), "max": round(step_ms[-1], 3)},
+            "box": box,
         }
         if comm_ms is not None:
             out["allreduce_exposed_ms_per_step"] = comm_ms
@@ -724,76 +951,9 @@ def main():
             out["allreduce_buckets"] = {"backward_ms": backward_ms, "rank0": bucket_rows,
                                         "note": "start / end of every bucket's all-reduce on the communication stream, ms after "
                                                 "the backward pass started on the GPU (one extra step behind the timed region)"}
-        def merge(a, b):     # forward and data-gradient launches run the same kernel on the same bytes
-            n = a[1] + b[1]
-            return ((a[0] * a[1] + b[0] * b[1]) / n, n) if n else (None, 0)
-
-        # this round's measurements of the committed build (scratch/r05_profiles.sh), quoted with their file and date: HBM traffic
-        # from the PMC passes (C4 shape only), the kernels' durations INSIDE the step from the kernel trace of this very command -
-        # a census by kernel name AND grid, so that the figure belongs to the roofline shape and to no other launch of the kernel
         tag = {"train_c4": "c4", "train_c3": "c3", "train_c2": "c2"}[args.workload]
-        quoted = args.conv_math == "bf16x6" and args.batch == 32 and args.condition == "colored"
-        pmc = _profile_json("r05_pmc_traffic.json") if quoted and rshape == (48, 96, 72) else None
-        trace = _profile_json(f"r05_in_step_kernel_us_{tag}.json") if quoted else None
-        cw_, hh_, ww_ = rshape
-        P_ = args.batch * (hh_ + 1) * (ww_ + 1) + ww_ + 1             # zero-padded flattened positions (conv3x3.hip)
-        single = {"fwd": ("conv3x3_x6_kernel<7, 3, 4, 1", f"{((P_ + 447) // 448) * 256},1,1") if cw_ == 48 else
-                         ("conv3x3_x6_kernel<4, 2, 4, 1", f"{((P_ + 255) // 256) * 256},1,1"),
-                  "wgrad": ("conv3x3_wgrad_split_kernel<3, %d>" % (3 if cw_ == 48 else 2), "256,1,512"),
-                  "reduce": ("wg3_reduce_kernel<%d>" % (3 if cw_ == 48 else 2), None)}
-
-        def grid_us(name, grid):      # average duration of the launches of `name` with this grid (None: any grid of that name)
-            if not trace:
-                return None
-            rows = [v for k, v in trace["by_grid"].items() if name in k and (grid is None or k.endswith("|" + grid))]
-            if not rows:
-                return None
-            return sum(v["ms_per_step"] for v in rows) / sum(v["calls_per_step"] for v in rows) * 1e3
-
-        def src(kind):
-            out_ = {}
-            if pmc:
-                out_["traffic"] = f"{pmc['source']}, {pmc['date']}"
-            if trace:
-                out_["avg_kernel_us_in_step"] = f"{trace['source']}, {trace['date']}"
-            return out_ or None
-
-        fwd_traffic = None
-        if pmc:
-            fwd_traffic = round((pmc["fwd"]["bytes"] + pmc["dgrad"]["bytes"]) / 2)
-        k_fwd = grid_us(*single["fwd"])
-        k_wg, k_red = grid_us(*single["wgrad"]), grid_us(*single["reduce"])
-        if k_red is not None and trace:
-            # the slab reduction of the roofline shape: its launches follow the weight-gradient launches of that grid one to one
-            red_rows = {k: v for k, v in trace["by_grid"].items() if single["reduce"][0] in k}
-            wg_calls = sum(v["calls_per_step"] for k, v in trace["by_grid"].items()
-                           if single["wgrad"][0] in k and k.endswith("|" + single["wgrad"][1]))
-            best = min(red_rows.values(), key=lambda v: abs(v["calls_per_step"] - wg_calls)) if red_rows else None
-            k_red = best["avg_us"] if best else k_red
-        main = roofline_entry(args.conv_math, args.batch, "fwd", merge(in_step["fwd"], in_step["dgrad"]),
-                              merge(solo["fwd"], solo["dgrad"]), fwd_traffic, rshape,
-                              round(k_fwd, 1) if k_fwd else None, src("fwd"))
-        wg = roofline_entry(args.conv_math, args.batch, "wgrad", in_step["wgrad"], solo["wgrad"],
-                            pmc["wgrad"]["bytes"] if pmc else None, rshape,
-                            round(k_wg + k_red, 1) if (k_wg and k_red) else None, src("wgrad"))
-        # `roofline` = the dominant kernel of the step by time (the 3x3 weight gradient: kernel + slab reduction); the forward /
-        # data-gradient launches of the same shape ride beside it.  Most weight gradients of the step run as GROUP launches
-        # (two branch convolutions of equal FLOPs per launch): their aggregate rate is reported next to the single launches.
-        if wg is not None and trace:
-            g_us = grid_us("conv3x3_wgrad_group_kernel", None)
-            gr_us = grid_us("wg3_reduce_group_kernel", None)
-            if g_us and gr_us:
-                flops2 = 2 * wg["algorithmic_flops"]
-                peak = PEAK_BF16_MFMA_TFLOPS / MFMAS_PER_PRODUCT.get(args.conv_math, 6)
-                wg["group_launches"] = {
-                    "kernel": "conv3x3_wgrad_group_kernel + wg3_reduce_group_kernel: two branch convolutions of one "
-                              "HighResolutionModule layer-step per launch (equal FLOPs, 2 x the roofline launch)",
-                    "avg_kernel_us_in_step": round(g_us + gr_us, 1),
-                    "frac_in_step_kernel": round(flops2 / ((g_us + gr_us) * 1e6) / peak, 4)}
-        if wg is not None:
-            out["roofline"] = wg
-        if main is not None:
-            out["roofline_fwd_dgrad"] = main
+        out["serialised"] = _serialised_census(tag)
+        out.update(roofline_objects(args, rshape, tag, in_step, solo, grp))
         if world == 1 and not args.no_cpu_baseline and args.workload == "train_c4":
             out["cpu_baseline"] = cpu_baseline()
     emit(out, rank, world, in_group=args.one_rank_exchange)

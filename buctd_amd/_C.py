@@ -141,6 +141,7 @@ SIGNATURES = {
     "buctd_gconv_x6_fwd_acc": (_I, [_I] * 6 + [_P] * 6),
     "buctd_conv3x3_bf16x6_group": (_I, [_I, C.POINTER(C3Conv), _P]),
     "buctd_conv3x3_bf16x6_persistent": (_I, [_I]),
+    "buctd_conv3x3_bf16x6_group_workgroups": (_I, [_I, C.POINTER(C3Conv)]),
     "buctd_gconv_wgrad_x6_supported": (_I, [_I] * 6),
     "buctd_gconv_wgrad_x6_workspace": (_SZ, [_I] * 6),
     "buctd_gconv_wgrad_x6": (_I, [_I] * 6 + [_P, _P, _P, _I, _P, _SZ, _P]),

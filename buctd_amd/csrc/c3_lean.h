@@ -76,7 +76,11 @@ __device__ __forceinline__ void c3l_epilogue(const C3Args& p, f32x4 (&acc)[MF][N
   double2* exch = reinterpret_cast<double2*>(smem + C3_EPI_EXCH_OFF);
 
   // byte offset of output row r of this wave (C3_OOB: pad position)
-  const unsigned obytes = (unsigned)p.N * p.H * p.W * p.Co * 4u;
+  // output map (conv_gather_x6.hip; omap = 0: the H x W grid itself): grid pixel (y, x) -> pixel (y * ost + oy0, x * ost + ox0)
+  // of an oH x oW tensor - the parity classes of a stride-2 data gradient
+  const int oH = p.omap ? p.oH : p.H, oW = p.omap ? p.oW : p.W, ost = p.omap ? p.ost : 1;
+  const int oy0 = p.omap ? p.oy0 : 0, ox0 = p.omap ? p.ox0 : 0;
+  const unsigned obytes = (unsigned)p.N * oH * oW * p.Co * 4u;
   const __amdgpu_buffer_rsrc_t r_out = c3_rsrc(p.out, obytes);
   int cnt = 0;
 #pragma unroll
@@ -88,7 +92,7 @@ __device__ __forceinline__ void c3l_epilogue(const C3Args& p, f32x4 (&acc)[MF][N
     const int rem = pp - n * p.IB;
     const int yy = fast_div(rem, p.sw_mul, p.sw_sh), xx = rem - yy * p.SW;
     if ((r < MR) & (pp < p.P) & (n < p.N) & (yy >= 1) & (xx >= 1) & (xx <= p.W))
-      myoff = (unsigned)(((n * p.H + yy - 1) * p.W + xx - 1) * p.Co) * 4u;
+      myoff = (unsigned)(((n * oH + (yy - 1) * ost + oy0) * oW + (xx - 1) * ost + ox0) * p.Co) * 4u;
     if (STATS) cnt += __popcll(__ballot(myoff != C3_OOB));
     if (r < MR) reinterpret_cast<unsigned*>(rowoff)[r] = myoff;
   }

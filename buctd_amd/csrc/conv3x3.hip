@@ -868,7 +868,7 @@ extern "C" int buctd_conv3x3_bf16x6_persistent(int on) {
   if (on >= 0) c3_persistent_on = on ? 1 : 0;
   return was;
 }
-static int c3_pers_try(int n, const C3Args* a, int lean, hipStream_t stream, bool* done) {
+static int c3_pers_try(int n, const C3Args* a, int lean, hipStream_t stream, bool* done, int* dry_wgs) {
   if (!c3_persistent_on) return BUCTD_OK;
   C3Plan pp[C3G_MAX];
   int order[C3G_MAX], var[C3G_MAX];
@@ -911,12 +911,13 @@ static int c3_pers_try(int n, const C3Args* a, int lean, hipStream_t stream, boo
   for (int i = n; i < C3G_MAX; ++i) h.tiles[i] = h.gx[i] = h.gy[i] = h.variant[i] = 0;
   if (lds > 160 * 1024) return BUCTD_OK;
   *done = true;
+  if (dry_wgs) { *dry_wgs = C3P_SLOTS; return BUCTD_OK; }
   return c3_pers_launch(h, fam, lean, C3P_SLOTS, lds, stream);
 }
 
 // n convolutions (argument blocks a[], tile plans pl[]) as ONE launch: the train-mode kernel of their common option set, else
 // the general group kernel (n > 1 only).  *done = false: the tile shapes have no common kernel family - nothing was launched.
-static int c3_group_launch(int n, const C3Args* a, const C3Plan* pl, hipStream_t stream, bool* done) {
+static int c3_group_launch(int n, const C3Args* a, const C3Plan* pl, hipStream_t stream, bool* done, int* dry_wgs = nullptr) {
   *done = false;
   int order[C3G_MAX];
   double cost[C3G_MAX];
@@ -929,7 +930,7 @@ static int c3_group_launch(int n, const C3Args* a, const C3Plan* pl, hipStream_t
   if (n == 1 && lean < 0) return BUCTD_OK;
   if (lean >= 0) {
     // more than one round of workgroups: the persistent form (a slot walks its tiles as one software pipeline)
-    const int rc = c3_pers_try(n, a, lean, stream, done);
+    const int rc = c3_pers_try(n, a, lean, stream, done, dry_wgs);
     if (rc || *done) return rc;
   }
   // the kernel family that holds the tile shapes of ALL members (128 x 32 tiles exist in both families)
@@ -966,6 +967,7 @@ static int c3_group_launch(int n, const C3Args* a, const C3Plan* pl, hipStream_t
   for (int i = n; i < C3G_MAX; ++i) h.tiles[i] = h.gx[i] = h.gy[i] = h.variant[i] = 0;
   if (lds > 160 * 1024) return BUCTD_OK;
   *done = true;
+  if (dry_wgs) { *dry_wgs = (int)(per_xcd * 8); return BUCTD_OK; }
   if (lean >= 0) return c3_lean_launch(h, fam, lean, per_xcd * 8, lds, stream);
   static unsigned char attr_done[2][BUCTD_MAX_DEVICES] = {{0}};
   void (*fn)(C3Group) = fam ? conv3x3_x6_group_kernel<1> : conv3x3_x6_group_kernel<0>;
@@ -1082,10 +1084,7 @@ extern "C" int buctd_conv3x3_bf16x6_bnstat_acc(int N, int H, int W, int Ci, int 
 /* Several 3x3 convolutions in ONE launch (include/buctd_hip.h: buctd_c3_conv): the tiles of all of them in one grid, each
  * computed exactly as its own buctd_conv3x3_bf16x6_acc / _bnstat_acc launch would.  Shapes whose tile plans have no place in
  * a group kernel are launched one after the other instead - the results are the same either way. */
-extern "C" int buctd_conv3x3_bf16x6_group(int n, const buctd_c3_conv* convs, void* stream) {
-  BUCTD_CHECK_ARG(n > 0 && n <= C3G_MAX && convs, "buctd_conv3x3_bf16x6_group: 1..%d convolutions", C3G_MAX);
-  C3Args a[C3G_MAX];
-  C3Plan pl[C3G_MAX];
+static int c3_group_fill(int n, const buctd_c3_conv* convs, C3Args* a, C3Plan* pl) {
   for (int k = 0; k < n; ++k) {
     const buctd_c3_conv& c = convs[k];
     C3InBn ib{nullptr, nullptr, c.in_gamma, c.in_beta, c.in_relu};
@@ -1096,6 +1095,14 @@ extern "C" int buctd_conv3x3_bf16x6_group(int n, const buctd_c3_conv* convs, voi
                            nullptr, nullptr, c.in_bn ? &ib : nullptr, c.bn_acc ? &bs : nullptr, &ac, a[k], pl[k]);
     if (rc) return rc;
   }
+  return BUCTD_OK;
+}
+
+extern "C" int buctd_conv3x3_bf16x6_group(int n, const buctd_c3_conv* convs, void* stream) {
+  BUCTD_CHECK_ARG(n > 0 && n <= C3G_MAX && convs, "buctd_conv3x3_bf16x6_group: 1..%d convolutions", C3G_MAX);
+  C3Args a[C3G_MAX];
+  C3Plan pl[C3G_MAX];
+  if (const int rc0 = c3_group_fill(n, convs, a, pl)) return rc0;
   bool done = false;
   const int rc = c3_group_launch(n, a, pl, (hipStream_t)stream, &done);
   if (rc || done) return rc;
@@ -1106,4 +1113,18 @@ extern "C" int buctd_conv3x3_bf16x6_group(int n, const buctd_c3_conv* convs, voi
     if (rc1) return rc1;
   }
   return BUCTD_OK;
+}
+
+/* The number of workgroups buctd_conv3x3_bf16x6_group(n, convs) launches as ONE kernel (0: the members have no common kernel
+ * and go out one launch each; < 0: error).  No launch - for tools that look a launch up in a kernel trace by its grid. */
+extern "C" int buctd_conv3x3_bf16x6_group_workgroups(int n, const buctd_c3_conv* convs) {
+  BUCTD_CHECK_ARG(n > 0 && n <= C3G_MAX && convs, "buctd_conv3x3_bf16x6_group_workgroups: 1..%d convolutions", C3G_MAX);
+  C3Args a[C3G_MAX];
+  C3Plan pl[C3G_MAX];
+  if (const int rc0 = c3_group_fill(n, convs, a, pl)) return rc0;
+  bool done = false;
+  int wgs = 0;
+  const int rc = c3_group_launch(n, a, pl, nullptr, &done, &wgs);
+  if (rc) return rc;
+  return done ? wgs : 0;
 }

@@ -446,6 +446,8 @@ static void wg_magic(unsigned d, unsigned* mul, unsigned* sh) {
 
 static bool wg3_plan(int np, int N, int H, int W, int Ci, int Co, WG3Plan* pl, int target = 0) {
   if ((np != 2 && np != 3) || c3_row_width(W) > WG_MAX_SW || H < 1 || W < 2) return false;
+  // (x and dy are addressed with 32-bit byte offsets below the out-of-range mark 2^31: wg3_tile)
+  if ((long)N * H * W * (Ci > Co ? Ci : Co) * 4 >= 2147483647L) return false;
   const int kb = np == 3 ? WGeo<3>::KB : WGeo<2>::KB;
   int cf;
   if (Ci % 48 == 0 && Co % 48 == 0) cf = 3;

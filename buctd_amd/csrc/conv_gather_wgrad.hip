@@ -21,7 +21,7 @@
 //   * every wave keeps its own accumulators (taps x CF x CF fragments); at the end the four sets meet in LDS, wave 0 writes
 //     the workgroup's partial slab, and a reduction kernel adds the slabs in a fixed order (deterministic) into dW
 //     ([Co][R][S][Ci]).
-#include "c3_common.h"
+#include "c3_lean.h"
 
 typedef __bf16 gw_bf16x4 __attribute__((ext_vector_type(4)));
 
@@ -82,12 +82,18 @@ __global__ __launch_bounds__(256, 2) void gconv_wgrad_x6_kernel(GwArgs p) {
 #pragma unroll
       for (int nf = 0; nf < CF; ++nf) acc[tp][mf][nf] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  // per k-step and staged row: element offset of the dY row (-1: beyond the last pixel), element offset of the source pixel of
-  // tap offset (0, 0) of this tap group, and one validity bit per tap of the group (bit q * 4 + s)
-  int dyoff[PL], xbase[PL];
+  // per k-step and staged row: BYTE offset of the dY row (C3_OOB beyond the last pixel), byte offset of the source pixel of
+  // tap offset (0, 0) of this tap group, and one validity bit per tap of the group (bit q * 4 + s).  Both tensors are read
+  // through buffer descriptors: an out-of-range offset returns zeros - no select when the piece is split (c3_lean.h)
+  const __amdgpu_buffer_rsrc_t r_x = c3_rsrc(p.x, (unsigned)p.N * p.H * p.W * p.Ci * 4u);
+  const __amdgpu_buffer_rsrc_t r_d = c3_rsrc(p.dy, (unsigned)p.N * p.Ho * p.Wo * p.Co * 4u);
+  unsigned dyoff[PL], xbase[PL];
   unsigned vmask = 0;
   const int ss = p.kind == 2 ? 2 : 1;
   const int dr = p.kind == 2 ? tg - 1 : 0;                       // the group's filter row
+  int sc4[PL];
+#pragma unroll
+  for (int q = 0; q < PL; ++q) sc4[q] = ((lane + 64 * q) % C4) * 4;
   auto decode = [&](int ks) {
     vmask = 0;
 #pragma unroll
@@ -95,45 +101,35 @@ __global__ __launch_bounds__(256, 2) void gconv_wgrad_x6_kernel(GwArgs p) {
       const int row = (lane + 64 * q) / C4;
       const int qq = ks * 32 + row;
       const bool ok = qq < p.Q;
-      const int n = fast_div(ok ? qq : 0, p.hw_mul, p.hw_sh);
-      const int rem = (ok ? qq : 0) - n * (p.Ho * p.Wo);
+      const int n = fast_div(qq, p.hw_mul, p.hw_sh);
+      const int rem = qq - n * (p.Ho * p.Wo);
       const int y = fast_div(rem, p.w_mul, p.w_sh), x = rem - y * p.Wo;
       const int sy = y * ss + dr, sx = x * ss;
-      dyoff[q] = ok ? qq * p.Co : -1;
-      xbase[q] = ((n * p.H + sy) * p.W + sx) * p.Ci;
-      const bool rok = ok && (unsigned)sy < (unsigned)p.H;
+      dyoff[q] = ok ? (unsigned)(qq * p.Co + co0 + sc4[q]) * 4u : C3_OOB;
+      xbase[q] = (unsigned)(((n * p.H + sy) * p.W + sx) * p.Ci + ci0 + sc4[q]) * 4u;
+      const bool rok = ok & ((unsigned)sy < (unsigned)p.H);
 #pragma unroll
       for (int sIdx = 0; sIdx < TPG; ++sIdx) {
         const int cx = sx + (p.kind == 2 ? sIdx - 1 : 0);
-        vmask |= ((rok && (unsigned)cx < (unsigned)p.W) ? 1u : 0u) << (q * 4 + sIdx);
+        vmask |= ((rok & ((unsigned)cx < (unsigned)p.W)) ? 1u : 0u) << (q * 4 + sIdx);
       }
     }
   };
   f32x4 dreg[PL], xreg[PL];
-  unsigned xmask = 0;
   auto load_d = [&]() {
 #pragma unroll
-    for (int q = 0; q < PL; ++q) {
-      const int c4 = ((lane + 64 * q) % C4) * 4;
-      dreg[q] = *reinterpret_cast<const f32x4*>(p.dy + (dyoff[q] >= 0 ? dyoff[q] + co0 + c4 : 0));
-    }
+    for (int q = 0; q < PL; ++q) dreg[q] = c3_bload(r_d, dyoff[q]);
   };
   auto load_x = [&](int sIdx) {      // tap sIdx of the group: source column offset sIdx - 1 (stride 2), 0 (1x1)
-    xmask = 0;
-    const int delta = (p.kind == 2 ? sIdx - 1 : 0) * p.Ci;
+    const int delta = (p.kind == 2 ? sIdx - 1 : 0) * p.Ci * 4;
 #pragma unroll
-    for (int q = 0; q < PL; ++q) {
-      const int c4 = ((lane + 64 * q) % C4) * 4;
-      const bool ok = (vmask >> (q * 4 + sIdx)) & 1u;
-      xmask |= (ok ? 1u : 0u) << q;
-      xreg[q] = *reinterpret_cast<const f32x4*>(p.x + (ok ? xbase[q] + delta + ci0 + c4 : 0));
-    }
+    for (int q = 0; q < PL; ++q) xreg[q] = c3_bload(r_x, ((vmask >> (q * 4 + sIdx)) & 1u) ? xbase[q] + (unsigned)delta : C3_OOB);
   };
-  auto store_tile = [&](unsigned char* T, const f32x4 (&r)[PL], auto okf) {
+  auto store_tile = [&](unsigned char* T, const f32x4 (&r)[PL]) {
 #pragma unroll
     for (int q = 0; q < PL; ++q) {
-      const int row = (lane + 64 * q) / C4, c4 = ((lane + 64 * q) % C4) * 4;
-      split_store_pk<3, LO>(T + row * RS, c4, okf(q) ? r[q] : (f32x4){0.f, 0.f, 0.f, 0.f});
+      const int row = (lane + 64 * q) / C4;
+      split_store_pk<3, LO>(T + row * RS, sc4[q], r[q]);
     }
   };
 
@@ -145,7 +141,7 @@ __global__ __launch_bounds__(256, 2) void gconv_wgrad_x6_kernel(GwArgs p) {
   }
   for (; ks < ks_end; ks += 4) {
     // dY tile of this k-step -> LDS -> A fragments (kept for all taps of the step)
-    store_tile(Dt, dreg, [&](int q) { return dyoff[q] >= 0; });
+    store_tile(Dt, dreg);
     bf16x8 a[3][CF];
 #pragma unroll
     for (int mf = 0; mf < CF; ++mf)
@@ -153,7 +149,7 @@ __global__ __launch_bounds__(256, 2) void gconv_wgrad_x6_kernel(GwArgs p) {
       for (int pc = 0; pc < 3; ++pc) a[pc][mf] = gw_tr_frag(Dt + lane_off + mf * 32 + pc * LO, RS);
 #pragma unroll
     for (int tp = 0; tp < TPG; ++tp) {
-      store_tile(Xt, xreg, [&](int q) { return (xmask >> q) & 1u; });
+      store_tile(Xt, xreg);
       // the next tile's global loads travel under this tap's multiplications
       if (tp + 1 < TPG) load_x(tp + 1);
       else if (ks + 4 < ks_end) {
@@ -274,7 +270,8 @@ static bool gw_plan(int kind, int N, int H, int W, int Ci, int Co, GwPlan* pl) {
   pl->Ho = kind == 2 ? H / 2 : H;
   pl->Wo = kind == 2 ? W / 2 : W;
   const long Q = (long)N * pl->Ho * pl->Wo;
-  if (pl->Wo < 2 || Q >= 2147483647L / 64 || (long)N * H * W * Ci >= 2147483647L || Q * Co >= 2147483647L) return false;
+  // (both tensors are addressed with 32-bit byte offsets below the out-of-range mark 2^31: c3_lean.h)
+  if (pl->Wo < 2 || Q >= 2147483647L / 64 || (long)N * H * W * Ci * 4 >= 2147483647L || Q * Co * 4 >= 2147483647L) return false;
   pl->ksteps = (int)((Q + 31) / 32);
   const int ch = cf * 16;
   const long pairs = (long)(Co / ch) * (Ci / ch);

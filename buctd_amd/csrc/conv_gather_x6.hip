@@ -22,10 +22,12 @@
 //     image in L2 ([step][output channel][32 h | 32 m | 32 l k-slots], built once per weight update by buctd_gconv_x6_prep),
 //     one step ahead.
 // VALU per MFMA: 16 gathered floats per thread and step x ~4 instructions against 72 MFMAs per wave (BN = 96) - under one.
-#include "c3_common.h"
+#include "c3_lean.h"
 #include <string.h>
 
 #define GC_MAXT 9
+// the train-mode epilogue's LDS (c3_lean.h): staging / reduction / exchange at the front of smem (C3_EPI_LDS), its column table behind
+#define GC_TAB_OFF (56 * 1024)
 
 struct GcClass {
   int ntaps, nhs, nsteps;            // taps, half-steps = ntaps * (SC / 16), steps = ceil(nhs / 2)
@@ -44,7 +46,10 @@ struct GcArgs {
   GcClass cls[4];
 };
 
-template <int MF, int NF, int WM, int WN>
+// MODE: -1 = the general epilogue (bias, eval-mode scale / shift, ReLU, partial-sum statistics), else an option set of the
+// train step as a template argument (c3_lean.h: 0 plain, C3M_STATS forward with the statistics accumulator, C3M_RES data gradient
+// with a skip gradient) - the straight-line epilogue of the 3x3 train-mode kernels.
+template <int MF, int NF, int WM, int WN, int MODE>
 __global__ __launch_bounds__(256, 2) void gconv_x6_kernel(GcArgs p) {
   constexpr int BM = WM * MF * 16, BN = WN * NF * 16, ROWB = 96, PST = 32, BROW = 192;
   constexpr int QA = BM / 64;                           // rows per thread and half-step (thread = row t >> 2 + 64 q, float4 t & 3)
@@ -68,27 +73,26 @@ __global__ __launch_bounds__(256, 2) void gconv_x6_kernel(GcArgs p) {
   constexpr bool PRIV = WN == 1;
   constexpr int RSTEP = PRIV ? 16 : 64;
   static_assert(!PRIV || MF * 16 / 16 == QA, "wave-private staging: MF passes of 16 rows == BM / 64");
-  long rowbase[QA];
+  // (branch-free: every pass in ONE basic block - the divisions of the passes interleave; a row outside the grid has no taps)
+  unsigned rowbase[QA];        // BYTE offset of the source pixel of tap offset (0, 0), this thread's channel slot included
   unsigned tapok[QA];
   const int arow = PRIV ? wave * (MF * 16) + (lane >> 2) : (t >> 2), c4 = t & 3;
+  const __amdgpu_buffer_rsrc_t r_src = c3_rsrc(p.src, (unsigned)e.N * p.SH * p.SWd * p.SC * 4u);
 #pragma unroll
   for (int q = 0; q < QA; ++q) {
     const int pp = p0 + arow + RSTEP * q;
-    rowbase[q] = 0;
-    tapok[q] = 0u;
-    if (pp < e.P) {
-      const int n = fast_div(pp, e.ib_mul, e.ib_sh);
-      const int rem = pp - n * e.IB;
-      const int yy = fast_div(rem, e.sw_mul, e.sw_sh), xx = rem - yy * e.SW;
-      if (n < e.N && yy >= 1 && xx >= 1 && xx <= e.W) {
-        const int sy0 = (yy - 1) * p.ss, sx0 = (xx - 1) * p.ss;
-        rowbase[q] = ((long)(n * p.SH + sy0) * p.SWd + sx0) * p.SC + c4 * 4;
-        for (int tp = 0; tp < c.ntaps; ++tp) {
-          const int sy = sy0 + (int)((c.pdy >> (2 * tp)) & 3u) - 1, sx = sx0 + (int)((c.pdx >> (2 * tp)) & 3u) - 1;
-          if ((unsigned)sy < (unsigned)p.SH && (unsigned)sx < (unsigned)p.SWd) tapok[q] |= 1u << tp;
-        }
-      }
+    const int n = fast_div(pp, e.ib_mul, e.ib_sh);
+    const int rem = pp - n * e.IB;
+    const int yy = fast_div(rem, e.sw_mul, e.sw_sh), xx = rem - yy * e.SW;
+    const bool real = (pp < e.P) & (n < e.N) & (yy >= 1) & (xx >= 1) & (xx <= e.W);
+    const int sy0 = (yy - 1) * p.ss, sx0 = (xx - 1) * p.ss;
+    rowbase[q] = (unsigned)(((n * p.SH + sy0) * p.SWd + sx0) * p.SC + c4 * 4) * 4u;
+    unsigned ok = 0u;
+    for (int tp = 0; tp < c.ntaps; ++tp) {
+      const int sy = sy0 + (int)((c.pdy >> (2 * tp)) & 3u) - 1, sx = sx0 + (int)((c.pdx >> (2 * tp)) & 3u) - 1;
+      ok |= (((unsigned)sy < (unsigned)p.SH) & ((unsigned)sx < (unsigned)p.SWd) ? 1u : 0u) << tp;
     }
+    tapok[q] = real ? ok : 0u;
   }
   const unsigned char* wbase = p.wp + c.wp_off + (size_t)(n0 + wave_n * NF * 16 + i16) * BROW + g * 16;
   const size_t wstep = (size_t)e.Co * BROW;
@@ -96,31 +100,24 @@ __global__ __launch_bounds__(256, 2) void gconv_x6_kernel(GcArgs p) {
   // the gathered A pieces travel TWO steps ahead of their MFMAs through two register sets (a step's 72 MFMAs per wave cover
   // ~0.5 us, a gathered L2 / HBM round trip under load takes 1-2 us), the weight fragments (hot in L2) one step ahead
   f32x4 areg[2][2][QA];                     // [set][half-step][row]
-  unsigned aok[2] = {0u, 0u};               // bit h * QA + q: that piece is a real source pixel (else zero)
   bf16x8 bnx[2][3][NF];                     // weight fragments: set st & 1 is multiplied, the other one travels
   int tap = 0, chunk = 0;                   // (tap, chunk) of the next half-step to load
-  // element offset of the current tap relative to tap offset (0, 0) - scalar
-  auto tap_delta = [&](int tp) -> long {
+  // byte offset of the current tap relative to tap offset (0, 0) - scalar
+  auto tap_delta = [&](int tp) -> int {
     const int dy = (int)((c.pdy >> (2 * tp)) & 3u) - 1, dx = (int)((c.pdx >> (2 * tp)) & 3u) - 1;
-    return ((long)dy * p.SWd + dx) * p.SC;
+    return (dy * p.SWd + dx) * p.SC * 4;
   };
-  long cur_delta = tap_delta(0);
-  // Every load is unconditional - a piece outside the source reads the tensor's first pixel and is zeroed when it is stored
-  // (a predicated load merged with zeros made the compiler wait for the data right behind the load: no prefetch at all).
-  auto load_a = [&](int st, f32x4 (&dst)[2][QA], unsigned& okm) {
-    okm = 0u;
+  int cur_delta = tap_delta(0);
+  // Every load is unconditional: a piece outside the source (or past the last half-step) carries an out-of-range offset, the
+  // buffer load returns zeros for it - no select when the piece is split, no mask to carry, 32-bit address arithmetic
+  auto load_a = [&](int st, f32x4 (&dst)[2][QA]) {
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
       const bool live = 2 * st + h < c.nhs;
-      const long d = cur_delta + chunk * 16;
+      const unsigned d = (unsigned)(cur_delta + chunk * 64);
       const unsigned tbit = live ? (1u << tap) : 0u;
 #pragma unroll
-      for (int q = 0; q < QA; ++q) {
-        const bool ok = (tapok[q] & tbit) != 0u;
-        const long off = ok ? rowbase[q] + d : (long)(c4 * 4);
-        dst[h][q] = *reinterpret_cast<const f32x4*>(p.src + off);
-        okm |= (ok ? 1u : 0u) << (h * QA + q);
-      }
+      for (int q = 0; q < QA; ++q) dst[h][q] = c3_bload(r_src, (tapok[q] & tbit) ? rowbase[q] + d : C3_OOB);
       if (live && ++chunk == p.cpt) {
         chunk = 0;
         ++tap;
@@ -136,16 +133,12 @@ __global__ __launch_bounds__(256, 2) void gconv_x6_kernel(GcArgs p) {
       for (int nf = 0; nf < NF; ++nf) dst[q][nf] = *reinterpret_cast<const bf16x8*>(wp + (size_t)nf * 16 * BROW + q * 64);
   };
   constexpr int ABUF = 2 * BM * ROWB;       // one A stage: two half-step tiles
-  auto store_a = [&](const f32x4 (&src)[2][QA], unsigned okm, int buf) {
+  auto store_a = [&](const f32x4 (&src)[2][QA], int buf) {
 #pragma unroll
     for (int h = 0; h < 2; ++h)
 #pragma unroll
-      for (int q = 0; q < QA; ++q) {
-        const bool ok = (okm >> (h * QA + q)) & 1u;
-        const f32x4 v = src[h][q];
-        split_store_pk<3, PST>(smem + (size_t)buf * ABUF + ((size_t)h * BM + arow + RSTEP * q) * ROWB, c4 * 4,
-                            (f32x4){ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f});
-      }
+      for (int q = 0; q < QA; ++q)
+        split_store_pk<3, PST>(smem + (size_t)buf * ABUF + ((size_t)h * BM + arow + RSTEP * q) * ROWB, c4 * 4, src[h][q]);
   };
 
   f32x4 acc[MF][NF];
@@ -164,7 +157,7 @@ __global__ __launch_bounds__(256, 2) void gconv_x6_kernel(GcArgs p) {
     bf16x8 (&bc)[3][NF] = bnx[SET];
     // unconditional on purpose (past the end: dummy pieces, the last weight step again): a skipped load is a merge of old
     // and new register contents, which the compiler resolves with copies that wait for the loads just issued
-    load_a(st + 2, areg[SET], aok[SET]);        // this set's stage st went to LDS during the previous step
+    load_a(st + 2, areg[SET]);        // this set's stage st went to LDS during the previous step
     load_b(st + 1 < c.nsteps ? st + 1 : st, bnx[1 - SET]);
     const unsigned char* ab = abase + SET * ABUF;
     bf16x8 a[2][3];
@@ -188,10 +181,8 @@ __global__ __launch_bounds__(256, 2) void gconv_x6_kernel(GcArgs p) {
       // a quarter of the next stage's split + store behind each fragment's MFMAs
       if (mf < 2 * QA && mf < MF) {
         const int h = mf / QA, q = mf % QA;
-        const bool ok = (aok[1 - SET] >> (h * QA + q)) & 1u;
-        const f32x4 v = areg[1 - SET][h][q];
         split_store_pk<3, PST>(smem + (size_t)(1 - SET) * ABUF + ((size_t)h * BM + arow + RSTEP * q) * ROWB, c4 * 4,
-                            (f32x4){ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f});
+                               areg[1 - SET][h][q]);
       }
       __builtin_amdgcn_sched_barrier(0);
     }
@@ -199,26 +190,25 @@ __global__ __launch_bounds__(256, 2) void gconv_x6_kernel(GcArgs p) {
 #pragma unroll
       for (int i = MF; i < 2 * QA; ++i) {
         const int h = i / QA, q = i % QA;
-        const bool ok = (aok[1 - SET] >> (h * QA + q)) & 1u;
-        const f32x4 v = areg[1 - SET][h][q];
         split_store_pk<3, PST>(smem + (size_t)(1 - SET) * ABUF + ((size_t)h * BM + arow + RSTEP * q) * ROWB, c4 * 4,
-                            (f32x4){ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f});
+                               areg[1 - SET][h][q]);
       }
     }
     if (!PRIV) __syncthreads();        // stage st + 1 is complete, stage st is read
   };
 
-  load_a(0, areg[0], aok[0]);
+  load_a(0, areg[0]);
   load_b(0, bnx[0]);
-  load_a(1, areg[1], aok[1]);
-  store_a(areg[0], aok[0], 0);
+  load_a(1, areg[1]);
+  store_a(areg[0], 0);
   if (!PRIV) __syncthreads();
   for (int st = 0; st < c.nsteps; st += 2) {
     step(st, IC<0>{});
     if (st + 1 < c.nsteps) step(st + 1, IC<1>{});
   }
   __syncthreads();
-  c3_epilogue<MF, NF, WM, WN>(e, acc, smem, bx, by, p0, n0);
+  if constexpr (MODE < 0) c3_epilogue<MF, NF, WM, WN>(e, acc, smem, bx, by, p0, n0);
+  else c3l_epilogue<MF, NF, WM, WN, MODE>(e, acc, smem, reinterpret_cast<float*>(smem + GC_TAB_OFF), p0, n0);
 }
 
 // ---- prepared weight images --------------------------------------------------------------------------------------------
@@ -390,7 +380,7 @@ static bool gc_geo(int kind, int dir, int N, int H, int W, int Ci, int Co, int* 
   const long P = (long)N * (*Hg + 1) * (*Wg + 2) + *Wg + 2;
   const long big = (long)N * H * W * (Ci > Co ? Ci : Co);
   GcPlan pl;
-  return gc_plan(*nout, P, &pl) && P < 2147483647L && big < 2147483647L;
+  return gc_plan(*nout, P, &pl) && P < 2147483647L && big * 4 < 2147483647L;      // (32-bit byte offsets below the out-of-range mark 2^31)
 }
 
 extern "C" int buctd_gconv_x6_supported(int kind, int N, int H, int W, int Ci, int Co, int dir) {
@@ -411,12 +401,16 @@ extern "C" int buctd_gconv_x6_stats_groups(int kind, int N, int H, int W, int Ci
 }
 
 template <int MF, int NF, int WM, int WN>
-static int gc_launch(const GcArgs& a, int tiles, int ncol, hipStream_t st) {
-  constexpr int BM = WM * MF * 16, LD = NF * 16 + 4, EP = MF >= 2 ? 2 : 1;
+static int gc_launch(const GcArgs& a, int tiles, int ncol, hipStream_t st, int mode) {
+  constexpr int BM = WM * MF * 16, BN = WN * NF * 16, LD = NF * 16 + 4, EP = MF >= 2 ? 2 : 1;
   constexpr size_t tile = (size_t)2 * 2 * BM * 96, epi = (size_t)4 * EP * 16 * LD * 4 + 4 * 128 * 4;
   constexpr size_t lds = tile > epi ? tile : epi;
-  static_assert(lds <= 64 * 1024, "gconv_x6: static LDS budget");
-  hipLaunchKernelGGL((gconv_x6_kernel<MF, NF, WM, WN>), dim3(tiles, ncol, a.ncls), dim3(256), lds, st, a);
+  static_assert(lds <= GC_TAB_OFF && C3_EPI_LDS <= GC_TAB_OFF && GC_TAB_OFF + 4 * BN * 4 <= 64 * 1024, "gconv_x6: static LDS budget");
+  const dim3 grid(tiles, ncol, a.ncls);
+  if (mode == C3M_STATS) hipLaunchKernelGGL((gconv_x6_kernel<MF, NF, WM, WN, C3M_STATS>), grid, dim3(256), GC_TAB_OFF + 4 * BN * 4, st, a);
+  else if (mode == C3M_RES) hipLaunchKernelGGL((gconv_x6_kernel<MF, NF, WM, WN, C3M_RES>), grid, dim3(256), GC_TAB_OFF + 4 * BN * 4, st, a);
+  else if (mode == 0) hipLaunchKernelGGL((gconv_x6_kernel<MF, NF, WM, WN, 0>), grid, dim3(256), GC_TAB_OFF + 4 * BN * 4, st, a);
+  else hipLaunchKernelGGL((gconv_x6_kernel<MF, NF, WM, WN, -1>), grid, dim3(256), lds, st, a);
   return BUCTD_OK;
 }
 
@@ -671,10 +665,15 @@ static int gc_run(int kind, int dir, int N, int H, int W, int Ci, int Co, const 
   }
   const int tiles = (e.P + pl.BM - 1) / pl.BM, ncol = nout / pl.BN;
   hipStream_t st = (hipStream_t)stream;
-  if (pl.NF == 3 && pl.WM == 2) gc_launch<4, 3, 2, 2>(a, tiles, ncol, st);
-  else if (pl.NF == 4 && pl.WM == 2) gc_launch<4, 4, 2, 2>(a, tiles, ncol, st);
-  else if (pl.NF == 4) gc_launch<2, 4, 4, 1>(a, tiles, ncol, st);
-  else gc_launch<2, 3, 4, 1>(a, tiles, ncol, st);
+  // the option sets of the train step take the straight-line epilogue (tensors below 2 GB: 32-bit byte offsets)
+  int mode = -1;
+  if (!bias && !scale && !relu && !stats_partials && !(stats_acc && residual) &&
+      (long)N * H * W * (Ci > Co ? Ci : Co) * 4 < 2147483648L)
+    mode = stats_acc ? C3M_STATS : residual ? C3M_RES : 0;
+  if (pl.NF == 3 && pl.WM == 2) gc_launch<4, 3, 2, 2>(a, tiles, ncol, st, mode);
+  else if (pl.NF == 4 && pl.WM == 2) gc_launch<4, 4, 2, 2>(a, tiles, ncol, st, mode);
+  else if (pl.NF == 4) gc_launch<2, 4, 4, 1>(a, tiles, ncol, st, mode);
+  else gc_launch<2, 3, 4, 1>(a, tiles, ncol, st, mode);
   BUCTD_CHECK_LAUNCH(who);
   return BUCTD_OK;
 }

@@ -22,6 +22,8 @@ from ._C import ConvDesc, MatmulDesc, check, lib, ptr, stream_ptr
 
 # Engine switches and their product defaults.  The product reads NO environment variable for them: experiments (scratch/ A/B
 # scripts) set BUCTD_TUNING=1, and only then buctd_amd/_tuning.py is imported and overrides entries from BUCTD_<NAME>.
+# (The only other variables the package looks at are the two test hooks of engine.init_distributed - BUCTD_SINGLE_DEVICE,
+# BUCTD_DIST_BACKEND - documented there.)
 _SW = {"CONV_MATH": "bf16x6", "PREP_BATCH": "1", "GCONV_X6": "1", "GCONV_MASK": "15", "NATIVE_BLOCK": "1", "FUSED_BOTTLENECK": "1",
        "FUSE_BN_IN": "1", "FC_O_X6": "1", "MHA_X6": "1", "MHA_PRESPLIT": "1", "ATTN_X6": "1", "WGRAD_STREAM": "1", "WGRAD_STREAMS": "1",
        "WGRAD_PRIO": "-1", "BRANCH_STREAMS": "1", "BRANCH_MAX": "2", "BRANCH_PRIO": "0", "C3_PERSISTENT": "0"}
@@ -90,9 +92,16 @@ class _AccPool:
         buf = torch.zeros(max(self.CHUNK, nbytes), dtype=torch.uint8, device=device)
         ev = torch.cuda.Event()
         ev.record(cur)
-        st = {"buf": buf, "off": 0, "ev": ev, "stream": cur.cuda_stream, "seen": {cur.cuda_stream}}
+        gen = self.state[device.index]["gen"] + 1 if device.index in self.state else 0
+        st = {"buf": buf, "off": 0, "ev": ev, "stream": cur.cuda_stream, "seen": {cur.cuda_stream}, "gen": gen}
         self.state[device.index] = st
         return st
+
+    def generation(self, device_index):
+        """Counts the rewinds / chunk changes of a device's pool: a slice taken under an older generation has been handed
+        out again (AccRef checks it)."""
+        st = self.state.get(device_index)
+        return st["gen"] if st is not None else -1
 
     def take(self, nbytes, device):
         """-> device address of `nbytes` zero bytes (256-byte aligned), usable on the current stream"""
@@ -117,6 +126,7 @@ class _AccPool:
         cur = torch.cuda.current_stream(device)
         st["buf"][:st["off"]].zero_()
         st["off"] = 0
+        st["gen"] += 1
         ev = torch.cuda.Event()
         ev.record(cur)
         st["ev"], st["stream"], st["seen"] = ev, cur.cuda_stream, {cur.cuda_stream}
@@ -130,13 +140,31 @@ def acc_bytes(Cn):
     return _memo(("accb", Cn), lambda: int(lib().buctd_bn_acc_bytes(Cn)))
 
 
+def step_boundary(device):
+    """Rewind the accumulator pool: every accumulator handed out so far is dead (its consumer ran) and every stream that used
+    one has been joined into the current stream.  The fused optimizers call this from step(); a training loop around any OTHER
+    optimizer (get_optimizer returns None for names the reference does not know either) calls it once per step - without it
+    the pool stays correct but takes, and zero-fills, a fresh 32 MB chunk whenever the current one is used up."""
+    acc_pool.reset(device)
+
+
 class AccRef:
-    """A statistics accumulator of Cn channels taken from the pool (device address only: the pool owns the memory)."""
-    __slots__ = ("ptr", "Cn")
+    """A statistics accumulator of Cn channels taken from the pool (device address only: the pool owns the memory).  `ptr`
+    refuses to serve a reference kept across a rewind of the pool - its slice has been handed out again."""
+    __slots__ = ("_ptr", "Cn", "_dev", "_gen")
 
     def __init__(self, Cn, device, n=1):
         self.Cn = Cn
-        self.ptr = acc_pool.take(n * acc_bytes(Cn), device)
+        self._ptr = acc_pool.take(n * acc_bytes(Cn), device)
+        self._dev = device.index
+        self._gen = acc_pool.generation(device.index)
+
+    @property
+    def ptr(self):
+        if acc_pool.generation(self._dev) != self._gen:
+            raise _C.BuctdHipError("stale statistics accumulator: the pool was rewound (optimizer step / ops.step_boundary) after "
+                                   "this reference was taken")
+        return self._ptr
 
 
 _seed_state = {"seed": None, "counter": 0}

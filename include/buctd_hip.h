@@ -141,6 +141,9 @@ int buctd_conv3x3_bf16x6_group(int n, const buctd_c3_conv* convs, void* stream);
  * HRNet-W48.  on = 1 / 0 switches it, on < 0 only queries; returns the previous setting.  Process-wide; call
  * it before launching from several threads. */
 int buctd_conv3x3_bf16x6_persistent(int on);
+/* The number of workgroups buctd_conv3x3_bf16x6_group(n, convs) launches as ONE kernel (0: the members share no kernel and go
+ * out one launch each; < 0: error).  No launch - for tools that find a launch in a kernel trace by its grid (bench.py). */
+int buctd_conv3x3_bf16x6_group_workgroups(int n, const buctd_c3_conv* convs);
 int buctd_conv3x3_bf16x3_supported(int N, int H, int W, int Ci, int Co);
 int buctd_conv3x3_bf16x3_stats_groups(int N, int H, int W, int Ci, int Co, int* ngroups, int* rows_per_group);
 size_t buctd_conv3x3_bf16x3_prep_bytes(int Ci, int Co, int flip);

@@ -339,3 +339,89 @@ def test_full_size_train_step_vs_oracle(dev, name, tag):
     # the HIP path must be as close to the fp64 truth as the fp32 CPU path is (3x), with floors for a flipped ReLU
     # (DESIGN.md 4): 2e-3 on the median, 2e-2 on the worst tensor - a wiring or scaling error of 2 % in one tensor shows
     assert med_h <= max(3 * med_c, 2e-3) and worst <= max(3 * worst_ref, 2e-2)
+
+
+@pytest.mark.slow
+def test_c4_train_step_at_bench_batch_through_the_engine(dev):
+    """The assembled BASELINE step (config C4 at the scripts' batch 32) through the SHIPPED engine path - engine.DataParallel +
+    flat gradient arena + FusedAdam, group launches and streams on, exactly what bench.py times - against the CPU oracle
+    evaluated here (reference lib/core/function.py:102-175).  Batch 32 selects kernels batch 2 never reaches in one piece: the
+    448-position tiles, the two-family group plans, the 1024 / n weight-gradient splits, the row-streaming 1x1 kernel.
+    Bars: loss 1e-4 relative, output 1e-3 absolute (unit-scale heat maps), the gradients of 24 sampled parameter tensors as
+    close to an fp64 evaluation as the fp32 CPU path is (3x, floors 2e-3 median / 2e-2 worst: a flipped ReLU), and the
+    parameters after the optimizer step against torch.optim.Adam on the oracle's gradients.   ~2 min of CPU: run with --runslow."""
+    import copy
+    from oracle import recipes, core as ocore
+    from buctd_amd import engine
+    from buctd_amd.core.loss import JointsMSELoss
+    B = 32
+    cfg, omodel, x1, joints1 = recipes.build("coam_w48_384x288")
+    g = torch.Generator().manual_seed(321)
+    # 32 different crops from the recipe's image: shifted, scaled copies + noise on the RGB channels
+    xs = []
+    for i in range(B):
+        xi = torch.roll(x1, shifts=(5 * i % 41, 3 * i % 29), dims=(2, 3)) * (1.0 - 0.01 * i)
+        xi[:, :3] += 0.1 * torch.randn(xi[:, :3].shape, generator=g)
+        xs.append(xi)
+    x = torch.cat(xs, 0)
+    joints = joints1.repeat(B, 1, 1).clone()
+    joints[..., :2] += torch.randn(joints[..., :2].shape, generator=g) * 6.0
+    tgt, wt = recipes.make_targets(cfg, joints, 77)
+    m = product_model(cfg, omodel, dev).train()
+    recipes.set_dropout(m, 0.0)
+    model = engine.DataParallel(m)
+    optimizer = engine.get_optimizer(cfg, model)
+    model.flatten()
+    names = [k for k, _ in m.named_parameters()]
+    p0 = {k: p.detach().clone() for k, p in m.named_parameters()}
+    y = model(x.to(dev))
+    loss = JointsMSELoss(True)(y, tgt.to(dev), wt.to(dev))
+    optimizer.zero_grad()
+    loss.backward()
+    torch.cuda.synchronize()
+    grads = {k: p.grad.detach().clone() for k, p in m.named_parameters() if p.grad is not None}
+    optimizer.step()
+    torch.cuda.synchronize()
+    # ---- oracle, fp32 (the reference path) and fp64 (the truth the gradient bar is measured against)
+    o32 = copy.deepcopy(omodel).train()
+    recipes.set_dropout(o32, 0.0)
+    y32 = o32(x)
+    l32 = ocore.JointsMSELoss(True)(y32, tgt, wt)
+    l32.backward()
+    g32 = {k: p.grad.detach() for k, p in o32.named_parameters() if p.grad is not None}
+    g64 = _oracle_grads(omodel, x, tgt, wt, torch.float64)
+    top = float(y32.detach().abs().max())
+    err = float((y.detach().cpu() - y32.detach()).abs().max())
+    print(f"C4 batch {B} through the engine: max|y| {top:.3f}, |hip - oracle| {err:.3e}, loss hip {loss.item():.6f} oracle {l32.item():.6f}")
+    assert err <= BAR * max(1.0, top)
+    assert rel(loss.item(), l32.item()) <= 1e-4
+    # ---- 24 sampled parameter tensors, spread over the network (every 1/24 of the parameter list with a gradient)
+    gmax = max(v.norm().item() for v in g64.values())
+    keys = [k for k in names if k in g64 and g64[k].norm().item() > 1e-6 * gmax]
+    sample = [keys[(i * len(keys)) // 24] for i in range(24)]
+    e_hip = [(grads[k].cpu().double() - g64[k]).norm().item() / g64[k].norm().item() for k in sample]
+    e_cpu = [(g32[k].double() - g64[k]).norm().item() / g64[k].norm().item() for k in sample]
+    med_h, med_c, worst, worst_ref = float(np.median(e_hip)), float(np.median(e_cpu)), max(e_hip), max(e_cpu)
+    print(f"C4 batch {B}: grad rel err vs fp64 over {len(sample)} sampled tensors - median hip {med_h:.2e} / cpu32 {med_c:.2e}; "
+          f"max hip {worst:.2e} ({sample[int(np.argmax(e_hip))]}) / cpu32 {worst_ref:.2e}")
+    assert med_h <= max(3 * med_c, 2e-3) and worst <= max(3 * worst_ref, 2e-2)
+    # ---- the optimizer step.  The first Adam step moves an element by -lr * g / (|g| + 1e-8): ~lr * sign(g) wherever the
+    # gradient is not tiny, and wherever it IS of the size of eps the move turns the gradient's relative error into an error
+    # of the same size - so the bar is the one of the gradients: the engine's move must be as close to the move of the fp64
+    # gradients as torch.optim.Adam's move on the fp32 CPU gradients is (3x, floor 5e-2 of the tensor's move)
+    opt = torch.optim.Adam(o32.parameters(), lr=cfg.TRAIN.LR)
+    opt.step()
+    pn = dict(m.named_parameters())
+    po = dict(o32.named_parameters())
+    lr = float(cfg.TRAIN.LR)
+    worst_move = 0.0
+    for k in sample:
+        dh = (pn[k].detach().cpu() - p0[k].cpu()).double()
+        do = (po[k].detach() - omodel.state_dict()[k]).double()
+        d64 = -lr * g64[k] / (g64[k].abs() + 1e-8)
+        assert float(do.abs().max()) <= 1.001 * lr and float(dh.abs().max()) <= 1.001 * lr, k
+        r_h, r_c = float((dh - d64).norm() / d64.norm()), float((do - d64).norm() / d64.norm())
+        worst_move = max(worst_move, r_h)
+        assert r_h <= max(3 * r_c, 5e-2), (f"{k}: the optimizer step is {r_h:.2e} of its norm from Adam on the fp64 gradients "
+                                            f"(torch.optim.Adam on the fp32 CPU gradients: {r_c:.2e})")
+    print(f"C4 batch {B}: FusedAdam step vs Adam on the fp64 gradients, worst sampled tensor {worst_move:.2e} of the move")
