@@ -49,8 +49,8 @@ static inline size_t c3l_tab_bytes(int Ci, int BN) { return (size_t)3 * Ci * 4 +
 // As c3_epilogue the tile leaves through a per-wave LDS staging slice as 16-byte pieces of contiguous rows; what differs:
 //   * the option set is a template argument: an item is ds_read_b128 + row offset + (residual) + store + its sums;
 //   * forward statistics are summed from the STAGED rows, where a lane holds four columns of one row and pad rows are simply
-//     skipped (no mask arithmetic), around a per-wave, per-column pivot pi = the wave's first accumulator row (any row of the
-//     tile is within a few sigma of the channel mean, so sum (v - pi)^2 keeps the accuracy of a centred sum where a raw
+//     skipped (no mask arithmetic), around a per-wave, per-column pivot pi = the wave's first REAL output row (any real row
+//     is within a few sigma of the channel mean, so sum (v - pi)^2 keeps the accuracy of a centred sum where a raw
 //     sum v^2 loses |mean|^2 / var of it): per lane <= MF terms in fp32, everything after that in fp64 -
 //         sum v = S1 + n pi,   sum v^2 = S2 + 2 pi S1 + n pi^2   - and one exact integer addition per workgroup and channel.
 template <int MF, int NF, int WM, int WN, int MODE>
@@ -83,6 +83,7 @@ __device__ __forceinline__ void c3l_epilogue(const C3Args& p, f32x4 (&acc)[MF][N
   const unsigned obytes = (unsigned)p.N * oH * oW * p.Co * 4u;
   const __amdgpu_buffer_rsrc_t r_out = c3_rsrc(p.out, obytes);
   int cnt = 0;
+  int r0 = -1;          // STATS: the wave's first REAL row (wave-uniform) - the pivot row
 #pragma unroll
   for (int h = 0; h < RH; ++h) {
     unsigned myoff = C3_OOB;
@@ -93,16 +94,34 @@ __device__ __forceinline__ void c3l_epilogue(const C3Args& p, f32x4 (&acc)[MF][N
     const int yy = fast_div(rem, p.sw_mul, p.sw_sh), xx = rem - yy * p.SW;
     if ((r < MR) & (pp < p.P) & (n < p.N) & (yy >= 1) & (xx >= 1) & (xx <= p.W))
       myoff = (unsigned)(((n * oH + (yy - 1) * ost + oy0) * oW + (xx - 1) * ost + ox0) * p.Co) * 4u;
-    if (STATS) cnt += __popcll(__ballot(myoff != C3_OOB));
+    if (STATS) {
+      const unsigned long long vm = __ballot(myoff != C3_OOB);
+      cnt += __popcll(vm);
+      if (r0 < 0 && vm) r0 = 64 * h + __builtin_ctzll(vm);
+    }
     if (r < MR) reinterpret_cast<unsigned*>(rowoff)[r] = myoff;
   }
   const int ncol0 = n0 + wave_n * NF * 16;
   float* piv = tab + wave * (NF * 16);                 // STATS: this wave's pivots
   const float* btab = tab + wave_n * NF * 16;          // BS: column tables of this wave, kinds BN floats apart
   if constexpr (STATS) {
-    if (g == 0) {
+    // pivot = the accumulator row of the wave's first real position (a pad position holds a partial sum - zero in a gathered
+    // convolution - that can be far from the channel mean): accumulator (mf0, nf, rg0) of the lanes of group g0
+    r0 = r0 < 0 ? 0 : r0;
+    const int mf0 = r0 >> 4, g0 = (r0 >> 2) & 3, rg0 = r0 & 3;
+    float pv[NF];
 #pragma unroll
-      for (int nf = 0; nf < NF; ++nf) piv[nf * 16 + i16] = acc[0][nf][0];
+    for (int nf = 0; nf < NF; ++nf) pv[nf] = 0.f;
+#pragma unroll
+    for (int mf = 0; mf < MF; ++mf)
+      if (mf == mf0) {
+#pragma unroll
+        for (int nf = 0; nf < NF; ++nf)
+          pv[nf] = rg0 == 0 ? acc[mf][nf][0] : rg0 == 1 ? acc[mf][nf][1] : rg0 == 2 ? acc[mf][nf][2] : acc[mf][nf][3];
+      }
+    if (g == g0) {
+#pragma unroll
+      for (int nf = 0; nf < NF; ++nf) piv[nf * 16 + i16] = pv[nf];
     }
   }
   __builtin_amdgcn_wave_barrier();             // rowoff, piv: written and read by this wave only (the LDS keeps a wave's order)

@@ -464,9 +464,13 @@ __global__ __launch_bounds__(512, 1) void conv1x1_rows_x6_kernel(R1Args p) {
   const unsigned char* bl = smem + (size_t)i16 * R1_WROW + g * 16;      // this lane's slot inside a 16-row group of the image
   float* stg = reinterpret_cast<float*>(smem + (size_t)KS * Co * R1_WROW + (size_t)wave * R1_STG);
 
-  float s1[NFT], s2[NFT];
+  // BatchNorm statistics of a wave's rows as sums AROUND A PIVOT (the wave's first output row, column by column): a raw fp32
+  // sum of squares loses |mean|^2 / var of its digits; converted to raw sums in fp64 at the end (c3_lean.h: c3l_epilogue)
+  float s1[NFT], s2[NFT], piv[NFT];
 #pragma unroll
-  for (int nf = 0; nf < NFT; ++nf) s1[nf] = s2[nf] = 0.f;
+  for (int nf = 0; nf < NFT; ++nf) s1[nf] = s2[nf] = piv[nf] = 0.f;
+  int nrows = 0;                 // real rows this LANE has added (its four row slots of every fragment)
+  bool first = true;
 
   const int nwaves = gridDim.x * 8;
   int blk = blockIdx.x * 8 + wave;
@@ -525,6 +529,15 @@ __global__ __launch_bounds__(512, 1) void conv1x1_rows_x6_kernel(R1Args p) {
     // epilogue: accumulator (mf, nf, rg) = row blk * 32 + mf * 16 + g * 4 + rg, column nf * 16 + i16.  Statistics from the
     // registers; the tile leaves through this wave's LDS staging slice, 16 rows x 64 columns at a time, so that every lane
     // stores (and reads the residual as) 16-byte pieces of contiguous runs
+    if (first && p.stats_acc) {          // the wave's first block: its first row (always a real one) is the pivot row
+      first = false;
+#pragma unroll
+      for (int nf = 0; nf < NFT; ++nf) piv[nf] = __shfl(acc[0][nf][0] + (p.bias ? p.bias[nf * 16 + i16] : 0.f), i16, 64);
+    }
+#pragma unroll
+    for (int mf = 0; mf < 2; ++mf)
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg) nrows += ((long)blk * 32 + mf * 16 + g * 4 + rg < p.rows) ? 1 : 0;
 #pragma unroll
     for (int mf = 0; mf < 2; ++mf) {
 #pragma unroll
@@ -538,8 +551,9 @@ __global__ __launch_bounds__(512, 1) void conv1x1_rows_x6_kernel(R1Args p) {
             const float v = acc[mf][nf][rg] + bv;
             stg[(g * 4 + rg) * R1_LD + nl * 16 + i16] = v;
             if ((long)blk * 32 + mf * 16 + g * 4 + rg < p.rows) {
-              s1[nf] += v;
-              s2[nf] += v * v;
+              const float d = v - piv[nf];
+              s1[nf] += d;
+              s2[nf] = __builtin_fmaf(d, d, s2[nf]);
             }
           }
         }
@@ -566,10 +580,12 @@ __global__ __launch_bounds__(512, 1) void conv1x1_rows_x6_kernel(R1Args p) {
     double2* exch = reinterpret_cast<double2*>(smem);       // [8 waves][Co]
 #pragma unroll
     for (int nf = 0; nf < NFT; ++nf) {
-      float a1 = s1[nf], a2 = s2[nf];
+      // this lane's rows as raw sums in fp64: sum v = S1 + n pi, sum v^2 = S2 + 2 pi S1 + n pi^2
+      const double pi = (double)piv[nf], nn = (double)nrows;
+      double a1 = (double)s1[nf] + nn * pi, a2 = (double)s2[nf] + 2.0 * pi * (double)s1[nf] + nn * pi * pi;
       a1 += __shfl_xor(a1, 16, 64); a1 += __shfl_xor(a1, 32, 64);
       a2 += __shfl_xor(a2, 16, 64); a2 += __shfl_xor(a2, 32, 64);
-      if (g == 0) exch[wave * Co + nf * 16 + i16] = make_double2((double)a1, (double)a2);
+      if (g == 0) exch[wave * Co + nf * 16 + i16] = make_double2(a1, a2);
     }
     __syncthreads();
     for (int c = t; c < Co; c += 512) {

@@ -169,3 +169,79 @@ def test_pool_hands_out_zeroed_slices_and_rewinds(dev):
         pool.take(256, dev)                         # a second stream is ordered behind the fill once
     assert other.cuda_stream in pool.state[dev.index]["seen"]
     torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("ratio", [1e2, 1e3])
+@pytest.mark.parametrize("case", [(4, 24, 18, 48, 48, 3), (32, 96, 72, 48, 48, 3), (2, 20, 20, 64, 256, 1), (16, 96, 72, 64, 256, 1)])
+def test_statistics_hold_at_large_mean_over_sigma(dev, ratio, case):
+    """|mean| / sigma of the convolution OUTPUT = 1e2 and 1e3 (a bias-like offset on every channel): the sums travel around a
+    per-wave pivot (3x3 kernels) / as fp64 terms and decode as s2 - s1 * mu in fp64, so the variance keeps its digits where a
+    raw fp32 sum of squares would lose |mean|^2 / var of them.  Reference: fp64 statistics of the device's own output."""
+    from buctd_amd import ops
+    N, H, W, Ci, Co, k = case
+    g = torch.Generator().manual_seed(Ci + Co + int(ratio))
+    # an input whose channel 0 is constant makes every output channel carry the offset w[:, 0].sum() * const
+    x = torch.randn(N, Ci, H, W, generator=g) * 0.05
+    x[:, 0] = 1.0
+    w = torch.randn(Co, Ci, k, k, generator=g) * (1.0 / (Ci * k * k) ** 0.5)
+    sig = float(torch.nn.functional.conv2d(x[:1], w, padding=k // 2).std())
+    w[:, 0] = 0.0
+    w[:, 0, k // 2, k // 2] = ratio * sig * (1.0 + 0.1 * torch.randn(Co, generator=g))     # offset = ratio * sigma on every channel
+    z, acc, info = ops.conv_fwd(nhwc(x).to(dev), wcl(w).to(dev), None, 1, k // 2, stats="acc")
+    assert info[0] == "acc"
+    bn = _Bn(Co, dev)
+    bnin = ops.BnAccInput(acc, z.numel() // Co, bn, True)
+    ops.bn_apply_acc(z, bnin, None, False)
+    zd = z.double().cpu().reshape(-1, Co)
+    mu, var = zd.mean(0), zd.var(0, unbiased=False)
+    got_ratio = float((mu.abs() / var.sqrt()).median())
+    assert got_ratio > 0.5 * ratio, f"the case is meant to have |mean| / sigma ~ {ratio:g}, has {got_ratio:.1f}"
+    invstd = 1.0 / torch.sqrt(var + bn.eps)
+    assert ((bnin.mean.double().cpu() - mu).abs() / mu.abs()).max() <= 3e-7
+    # (a raw fp32 sum of squares would be off by ~ratio^2 * 2^-24: 6e-4 at 1e2, 6e-2 at 1e3)
+    assert ((bnin.invstd.double().cpu() - invstd).abs() / invstd).max() <= 2e-5 * max(1.0, ratio / 1e2)
+
+
+def test_nan_in_every_shard_still_decodes_as_nan(dev):
+    """a diverged activation poisons the accumulator copies of ALL XCDs: 4 x 2^61 wraps negative and 8 x 2^61 to zero, so the
+    poison mark must be checked per copy before the copies are added (bn_acc.h: bnacc_gather_lds) - every consumer, not only
+    the convolution prologue, must decode NaN"""
+    from buctd_amd import ops
+    g = torch.Generator().manual_seed(11)
+    x = nhwc(torch.randn(8, 48, 96, 72, generator=g))
+    x[:, ::7, ::5, 3] = float("nan")                 # NaNs in every tile of every image: all eight shards see one
+    w = wcl(torch.randn(48, 48, 3, 3, generator=g) * 0.05).to(dev)
+    bn = _Bn(48, dev)
+    z, acc, info = ops.conv_fwd(x.to(dev), w, None, 1, 1, stats="acc")
+    bnin = ops.BnAccInput(acc, z.numel() // 48, bn, True)
+    y = ops.bn_apply_acc(z, bnin, None, False)
+    torch.cuda.synchronize()
+    assert torch.isnan(bnin.mean).any() and torch.isnan(bnin.invstd).any() and torch.isnan(y).any()
+    assert not torch.isfinite(bn.running_mean).all()
+
+
+def test_wide_batchnorm_takes_the_accumulator_path(dev):
+    """Co = 2048 (ResNet-50 layer4): 90 KB of dynamic LDS in bn_apply_acc - above the 64 KB default limit"""
+    from buctd_amd import ops
+    g = torch.Generator().manual_seed(2048)
+    Ci, Co = 64, 2048
+    x = torch.randn(4, Ci, 8, 6, generator=g)
+    w = torch.randn(Co, Ci, 1, 1, generator=g) * Ci ** -0.5
+    z, acc, info = ops.conv_fwd(nhwc(x).to(dev), wcl(w).to(dev), None, 1, 0, stats="acc")
+    if info[0] != "acc":
+        pytest.skip("this shape does not take the accumulator form")
+    bn = _Bn(Co, dev)
+    bnin = ops.BnAccInput(acc, z.numel() // Co, bn, True)
+    y = ops.bn_apply_acc(z, bnin, None, True)
+    zd = z.double().cpu().reshape(-1, Co)
+    yr = torch.relu((zd - zd.mean(0)) / torch.sqrt(zd.var(0, unbiased=False) + bn.eps) * bn.weight.double().cpu() + bn.bias.double().cpu())
+    assert (y.double().cpu().reshape(-1, Co) - yr).abs().max() <= 2e-5 * max(1.0, yr.abs().max().item())
+
+
+def test_stale_accumulator_reference_is_refused(dev):
+    from buctd_amd import ops, _C
+    a = ops.AccRef(48, dev)
+    _ = a.ptr
+    ops.step_boundary(dev)
+    with pytest.raises(_C.BuctdHipError):
+        _ = a.ptr
