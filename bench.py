@@ -366,9 +366,10 @@ def group_launch_probe(batch, rshape, device):
         b.synchronize()
         return a.elapsed_time(b) / reps * 1e3
 
+    wg_wgs = int(lib.buctd_conv3x3_wgrad_bf16x6_group_workgroups(2, wg))
     fwd_us = timed(lambda: _C.check(lib.buctd_conv3x3_bf16x6_group(2, arr, main.cuda_stream), "group"))
     wg_us = timed(lambda: _C.check(lib.buctd_conv3x3_wgrad_bf16x6_group(2, wg, main.cuda_stream), "wgrad group"))
-    return {"fwd_us": fwd_us, "wgrad_us": wg_us, "fwd_workgroups": wgs, "shapes": shapes, "launches": 60}
+    return {"fwd_us": fwd_us, "wgrad_us": wg_us, "fwd_workgroups": wgs, "wgrad_workgroups": wg_wgs, "shapes": shapes, "launches": 60}
 
 
 def roofline_objects(args, rshape, tag, in_step, solo, grp):
@@ -454,14 +455,15 @@ def roofline_objects(args, rshape, tag, in_step, solo, grp):
         {"all_launches_in_step": ({"calls_per_step": round(sum(v["calls_per_step"] for k, v in trace["by_grid"].items() if "conv3x3_x6_lean_kernel" in k), 1),
                                    "ms_per_step": round(sum(v["ms_per_step"] for k, v in trace["by_grid"].items() if "conv3x3_x6_lean_kernel" in k), 3)}
                                   if trace else None)})
-    us_wg = grid_us("conv3x3_wgrad_group_kernel", "262144,1,1")
+    w_grid = f"{grp['wgrad_workgroups'] * 256},1,1" if grp and grp.get("wgrad_workgroups", 0) > 0 else None
+    us_wg = grid_us("conv3x3_wgrad_group_kernel", w_grid) if w_grid else None
     us_red = grid_us("wg3_reduce_group_kernel", None)
     if trace and us_red:
         # the slab reduction that follows the two-member weight-gradient launches: five chunk pairs (1 + 4)
         us_red = grid_us("wg3_reduce_group_kernel", "86016,5,1") or us_red
     res["roofline_wgrad"] = obj(
         f"conv3x3_wgrad_group_kernel<3, {3 if cw == 48 else 2}> + wg3_reduce_group_kernel (csrc/conv3x3_wgrad.hip)",
-        f"weight gradients of the same two convolutions in one launch + their slab reduction, N={n}",
+        f"weight gradients of the same two convolutions in one launch (grid {w_grid}) + their slab reduction, N={n}",
         2 * flops1, b2, (us_wg + us_red) if (us_wg and us_red) else None, grp["wgrad_us"] if grp else None,
         grp["launches"] if grp else 0, round(pmc["wgrad_group"]["bytes"]) if pmc and "wgrad_group" in pmc else None)
 

@@ -149,6 +149,7 @@ SIGNATURES = {
     "buctd_bn_bwd_acc_group": (_I, [_I, C.POINTER(BnBwdItem), _P]),
     "buctd_conv3x3_wgrad_bf16x6_group_workspace": (_SZ, [_I] * 6),
     "buctd_conv3x3_wgrad_bf16x6_group": (_I, [_I, C.POINTER(Wg3Conv), _P]),
+    "buctd_conv3x3_wgrad_bf16x6_group_workgroups": (_I, [_I, C.POINTER(Wg3Conv)]),
     "buctd_stream_fork": (_I, [_P, _P]),
     "buctd_basic_branches_fwd_train": (_I, [_I, _I, C.POINTER(BasicBlockDesc), _P]),
     "buctd_basic_branches_bwd": (_I, [_I, _I, C.POINTER(BasicBlockDesc), C.POINTER(BasicBlockGrads), _P, _P]),

@@ -555,10 +555,12 @@ static int wg3_run(int np, int N, int H, int W, int Ci, int Co, const float* x, 
 // ---- the weight gradients of several convolutions in one launch (+ one launch for their slab reductions) ----------------
 // A convolution launched alone is cut into 512 position splits so that its ONE round of workgroups fills the chip; every
 // split pays the 2 * SW + 2 halo rows of its first stage and writes (and the reduction re-reads) an 84 KB slab.  n
-// convolutions in one grid fill the chip together: each gets WG3_GROUP_SLOTS / n workgroups, i.e. 1 / n of the halo and slab
-// traffic per convolution - and the launch is more than one round, so prologues and slab stores overlap other main loops.
-#define WG3_GROUP_SLOTS 1024      // 512 / 768 / 1536 / 2048 measured within 3 % of each other (scratch/time_group_wgrad.py)
-static int wg3_group_target(int n) { return WG3_GROUP_SLOTS / n; }
+// convolutions in one grid fill the chip together with fewer splits each, i.e. less halo and slab traffic per convolution.
+// 256 workgroups per member, whatever the number of members (round 6, after the kernel itself got faster the slab share
+// decides: two members 107 us at 2 x 256 against 115 at 2 x 512 and 128 at 2 x 768; three members 165 at 3 x 256 against 191 at
+// 3 x 341 and 217 at 3 x 170; four members 246 at 4 x 256; C4 +0.8 % in an interleaved A/B - scratch/time_group_wgrad.py)
+#define WG3_GROUP_PER_MEMBER 256
+static int wg3_group_target(int n) { (void)n; return WG3_GROUP_PER_MEMBER; }
 
 extern "C" size_t buctd_conv3x3_wgrad_bf16x6_group_workspace(int n, int N, int H, int W, int Ci, int Co) {
   WG3Plan pl;
@@ -609,6 +611,22 @@ extern "C" int buctd_conv3x3_wgrad_bf16x6_group(int n, const buctd_wg3_conv* con
   else hipLaunchKernelGGL(wg3_reduce_group_kernel<2>, rgrid, dim3(256), 0, st, r);
   BUCTD_CHECK_LAUNCH("buctd_conv3x3_wgrad_bf16x6_group (reduce)");
   return BUCTD_OK;
+}
+
+/* The number of workgroups of the weight-gradient kernel buctd_conv3x3_wgrad_bf16x6_group(n, convs) launches (< 0: error; no
+ * launch, no workspace needed) - for tools that look the launch up in a kernel trace by its grid (bench.py). */
+extern "C" int buctd_conv3x3_wgrad_bf16x6_group_workgroups(int n, const buctd_wg3_conv* convs) {
+  BUCTD_CHECK_ARG(n > 0 && n <= WG3G_MAX && convs, "buctd_conv3x3_wgrad_bf16x6_group_workgroups: 1..%d convolutions", WG3G_MAX);
+  long total = 0;
+  for (int k = 0; k < n; ++k) {
+    const buctd_wg3_conv& c = convs[k];
+    WG3Plan pl;
+    BUCTD_CHECK_ARG(wg3_plan(3, c.N, c.H, c.W, c.Ci, c.Co, &pl, n > 1 ? wg3_group_target(n) : 0),
+                    "buctd_conv3x3_wgrad_bf16x6_group_workgroups: unsupported shape");
+    const int ch = pl.CF * 16;
+    total += (long)(c.Co / ch) * ((c.Ci + ch - 1) / ch) * pl.nsplit;
+  }
+  return (int)total;
 }
 
 static size_t wg3_workspace(int np, int N, int H, int W, int Ci, int Co) {

@@ -193,6 +193,8 @@ typedef struct {
 } buctd_wg3_conv;
 size_t buctd_conv3x3_wgrad_bf16x6_group_workspace(int n, int N, int H, int W, int Ci, int Co);
 int buctd_conv3x3_wgrad_bf16x6_group(int n, const buctd_wg3_conv* convs, void* stream);
+/* workgroups of the weight-gradient kernel that call launches (no launch; tools that search a kernel trace by grid: bench.py) */
+int buctd_conv3x3_wgrad_bf16x6_group_workgroups(int n, const buctd_wg3_conv* convs);
 int buctd_conv3x3_wgrad_bf16x3_supported(int N, int H, int W, int Ci, int Co);
 size_t buctd_conv3x3_wgrad_bf16x3_workspace(int N, int H, int W, int Ci, int Co);
 int buctd_conv3x3_wgrad_bf16x3(int N, int H, int W, int Ci, int Co, const float* x, const float* dy, float* dw,

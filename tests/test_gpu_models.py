@@ -405,23 +405,21 @@ def test_c4_train_step_at_bench_batch_through_the_engine(dev):
     print(f"C4 batch {B}: grad rel err vs fp64 over {len(sample)} sampled tensors - median hip {med_h:.2e} / cpu32 {med_c:.2e}; "
           f"max hip {worst:.2e} ({sample[int(np.argmax(e_hip))]}) / cpu32 {worst_ref:.2e}")
     assert med_h <= max(3 * med_c, 2e-3) and worst <= max(3 * worst_ref, 2e-2)
-    # ---- the optimizer step.  The first Adam step moves an element by -lr * g / (|g| + 1e-8): ~lr * sign(g) wherever the
-    # gradient is not tiny, and wherever it IS of the size of eps the move turns the gradient's relative error into an error
-    # of the same size - so the bar is the one of the gradients: the engine's move must be as close to the move of the fp64
-    # gradients as torch.optim.Adam's move on the fp32 CPU gradients is (3x, floor 5e-2 of the tensor's move)
-    opt = torch.optim.Adam(o32.parameters(), lr=cfg.TRAIN.LR)
-    opt.step()
+    # ---- the optimizer step: the first Adam step moves an element by -lr * g / (|g| + 1e-8) (bias-corrected moments of one
+    # gradient).  Held against the engine's OWN gradients (captured before step()), element by element: this pins the flat
+    # arena, the bucket cut and the fused kernel exactly, independent of the gradient noise a flipped ReLU leaves in a tensor
+    # (where |g| is of the size of eps the move amplifies that noise: 18 % of the move for one BatchNorm bias whose gradient is
+    # 1.4e-2 from fp64 - within the gradient bar above, meaningless as a bar on the optimizer)
     pn = dict(m.named_parameters())
-    po = dict(o32.named_parameters())
     lr = float(cfg.TRAIN.LR)
     worst_move = 0.0
-    for k in sample:
+    for k in names:
+        if k not in grads:
+            continue
+        gh = grads[k].double().cpu()
+        want = -lr * gh / (gh.abs() + 1e-8)
         dh = (pn[k].detach().cpu() - p0[k].cpu()).double()
-        do = (po[k].detach() - omodel.state_dict()[k]).double()
-        d64 = -lr * g64[k] / (g64[k].abs() + 1e-8)
-        assert float(do.abs().max()) <= 1.001 * lr and float(dh.abs().max()) <= 1.001 * lr, k
-        r_h, r_c = float((dh - d64).norm() / d64.norm()), float((do - d64).norm() / d64.norm())
-        worst_move = max(worst_move, r_h)
-        assert r_h <= max(3 * r_c, 5e-2), (f"{k}: the optimizer step is {r_h:.2e} of its norm from Adam on the fp64 gradients "
-                                            f"(torch.optim.Adam on the fp32 CPU gradients: {r_c:.2e})")
-    print(f"C4 batch {B}: FusedAdam step vs Adam on the fp64 gradients, worst sampled tensor {worst_move:.2e} of the move")
+        r = float((dh - want).abs().max()) / lr
+        worst_move = max(worst_move, r)
+        assert r <= 2e-3, f"{k}: the optimizer step differs from Adam on the engine's own gradient by {r:.2e} lr"
+    print(f"C4 batch {B}: FusedAdam step vs Adam's formula on the engine's gradients, all {len(grads)} tensors: worst element {worst_move:.2e} lr")
