@@ -232,9 +232,13 @@ def _grad_errors(m, omodel, xin, tgt, wt, dev):
 def test_train_step_at_the_original_seed_differs_by_a_relu_flip_only(dev, name):
     """The goldens of these two nets use recipe seeds other than 1234 (oracle/recipes.py:SEEDS) because at 1234 one
     pre-activation sits within fp32 round-off of zero and lands on different sides of its ReLU in different implementations.
-    The original seed stays a case, under the metric that tells a flip from a bug: the gradients meet the statistical bars on
-    the recipe input, or - a flip being a property of ONE input - the same weights meet them on two perturbed inputs while the
-    recipe input stays an order of magnitude under what a wiring or scaling error produces."""
+    The original seed stays a case, under the metric that tells a flip from a bug: an arithmetic, wiring or scaling defect does
+    not care about 1e-6 of relative noise on the input, a flip does.  scratch/flip_probe.py on these nets (3x2-pixel branches,
+    12 samples per BatchNorm channel): under such noise the worst gradient error of the HIP path, of its exact-fp32 mode AND of
+    the fp32 CPU oracle against fp64 all jump between the fp32 level (5e-5) and 1e-2 .. 1e-1 from copy to copy - about one
+    copy in three carries a flip in any fp32 implementation.  So: the gradients meet the statistical bars on the recipe input,
+    or on at least two of up to seven copies of it with relative noise 1e-6 (same weights), while every evaluated copy keeps
+    its head clean (a flip sits inside the trunk) and stays an order of magnitude under what a defect produces."""
     from oracle import recipes
     cfg, omodel, x, joints = recipes.build(name, seed=1234)
     tgt, wt = recipes.make_targets(cfg, joints, 77)
@@ -244,29 +248,27 @@ def test_train_step_at_the_original_seed_differs_by_a_relu_flip_only(dev, name):
     def bars(mh, mc, wh, wc):
         return mh <= max(3 * mc, 2e-3) and wh <= max(3 * wc, 2e-2)
 
-    mh, mc, wh, wc, wk = _grad_errors(m, omodel, x, tgt, wt, dev)
-    print(f"{name} @ seed 1234: median hip {mh:.2e} / cpu32 {mc:.2e}, worst hip {wh:.2e} at {wk} / cpu32 {wc:.2e}")
-    if bars(mh, mc, wh, wc):
-        return
-    # where the error originates (first tensor beyond the bar in backward order): a flip sits INSIDE the trunk, so the tensors
-    # between it and the loss - at least the head - are clean
-    on = _grad_errors.onset
-    if on is not None:
-        print(f"{name} @ seed 1234: first tensor in backward order beyond the bar: {on[1]} ({on[2]:.2e}); {on[0]} tensors between it "
-              f"and the loss are clean")
-        assert on[0] > 0, f"{name} @ seed 1234: the gradient of the last layer ({on[3]}) is already off"
-    others = []
-    for alt in (1, 2):
-        ga = torch.Generator().manual_seed(9100 + alt)
-        xa = x + 0.25 * torch.randn(x.shape, generator=ga) * (torch.arange(x.shape[1]).view(1, -1, 1, 1) < 3)   # RGB only
-        others.append(_grad_errors(m, omodel, xa, tgt, wt, dev))
-    print(f"{name} @ seed 1234: two perturbed inputs: {others}")
-    assert all(bars(*o[:4]) for o in others), f"{name} @ seed 1234: beyond the bars on perturbed inputs too {others}: not a flipped ReLU"
-    # the discriminator is the line above (a wiring or scaling error does not care which input it sees); the size of a flip's
-    # effect only gets a loose cap: with 12 samples per BatchNorm channel in the 3x2-pixel branch of the CoAM net one flipped
-    # unit moves most gradients by 5-10 % (oracle/recipes.py), measured here 5e-2 median / 0.19 worst against 3e-5 / 1e-3 on
-    # the perturbed inputs
-    assert mh <= 1e-1 and wh <= 5e-1, f"{name} @ seed 1234: median {mh:.2e} / worst {wh:.2e} at {wk}"
+    met, seen = 0, []
+    for k in range(8):
+        xk = x
+        if k:
+            xk = x * (1 + 1e-6 * torch.randn(x.shape, generator=torch.Generator().manual_seed(9100 + k)))
+        mh, mc, wh, wc, wk = _grad_errors(m, omodel, xk, tgt, wt, dev)
+        on = _grad_errors.onset
+        ok = bars(mh, mc, wh, wc)
+        seen.append((k, ok, mh, wh, wk))
+        print(f"{name} @ seed 1234, {'recipe input' if not k else 'noise copy %d' % k}: median hip {mh:.2e} / cpu32 {mc:.2e}, worst hip "
+              f"{wh:.2e} at {wk} / cpu32 {wc:.2e}" + ("" if on is None else f"; first tensor in backward order beyond the bar: "
+              f"{on[1]} ({on[2]:.2e}) after {on[0]} clean ones"))
+        if not ok:
+            # a flip sits INSIDE the trunk: the tensors between it and the loss - at least the head - are clean, and its effect
+            # is bounded (one flipped unit moves most gradients of the 3x2-pixel branch by 5-10 %: oracle/recipes.py)
+            assert on is None or on[0] > 0, f"{name} @ seed 1234: the gradient of the last layer ({on[3]}) is already off"
+            assert mh <= 1e-1 and wh <= 5e-1, f"{name} @ seed 1234: median {mh:.2e} / worst {wh:.2e} at {wk}"
+        met += ok
+        if (k == 0 and ok) or met >= 2:
+            return
+    raise AssertionError(f"{name} @ seed 1234: the bars are met on {met} of {len(seen)} noise copies {seen}: not a flipped ReLU")
 
 
 @pytest.mark.parametrize("name", FULL)
