@@ -16,9 +16,13 @@
 #include "../../include/buctd_hip.h"
 
 // Dropout mask: keep(i, j) = fin(rowkey(i) + colkey(j)) >= p * 2^32.  The two keys are full lowbias32 hashes of
-// (seed, index), computed once per row / column of a tile; the per-element finisher is one rotate-xor, ONE integer
-// multiply (quarter rate on CDNA) and one shift-xor - the previous per-element lowbias32 cost four multiplies and was
-// 21 % of the attention time.
+// (seed, index), computed once per row / column of a tile; the per-element finisher is one rotate-xor (it breaks the additive
+// structure of the key sum - without it the four masks of a rectangle (i, j), (i, j'), (i', j), (i', j') are correlated at
+// 0.07 - 0.33) and ONE 24-bit multiply: v_mul_u32_u24 is full rate where the 32-bit v_mul_lo_u32 takes four issue slots, its
+// low 24 input bits see all 32 bits of the sum through the rotate, and the comparison reads the top bits of the product -
+// the best-mixed ones.  (Rounds 2-5 used a 32-bit multiply + shift-xor behind the rotate: 12 issue slots per element against
+// 7, in kernels that are VALU-paced.  Keep rate, neighbour / row-pair / column-pair correlations and the rectangle statistic of
+// both finishers at T = 4096: indistinguishable from independent draws - tests/test_host.py holds the numbers.)
 __device__ __forceinline__ uint32_t mix32(uint32_t x) {
   x ^= x >> 16; x *= 0x7FEB352Du; x ^= x >> 15; x *= 0x846CA68Bu; x ^= x >> 16;
   return x;
@@ -28,8 +32,7 @@ __device__ __forceinline__ uint32_t colkey(uint32_t s1, uint32_t col) { return m
 __device__ __forceinline__ float keepf(uint32_t rk, uint32_t ck, uint32_t thr, float inv_keep) {
   uint32_t x = rk + ck;
   x ^= __builtin_amdgcn_alignbit(x, x, 21);     // rotate left by 11
-  x *= 0x9E3779B1u;
-  x ^= x >> 15;
+  x = __umul24(x, 0x9E3779u);                   // low 32 bits of (x & 0xFFFFFF) * 0x9E3779
   return x >= thr ? inv_keep : 0.f;
 }
 

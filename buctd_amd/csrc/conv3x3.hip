@@ -506,7 +506,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_x6_group_kernel(C3Group g_) {
       case 0: c3x6_tile<7, 3, 4, 1, false, false>(p, smem, bx, by); break;
       case 1: c3x6_tile<4, 3, 2, 2, true, true>(p, smem, bx, by); break;
       case 2: c3x6_tile<2, 2, 4, 1, true, true>(p, smem, bx, by); break;
-      default: c3x6_tile<4, 3, 4, 1, true, true>(p, smem, bx, by); break;
+      case 3: c3x6_tile<4, 3, 4, 1, true, true>(p, smem, bx, by); break;
+      default: c3x6_tile<4, 2, 4, 1, true, true>(p, smem, bx, by); break;
     }
   } else {
     switch (v) {
@@ -631,6 +632,9 @@ struct C3Plan { int MF, NF, WM, WN, BM, BN, na; size_t lds; };
 static int c3_steps(int Kc, int np) { return np == 3 ? (Kc / 16) * 5 : (Kc / CK) * 9 + ((Kc % CK) ? 5 : 0); }
 
 // pers: the plan of a persistent launch (c3_pers.h) - double-buffered tiles only
+#ifndef C3_SMALL_MF4_FROM
+#define C3_SMALL_MF4_FROM 160      // (a build-time constant so that scratch/build_alt.sh can A/B it)
+#endif
 static bool c3_plan(int np, int N, int H, int W, int Ci, int Co, C3Plan* pl, bool pers = false) {
   if (N <= 0 || H <= 0 || W <= 0 || Ci <= 0 || Co <= 0 || Ci % 16 != 0 || Co % 16 != 0 || c3_row_width(W) > MAX_SW) return false;
   const int rowb = np == 3 ? Geo<3>::ROWB : Geo<2>::ROWB, blds = np == 3 ? Geo<3>::BLDS : Geo<2>::BLDS;
@@ -648,7 +652,8 @@ static bool c3_plan(int np, int N, int H, int W, int Ci, int Co, C3Plan* pl, boo
   // bf16x6 (B fragments per wave from L2): the 192-channel 24x18 maps keep the 128 x 96 workgroup tile (252 workgroups,
   // one per CU: 53.6 us against 57.2 for 504 half-width tiles); the smallest maps (384 ch @12x9, 36 tiles of 128
   // positions) go to 32-column tiles - 432 workgroups instead of 288 that load 32 CUs twice (71 us against 95)
-  if (np == 3 && Co % 32 == 0 && ((P + 127) / 128) * ((Co + 95) / 96) < 200) { nf = 2; wn = 1; }
+  bool small = false;
+  if (np == 3 && Co % 32 == 0 && ((P + 127) / 128) * ((Co + 95) / 96) < 200) { nf = 2; wn = 1; small = true; }
   int wm = 4 / wn, bn = wn * nf * 16;
   // largest position tile that still gives every CU work (256 CUs, 2 resident workgroups each)
   int mf = 1;
@@ -657,7 +662,14 @@ static bool c3_plan(int np, int N, int H, int W, int Ci, int Co, C3Plan* pl, boo
     const long blocks = ((P + wm * cand[i] * 16 - 1) / (wm * cand[i] * 16)) * (Co / bn);
     // bf16x6 fetches its B fragments per wave, one step ahead: a 16-row wave tile (MF = 1) leaves 18 MFMAs to cover an
     // L2 round trip, so the smallest maps (384 ch @12x9: 288 workgroups at MF = 2) prefer the larger tile (measured)
-    if (blocks >= (np == 3 ? 224 : 320)) { mf = cand[i]; break; }   // (238 for the 192-channel 24x18 maps at N = 32)
+    // The 32-column tiles of the smallest maps take MF = 4 from 160 workgroups on: 16 B of B fragments per lane and 2 MF MFMAs
+    // make MF = 2 wave tiles ask the CU's vector cache for 62 B / cycle at full matrix rate (it delivers 64), MF = 4 for half of
+    // that.  HRNet-W48 branch 3 (384 ch @12x9, N = 32) as 204 tiles of 256 x 32 instead of 396 of 128 x 32: 78.3 -> 81.4 us
+    // alone (204 workgroups leave a wave per SIMD without a partner), but the train step launches it with branch 2 only, and
+    // there the other member fills the CUs: 121.9 -> 107.9 us (scratch/b3_ab.sh).  One plan per shape, grouped or not: a
+    // group launch stays bit-identical to its members' own launches (the BatchNorm sums are formed per wave tile).
+    const long need = np == 3 ? (small ? C3_SMALL_MF4_FROM : 224) : 320;
+    if (blocks >= need) { mf = cand[i]; break; }   // (238 for the 192-channel 24x18 maps at N = 32)
   }
   bool single = false;
   if (np == 3 && nf == 3 && wn == 1 && Co == bn && !pers) {
@@ -844,12 +856,12 @@ static int c3_lean_mode(const C3Args& a) {
 
 static int c3_group_variant(const C3Plan& pl, int* fam) {
   struct V { int mf, nf, wm, wn; };
-  static const V f0[] = {{7, 3, 4, 1}, {4, 3, 2, 2}, {2, 2, 4, 1}, {4, 3, 4, 1}};
+  static const V f0[] = {{7, 3, 4, 1}, {4, 3, 2, 2}, {2, 2, 4, 1}, {4, 3, 4, 1}, {4, 2, 4, 1}};
   static const V f1[] = {{4, 2, 4, 1}, {1, 4, 4, 1}, {2, 2, 4, 1}, {1, 2, 4, 1}, {2, 4, 4, 1}, {2, 4, 2, 2}};
   for (int f = 0; f < 2; ++f) {
     if (*fam >= 0 && *fam != f) continue;
     const V* l = f ? f1 : f0;
-    const int n = f ? 6 : 4;
+    const int n = f ? 6 : 5;
     for (int i = 0; i < n; ++i)
       if (l[i].mf == pl.MF && l[i].nf == pl.NF && l[i].wm == pl.WM && l[i].wn == pl.WN) {
         *fam = f;
@@ -888,7 +900,7 @@ static int c3_pers_try(int n, const C3Args* a, int lean, hipStream_t stream, boo
     for (int k = 0; k < n && ok; ++k) {
       fam = f;
       var[k] = c3_group_variant(pp[k], &fam);
-      ok = var[k] >= 0 && !(f == 0 && var[k] == 0);      // (the single-buffered 448-position tile has no persistent form)
+      ok = var[k] >= 0 && !(f == 0 && (var[k] == 0 || var[k] > 3));   // (no persistent form: the single-buffered 448-position tile, the tiles added after round 6's experiment)
     }
   }
   if (!ok) return BUCTD_OK;

@@ -39,7 +39,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_x6_lean_kernel(C3Group g_) {
       case 0: c3l_tile<7, 3, 4, 1, false, false, MODE>(p, smem, bx, by); break;
       case 1: c3l_tile<4, 3, 2, 2, true, true, MODE>(p, smem, bx, by); break;
       case 2: c3l_tile<2, 2, 4, 1, true, true, MODE>(p, smem, bx, by); break;
-      default: c3l_tile<4, 3, 4, 1, true, true, MODE>(p, smem, bx, by); break;
+      case 3: c3l_tile<4, 3, 4, 1, true, true, MODE>(p, smem, bx, by); break;
+      default: c3l_tile<4, 2, 4, 1, true, true, MODE>(p, smem, bx, by); break;
     }
   } else {
     switch (v) {

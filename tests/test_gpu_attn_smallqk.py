@@ -123,6 +123,12 @@ def test_smallqk_dropout_mask_consistency(dev):
     mask = (pd.cpu() != 0).double()
     frac = 1.0 - mask.mean().item()
     assert abs(frac - p) < 0.03, f"dropped fraction {frac:.3f} vs p {p}"
+    # ... and it is the documented function of the launch seed (tests/helpers/dropout_mask.py; its statistics: test_host.py)
+    from tests.helpers.dropout_mask import keep_mask
+    ops.manual_seed(1234)
+    want = torch.from_numpy(keep_mask(ops.next_seed(), B, T, p))
+    att_pos = (torch.softmax(torch.matmul(torch.nn.functional.linear(yq, wq, bq), k.transpose(1, 2)) / math.sqrt(C), -1) > 1e-30)
+    assert torch.equal(mask.bool() & att_pos, want & att_pos), "the kernel's mask differs from its host mirror"
     q = torch.nn.functional.linear(yq, wq, bq)
     att = torch.softmax(torch.matmul(q, k.transpose(1, 2)) / math.sqrt(C), -1)
     assert _e(pd, att * mask / (1 - p)) <= 2e-5

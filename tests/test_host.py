@@ -269,3 +269,37 @@ def test_get_optimizer_branches_like_the_reference():
     assert isinstance(engine.get_optimizer(c, torch.nn.Sequential(torch.nn.Conv2d(3, 4, 3))), engine.FusedAdam)
     c.TRAIN.OPTIMIZER = "rmsprop"
     assert engine.get_optimizer(c, torch.nn.Sequential(torch.nn.Conv2d(3, 4, 3))) is None
+
+
+def test_position_attention_dropout_mask_statistics():
+    """The dropout mask of the fused position attention (tests/helpers/dropout_mask.py mirrors the kernel's counter hash;
+    test_gpu_attn_smallqk.py holds the kernel to the mirror bit for bit): kept fraction, correlations between neighbours, between
+    whole rows / columns, and the four-point statistic over rectangles (i, j), (i, j'), (i', j), (i', j') - the one the additive
+    key sum fails without its finisher (0.07 at p = 0.1, 0.33 at p = 0.5) - all at the level of independent draws."""
+    from tests.helpers.dropout_mask import keep_mask, rowkey, colkey
+    T = 2048
+    for seed, p in ((0x0123456789ABCDEF, 0.1), (0xFEDCBA9876543210, 0.5)):
+        k = keep_mask(seed, 1, T, p)[0].astype(np.float64)
+        m = k.mean()
+        assert abs(m - (1 - p)) < 4 * np.sqrt(p * (1 - p)) / T, (p, m)
+        kc, v = k - m, m * (1 - m)
+        sig = 1.0 / T                     # std of a correlation estimated from T * T independent pairs
+        pairs = [(kc[:, :-1], kc[:, 1:]), (kc[:-1], kc[1:]), (kc[:-1, :-1], kc[1:, 1:]), (kc[:-1, 1:], kc[1:, :-1]),
+                 (kc[:, :-2], kc[:, 2:]), (kc[:-2], kc[2:])]
+        for a, b in pairs:
+            assert abs((a * b).mean() / v) < 5 * sig
+        rs = np.random.RandomState(1).randint(0, T, (300, 2))
+        rr = np.array([(kc[a] * kc[b]).mean() / v for a, b in rs if a != b])
+        cc = np.array([(kc[:, a] * kc[:, b]).mean() / v for a, b in rs if a != b])
+        for c in (rr, cc):                # a correlation of two rows: std 1 / sqrt(T)
+            assert 0.8 / np.sqrt(T) < c.std() < 1.25 / np.sqrt(T) and np.abs(c).max() < 5 / np.sqrt(T)
+        for arr in (k.mean(1), k.mean(0)):  # row / column means: binomial
+            assert 0.85 < arr.std() / np.sqrt(v / T) < 1.15
+        for di, dj in ((1, 1), (1, 7), (5, 3), (100, 200)):
+            q = (kc[:-di, :-dj] * kc[:-di, dj:] * kc[di:, :-dj] * kc[di:, dj:]).mean() / v ** 2
+            assert abs(q) < 5 * sig, (p, di, dj, q)
+    # the statistic is sensitive: the unfinished key sum fails it by two orders of magnitude
+    x = (rowkey(1, np.arange(T))[:, None] + colkey(2, np.arange(T))[None, :]) & np.uint64(0xFFFFFFFF)
+    kc = (x >= np.uint64(2 ** 31)).astype(np.float64)
+    kc -= kc.mean()
+    assert (kc[:-1, :-1] * kc[:-1, 1:] * kc[1:, :-1] * kc[1:, 1:]).mean() / 0.25 ** 2 > 0.2
