@@ -28,7 +28,10 @@ typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 
 template <int NP> struct WGeo;
 template <> struct WGeo<2> { static constexpr int KB = 96; };
-template <> struct WGeo<3> { static constexpr int KB = 64; };
+#ifndef WG_KB3
+#define WG_KB3 64       // (a build-time constant so that scratch/build_alt.sh can A/B it)
+#endif
+template <> struct WGeo<3> { static constexpr int KB = WG_KB3; };
 // The X ring holds exactly the R = KB + 2*SW + 2 rows a stage needs (a runtime size: W = 72 -> 214 rows at KB = 64, which
 // is what lets two workgroups of the six-byte-per-element mode share a CU's 160 KB).
 
@@ -263,17 +266,25 @@ __device__ __forceinline__ void wg3_tile(const WG3Args& p, unsigned char* smem, 
     slot_new = ring_slot(slot_new + KB, R);
     rel_next += KB;
     __syncthreads();
-    // X fragment of n-fragment j in k-step ks: tap and channel fragment are scalars (the wave id is), only the ring slot of
-    // the lane's row is vector work; read one n-fragment ahead of its MFMAs, across the k-step boundary
-    const int rb = slot_base + lane_row;
+    // X fragment of n-fragment j in k-step ks: tap, channel fragment and the ring slot of the window's first row are scalars (the
+    // wave id is); the lane's part is ONE add and the wrap of its row, taken in byte space (a byte offset is beyond the ring
+    // exactly when its row is: the offset inside a row stays below RS) as an unsigned minimum - o - ringb wraps to a huge
+    // number unless o >= ringb.  Six VALU instructions per n-fragment where slot arithmetic per row + two 24-bit multiplies
+    // took twelve to sixteen (what-if without any ring arithmetic: -8 us of the 107 of a {0,1} launch);
+    // read one n-fragment ahead of its MFMAs, across the k-step boundary
+    const unsigned ringb = (unsigned)R * RS;
     bf16x8 b[2][NP];
     auto read_b = [&](int ks, int j, bf16x8 (&dst)[NP]) {
       const int nf = wave + 4 * j;
       const int tap = nf / CF, cf = nf - tap * CF;
       const int shift = (tap / 3) * p.SW + tap % 3 + ks * 32;      // X row of position k + shift(tap) (the ring starts at -halo)
-      const int r0 = ring_slot(rb + shift, R), r1 = ring_slot(r0 + 16, R);
-      const unsigned char* q0 = Xt + (__umul24(r0, RS) + lane_col + cf * 32);     // 32-bit LDS offsets
-      const unsigned char* q1 = Xt + (__umul24(r1, RS) + lane_col + cf * 32);
+      const int s = ring_slot(slot_base + shift, R);
+      unsigned o0 = (unsigned)lane_off + (unsigned)(s * RS + cf * 32);
+      o0 = o0 - ringb < o0 ? o0 - ringb : o0;
+      unsigned o1 = o0 + 16 * RS;
+      o1 = o1 - ringb < o1 ? o1 - ringb : o1;
+      const unsigned char* q0 = Xt + o0;
+      const unsigned char* q1 = Xt + o1;
 #pragma unroll
       for (int pc = 0; pc < NP; ++pc) dst[pc] = tr_frag2(q0 + pc * LO, q1 + pc * LO);
     };
