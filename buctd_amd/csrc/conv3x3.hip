@@ -632,9 +632,6 @@ struct C3Plan { int MF, NF, WM, WN, BM, BN, na; size_t lds; };
 static int c3_steps(int Kc, int np) { return np == 3 ? (Kc / 16) * 5 : (Kc / CK) * 9 + ((Kc % CK) ? 5 : 0); }
 
 // pers: the plan of a persistent launch (c3_pers.h) - double-buffered tiles only
-#ifndef C3_SMALL_MF4_FROM
-#define C3_SMALL_MF4_FROM 160      // (a build-time constant so that scratch/build_alt.sh can A/B it)
-#endif
 static bool c3_plan(int np, int N, int H, int W, int Ci, int Co, C3Plan* pl, bool pers = false) {
   if (N <= 0 || H <= 0 || W <= 0 || Ci <= 0 || Co <= 0 || Ci % 16 != 0 || Co % 16 != 0 || c3_row_width(W) > MAX_SW) return false;
   const int rowb = np == 3 ? Geo<3>::ROWB : Geo<2>::ROWB, blds = np == 3 ? Geo<3>::BLDS : Geo<2>::BLDS;
@@ -668,7 +665,7 @@ static bool c3_plan(int np, int N, int H, int W, int Ci, int Co, C3Plan* pl, boo
     // alone (204 workgroups leave a wave per SIMD without a partner), but the train step launches it with branch 2 only, and
     // there the other member fills the CUs: 121.9 -> 107.9 us (scratch/b3_ab.sh).  One plan per shape, grouped or not: a
     // group launch stays bit-identical to its members' own launches (the BatchNorm sums are formed per wave tile).
-    const long need = np == 3 ? (small ? C3_SMALL_MF4_FROM : 224) : 320;
+    const long need = np == 3 ? (small ? 160 : 224) : 320;
     if (blocks >= need) { mf = cand[i]; break; }   // (238 for the 192-channel 24x18 maps at N = 32)
   }
   bool single = false;

@@ -28,10 +28,7 @@ typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 
 template <int NP> struct WGeo;
 template <> struct WGeo<2> { static constexpr int KB = 96; };
-#ifndef WG_KB3
-#define WG_KB3 64       // (a build-time constant so that scratch/build_alt.sh can A/B it)
-#endif
-template <> struct WGeo<3> { static constexpr int KB = WG_KB3; };
+template <> struct WGeo<3> { static constexpr int KB = 64; };
 // The X ring holds exactly the R = KB + 2*SW + 2 rows a stage needs (a runtime size: W = 72 -> 214 rows at KB = 64, which
 // is what lets two workgroups of the six-byte-per-element mode share a CU's 160 KB).
 
