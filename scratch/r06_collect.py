@@ -6,8 +6,9 @@ S, D = os.path.join(ROOT, "gpurun_out", "r06"), os.path.join(ROOT, "profiles")
 date = sys.argv[1] if len(sys.argv) > 1 else datetime.date.today().isoformat()
 def rd(n): return open(os.path.join(S, n)).read()
 def wr(n, txt): open(os.path.join(D, n), "w").write(txt)
-for w in ("train_c4", "train_c3", "train_c2", "infer_c5", "train_c4_mono"):
-    shutil.copy(os.path.join(S, f"bench_line_{w}.json"), os.path.join(D, f"r06_bench_line_{w}.json"))
+for w in ("train_c4", "train_c3", "train_c2", "infer_c5", "train_c4_mono"):      # (absent in the first of the script's two collections)
+    if os.path.isfile(os.path.join(S, f"bench_line_{w}.json")) and os.path.getsize(os.path.join(S, f"bench_line_{w}.json")) > 0:
+        shutil.copy(os.path.join(S, f"bench_line_{w}.json"), os.path.join(D, f"r06_bench_line_{w}.json"))
 for tag, w in (("c4", "train_c4"), ("c3", "train_c3"), ("c2", "train_c2")):
     wr(f"r06_kernel_trace_stats_bench_{tag}.txt", f"rocprofv3 --kernel-trace of: python bench.py --workload {w} --steps 10 --warmup 3 --no-cpu-baseline --no-kernel-timer (round 6, {date})\n" + rd(f"kernel_trace_stats_{tag}.txt"))
     shutil.copy(os.path.join(S, f"in_step_kernel_us_{tag}.json"), os.path.join(D, f"r06_in_step_kernel_us_{tag}.json"))

@@ -19,13 +19,6 @@ for t in c4:train_c4 c3:train_c3 c2:train_c2; do
   fi
 done
 cd $GRAFT_REPO_ROOT
-# the bench lines quote the census of THIS tree: the in-step JSONs first, then the lines
-for tag in c4 c3 c2; do [ -f $O/in_step_kernel_us_$tag.json ] && cp $O/in_step_kernel_us_$tag.json profiles/r06_in_step_kernel_us_$tag.json; done
-for w in train_c4 train_c3 train_c2 infer_c5; do
-  extra=""; [ $w = train_c4 ] || extra="--no-cpu-baseline"
-  timeout 600 python bench.py --workload $w --steps 20 --warmup 5 $extra 2>/dev/null | tail -1 > $O/bench_line_$w.json
-done
-timeout 300 python bench.py --condition mono --steps 20 --warmup 5 --no-cpu-baseline 2>/dev/null | tail -1 > $O/bench_line_train_c4_mono.json
 bash scratch/pmc_run.sh r6fwd bf16x6 fwd > /dev/null 2>&1; python scratch/pmc_summary.py gpurun_out/pmc_r6fwd conv3x3 > $O/pmc_fwd.txt 2>&1
 bash scratch/pmc_run.sh r6wg bf16x6 wgrad > /dev/null 2>&1; python scratch/pmc_summary.py gpurun_out/pmc_r6wg "" > $O/pmc_wgrad.txt 2>&1
 bash scratch/pmc_run.sh r6dg bf16x6 dgrad > /dev/null 2>&1; python scratch/pmc_summary.py gpurun_out/pmc_r6dg conv3x3 > $O/pmc_dgrad.txt 2>&1
@@ -33,4 +26,12 @@ bash scratch/pmc_run.sh r6fwdg bf16x6 fwd_group > /dev/null 2>&1; python scratch
 bash scratch/pmc_run.sh r6wgg bf16x6 wgrad_group > /dev/null 2>&1; python scratch/pmc_summary.py gpurun_out/pmc_r6wgg "" > $O/pmc_wgrad_group.txt 2>&1
 python scratch/pmc_traffic_json.py gpurun_out $O/kernel_trace_stats_c4.txt $O $D > $O/traffic_line.txt 2>&1
 bash scratch/serial_census.sh r06 > /dev/null 2>&1
+# the bench lines quote the census, the PMC traffic and the in-step durations of THIS tree: everything above goes to profiles/
+# first (on this box's copy), then the lines
+python scratch/r06_collect.py > /dev/null 2>&1
+for w in train_c4 train_c3 train_c2 infer_c5; do
+  extra=""; [ $w = train_c4 ] || extra="--no-cpu-baseline"
+  timeout 600 python bench.py --workload $w --steps 20 --warmup 5 $extra 2>/dev/null | tail -1 > $O/bench_line_$w.json
+done
+timeout 300 python bench.py --condition mono --steps 20 --warmup 5 --no-cpu-baseline 2>/dev/null | tail -1 > $O/bench_line_train_c4_mono.json
 ls -la $O
