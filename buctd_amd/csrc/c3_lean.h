@@ -384,6 +384,7 @@ struct C3Stager {
 // smem = [DBUF ? 2 : 1][arows][ROWB] A buffers | [3][Ci] input-BatchNorm table | [4][BN] epilogue table
 template <int MF, int NF, int WM, int WN, bool DBUF, bool BPF_, int MODE>
 __device__ __forceinline__ void c3l_tile(const C3Args& p, unsigned char* smem, int bx, int by) {
+  static_assert(DBUF || !BPF_, "c3l_tile: the single-buffer form fetches its B fragments in place (the next chunk's rows ride behind them)");
   constexpr bool IN_BN = (MODE & C3M_IN_BN) != 0;
   constexpr bool BSR = (MODE & C3M_BS_REBUILD) != 0, BS = BSR || (MODE & C3M_BS_Y) != 0;
   constexpr int ROWB = Geo<3>::ROWB, PST = Geo<3>::PST, CPR = Geo<3>::CPR;
@@ -407,6 +408,17 @@ __device__ __forceinline__ void c3l_tile(const C3Args& p, unsigned char* smem, i
   stg.init(p);
   stg.make(p, p0);
   auto load_a = [&](int c0) { stg.load(c0); };
+  // Single-buffer tiles (!DBUF) fetch the NEXT chunk's rows inside the current chunk, a quarter behind each of its first four
+  // B loads: gfx9 counts vector-memory loads in ONE in-order counter, so a wait for a B fragment also waits for every row load
+  // issued before it - issued in one batch in front of the chunk (as the double-buffered form can afford: its B fragments are
+  // a step ahead) the first B wait of the chunk stood through a whole HBM round trip; now a B wait sees row loads that are at
+  // least one step (126 MFMAs) old.  (Pad rows carry the out-of-range offset: no test per pass.)
+  auto load_a_part = [&](int c0, int part) {
+    constexpr int Q = (PA + 3) / 4;
+#pragma unroll
+    for (int q = part * Q; q < (part + 1) * Q; ++q)
+      if (q < PA) stg.areg[q] = c3_bload(stg.r_x, stg.goff[q] + (unsigned)c0 * 4u);
+  };
   auto store_a = [&](unsigned char* At, int c0) { stg.store(p, At, c0, bntab); };
 
   // B fragments of this lane: image [step][Co/16][3][64][16 B]
@@ -468,6 +480,11 @@ __device__ __forceinline__ void c3l_tile(const C3Args& p, unsigned char* smem, i
         else load_b(gs < last_step ? gs + 1 : last_step, bn);
       } else {
         load_b(gs, bc);
+        if (!DBUF && s < 4 && ch + 1 < nchunks) {
+          __builtin_amdgcn_sched_barrier(0);
+          load_a_part((ch + 1) * 16, s);
+          __builtin_amdgcn_sched_barrier(0);
+        }
       }
       if (DBUF && s == 2 && ch + 2 < nchunks) {
         __builtin_amdgcn_sched_barrier(0);
@@ -523,12 +540,11 @@ __device__ __forceinline__ void c3l_tile(const C3Args& p, unsigned char* smem, i
   }
   if constexpr (IN_BN) __syncthreads();
   store_a(smem, 0);
-  if (nchunks > 1) load_a(16);
+  if (DBUF && nchunks > 1) load_a(16);
   __syncthreads();
   for (int ch = 0; ch < nchunks; ++ch) {
     if (!DBUF && ch > 0) {   // single buffer (the largest position tiles): restage between two barriers
       store_a(smem, ch * 16);
-      if (ch + 1 < nchunks) load_a((ch + 1) * 16);
       __syncthreads();
     }
     run_chunk(ch);
