@@ -750,6 +750,10 @@ def main():
                     help="--gpus 1 only: initialise an RCCL process group of ONE rank and run the whole gradient exchange "
                          "(buckets, communication stream, collectives, 1 branch stream) - the per-GPU cost of the data-parallel "
                          "machinery without a second GPU; not the headline configuration")
+    ap.add_argument("--step-graph", action="store_true",
+                    help="--gpus 1, models without train-mode dropout (train_c2 / train_c3): forward + loss + backward are captured "
+                         "once as a hipGraph (engine.StepGraph) and replayed per step; the same kernels, bit-identical results, one "
+                         "hipGraphLaunch instead of ~1000 host-side launches - the host-bound C2 step becomes GPU-bound")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timer", action="store_true")
     args = ap.parse_args()
@@ -807,12 +811,22 @@ def main():
     model.train()
     state = {"pending": None}
 
+    graph_step = None
+    if args.step_graph:
+        if world != 1 or args.one_rank_exchange:
+            raise SystemExit("--step-graph captures the single-GPU step (the gradient exchange is launched from host callbacks)")
+        graph_step = engine.StepGraph(model, criterion, optimizer, warmup=2)
+        describe += " [forward + loss + backward replayed from a hipGraph]"
+
     def step():
-        out = model(x)
-        loss = criterion(out, target, weight)
-        optimizer.zero_grad()
-        loss.backward()
-        optimizer.step()
+        if graph_step is not None:
+            out, loss = graph_step(x, target, weight)
+        else:
+            out = model(x)
+            loss = criterion(out, target, weight)
+            optimizer.zero_grad()
+            loss.backward()
+            optimizer.step()
         if state["pending"] is not None:
             state["pending"].resolve(losses, acc)
         state["pending"] = _DeferredStats(loss, out, target, args.batch)
@@ -822,6 +836,8 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    while graph_step is not None and graph_step.replays == 0:
+        step()          # eager settling steps + the capture, in front of the warm-up steps the command line asks for
     for _ in range(args.warmup):
         step()
     fence()
@@ -846,6 +862,7 @@ def main():
     # bracketed); not part of `value`
     in_step = {k: (None, 0) for k in ("fwd", "dgrad", "wgrad")}
     if not args.no_kernel_timer:
+        graph_step = None       # the bracketed launches below are eager launches
         install_timer(timer)
         step()
         fence()
@@ -939,7 +956,7 @@ def main():
                        "params": sum(p.numel() for p in net.parameters()), "parallelism": f"dp{world}",
                        # HIP streams of this rank: main + branch / weight-gradient streams (+ communication under --gpus N)
                        "hip_streams": 1 + len(ops.compute_streams(device)) + (1 if world > 1 or args.one_rank_exchange else 0),
-                       "conv_math": args.conv_math, "loss": round(losses.avg, 6)},
+                       "conv_math": args.conv_math, "loss": round(losses.avg, 6), "step_graph": bool(args.step_graph)},
             # is a slow line a slow box or a slow build?  the spread of the timed steps (GPU time between one event per step
             # on the main stream) and what the SMU reported in the middle of the timed region
             "step_ms": {"min": round(step_ms[0], 3), "median": round(step_ms[len(step_ms) // 2], 3), "max": round(step_ms[-1], 3)},

@@ -92,7 +92,10 @@ def _train_line(epoch, i, total, batch_time, data_time, losses, acc, batch):
 
 
 def train(config, train_loader, model, criterion, optimizer, epoch, output_dir, tb_log_dir, writer_dict,
-          print_prefix=''):
+          print_prefix='', step_graph=None):
+    """reference lib/core/function.py:102-175, same positional signature.  step_graph (an engine.StepGraph built on the same
+    model / criterion / optimizer; not in the reference): the device work of an iteration is replayed from a hipGraph instead
+    of being enqueued kernel by kernel - for host-bound configurations (HRNet-W32 at 256x192)."""
     batch_time, data_time, losses, acc = AverageMeter(), AverageMeter(), AverageMeter(), AverageMeter()
     model.train()
     conditional = bool(config.MODEL.CONDITIONAL_TOPDOWN)
@@ -103,11 +106,14 @@ def train(config, train_loader, model, criterion, optimizer, epoch, output_dir, 
         input = (input if conditional else input[:, :3]).cuda(non_blocking=True)
         target = target.cuda(non_blocking=True)
         target_weight = target_weight.cuda(non_blocking=True)
-        output, loss = _forward_with_loss(model, criterion, input, target, target_weight)
+        if step_graph is not None:
+            output, loss = step_graph(input, target, target_weight)
+        else:
+            output, loss = _forward_with_loss(model, criterion, input, target, target_weight)
 
-        optimizer.zero_grad()
-        loss.backward()
-        optimizer.step()
+            optimizer.zero_grad()
+            loss.backward()
+            optimizer.step()
 
         # stats of the previous iteration are on the host by now; this iteration's are queued behind the step
         if pending is not None:

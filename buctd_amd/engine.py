@@ -506,6 +506,118 @@ def get_optimizer(cfg, model):
     return None       # the reference returns None for any other name (utils.py:259, 274)
 
 
+class StepGraph:
+    """The device work of one training iteration - forward, loss, backward, gradient collection - captured ONCE as a hipGraph
+    and replayed per step; the optimizer step stays an eager launch behind it (its bias corrections are launch arguments).
+
+    Why: the eager engine enqueues ~1000-1600 kernels per step through Python (autograd nodes + ctypes calls): 23-35 ms of
+    host time.  HRNet-W32 at 256x192 (BASELINE config C2) has 17 ms of GPU work per batch of 32, so the eager step is bound
+    by the host; a replay is one hipGraphLaunch.  The streams the engine forks (branch streams, weight-gradient stream) become
+    parallel branches of the graph; nothing about the kernels or their order on a stream changes, so a replayed step is
+    bit-identical to the eager one (tests/test_gpu_step_graph.py).
+
+    Use (what core.function.train does when handed one):  `output, loss = step(input, target, target_weight)` in place of
+    forward / zero_grad / backward / optimizer.step().  The first `warmup` calls with a given input signature run the eager
+    engine (they are ordinary training steps: caches, workspaces, streams and LDS limits settle); the next call captures;
+    every later call copies the batch into the graph's static input buffers and replays.  A batch of another shape (the last,
+    ragged batch of an epoch) runs the eager engine.  `output` and `loss` are the graph's static tensors: read or copy them
+    before the next call.
+
+    Not capturable, and refused loudly: train-mode dropout (the mask seed is a launch argument: CoAM / TransPose run eager),
+    a gradient exchange over a process group (the buckets are launched from host callbacks)."""
+
+    def __init__(self, model, criterion, optimizer, warmup=3, streams="single", allow_repeated_dropout_masks=False):
+        if streams not in ("single", "engine"):
+            raise ValueError("streams: 'single' (a linear graph) or 'engine' (the engine's branch / weight-gradient streams "
+                             "become parallel branches of the graph)")
+        if not isinstance(optimizer, (FusedAdam, FusedSGD)):
+            raise TypeError("StepGraph replays into a flat gradient arena: it needs engine.FusedAdam / FusedSGD")
+        if isinstance(model, DataParallel) and model._exchange:
+            raise NotImplementedError("StepGraph: the bucketed gradient exchange is launched from host callbacks and is not "
+                                      "captured; run the eager engine under a process group")
+        self.model, self.criterion, self.optimizer = model, criterion, optimizer
+        self.warmup = int(warmup)
+        self.streams = streams
+        self._allow_seeds = bool(allow_repeated_dropout_masks)     # measurement only: every replay repeats one mask
+        self._seen = {}
+        self._graphs = {}
+        self._dropout = False
+        self.replays = 0
+
+    @staticmethod
+    def _signature(tensors):
+        return tuple((tuple(t.shape), t.dtype, t.device) for t in tensors)
+
+    def _forward_backward(self, x, target, weight):
+        outputs = self.model(x)
+        heads = outputs if isinstance(outputs, list) else [outputs]
+        loss = None
+        for head in heads:
+            term = self.criterion(head, target, weight)
+            loss = term if loss is None else loss + term
+        self.optimizer.zero_grad()
+        loss.backward()
+        return heads[-1], loss
+
+    def _capture(self, x, target, weight):
+        dev = x.device
+        flat = self.optimizer.flat
+        static = [t.clone() for t in (x, target, weight)]
+        bns = [m for m in self.model.modules() if isinstance(m, bnn.BatchNorm2d)]
+        before = [m._pending_batches for m in bns]
+        graph = torch.cuda.CUDAGraph()
+        self.optimizer.zero_grad()
+        ops.begin_capture(self._allow_seeds)
+        forks = ops.set_stream_forks(self.streams == "engine")
+        try:
+            with torch.cuda.graph(graph):
+                ops.acc_pool.rebase(dev)              # the pool's ordering event becomes an edge of the graph
+                out, loss = self._forward_backward(*static)
+                flat.collect()                        # gradients autograd accumulated outside the arena are copied per replay
+                ops.acc_pool.zero_used(dev)           # a replay leaves its statistics accumulators zeroed for the next one
+                used = ops.acc_pool.used(dev)
+        finally:
+            ops.set_stream_forks(*forks)
+            keep = ops.end_capture()
+        ops.acc_pool.rebase(dev, used)                # eager edge: zero before the first replay, fresh (uncaptured) event
+        counts = [(m, m._pending_batches - b) for m, b in zip(bns, before) if m._pending_batches != b]
+        for m, b in zip(bns, before):
+            m._pending_batches = b                    # the capture enqueued nothing: its batches are counted per replay
+        return {"graph": graph, "static": static, "out": out, "loss": loss, "bn_counts": counts, "keep": keep}
+
+    def __call__(self, x, target, weight):
+        key = self._signature((x, target, weight))
+        g = self._graphs.get(key)
+        if g is None:
+            n = self._seen.get(key, 0)
+            self._seen[key] = n + 1
+            if n < self.warmup or not x.is_cuda or not self.model.training:
+                drawn = ops.seeds_drawn()
+                out, loss = self._forward_backward(x, target, weight)
+                self.optimizer.step()
+                self._dropout = self._dropout or ops.seeds_drawn() != drawn
+                return out, loss
+            if self._dropout and not self._allow_seeds:
+                raise NotImplementedError("StepGraph: this model draws train-mode dropout masks; the mask seed is a launch "
+                                          "argument, a replay would repeat one mask - run the eager engine")
+            g = self._graphs[key] = self._capture(x, target, weight)
+        for dst, src in zip(g["static"], (x, target, weight)):
+            if dst.data_ptr() != src.data_ptr():
+                dst.copy_(src, non_blocking=True)
+        g["graph"].replay()
+        for m, c in g["bn_counts"]:
+            m._pending_batches += c
+        self.replays += 1
+        self.optimizer.step()
+        return g["out"], g["loss"]
+
+    def static_inputs(self, x, target, weight):
+        """The static input buffers of the graph captured for this signature (None before the capture): a loader that writes
+        its batches there saves the per-step copy."""
+        g = self._graphs.get(self._signature((x, target, weight)))
+        return None if g is None else tuple(g["static"])
+
+
 _comm_streams = {}      # device index -> the communication stream reserved by reserve_streams
 
 

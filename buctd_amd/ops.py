@@ -31,6 +31,47 @@ if os.environ.get("BUCTD_TUNING") == "1":
     from . import _tuning
     _tuning.override(_SW)
 
+# hipGraph capture of a training step (engine.StepGraph)
+# --------------------------------------------------------------------------------------
+# While a step is being captured, a wait on an event that was recorded BEFORE the capture began must not be issued: HIP
+# refuses it (hipErrorStreamCaptureIsolation), and it is not needed - the capture starts behind a device synchronisation
+# and a replay is launched into the stream that carried the eager work in front of it.  Events recorded inside the capture
+# are registered here and waited on as usual (they are edges of the graph).
+_capture = {"on": False, "events": set(), "allow_seeds": False}
+
+
+def capturing():
+    return _capture["on"]
+
+
+def _new_event(stream=None):
+    """An event recorded now on `stream` (default: the current one) that other streams may have to wait on later."""
+    ev = torch.cuda.Event()
+    ev.record(stream) if stream is not None else ev.record()
+    if _capture["on"]:
+        _capture["events"].add(id(ev))
+        _capture.setdefault("keep", []).append(ev)     # ids stay unique while the capture lasts
+    return ev
+
+
+def _wait_event(stream, ev):
+    if _capture["on"] and id(ev) not in _capture["events"]:
+        return
+    stream.wait_event(ev)
+
+
+def begin_capture(allow_seeds=False):
+    _capture.update(on=True, events=set(), keep=[], allow_seeds=bool(allow_seeds))
+
+
+def end_capture():
+    """-> what must stay alive as long as the captured graph does (events, workspaces outgrown during the capture)"""
+    keep = _capture.get("keep", [])
+    _capture.update(on=False, events=set(), keep=[], allow_seeds=False)
+    return keep
+
+
+# --------------------------------------------------------------------------------------
 # --------------------------------------------------------------------------------------
 # workspace + RNG seed bookkeeping
 # --------------------------------------------------------------------------------------
@@ -58,11 +99,16 @@ def workspace_on(stream, nbytes, device):
         # growth (rare: the first step visits increasingly large shapes): the old buffer may still be written by kernels
         # queued on `stream`, and it was allocated under whatever stream was current - it is kept alive until an event
         # recorded on `stream` here has passed (checked at the next growth), then handed back to the allocator
-        _retired_workspaces[:] = [(b, ev) for b, ev in _retired_workspaces if not ev.query()]
-        if buf is not None:
-            ev = torch.cuda.Event()
-            ev.record(stream)
-            _retired_workspaces.append((buf, ev))
+        if _capture["on"]:
+            # an event query is not permitted while a stream captures; the outgrown buffer simply stays alive with the graph
+            if buf is not None:
+                _capture["keep"].append(buf)
+        else:
+            _retired_workspaces[:] = [(b, ev) for b, ev in _retired_workspaces if not ev.query()]
+            if buf is not None:
+                ev = torch.cuda.Event()
+                ev.record(stream)
+                _retired_workspaces.append((buf, ev))
         buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
         buf.record_stream(stream)
         _workspaces[key] = buf
@@ -90,8 +136,7 @@ class _AccPool:
     def _new_chunk(self, device, nbytes):
         cur = torch.cuda.current_stream(device)
         buf = torch.zeros(max(self.CHUNK, nbytes), dtype=torch.uint8, device=device)
-        ev = torch.cuda.Event()
-        ev.record(cur)
+        ev = _new_event(cur)
         gen = self.state[device.index]["gen"] + 1 if device.index in self.state else 0
         st = {"buf": buf, "off": 0, "ev": ev, "stream": cur.cuda_stream, "seen": {cur.cuda_stream}, "gen": gen}
         self.state[device.index] = st
@@ -111,7 +156,7 @@ class _AccPool:
             st = self._new_chunk(device, nbytes)
         cur = torch.cuda.current_stream(device)
         if cur.cuda_stream not in st["seen"]:
-            cur.wait_event(st["ev"])
+            _wait_event(cur, st["ev"])
             st["buf"].record_stream(cur)
             st["seen"].add(cur.cuda_stream)
         p = st["buf"].data_ptr() + st["off"]
@@ -123,14 +168,34 @@ class _AccPool:
         st = self.state.get(device.index)
         if st is None or st["off"] == 0:
             return
+        self.rebase(device, st["off"])
+
+    def rebase(self, device, nbytes=0):
+        """Zero the first `nbytes` of the current chunk on the current stream, rewind, and make the current stream the one
+        every other stream orders itself behind.  engine.StepGraph calls it at both edges of a capture: inside, so that the
+        ordering event of the pool is an edge of the graph; behind, so that eager code never meets a captured event."""
+        st = self.state.get(device.index)
+        if st is None:
+            return 0
         cur = torch.cuda.current_stream(device)
-        st["buf"][:st["off"]].zero_()
+        if nbytes:
+            st["buf"][:nbytes].zero_()
+        high = st["off"]
         st["off"] = 0
         st["gen"] += 1
-        ev = torch.cuda.Event()
-        ev.record(cur)
-        st["ev"], st["stream"], st["seen"] = ev, cur.cuda_stream, {cur.cuda_stream}
+        st["ev"], st["stream"], st["seen"] = _new_event(cur), cur.cuda_stream, {cur.cuda_stream}
         st["buf"].record_stream(cur)
+        return high
+
+    def used(self, device):
+        st = self.state.get(device.index)
+        return st["off"] if st is not None else 0
+
+    def zero_used(self, device):
+        """Zero what has been handed out so far (current stream), without rewinding."""
+        st = self.state.get(device.index)
+        if st is not None and st["off"]:
+            st["buf"][:st["off"]].zero_()
 
 
 acc_pool = _AccPool()
@@ -183,7 +248,16 @@ def manual_seed(seed):
     _seed_state["counter"] = 0
 
 
+def seeds_drawn():
+    """How many dropout seeds have been handed out (engine.StepGraph: did a warm-up step draw any?)."""
+    return _seed_state["counter"]
+
+
 def next_seed():
+    if _capture["on"] and not _capture["allow_seeds"]:
+        raise _C.BuctdHipError("a dropout seed was drawn while a step graph was being captured: the seed is a launch argument, "
+                               "a replay would repeat this step's mask - models with train-mode dropout (CoAM, TransPose) "
+                               "run the eager engine")
     if _seed_state["seed"] is None:
         # first use without an explicit ops.manual_seed: follow torch.manual_seed (and the rank, if a process group
         # is up), so that runs honour the user's seed and replicas draw different masks
@@ -413,7 +487,7 @@ def _prep_all(device):
 def _prep_wait(device):
     """A batched refresh ran on the optimizer's stream: other streams order themselves behind it once."""
     ev = _prep_registry["event"]
-    if ev is not None:
+    if ev is not None and not _capture["on"]:     # a capture is ordered behind the refresh as a whole
         cur = torch.cuda.current_stream(device).cuda_stream
         if cur != _prep_registry["stream"] and cur not in _prep_registry["waited"]:
             torch.cuda.current_stream(device).wait_event(ev)
@@ -843,6 +917,16 @@ _branch = {"on": _SW["BRANCH_STREAMS"] == "1", "streams": {}}
 _BRANCH_MAX = int(_SW["BRANCH_MAX"])
 
 
+def set_stream_forks(branch, wgrad=None):
+    """Turn the engine's stream forks on / off (branch streams of fork_join, the weight-gradient stream); returns the previous
+    pair.  engine.StepGraph captures a LINEAR graph with both off: on ROCm 7.2 a replay pays ~70 us of host time per
+    cross-queue edge of the graph."""
+    old = (_branch["on"], _side["on"])
+    _branch["on"] = bool(branch)
+    _side["on"] = bool(branch if wgrad is None else wgrad)
+    return old
+
+
 def set_branch_max(n):
     """Cap on the number of branch streams (besides the main stream).  The default runtime serves four hardware queues and any
     fifth HIP stream costs 25-32 %: engine.DataParallel lowers the cap to 1 when it adds its communication
@@ -1019,11 +1103,10 @@ def _x6_weight_image(w, V, K, transposed):
     if tag not in cache:
         ld = w.shape[1]
         cache[tag] = x6_image(w, V, K, 0, vs=1, ks=ld) if transposed else x6_image(w, V, K, 0, vs=ld, ks=1)
-        cache[tag + "_ev"] = torch.cuda.Event()
-        cache[tag + "_ev"].record()
+        cache[tag + "_ev"] = _new_event()
         cache[tag + "_stream"] = torch.cuda.current_stream(w.device).cuda_stream
     elif torch.cuda.current_stream(w.device).cuda_stream != cache[tag + "_stream"]:
-        torch.cuda.current_stream(w.device).wait_event(cache[tag + "_ev"])
+        _wait_event(torch.cuda.current_stream(w.device), cache[tag + "_ev"])
     return cache[tag]
 
 
@@ -1139,15 +1222,14 @@ def bn_fold_cached(bn, gamma, beta, eps):
     cur = torch.cuda.current_stream(gamma.device)
     if cache is None or cache[0] != key:
         scale, shift = bn_fold(gamma, beta, rm, rv, eps)
-        ev = torch.cuda.Event()
-        ev.record()
+        ev = _new_event()
         cache = (key, scale, shift, ev, cur.cuda_stream, set())
         try:
             object.__setattr__(bn, "_buctd_fold", cache)
         except (AttributeError, TypeError):
             return scale, shift
     elif cur.cuda_stream != cache[4] and cur.cuda_stream not in cache[5]:
-        cur.wait_event(cache[3])            # folded on another stream: order this stream behind it, once
+        _wait_event(cur, cache[3])            # folded on another stream: order this stream behind it, once
         cache[5].add(cur.cuda_stream)
     return cache[1], cache[2]
 

@@ -1,0 +1,179 @@
+"""engine.StepGraph: forward + loss + backward of a training iteration captured once as a hipGraph and replayed
+(reference loop: lib/core/function.py:102-175 - forward / zero_grad / backward / optimizer.step per batch).  A replay
+launches the kernels of the eager step, on the same streams' order, so everything it produces - loss, output, parameters,
+BatchNorm running statistics, optimizer state - must equal the eager engine's bit for bit, step after step, on batches
+that differ from step to step."""
+import copy
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _prenet_cfg(width=16, modules=(1, 2, 2)):
+    from buctd_amd.config import cfg as base, hrnet_extra
+    c = base.clone()
+    c.defrost()
+    c.MODEL.NAME = "pose_hrnet"
+    c.MODEL.NUM_JOINTS = 17
+    c.MODEL.IMAGE_SIZE = [64, 96]
+    c.MODEL.HEATMAP_SIZE = [16, 24]
+    c.MODEL.SIGMA = 2
+    c.MODEL.PRETRAINED = ""
+    c.MODEL.CONDITIONAL_TOPDOWN = True
+    c.MODEL.EXTRA = hrnet_extra(width, use_pre_net=True, modules=modules)
+    c.DATASET.DATASET = "coco"
+    c.DATASET.COLORED = True
+    c.TRAIN.LR = 1e-3
+    c.freeze()
+    return c
+
+
+def _batch(cfg, n, seed, device):
+    g = torch.Generator().manual_seed(seed)
+    w, h = cfg.MODEL.IMAGE_SIZE
+    hw, hh = cfg.MODEL.HEATMAP_SIZE
+    k = cfg.MODEL.NUM_JOINTS
+    x = torch.randn(n, 6, h, w, generator=g).to(device)
+    t = torch.rand(n, k, hh, hw, generator=g).to(device)
+    wt = (torch.rand(n, k, 1, generator=g) < 0.8).float().to(device)
+    return x, t, wt
+
+
+def _pair(cfg, device):
+    from buctd_amd import engine, models
+    from buctd_amd.core.loss import JointsMSELoss
+    torch.manual_seed(7)
+    net_a = models.pose_hrnet.get_pose_net(cfg, is_train=True).to(device)
+    net_b = copy.deepcopy(net_a)
+    out = []
+    for net in (net_a, net_b):
+        model = engine.DataParallel(net)
+        opt = engine.get_optimizer(cfg, model)
+        model.train()
+        out.append((model, opt))
+    return out, JointsMSELoss(True)
+
+
+@pytest.mark.parametrize("streams", ["single", "engine"])
+def test_replayed_steps_equal_eager_steps_bit_for_bit(dev, streams):
+    from buctd_amd import engine
+    cfg = _prenet_cfg()
+    ((eager, eopt), (graphed, gopt)), crit = _pair(cfg, dev)
+    step = engine.StepGraph(graphed, crit, gopt, warmup=2, streams=streams)
+    for i in range(7):
+        x, t, w = _batch(cfg, 4, 100 + i, dev)
+        # the two engines own different arenas: set each one current before its step (as two processes would have it)
+        engine.ops.set_grad_arena(eopt.flat)
+        out_e = eager(x)
+        loss_e = crit(out_e, t, w)
+        eopt.zero_grad()
+        loss_e.backward()
+        eopt.step()
+        engine.ops.set_grad_arena(gopt.flat)
+        out_g, loss_g = step(x, t, w)
+        assert torch.equal(loss_e.detach(), loss_g.detach()), (i, float(loss_e), float(loss_g))
+        assert torch.equal(out_e.detach(), out_g.detach()), i
+    assert step.replays == 5
+    assert torch.equal(eopt.flat.flat, gopt.flat.flat)
+    assert torch.equal(eopt.exp_avg, gopt.exp_avg) and torch.equal(eopt.exp_avg_sq, gopt.exp_avg_sq)
+    sd_e, sd_g = eager.module.state_dict(), graphed.module.state_dict()
+    for k in sd_e:
+        assert torch.equal(sd_e[k], sd_g[k]), k
+    assert int(sd_g["bn1.num_batches_tracked"]) == 7
+
+
+def test_a_ragged_batch_runs_eager_and_the_graph_survives_it(dev):
+    from buctd_amd import engine
+    from buctd_amd.core.loss import JointsMSELoss
+    cfg = _prenet_cfg()
+    ((eager, eopt), (graphed, gopt)), crit = _pair(cfg, dev)
+    step = engine.StepGraph(graphed, crit, gopt, warmup=1)
+    sizes = [4, 4, 4, 3, 4, 4]          # the fourth batch is the ragged tail of an epoch
+    for i, n in enumerate(sizes):
+        x, t, w = _batch(cfg, n, 300 + i, dev)
+        engine.ops.set_grad_arena(eopt.flat)
+        loss_e = crit(eager(x), t, w)
+        eopt.zero_grad()
+        loss_e.backward()
+        eopt.step()
+        engine.ops.set_grad_arena(gopt.flat)
+        _, loss_g = step(x, t, w)
+        assert torch.equal(loss_e.detach(), loss_g.detach()), (i, float(loss_e), float(loss_g))
+    assert step.replays == 4
+    assert torch.equal(eopt.flat.flat, gopt.flat.flat)
+
+
+def test_train_entry_point_takes_a_step_graph(dev):
+    """core.function.train(..., step_graph=...) runs the reference loop with the captured step: same losses in the log
+    as the eager loop."""
+    from buctd_amd import engine
+    from buctd_amd.core.function import train
+    from buctd_amd.core.loss import JointsMSELoss
+    cfg = _prenet_cfg()
+    ((eager, eopt), (graphed, gopt)), crit = _pair(cfg, dev)
+    loader = []
+    for i in range(5):
+        x, t, w = _batch(cfg, 2, 500 + i, torch.device("cpu"))
+        loader.append((x, t, w, {}))
+
+    class Writer:
+        def __init__(self):
+            self.losses = []
+
+        def add_scalar(self, k, v, s):
+            if k == "train_loss":
+                self.losses.append(float(v))
+
+    c = cfg.clone()
+    c.defrost()
+    c.PRINT_FREQ = 1
+    c.freeze()
+    we, wg = {"writer": Writer(), "train_global_steps": 0}, {"writer": Writer(), "train_global_steps": 0}
+    engine.ops.set_grad_arena(eopt.flat)
+    train(c, loader, eager, crit, eopt, 0, "/tmp", "/tmp", we)
+    engine.ops.set_grad_arena(gopt.flat)
+    step = engine.StepGraph(graphed, crit, gopt, warmup=1)
+    train(c, loader, graphed, crit, gopt, 0, "/tmp", "/tmp", wg, step_graph=step)
+    assert step.replays == 4
+    assert we["writer"].losses == wg["writer"].losses
+    assert torch.equal(eopt.flat.flat, gopt.flat.flat)
+
+
+def test_dropout_models_are_refused(dev):
+    """The mask seed of train-mode dropout is a launch argument: a replay would repeat one mask, so the capture is refused."""
+    from buctd_amd import engine, models
+    from buctd_amd._C import BuctdHipError
+    from buctd_amd.config import cfg as base, hrnet_extra
+    from buctd_amd.core.loss import JointsMSELoss
+    c = base.clone()
+    c.defrost()
+    c.MODEL.NAME = "pose_hrnet_coam"
+    c.MODEL.NUM_JOINTS = 14
+    c.MODEL.IMAGE_SIZE = [64, 96]
+    c.MODEL.HEATMAP_SIZE = [16, 24]
+    c.MODEL.ATT_MODULES = [False, True, False, False]
+    c.MODEL.CONDITIONAL_TOPDOWN = True
+    c.MODEL.EXTRA = hrnet_extra(16, use_attention=True, modules=(1, 2, 2))
+    c.DATASET.COLORED = True
+    c.freeze()
+    torch.manual_seed(3)
+    net = models.pose_hrnet_coam.get_pose_net(c, is_train=True).to(dev)
+    model = engine.DataParallel(net)
+    opt = engine.get_optimizer(c, model)
+    model.train()
+    step = engine.StepGraph(model, JointsMSELoss(True), opt, warmup=1)
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(2, 6, 96, 64, generator=g).to(dev)
+    t = torch.rand(2, 14, 24, 16, generator=g).to(dev)
+    w = torch.ones(2, 14, 1, device=dev)
+    step(x, t, w)
+    with pytest.raises((BuctdHipError, NotImplementedError)):
+        step(x, t, w)
+    # the refusal leaves the engine usable: the eager step still runs
+    loss = JointsMSELoss(True)(model(x), t, w)
+    opt.zero_grad()
+    loss.backward()
+    opt.step()
+    assert torch.isfinite(loss)
