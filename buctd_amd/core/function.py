@@ -43,21 +43,33 @@ class AverageMeter(object):
         self.avg = self.sum / self.count if self.count else 0
 
 
+_ZERO_COPY = ops._SW["STATS_ZERO_COPY"] == "1"
+
+
 class _DeferredStats:
     """Loss scalar + decoded key points of one iteration, travelling to the host asynchronously."""
 
     def __init__(self, loss, output, target, n):
-        with torch.no_grad():
-            p_out, _, _ = ops.argmax_decode(output.detach().contiguous())
-            p_tgt, _, _ = ops.argmax_decode(target.contiguous())
         self.h, self.w = output.shape[2], output.shape[3]
         self.n = n
+        shape = (output.shape[0], output.shape[1], 2)
         self.loss = torch.empty((), dtype=torch.float32, pin_memory=True)
-        self.p_out = torch.empty(p_out.shape, dtype=torch.float32, pin_memory=True)
-        self.p_tgt = torch.empty(p_tgt.shape, dtype=torch.float32, pin_memory=True)
-        self.loss.copy_(loss.detach(), non_blocking=True)
-        self.p_out.copy_(p_out, non_blocking=True)
-        self.p_tgt.copy_(p_tgt, non_blocking=True)
+        self.p_out = torch.empty(shape, dtype=torch.float32, pin_memory=True)
+        self.p_tgt = torch.empty(shape, dtype=torch.float32, pin_memory=True)
+        with torch.no_grad():
+            if _ZERO_COPY:
+                # the decode kernels write the 3.5 KB of coordinates (and a one-float kernel the loss) straight into pinned
+                # host memory: three copy-engine transfers less per step, and the next step's first kernel does not queue
+                # behind a copy (the gap in front of nchw_to_nhwc in profiles/r06_critical_path.txt)
+                ops.argmax_decode(output.detach().contiguous(), preds_out=self.p_out)
+                ops.argmax_decode(target.contiguous(), preds_out=self.p_tgt)
+                ops.scalar_to_host(loss.detach(), self.loss)
+            else:
+                p_out, _, _ = ops.argmax_decode(output.detach().contiguous())
+                p_tgt, _, _ = ops.argmax_decode(target.contiguous())
+                self.loss.copy_(loss.detach(), non_blocking=True)
+                self.p_out.copy_(p_out, non_blocking=True)
+                self.p_tgt.copy_(p_tgt, non_blocking=True)
         self.event = torch.cuda.Event()
         self.event.record()
 

@@ -26,7 +26,7 @@ from ._C import ConvDesc, MatmulDesc, check, lib, ptr, stream_ptr
 # BUCTD_DIST_BACKEND - documented there.)
 _SW = {"CONV_MATH": "bf16x6", "PREP_BATCH": "1", "GCONV_X6": "1", "GCONV_MASK": "15", "NATIVE_BLOCK": "1", "FUSED_BOTTLENECK": "1",
        "FUSE_BN_IN": "1", "FC_O_X6": "1", "MHA_X6": "1", "MHA_PRESPLIT": "1", "ATTN_X6": "1", "WGRAD_STREAM": "1", "WGRAD_STREAMS": "1",
-       "WGRAD_PRIO": "-1", "BRANCH_STREAMS": "1", "BRANCH_MAX": "2", "BRANCH_PRIO": "0", "C3_PERSISTENT": "0"}
+       "WGRAD_PRIO": "-1", "BRANCH_STREAMS": "1", "BRANCH_MAX": "2", "BRANCH_PRIO": "0", "C3_PERSISTENT": "0", "STATS_ZERO_COPY": "1"}
 if os.environ.get("BUCTD_TUNING") == "1":
     from . import _tuning
     _tuning.override(_SW)
@@ -1367,20 +1367,32 @@ def joints_mse(pred, gt, w, want_grad, gscale=1.0):
     return loss, grad
 
 
-def argmax_decode(hm, refine=False):
-    """refine: also return the quarter-pixel offsets of get_final_preds' POST_PROCESS step ([N,K,2])."""
+def argmax_decode(hm, refine=False, preds_out=None):
+    """refine: also return the quarter-pixel offsets of get_final_preds' POST_PROCESS step ([N,K,2]).
+    preds_out: a pinned host tensor [N,K,2] the kernel writes the coordinates into directly (the GPU maps pinned memory)."""
     N, K, H, W = hm.shape
-    preds = torch.empty((N, K, 2), dtype=torch.float32, device=hm.device)
+    preds = preds_out if preds_out is not None else torch.empty((N, K, 2), dtype=torch.float32, device=hm.device)
+    if preds_out is not None and not (preds_out.is_pinned() and preds_out.is_contiguous() and tuple(preds_out.shape) == (N, K, 2)
+                                      and preds_out.dtype == torch.float32):
+        raise _C.BuctdHipError("argmax_decode: preds_out must be a pinned contiguous fp32 [N, K, 2] host tensor")
     maxvals = torch.empty((N, K, 1), dtype=torch.float32, device=hm.device)
     idx = torch.empty((N, K), dtype=torch.int32, device=hm.device)
     if refine:
         quarter = torch.empty((N, K, 2), dtype=torch.float32, device=hm.device)
-        check(lib().buctd_argmax_decode_refined(ptr(hm), N * K, H, W, ptr(preds), ptr(maxvals), ptr(idx), ptr(quarter),
+        check(lib().buctd_argmax_decode_refined(ptr(hm), N * K, H, W, preds.data_ptr(), ptr(maxvals), ptr(idx), ptr(quarter),
                                                 stream_ptr()), "argmax_decode_refined")
         return preds, maxvals, idx, quarter
-    check(lib().buctd_argmax_decode(ptr(hm), N * K, H, W, ptr(preds), ptr(maxvals), ptr(idx), stream_ptr()),
+    check(lib().buctd_argmax_decode(ptr(hm), N * K, H, W, preds.data_ptr(), ptr(maxvals), ptr(idx), stream_ptr()),
           "argmax_decode")
     return preds, maxvals, idx
+
+
+def scalar_to_host(src, dst):
+    """One float from device memory into a pinned host tensor, written by a kernel on the current stream (no copy engine)."""
+    if not (dst.is_pinned() and dst.dtype == torch.float32 and dst.numel() == 1 and src.numel() == 1):
+        raise _C.BuctdHipError("scalar_to_host: one fp32 value into a pinned host tensor")
+    check(lib().buctd_copy_channels(ptr(src), 1, 1, 0, dst.data_ptr(), 1, 0, 1, stream_ptr()), "scalar_to_host")
+    return dst
 
 
 def gaussian_target(joints, vis, heatmap_size, image_size, sigma):
