@@ -174,6 +174,8 @@ SIGNATURES = {
     "buctd_nhwc_to_nchw": (_I, [_P, _I, _I, _I, _I, _P, _P]),
     "buctd_fuse_sum": (_I, [C.POINTER(_P), _PI, _I, _I, _I, _I, _I, _I, _P, _P]),
     "buctd_fuse_sum_bwd": (_I, [_P, _P, _I, _I, _I, _I, _I, _P, _P]),
+    "buctd_fuse_sum_bwd_bnstat": (_I, [_P, _P, _I, _I, _I, _I, _I, _P, _I, C.POINTER(_P), C.POINTER(_P), C.POINTER(_P),
+                                       C.POINTER(_P), _P]),
     "buctd_resize_bilinear": (_I, [_P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P]),
     "buctd_maxpool3x3s2_fwd": (_I, [_P, _I, _I, _I, _I, _P, _P, _P]),
     "buctd_maxpool3x3s2_bwd": (_I, [_P, _P, _I, _I, _I, _I, _P, _P]),

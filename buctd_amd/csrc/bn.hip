@@ -946,6 +946,156 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_acc_group_kernel(BnGroup<Bn
   bn_bwd_reduce_acc_body(g.s[k], bid, sm);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Backward of a fuse row (reference lib/models/pose_hrnet.py:257-265: y = relu(sum_j upsample(term_j))) together with the
+// BatchNorm-backward sums of the terms that are conv -> BatchNorm outputs: the kernel that forms g = window sum of the masked
+// upstream gradient also adds sum(g) and sum(g * zhat_t) of up to FSB_MAX terms into their accumulators (bn_acc.h), so that
+// their BatchNorm backward starts at the apply kernel (acc_ready) - one reduction launch and one pass over g and z less per
+// term.  g is written exactly as fuse_sum_bwd_kernel writes it; a workgroup owns a contiguous run of rows (fixed partition:
+// the sums are reproducible run to run).
+#define FSB_MAX 3
+struct FuseBwdStatArgs {
+  const float* dy;
+  const float* y;        // forward output of the fuse row (ReLU mask), or nullptr
+  float* g;
+  int shift, N, H, W, C;
+  long rows_per_block;
+  int nt;
+  const float* z[FSB_MAX];
+  const float* mean[FSB_MAX];
+  const float* invstd[FSB_MAX];
+  long long* acc[FSB_MAX];
+};
+__global__ __launch_bounds__(256) void fuse_bwd_stats_kernel(FuseBwdStatArgs p) {
+  __shared__ f32x4 sm[1 + FSB_MAX][256];
+  const float* __restrict__ dy = p.dy;
+  const float* __restrict__ y = p.y;
+  const int C = p.C, c4n = C >> 2, rl = 256 / c4n;
+  const int tc = threadIdx.x % c4n, tr = threadIdx.x / c4n;
+  const int f = 1 << p.shift, hs = p.H >> p.shift, ws = p.W >> p.shift;
+  const long rows = (long)p.N * hs * ws;
+  const long r0 = (long)blockIdx.x * p.rows_per_block;
+  long r1 = r0 + p.rows_per_block;
+  if (r1 > rows) r1 = rows;
+  f32x4 s1 = (f32x4){0.f, 0.f, 0.f, 0.f};
+  f32x4 s2[FSB_MAX];
+  f32x4 mu[FSB_MAX], is[FSB_MAX];
+#pragma unroll
+  for (int t = 0; t < FSB_MAX; ++t) {
+    s2[t] = s1;
+    mu[t] = is[t] = s1;
+    if (t < p.nt && tr < rl) {
+      mu[t] = reinterpret_cast<const f32x4*>(p.mean[t])[tc];
+      is[t] = reinterpret_cast<const f32x4*>(p.invstd[t])[tc];
+    }
+  }
+  if (tr < rl) {
+    auto window = [&](long r) -> f32x4 {      // g of low-resolution row r: the masked upstream gradient summed over its window
+      long pix = r;
+      const int w = (int)(pix % ws);
+      pix /= ws;
+      const int h = (int)(pix % hs);
+      const int n = (int)(pix / hs);
+      f32x4 a = (f32x4){0.f, 0.f, 0.f, 0.f};
+      for (int dh = 0; dh < f; ++dh)
+        for (int dw = 0; dw < f; ++dw) {
+          const long o = (((long)n * p.H + h * f + dh) * p.W + w * f + dw) * c4n + tc;
+          f32x4 d = reinterpret_cast<const f32x4*>(dy)[o];
+          if (y) {
+            const f32x4 yy = reinterpret_cast<const f32x4*>(y)[o];
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+              if (!(yy[j] > 0.f)) d[j] = 0.f;
+          }
+          a += d;
+        }
+      return a;
+    };
+    auto tail = [&](long o, f32x4 a, const f32x4 (&zz)[FSB_MAX]) {
+      reinterpret_cast<f32x4*>(p.g)[o] = a;
+      s1 += a;
+#pragma unroll
+      for (int t = 0; t < FSB_MAX; ++t)
+        if (t < p.nt) s2[t] += a * (zz[t] - mu[t]) * is[t];
+    };
+    long r = r0 + tr;
+    const long step = rl;
+    if (f == 1) {
+      // same resolution (the down-sampling chains): four rows in flight per lane, as in bn_bwd_reduce_acc_body
+      for (; r + 3 * step < r1; r += 4 * step) {
+        f32x4 d[4], yy[4], zz[4][FSB_MAX];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const long o = (r + u * step) * c4n + tc;
+          d[u] = reinterpret_cast<const f32x4*>(dy)[o];
+          yy[u] = y ? reinterpret_cast<const f32x4*>(y)[o] : (f32x4){1.f, 1.f, 1.f, 1.f};
+#pragma unroll
+          for (int t = 0; t < FSB_MAX; ++t)
+            zz[u][t] = t < p.nt ? reinterpret_cast<const f32x4*>(p.z[t])[o] : (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            if (!(yy[u][j] > 0.f)) d[u][j] = 0.f;
+          tail((r + u * step) * c4n + tc, d[u], zz[u]);
+        }
+      }
+    }
+    for (; r < r1; r += step) {
+      const long o = r * c4n + tc;
+      f32x4 zz[FSB_MAX];
+#pragma unroll
+      for (int t = 0; t < FSB_MAX; ++t)
+        zz[t] = t < p.nt ? reinterpret_cast<const f32x4*>(p.z[t])[o] : (f32x4){0.f, 0.f, 0.f, 0.f};
+      tail(o, window(r), zz);
+    }
+  }
+  sm[0][threadIdx.x] = s1;
+#pragma unroll
+  for (int t = 0; t < FSB_MAX; ++t) sm[1 + t][threadIdx.x] = s2[t];
+  __syncthreads();
+  if (tr == 0) {
+    for (int k = 1; k < rl; ++k) {
+      s1 += sm[0][k * c4n + tc];
+#pragma unroll
+      for (int t = 0; t < FSB_MAX; ++t) s2[t] += sm[1 + t][k * c4n + tc];
+    }
+    sm[0][tc] = s1;
+#pragma unroll
+    for (int t = 0; t < FSB_MAX; ++t) sm[1 + t][tc] = s2[t];
+  }
+  __syncthreads();
+  const unsigned shard = bnacc_shard();
+  for (int c = threadIdx.x; c < C; c += 256) {
+    const double v1 = (double)reinterpret_cast<const float*>(&sm[0][0])[c];
+#pragma unroll
+    for (int t = 0; t < FSB_MAX; ++t)
+      if (t < p.nt) bnacc_add(p.acc[t], C, shard, c, v1, (double)reinterpret_cast<const float*>(&sm[1 + t][0])[c]);
+  }
+}
+
+extern "C" int buctd_fuse_sum_bwd_bnstat(const float* dy, const float* y, int shift, int N, int H, int W, int C, float* g, int nt,
+                                         const float* const* z, const float* const* mean, const float* const* invstd,
+                                         void* const* acc, void* stream) {
+  BUCTD_CHECK_ARG(dy && g && shift >= 0 && shift <= 5 && N > 0 && C > 0 && C % 4 == 0 && C / 4 <= 256,
+                  "buctd_fuse_sum_bwd_bnstat: bad argument (C must be a multiple of 4, <= 1024)");
+  BUCTD_CHECK_ARG((H >> shift) << shift == H && (W >> shift) << shift == W, "buctd_fuse_sum_bwd_bnstat: H/W not divisible by 2^shift");
+  BUCTD_CHECK_ARG(nt >= 1 && nt <= FSB_MAX && z && mean && invstd && acc, "buctd_fuse_sum_bwd_bnstat: 1..%d BatchNorm terms", FSB_MAX);
+  FuseBwdStatArgs a;
+  a.dy = dy; a.y = y; a.g = g; a.shift = shift; a.N = N; a.H = H; a.W = W; a.C = C; a.nt = nt;
+  for (int t = 0; t < FSB_MAX; ++t) {
+    const int k = t < nt ? t : 0;
+    BUCTD_CHECK_ARG(z[k] && mean[k] && invstd[k] && acc[k], "buctd_fuse_sum_bwd_bnstat: null pointer in term %d", k);
+    a.z[t] = z[k]; a.mean[t] = mean[k]; a.invstd[t] = invstd[k]; a.acc[t] = (long long*)acc[k];
+  }
+  const long rows = (long)N * (H >> shift) * (W >> shift);
+  const long nb = bwd2_blocks(rows, &a.rows_per_block);
+  hipLaunchKernelGGL(fuse_bwd_stats_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, a);
+  BUCTD_CHECK_LAUNCH("buctd_fuse_sum_bwd_bnstat");
+  return BUCTD_OK;
+}
+
 // dz = gamma * invstd * (g - s1 / M - zhat * s2 / M); dres = g.  LDS: [4][C] accumulator words | [6][C] floats (mean, invstd,
 // gamma, beta, s1, s2)
 __device__ __forceinline__ void bn_bwd_apply_acc_body(const BnBwdArgs& p, unsigned bid, unsigned nblk, unsigned char* lds_raw) {

@@ -26,7 +26,7 @@ from ._C import ConvDesc, MatmulDesc, check, lib, ptr, stream_ptr
 # BUCTD_DIST_BACKEND - documented there.)
 _SW = {"CONV_MATH": "bf16x6", "PREP_BATCH": "1", "GCONV_X6": "1", "GCONV_MASK": "15", "NATIVE_BLOCK": "1", "FUSED_BOTTLENECK": "1",
        "FUSE_BN_IN": "1", "FC_O_X6": "1", "MHA_X6": "1", "MHA_PRESPLIT": "1", "ATTN_X6": "1", "WGRAD_STREAM": "1", "WGRAD_STREAMS": "1",
-       "WGRAD_PRIO": "-1", "BRANCH_STREAMS": "1", "BRANCH_MAX": "2", "BRANCH_PRIO": "0", "C3_PERSISTENT": "0", "STATS_ZERO_COPY": "1"}
+       "WGRAD_PRIO": "-1", "BRANCH_STREAMS": "1", "BRANCH_MAX": "2", "BRANCH_PRIO": "0", "C3_PERSISTENT": "0", "STATS_ZERO_COPY": "1", "FUSE_BWD_BNSTAT": "0", "FUSE_BWD_BNSTAT_S0": "0"}
 if os.environ.get("BUCTD_TUNING") == "1":
     from . import _tuning
     _tuning.override(_SW)
@@ -699,6 +699,8 @@ def set_fused_bottleneck(on):
     return old
 # experiment switches, read ONCE at import (the hot path consults module constants, never the environment)
 _FUSE_BN_IN = _SW["FUSE_BN_IN"] == "1"
+_FUSE_BWD_BNSTAT = _SW["FUSE_BWD_BNSTAT"] == "1"
+_FUSE_BWD_BNSTAT_S0 = _SW["FUSE_BWD_BNSTAT_S0"] == "1"
 _FC_O_X6 = _SW["FC_O_X6"] != "0"
 _MHA_X6 = _SW["MHA_X6"] != "0"
 _MHA_PRESPLIT = _SW["MHA_PRESPLIT"] != "0"
@@ -1015,6 +1017,7 @@ def fork_join(fns, inputs, tag=0):
 
 def _join_side():
     _side["joined"] = True
+    _bwd_sums.clear()
     wait_side_stream()
 
 
@@ -1331,6 +1334,30 @@ def fuse_sum_bwd(dy, y, shift):
     return g
 
 
+# (gradient address, z address) -> AccRef holding the BatchNorm-backward sums of that pair, formed by the kernel that wrote the
+# gradient (fuse_sum_bwd_bnstat); ConvBnAct.backward pops its entry.  Emptied at the end of every backward pass (_join_side).
+_bwd_sums = {}
+
+
+def fuse_sum_bwd_bnstat(dy, y, shift, bns):
+    """fuse_sum_bwd + the BatchNorm-backward sums of up to three conv -> BatchNorm terms of this shift (bns: (z, mean, invstd)
+    each) in one pass; the accumulators are left in _bwd_sums for the terms' ConvBnAct.backward."""
+    N, H, W, Cn = dy.shape
+    g = torch.empty((N, H >> shift, W >> shift, Cn), dtype=torch.float32, device=dy.device)
+    n = len(bns)
+    accs = [AccRef(Cn, dy.device) for _ in bns]
+    zs = (C.c_void_p * n)(*[b[0].data_ptr() for b in bns])
+    ms = (C.c_void_p * n)(*[b[1].data_ptr() for b in bns])
+    iv = (C.c_void_p * n)(*[b[2].data_ptr() for b in bns])
+    ac = (C.c_void_p * n)(*[a.ptr for a in accs])
+    check(lib().buctd_fuse_sum_bwd_bnstat(ptr(dy), ptr(y), shift, N, H, W, Cn, ptr(g), n, zs, ms, iv, ac, stream_ptr()),
+          "fuse_sum_bwd_bnstat")
+    for b, a in zip(bns, accs):
+        _bwd_sums[(g.data_ptr(), b[0].data_ptr())] = a
+    _queue_join()       # the registry is emptied with the backward pass
+    return g
+
+
 def resize_bilinear_from_nchw(x, c0, cc, Ho, Wo):
     _f32(x, "resize input")
     N, Ct, H, W = x.shape
@@ -1536,6 +1563,10 @@ class ConvBnAct(torch.autograd.Function):
             ctx.has_res = residual is not None
             # without a residual the ReLU mask is rebuilt from z in the backward kernels: y is not kept (nor re-read)
             ctx.save_for_backward(x, z, mean, invstd, y if (relu and ctx.has_res) else None)
+            if _FUSE_BWD_BNSTAT and info[0] == "acc" and not relu and residual is None and bn_acc_ok(Cn):
+                # a plain conv -> BatchNorm output: a FuseSum consuming it can form this BatchNorm's backward sums while it
+                # writes the gradient (FuseSum.backward); z / mean / invstd are kept alive by this node anyway
+                y._buctd_bn = (z, mean, invstd)
             return y
         scale, shift = bn_fold_cached(bn, gamma, beta, eps)
         if transposed_shape is None:
@@ -1559,8 +1590,9 @@ class ConvBnAct(torch.autograd.Function):
         dgamma, acc_g = grad_target(bn.weight)
         dbeta, acc_b = grad_target(bn.bias)
         assert acc_g == acc_b
+        ready = _bwd_sums.pop((dy.data_ptr(), z.data_ptr()), None) if _bwd_sums else None
         dz, dres = bn_bwd(dy, y, z, mean, invstd, bn.weight, relu, ctx.has_res and relu, dgamma, dbeta, acc_g,
-                          beta=bn.bias)
+                          beta=bn.bias, acc=ready, acc_ready=ready is not None)
         if ctx.has_res and not relu:
             dres = dy
         dx = None
@@ -2203,6 +2235,8 @@ class FuseSum(torch.autograd.Function):
         out = fuse_sum(list(terms), list(shifts), relu)
         ctx.shifts, ctx.relu = shifts, relu
         ctx.save_for_backward(out if relu else None)
+        # terms that are plain conv -> BatchNorm outputs (ConvBnAct.forward tags them): (z, mean, invstd) of their BatchNorm
+        ctx.term_bn = tuple(getattr(t, "_buctd_bn", None) for t in terms) if _FUSE_BWD_BNSTAT else None
         return out
 
     @staticmethod
@@ -2216,8 +2250,18 @@ class FuseSum(torch.autograd.Function):
                 grads.append(None)
                 continue
             if s not in cache:
-                cache[s] = fuse_sum_bwd(dy, y, s) if (s > 0 or ctx.relu) else dy
+                if s > 0 or ctx.relu:
+                    bns = []
+                    # s > 0 only: the shift-0 gradient also feeds the identity term - the branch chain, which is the critical
+                    # path of the backward pass - and must not wait for extra passes over the terms' z (measured: -0.8 %)
+                    if ctx.term_bn is not None and (s > 0 or _FUSE_BWD_BNSTAT_S0):
+                        bns = [ctx.term_bn[k] for k, sk in enumerate(ctx.shifts)
+                               if sk == s and ctx.needs_input_grad[2 + k] and ctx.term_bn[k] is not None][:3]
+                    cache[s] = fuse_sum_bwd_bnstat(dy, y, s, bns) if bns else fuse_sum_bwd(dy, y, s)
+                else:
+                    cache[s] = dy
             grads.append(cache[s])
+        ctx.term_bn = None
         return (None, None, *grads)
 
 

@@ -298,6 +298,14 @@ typedef struct {
   int acc_ready;
 } buctd_bn_bwd_item;
 int buctd_bn_bwd_acc_group(int n, const buctd_bn_bwd_item* items, void* stream);
+/* Backward of a fuse row (lib/models/pose_hrnet.py:257-265, y = relu(sum_j upsample(term_j))) for the terms of one shift,
+ * exactly buctd_fuse_sum_bwd (g [N][H>>shift][W>>shift][C] = window sum of dy * (y > 0); y may be NULL), plus the
+ * BatchNorm-backward sums of nt <= 3 terms that are conv -> BatchNorm outputs of that resolution: sum(g) and
+ * sum(g * (z_t - mean_t) * invstd_t) are added into acc[t] (buctd_bn_acc_bytes(C) each, zero on entry), so that
+ * buctd_bn_bwd_acc(..., acc[t], acc_ready = 1) can follow without its reduction launch. */
+int buctd_fuse_sum_bwd_bnstat(const float* dy, const float* y, int shift, int N, int H, int W, int C, float* g, int nt,
+                              const float* const* z, const float* const* mean, const float* const* invstd,
+                              void* const* acc, void* stream);
 /* eval-mode helpers: scale = gamma/sqrt(var+eps), shift = beta - mean*scale */
 int buctd_bn_fold(const float* gamma, const float* beta, const float* running_mean, const float* running_var,
                   float eps, int C, float* scale, float* shift, void* stream);

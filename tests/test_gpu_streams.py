@@ -51,3 +51,60 @@ def test_streams_first_call_eval_full_size(dev):
     y1, _, _ = _run(dev, "coam_w48_384x288", True, False)
     y0, _, _ = _run(dev, "coam_w48_384x288", False, False)
     assert np.array_equal(y1, y0)
+
+
+def test_fuse_row_backward_forms_the_batchnorm_sums_of_its_terms(dev):
+    """FuseSum.backward (reference pose_hrnet.py:257-265) hands the conv -> BatchNorm terms of a fuse row their backward sums
+    (buctd_fuse_sum_bwd_bnstat): the gradients must equal those of the path with a reduction launch per BatchNorm - to the
+    rounding of a different fp32 partition of the same sums - and the reduction launches must really be gone."""
+    import copy
+    from buctd_amd import engine, models, ops
+    from buctd_amd.config import cfg as base, hrnet_extra
+    from buctd_amd.core.loss import JointsMSELoss
+    c = base.clone()
+    c.defrost()
+    c.MODEL.NAME = "pose_hrnet"
+    c.MODEL.NUM_JOINTS = 17
+    c.MODEL.IMAGE_SIZE = [64, 96]
+    c.MODEL.HEATMAP_SIZE = [16, 24]
+    c.MODEL.CONDITIONAL_TOPDOWN = True
+    c.MODEL.EXTRA = hrnet_extra(16, use_pre_net=True, modules=(1, 2, 2))
+    c.freeze()
+    torch.manual_seed(11)
+    net = models.pose_hrnet.get_pose_net(c, is_train=True).to(dev).train()
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(4, 6, 96, 64, generator=g).to(dev)
+    t = torch.rand(4, 17, 24, 16, generator=g).to(dev)
+    w = torch.ones(4, 17, 1, device=dev)
+    crit = JointsMSELoss(True)
+    calls = {"n": 0}
+    raw = ops.fuse_sum_bwd_bnstat
+
+    def counted(*a, **k):
+        calls["n"] += 1
+        return raw(*a, **k)
+
+    grads = {}
+    old, old0 = ops._FUSE_BWD_BNSTAT, ops._FUSE_BWD_BNSTAT_S0
+    ops._FUSE_BWD_BNSTAT_S0 = True         # the same-resolution terms too (the product fuses the up-sampled ones only)
+    try:
+        ops.fuse_sum_bwd_bnstat = counted
+        for flag in (False, True):
+            ops._FUSE_BWD_BNSTAT = flag      # read by ConvBnAct.forward (tags) and FuseSum (both directions) at call time
+            m = copy.deepcopy(net)
+            loss = crit(m(x), t, w)
+            loss.backward()
+            torch.cuda.synchronize()
+            grads[flag] = {k: p.grad.detach().clone() for k, p in m.named_parameters() if p.grad is not None}
+            assert not ops._bwd_sums, "every accumulator a fuse row left must have been consumed"
+    finally:
+        ops._FUSE_BWD_BNSTAT, ops._FUSE_BWD_BNSTAT_S0 = old, old0
+        ops.fuse_sum_bwd_bnstat = raw
+    assert calls["n"] >= 5, calls            # fuse rows of the small net whose terms take the accumulator path
+    assert grads[False].keys() == grads[True].keys()
+    worst = 0.0
+    for k, a in grads[False].items():
+        b = grads[True][k]
+        scale = float(a.abs().max()) + 1e-12
+        worst = max(worst, float((a - b).abs().max()) / scale)
+    assert worst <= 2e-5, worst
