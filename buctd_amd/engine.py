@@ -12,6 +12,7 @@ BatchNorm statistics stay per replica, like under nn.DataParallel (no SyncBN); b
 checkpoint sees (broadcast_buffers()).
 """
 import os
+import time
 
 import torch
 import torch.distributed as dist
@@ -526,7 +527,8 @@ class StepGraph:
     Not capturable, and refused loudly: train-mode dropout (the mask seed is a launch argument: CoAM / TransPose run eager),
     a gradient exchange over a process group (the buckets are launched from host callbacks)."""
 
-    def __init__(self, model, criterion, optimizer, warmup=3, streams="single", allow_repeated_dropout_masks=False):
+    def __init__(self, model, criterion, optimizer, warmup=3, streams="single", allow_repeated_dropout_masks=False,
+                 autoselect=False):
         if streams not in ("single", "engine"):
             raise ValueError("streams: 'single' (a linear graph) or 'engine' (the engine's branch / weight-gradient streams "
                              "become parallel branches of the graph)")
@@ -539,6 +541,12 @@ class StepGraph:
         self.warmup = int(warmup)
         self.streams = streams
         self._allow_seeds = bool(allow_repeated_dropout_masks)     # measurement only: every replay repeats one mask
+        # autoselect: the last eager settling step and the first two replays of a signature are timed (device drained around
+        # them - they are ordinary training steps on the caller's batches) and the signature keeps the faster path: a linear
+        # graph wins below ~batch 32 on HRNet-W32 and loses the stream concurrency of the eager engine above
+        self.autoselect = bool(autoselect)
+        self._eager_s = {}
+        self._eager_only = set()
         self._seen = {}
         self._graphs = {}
         self._dropout = False
@@ -583,7 +591,7 @@ class StepGraph:
         counts = [(m, m._pending_batches - b) for m, b in zip(bns, before) if m._pending_batches != b]
         for m, b in zip(bns, before):
             m._pending_batches = b                    # the capture enqueued nothing: its batches are counted per replay
-        return {"graph": graph, "static": static, "out": out, "loss": loss, "bn_counts": counts, "keep": keep}
+        return {"graph": graph, "static": static, "out": out, "loss": loss, "bn_counts": counts, "keep": keep, "clocked": 0}
 
     def __call__(self, x, target, weight):
         key = self._signature((x, target, weight))
@@ -591,10 +599,17 @@ class StepGraph:
         if g is None:
             n = self._seen.get(key, 0)
             self._seen[key] = n + 1
-            if n < self.warmup or not x.is_cuda or not self.model.training:
+            if n < self.warmup or not x.is_cuda or not self.model.training or key in self._eager_only:
                 drawn = ops.seeds_drawn()
+                clocked = self.autoselect and x.is_cuda and n == self.warmup - 1 and n > 0
+                if clocked:
+                    torch.cuda.synchronize(x.device)
+                    t0 = time.perf_counter()
                 out, loss = self._forward_backward(x, target, weight)
                 self.optimizer.step()
+                if clocked:
+                    torch.cuda.synchronize(x.device)
+                    self._eager_s[key] = time.perf_counter() - t0
                 self._dropout = self._dropout or ops.seeds_drawn() != drawn
                 return out, loss
             if self._dropout and not self._allow_seeds:
@@ -604,11 +619,25 @@ class StepGraph:
         for dst, src in zip(g["static"], (x, target, weight)):
             if dst.data_ptr() != src.data_ptr():
                 dst.copy_(src, non_blocking=True)
+        clocked = self.autoselect and key in self._eager_s and g["clocked"] < 2
+        if clocked:
+            torch.cuda.synchronize(x.device)
+            t0 = time.perf_counter()
         g["graph"].replay()
         for m, c in g["bn_counts"]:
             m._pending_batches += c
         self.replays += 1
         self.optimizer.step()
+        if clocked:
+            torch.cuda.synchronize(x.device)
+            g["clocked"] += 1
+            g["replay_s"] = min(g.get("replay_s", 1e9), time.perf_counter() - t0)
+            if g["clocked"] == 2 and g["replay_s"] > self._eager_s[key]:
+                # the eager engine is faster for this signature: drop the graph (its outputs stay valid tensors)
+                self._eager_only.add(key)
+                out, loss = g["out"], g["loss"]
+                del self._graphs[key]
+                return out, loss
         return g["out"], g["loss"]
 
     def static_inputs(self, x, target, weight):
@@ -616,6 +645,88 @@ class StepGraph:
         its batches there saves the per-step copy."""
         g = self._graphs.get(self._signature((x, target, weight)))
         return None if g is None else tuple(g["static"])
+
+
+class ForwardGraph(torch.nn.Module):
+    """Eval-mode forward of `module` replayed from a hipGraph, one graph per input signature - the serving path: top-down pose
+    inference runs the network on the few person crops of an image (tools/inference.py, lib/core/function.py:178-336 at small
+    TEST.BATCH_SIZE), where the eager engine's ~400-900 launches cost more host time than the kernels take on the GPU.
+
+    Drop-in for the module inside validate() / dataset.pipeline.IterativeRefiner: `net = engine.ForwardGraph(net)`; calls in
+    train mode, with gradients enabled, or on a CPU tensor go straight to the module.  The first `warmup` calls of a signature
+    run the eager engine (filter images, folded BatchNorms and workspaces settle), the next one captures a LINEAR graph (the
+    runtime re-enqueues a graph with cross-queue edges node by node: DESIGN.md 3.14l), later ones copy the input into the
+    graph's static buffer and replay.  Outputs are copies by default (`static_output=True` hands out the graph's own output
+    tensors: valid until the next call of the same signature).  Parameters are read at replay time, so a checkpoint loaded in
+    place is picked up - but anything keyed on the weights (prepared filter images, folded BatchNorms) is rebuilt by the eager
+    engine, not by a replay: after changing weights call `reset()`; engine.FusedAdam steps are noticed automatically."""
+
+    def __init__(self, module, warmup=2, static_output=False, max_graphs=8, autoselect=True):
+        super().__init__()
+        self.module = module
+        self.warmup, self.static_output, self.max_graphs = int(warmup), bool(static_output), int(max_graphs)
+        # autoselect: right after a capture the eager forward and the replay are timed (three runs each, device drained) and
+        # the signature keeps the faster one - a linear graph loses the stream concurrency of the eager engine, which is worth
+        # ~10 % from 16 persons per call on (profiles/r06_forward_graph_by_batch.txt)
+        self.autoselect = bool(autoselect)
+        self._seen, self._graphs = {}, {}
+        self._epoch = None
+        self.replays = 0
+
+    def reset(self):
+        self._seen, self._graphs = {}, {}
+
+    def forward(self, x, *args, **kwargs):
+        if (self.module.training or torch.is_grad_enabled() or args or kwargs or not torch.is_tensor(x) or not x.is_cuda):
+            return self.module(x, *args, **kwargs)
+        epoch = ops.weights_epoch()
+        if epoch != self._epoch:          # an optimizer step rewrote the parameters: prepared images are refreshed eagerly
+            self.reset()
+            self._epoch = epoch
+        key = (tuple(x.shape), x.dtype, x.device, x.stride())
+        g = self._graphs.get(key)
+        if g is None:
+            n = self._seen.get(key, 0)
+            self._seen[key] = n + 1
+            if n < self.warmup or len(self._graphs) >= self.max_graphs:
+                return self.module(x)
+            g = self._graphs[key] = self._capture(x)
+        if not g["use"]:
+            return self.module(x)
+        if g["x"].data_ptr() != x.data_ptr():
+            g["x"].copy_(x, non_blocking=True)
+        g["graph"].replay()
+        self.replays += 1
+        out = g["out"]
+        if self.static_output:
+            return out
+        return [o.clone() for o in out] if isinstance(out, list) else out.clone()
+
+    def _capture(self, x):
+        static = x.clone()
+        graph = torch.cuda.CUDAGraph()
+        ops.begin_capture(allow_seeds=True)     # eval mode: the attention cores draw a seed but drop nothing (p = 0)
+        forks = ops.set_stream_forks(False)
+        try:
+            with torch.cuda.graph(graph):
+                out = self.module(static)
+        finally:
+            ops.set_stream_forks(*forks)
+            keep = ops.end_capture()
+        use = True
+        if self.autoselect:
+            import time
+
+            def clock(fn):
+                fn()
+                torch.cuda.synchronize(x.device)
+                t0 = time.perf_counter()
+                for _ in range(3):
+                    fn()
+                torch.cuda.synchronize(x.device)
+                return time.perf_counter() - t0
+            use = clock(graph.replay) <= clock(lambda: self.module(static))
+        return {"graph": graph, "x": static, "out": out, "keep": keep, "use": use}
 
 
 _comm_streams = {}      # device index -> the communication stream reserved by reserve_streams

@@ -421,6 +421,11 @@ _PREP_BATCH = _SW["PREP_BATCH"] == "1"
 _prep_registry = {"weights": [], "table": None, "table_key": None, "event": None, "stream": None, "waited": set()}
 
 
+def weights_epoch():
+    """Counts the in-place parameter rewrites announced by weights_updated() (the fused optimizers)."""
+    return _weights_epoch["n"]
+
+
 def weights_updated():
     """Called by whoever rewrites parameters through raw pointers (FusedAdam): invalidates prepared filter images."""
     _weights_epoch["n"] += 1

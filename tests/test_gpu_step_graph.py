@@ -177,3 +177,86 @@ def test_dropout_models_are_refused(dev):
     loss.backward()
     opt.step()
     assert torch.isfinite(loss)
+
+
+def test_forward_graph_equals_the_eager_eval_forward(dev):
+    """engine.ForwardGraph: the eval-mode forward replayed from a hipGraph (the small-batch serving path) returns the eager
+    engine's heat maps bit for bit, per input signature, on changing inputs; train mode and grad mode go to the module."""
+    from buctd_amd import engine, models
+    cfg = _prenet_cfg()
+    torch.manual_seed(9)
+    net = models.pose_hrnet.get_pose_net(cfg, is_train=False).to(dev).eval()
+    fg = engine.ForwardGraph(net, warmup=1, autoselect=False)
+    with torch.no_grad():
+        for i in range(6):
+            n = 3 if i % 2 == 0 else 1                 # two signatures, interleaved
+            x, _, _ = _batch(cfg, n, 700 + i, dev)
+            ref = net(x)
+            got = fg(x)
+            assert torch.equal(ref, got), i
+    assert fg.replays == 4                             # call 0 of each signature runs eager, call 1 captures and replays
+    assert len(fg._graphs) == 2
+    # outputs are copies: an earlier result survives the next replay of its signature
+    with torch.no_grad():
+        xa, _, _ = _batch(cfg, 3, 800, dev)
+        xb, _, _ = _batch(cfg, 3, 801, dev)
+        ya = fg(xa)
+        keep = ya.clone()
+        fg(xb)
+        assert torch.equal(ya, keep)
+    # with gradients enabled the module itself runs
+    x, _, _ = _batch(cfg, 3, 802, dev)
+    before = fg.replays
+    y = fg(x)
+    assert fg.replays == before and y.requires_grad
+
+
+def test_validate_runs_on_a_forward_graph(dev):
+    """validate() (reference lib/core/function.py:178-336) with the network wrapped in engine.ForwardGraph: same predictions
+    table as with the plain module, flip test on."""
+    import numpy as np
+    from buctd_amd import engine, models
+    from buctd_amd.core.function import validate
+    from buctd_amd.core.loss import JointsMSELoss
+    cfg = _prenet_cfg()
+    c = cfg.clone()
+    c.defrost()
+    c.TEST.FLIP_TEST = True
+    c.TEST.POST_PROCESS = True
+    c.TEST.SHIFT_HEATMAP = True
+    c.PRINT_FREQ = 100
+    c.freeze()
+    torch.manual_seed(13)
+    net = models.pose_hrnet.get_pose_net(c, is_train=False).to(dev).eval()
+
+    class Dataset:
+        flip_pairs = [[1, 2], [3, 4], [5, 6], [7, 8], [9, 10], [11, 12], [13, 14], [15, 16]]
+        image_size = c.MODEL.IMAGE_SIZE
+        kpt_colors = [[(37 * k) % 256, (91 * k) % 256, (53 * k) % 256] for k in range(17)]
+
+        def __init__(self, n):
+            self.n, self.captured = n, None
+
+        def __len__(self):
+            return self.n
+
+        def evaluate(self, cfg, preds, output_dir, all_boxes, img_path, *a, **k):
+            self.captured = preds.copy()
+            return {"AP": 0.0}, 0.0
+
+    batches = []
+    for i in range(4):
+        x, t, w = _batch(c, 2, 900 + i, torch.device("cpu"))
+        g = torch.Generator().manual_seed(950 + i)
+        meta = {"center": torch.rand(2, 2, generator=g) * 100 + 50, "scale": torch.rand(2, 2, generator=g) + 0.5,
+                "score": torch.rand(2, generator=g), "annotation_id": torch.arange(2) + 2 * i,
+                "image": [f"im_{i}_{j}.jpg" for j in range(2)],
+                "cond_joints": torch.cat([torch.rand(2, 17, 2, generator=g) * 60, torch.zeros(2, 17, 1)], 2),
+                "cond_joints_vis": torch.ones(2, 17, 3)}
+        batches.append((x, t, w, meta))
+    tables = []
+    for model in (net, engine.ForwardGraph(net, warmup=1)):
+        ds = Dataset(8)
+        validate(c, batches, ds, model, JointsMSELoss(True), "/tmp", "/tmp", None)
+        tables.append(ds.captured)
+    assert np.array_equal(tables[0], tables[1])
