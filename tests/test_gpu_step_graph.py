@@ -260,3 +260,33 @@ def test_validate_runs_on_a_forward_graph(dev):
         validate(c, batches, ds, model, JointsMSELoss(True), "/tmp", "/tmp", None)
         tables.append(ds.captured)
     assert np.array_equal(tables[0], tables[1])
+
+
+def test_autoselect_keeps_results_whichever_path_wins(dev):
+    """StepGraph(autoselect=True) times its last settling step and its first two replays and keeps the faster path per
+    signature; ForwardGraph does the same right after its capture.  Whichever wins, the results are the eager engine's."""
+    from buctd_amd import engine
+    cfg = _prenet_cfg()
+    ((eager, eopt), (graphed, gopt)), crit = _pair(cfg, dev)
+    step = engine.StepGraph(graphed, crit, gopt, warmup=2, autoselect=True)
+    for i in range(8):
+        x, t, w = _batch(cfg, 2, 1100 + i, dev)
+        engine.ops.set_grad_arena(eopt.flat)
+        loss_e = crit(eager(x), t, w)
+        eopt.zero_grad()
+        loss_e.backward()
+        eopt.step()
+        engine.ops.set_grad_arena(gopt.flat)
+        _, loss_g = step(x, t, w)
+        assert torch.equal(loss_e.detach(), loss_g.detach()), (i, float(loss_e), float(loss_g))
+    assert step.replays >= 2
+    assert torch.equal(eopt.flat.flat, gopt.flat.flat)
+    key = next(iter(step._seen))
+    assert (key in step._graphs) != (key in step._eager_only)
+    net = graphed.module.eval()
+    fg = engine.ForwardGraph(net, warmup=1, autoselect=True)
+    with torch.no_grad():
+        for i in range(4):
+            x, _, _ = _batch(cfg, 2, 1200 + i, dev)
+            assert torch.equal(net(x), fg(x)), i
+    assert len(fg._graphs) == 1
