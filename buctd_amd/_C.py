@@ -52,6 +52,11 @@ class C3Conv(C.Structure):             # mirrors buctd_c3_conv
                 [(n, C.c_void_p) for n in ("bn_z", "bn_y", "bn_mean", "bn_invstd", "bn_gamma", "bn_beta", "bn_acc")])
 
 
+class C3ConvEval(C.Structure):         # mirrors buctd_c3_conv_eval
+    _fields_ = ([(n, C.c_int) for n in ("N", "H", "W", "Ci", "Co")] +
+                [(n, C.c_void_p) for n in ("x", "wprep", "scale", "shift", "residual")] + [("relu", C.c_int), ("y", C.c_void_p)])
+
+
 class BnApplyItem(C.Structure):        # mirrors buctd_bn_apply_item
     _fields_ = [("z", C.c_void_p), ("st", BnAccIn), ("gamma", C.c_void_p), ("beta", C.c_void_p), ("residual", C.c_void_p),
                 ("relu", C.c_int), ("y", C.c_void_p), ("rows", C.c_long), ("C", C.c_int)]
@@ -140,6 +145,7 @@ SIGNATURES = {
     "buctd_conv3x3_bf16x6_bnstat_acc": (_I, [_I] * 5 + [_P] * 12),
     "buctd_gconv_x6_fwd_acc": (_I, [_I] * 6 + [_P] * 6),
     "buctd_conv3x3_bf16x6_group": (_I, [_I, C.POINTER(C3Conv), _P]),
+    "buctd_conv3x3_bf16x6_group_eval": (_I, [_I, C.POINTER(C3ConvEval), _P]),
     "buctd_conv3x3_bf16x6_persistent": (_I, [_I]),
     "buctd_conv3x3_bf16x6_group_workgroups": (_I, [_I, C.POINTER(C3Conv)]),
     "buctd_gconv_wgrad_x6_supported": (_I, [_I] * 6),

@@ -516,7 +516,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_x6_group_kernel(C3Group g_) {
       case 2: c3x6_tile<2, 2, 4, 1, true, true>(p, smem, bx, by); break;
       case 3: c3x6_tile<1, 2, 4, 1, true, true>(p, smem, bx, by); break;
       case 4: c3x6_tile<2, 4, 4, 1, true, true>(p, smem, bx, by); break;
-      default: c3x6_tile<2, 4, 2, 2, true, true>(p, smem, bx, by); break;
+      case 5: c3x6_tile<2, 4, 2, 2, true, true>(p, smem, bx, by); break;
+      case 6: c3x6_tile<1, 3, 4, 1, true, true>(p, smem, bx, by); break;
+      default: c3x6_tile<2, 3, 4, 1, true, true>(p, smem, bx, by); break;
     }
   }
 }
@@ -851,14 +853,17 @@ static int c3_lean_mode(const C3Args& a) {
   }
 }
 
-static int c3_group_variant(const C3Plan& pl, int* fam) {
+// general: the launch runs conv3x3_x6_group_kernel (no train-mode option set) - its family 1 also holds the small 48-column
+// tiles (MF = 1 / 2, NF = 3) that HRNet-W48 gets at a few persons per call, so that an eval-mode group of W48 branches
+// (buctd_conv3x3_bf16x6_group_eval) shares a kernel at small batches too; the train-mode kernels (c3_lean.h) do not have them
+static int c3_group_variant(const C3Plan& pl, int* fam, bool general = false) {
   struct V { int mf, nf, wm, wn; };
   static const V f0[] = {{7, 3, 4, 1}, {4, 3, 2, 2}, {2, 2, 4, 1}, {4, 3, 4, 1}, {4, 2, 4, 1}};
-  static const V f1[] = {{4, 2, 4, 1}, {1, 4, 4, 1}, {2, 2, 4, 1}, {1, 2, 4, 1}, {2, 4, 4, 1}, {2, 4, 2, 2}};
+  static const V f1[] = {{4, 2, 4, 1}, {1, 4, 4, 1}, {2, 2, 4, 1}, {1, 2, 4, 1}, {2, 4, 4, 1}, {2, 4, 2, 2}, {1, 3, 4, 1}, {2, 3, 4, 1}};
   for (int f = 0; f < 2; ++f) {
     if (*fam >= 0 && *fam != f) continue;
     const V* l = f ? f1 : f0;
-    const int n = f ? 6 : 5;
+    const int n = f ? (general ? 8 : 6) : 5;
     for (int i = 0; i < n; ++i)
       if (l[i].mf == pl.MF && l[i].nf == pl.NF && l[i].wm == pl.WM && l[i].wn == pl.WN) {
         *fam = f;
@@ -950,7 +955,7 @@ static int c3_group_launch(int n, const C3Args* a, const C3Plan* pl, hipStream_t
     ok = true;
     for (int k = 0; k < n && ok; ++k) {
       fam = f;
-      var[k] = c3_group_variant(pl[k], &fam);
+      var[k] = c3_group_variant(pl[k], &fam, lean < 0);
       ok = var[k] >= 0;
     }
   }
@@ -1121,6 +1126,26 @@ extern "C" int buctd_conv3x3_bf16x6_group(int n, const buctd_c3_conv* convs, voi
     if (!rc1 && !d1) rc1 = c3_dispatch<3>(a[k], pl[k], (hipStream_t)stream);
     if (rc1) return rc1;
   }
+  return BUCTD_OK;
+}
+
+/* The k-th convolutions of the branches of a HighResolutionModule in EVAL mode - folded BatchNorm (scale / shift), skip
+ * connection and ReLU in the epilogue - as one launch: each entry is one buctd_conv3x3_bf16x6 call, bit-identical to it. */
+extern "C" int buctd_conv3x3_bf16x6_group_eval(int n, const buctd_c3_conv_eval* convs, void* stream) {
+  BUCTD_CHECK_ARG(n > 0 && n <= C3G_MAX && convs, "buctd_conv3x3_bf16x6_group_eval: 1..%d convolutions", C3G_MAX);
+  C3Args a[C3G_MAX];
+  C3Plan pl[C3G_MAX];
+  for (int k = 0; k < n; ++k) {
+    const buctd_c3_conv_eval& c = convs[k];
+    const int rc = c3_fill(3, c.N, c.H, c.W, c.Ci, c.Co, c.x, c.wprep, nullptr, c.scale, c.shift, c.residual, c.relu, c.y,
+                           nullptr, nullptr, nullptr, nullptr, nullptr, a[k], pl[k]);
+    if (rc) return rc;
+  }
+  bool done = false;
+  const int rc = n > 1 ? c3_group_launch(n, a, pl, (hipStream_t)stream, &done) : BUCTD_OK;
+  if (rc || done) return rc;
+  for (int k = 0; k < n; ++k)
+    if (const int rc1 = c3_dispatch<3>(a[k], pl[k], (hipStream_t)stream)) return rc1;
   return BUCTD_OK;
 }
 

@@ -201,10 +201,32 @@ class HighResolutionModule(nn.Module):
                 ys[i] = y
         return ys
 
+    def _branches_grouped_eval(self, x):
+        """Eval mode: the k-th convolutions of all branches in one launch (ops.basic_branches_eval), or None."""
+        if self.training or torch.is_grad_enabled() or not all(type(br) is BlockChain and len(br) > 0 for br in self.branches):
+            return None
+        chains = []
+        for br in self.branches:
+            if not all(type(m) is BasicBlock and m.downsample is None and m.stride == 1 and m.conv1.bias is None
+                       and m.conv2.bias is None and not m.bn1.training and not m.bn2.training
+                       and m.bn1.running_mean is not None and m.bn2.running_mean is not None for m in br):
+                return None
+            chains.append([(m.conv1.weight, m.bn1, m.conv2.weight, m.bn2) for m in br])
+        xs = [x[i] for i in range(self.num_branches)]
+        for chain in chains:
+            for (w1, _, w2, _) in chain:
+                nn._as_channels_last_(w1)
+                nn._as_channels_last_(w2)
+        if not ops.eval_branches_ok(xs, chains):
+            return None
+        return ops.basic_branches_eval(xs, chains)
+
     def forward(self, x):
         if self.num_branches == 1:
             return [self.branches[0](x[0])]
         xs = self._branches_grouped(x)
+        if xs is None:
+            xs = self._branches_grouped_eval(x)
         if xs is None:
             xs = ops.fork_join([lambda i=i: self.branches[i](x[i]) for i in range(self.num_branches)],
                                [x[i] for i in range(self.num_branches)])

@@ -2077,6 +2077,61 @@ def group_branches_ok(xs, chains):
     return len(cfs) == 1 and 0 not in cfs
 
 
+def eval_branches_ok(xs, chains):
+    """The eval-mode counterpart of group_branches_ok: every branch convolution has a bf16x6 3x3 kernel."""
+    if not (_GROUP_BRANCHES["on"] and _conv_math["mode"] == "bf16x6" and 2 <= len(xs) <= 4 and len({len(c) for c in chains}) == 1):
+        return False
+    for x, chain in zip(xs, chains):
+        if not (x.is_cuda and x.dim() == 4 and x.dtype == torch.float32 and x.is_contiguous()):
+            return False
+        for (w1, _, w2, _) in chain:
+            if not (_bf16x3_ok(conv_desc(x.shape, _wshape(w1), 1, 1)) and _bf16x3_ok(conv_desc(x.shape, _wshape(w2), 1, 1))):
+                return False
+            if _wshape(w1)[0] != x.shape[-1] or _wshape(w2)[0] != x.shape[-1]:
+                return False
+
+    def one_kernel():
+        # do the tile shapes of all branches live in one group kernel?  (small maps at one or two persons per call do not:
+        # then the branches keep their own launches on the branch streams)
+        items = (_C.C3Conv * len(xs))()
+        for it, x in zip(items, xs):
+            it.N, it.H, it.W, it.Ci, it.Co = x.shape[0], x.shape[1], x.shape[2], x.shape[3], x.shape[3]
+            it.x = it.wprep = it.y = xs[0].data_ptr()      # no launch: the query only reads the shapes
+        return lib().buctd_conv3x3_bf16x6_group_workgroups(len(xs), items) > 0
+    return _memo(("evalgrp",) + tuple(tuple(x.shape) for x in xs), one_kernel)
+
+
+def basic_branches_eval(xs, chains):
+    """Eval-mode forward of the branches of a HighResolutionModule (pose_hrnet.py:177-185): the k-th convolutions of all
+    branches - folded BatchNorm, skip connection and ReLU in the epilogue - share a launch (buctd_conv3x3_bf16x6_group_eval).
+    The same kernels on the same tiles as the per-branch path: bit-identical, 2 n launches instead of 2 n nb."""
+    nb, n = len(xs), len(chains[0])
+    cur = list(xs)
+    for k in range(n):
+        folded = [(bn_fold_cached(ch[k][1], ch[k][1].weight, ch[k][1].bias, ch[k][1].eps),
+                   bn_fold_cached(ch[k][3], ch[k][3].weight, ch[k][3].bias, ch[k][3].eps)) for ch in chains]
+        mids = [torch.empty_like(x) for x in cur]
+        outs = [torch.empty_like(x) for x in cur]
+        for half, dst in ((0, mids), (1, outs)):
+            items = (_C.C3ConvEval * nb)()
+            for b in range(nb):
+                x = cur[b] if half == 0 else mids[b]
+                w = chains[b][k][2 * half]
+                weight_rsc(w)
+                N, H, W, Cn = x.shape
+                sc, sh = folded[b][half]
+                it = items[b]
+                it.N, it.H, it.W, it.Ci, it.Co = N, H, W, Cn, _wshape(w)[0]
+                it.x, it.wprep = x.data_ptr(), _conv3x3_prepared(w, 0).data_ptr()
+                it.scale, it.shift = sc.data_ptr(), sh.data_ptr()
+                it.residual = cur[b].data_ptr() if half == 1 else None
+                it.relu = 1
+                it.y = dst[b].data_ptr()
+            check(lib().buctd_conv3x3_bf16x6_group_eval(nb, items, stream_ptr()), "conv3x3_group_eval")
+        cur = outs
+    return cur
+
+
 class BasicBranchesFn(torch.autograd.Function):
     """The branches of a HighResolutionModule (pose_hrnet.py:177-185, 247-249) - nb chains of n residual BasicBlocks on maps of
     different size - as ONE autograd node and one library call per direction (block.hip: buctd_basic_branches_*).  The k-th

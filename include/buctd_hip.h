@@ -134,6 +134,20 @@ typedef struct {
   void* bn_acc;                                                          /* ... into this accumulator (NULL: none) */
 } buctd_c3_conv;
 int buctd_conv3x3_bf16x6_group(int n, const buctd_c3_conv* convs, void* stream);
+/* The same for EVAL mode (validate(), lib/core/function.py:178-336; inference): the k-th convolutions of the branches with the
+ * folded BatchNorm (y = conv * scale + shift), the skip connection and the ReLU in the epilogue - each entry is one
+ * buctd_conv3x3_bf16x6(N, H, W, Ci, Co, x, wprep, NULL, scale, shift, residual, relu, y, NULL, NULL, stream) call, bit-identical
+ * to it; members that share no kernel go out one launch each.  n <= 4. */
+typedef struct {
+  int N, H, W, Ci, Co;
+  const float* x;
+  const void* wprep;
+  const float *scale, *shift;     /* both or neither */
+  const float* residual;
+  int relu;
+  float* y;
+} buctd_c3_conv_eval;
+int buctd_conv3x3_bf16x6_group_eval(int n, const buctd_c3_conv_eval* convs, void* stream);
 /* Train-mode launches (the option sets of block.hip: statistics accumulator, input BatchNorm from an accumulator, skip
  * gradient, BatchNorm-backward sums) run kernels specialised on the option set (csrc/conv3x3_lean.hip).  Their PERSISTENT
  * form (csrc/conv3x3_pers.hip: a grid of resident workgroups, each walking its share of the tiles as one software pipeline

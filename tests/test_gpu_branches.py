@@ -138,3 +138,49 @@ def test_module_forward_uses_group_path_and_matches_per_branch(dev):
             ops.set_group_branches(old)
     for a, b in zip(outs[True], outs[False]):
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("width,batch", [(32, 8), (48, 4)])
+def test_eval_branches_share_launches_and_match_the_per_branch_path(dev, width, batch):
+    """Eval mode (validate(), reference lib/core/function.py:178-336): the k-th convolutions of the branches of a
+    HighResolutionModule (pose_hrnet.py:177-185) go out as one launch (buctd_conv3x3_bf16x6_group_eval) - the same kernels
+    on the same tiles as one launch per branch and convolution, so the heat maps are bit-identical."""
+    import torch
+    from buctd_amd import models, ops
+    from buctd_amd.config import cfg as base, hrnet_extra
+    c = base.clone()
+    c.defrost()
+    c.MODEL.NAME = "pose_hrnet"
+    c.MODEL.NUM_JOINTS = 17
+    c.MODEL.IMAGE_SIZE = [192, 256]
+    c.MODEL.HEATMAP_SIZE = [48, 64]
+    c.MODEL.CONDITIONAL_TOPDOWN = True
+    c.MODEL.EXTRA = hrnet_extra(width, use_pre_net=True, modules=(1, 1, 1))
+    c.freeze()
+    torch.manual_seed(21)
+    net = models.pose_hrnet.get_pose_net(c, is_train=False).to(dev).eval()
+    # running statistics away from their initial values, as after training
+    g = torch.Generator().manual_seed(3)
+    for m in net.modules():
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.running_mean.copy_(torch.randn(m.running_mean.shape, generator=g).to(dev) * 0.1)
+            m.running_var.copy_((torch.rand(m.running_var.shape, generator=g) + 0.5).to(dev))
+    x = torch.randn(batch, 6, 256, 192, generator=g).to(dev)
+    calls = {"n": 0}
+    raw = ops.basic_branches_eval
+
+    def counted(xs, chains):
+        calls["n"] += 1
+        return raw(xs, chains)
+
+    ops.basic_branches_eval = counted
+    try:
+        with torch.no_grad():
+            grouped = net(x)
+            ops._GROUP_BRANCHES["on"] = False
+            plain = net(x)
+    finally:
+        ops._GROUP_BRANCHES["on"] = True
+        ops.basic_branches_eval = raw
+    assert calls["n"] == 3, calls            # one module each in stages 2, 3 and 4
+    assert torch.equal(grouped, plain)
