@@ -228,7 +228,10 @@ def _grad_errors(m, omodel, xin, tgt, wt, dev):
     return float(np.median(eh)), float(np.median(ec)), max(eh), max(ec), keys[int(np.argmax(eh))]
 
 
-@pytest.mark.parametrize("name", ["coam_w16_96x64_mono_default_att", "transpose_w16_96x64"])
+# (the TransPose case spends 30 s in the CPU oracle's noise copies: with --runslow; the suite has to stay well inside the
+# driver's 1200 s on a box whose CPUs are shared - 568 s on a box at load 35-58, 1330 s measured on a busier one)
+@pytest.mark.parametrize("name", ["coam_w16_96x64_mono_default_att",
+                                  pytest.param("transpose_w16_96x64", marks=pytest.mark.slow)])
 def test_train_step_at_the_original_seed_differs_by_a_relu_flip_only(dev, name):
     """The goldens of these two nets use recipe seeds other than 1234 (oracle/recipes.py:SEEDS) because at 1234 one
     pre-activation sits within fp32 round-off of zero and lands on different sides of its ReLU in different implementations.
@@ -292,7 +295,11 @@ def test_full_size_baseline_configs_forward(dev, name):
     assert np.array_equal(y.reshape(y.shape[0], y.shape[1], -1).argmax(2), gold["argmax"])
 
 
-@pytest.mark.parametrize("name,tag", [("coam_w48_384x288", "C4"), ("prenet_w48_384x288", "C3"), ("prenet_w32_256x192", "C2")])
+# C3 is C4's trunk without the attention block: its full-size train step (52 s of CPU oracle) runs with --runslow; its
+# full-size forward golden stays in the default suite
+@pytest.mark.parametrize("name,tag", [("coam_w48_384x288", "C4"),
+                                      pytest.param("prenet_w48_384x288", "C3", marks=pytest.mark.slow),
+                                      ("prenet_w32_256x192", "C2")])
 def test_full_size_train_step_vs_oracle(dev, name, tag):
     """BASELINE configs C4 (CoAM-W48 384x288, the bench workload), C3 (preNet W48 384x288) and C2 (preNet W32 256x192) at
     full size in TRAIN mode: the kernels only these sizes reach - 512-position conv tiles, the full-resolution preNet 7x7
