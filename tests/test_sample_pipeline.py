@@ -219,3 +219,32 @@ def test_iterative_refinement_matches_oracle_loop(dev):
             nxt.append(dict(r, center=c, scale=s, score=float(sc), cond_joints=cond, cond_joints_vis=np.ones((14, 3)),
                             joints_3d=np.zeros((14, 3)), joints_3d_vis=np.ones((14, 3))))
         cur = nxt
+
+
+@pytest.mark.gpu
+def test_iterative_refinement_on_a_forward_graph_equals_the_eager_loop(dev):
+    """The same three chained passes with the network wrapped in engine.ForwardGraph (the serving path: a few persons per
+    call): every pass returns exactly what the eager network returns - predictions, scores, boxes."""
+    from oracle import core as oc, recipes
+    from buctd_amd import engine, models
+    from buctd_amd.dataset.pipeline import DeviceSamplePipeline, IterativeRefiner
+    cfg, omodel, _, _ = recipes.build("coam_w16_96x64_colored")
+    cfg.DATASET.update({"BU_BBOX_MARGIN": 25, "FLIP": False})
+    cfg.TEST.update({"SCALE_THRE": 1.25, "IN_VIS_THRE": 0.2})
+    m = models.pose_hrnet_coam.get_pose_net(cfg, is_train=False)
+    m.load_state_dict(omodel.state_dict(), strict=True)
+    m = m.to(dev).eval()
+    pipe = DeviceSamplePipeline(cfg, oc.CROWDPOSE_FLIP_PAIRS, range(8), oc.CROWDPOSE_KPT_COLORS, MEAN, STD, is_train=False)
+    recs = _records(3, 21)
+
+    def run(model):
+        return IterativeRefiner(cfg, model, pipe).run([dict(r, image=torch.from_numpy(r["image_np"]).to(dev)) for r in recs], 3)
+
+    eager = run(m)
+    fg = engine.ForwardGraph(m, warmup=1, autoselect=False)
+    graphed = run(fg)
+    graphed2 = run(fg)              # all three passes replayed
+    assert fg.replays >= 4
+    for a, b, c in zip(eager, graphed, graphed2):
+        for k in ("preds", "score", "box_score", "keypoint_score", "center", "scale"):
+            assert np.array_equal(a[k], b[k]) and np.array_equal(a[k], c[k]), k
