@@ -154,8 +154,8 @@ class _AccPool:
         st = self.state.get(device.index)
         if st is None or st["off"] + nbytes > st["buf"].numel():
             st = self._new_chunk(device, nbytes)
-        cur = torch.cuda.current_stream(device)
-        if cur.cuda_stream not in st["seen"]:
+        if _C.current_stream_handle() not in st["seen"]:       # (the raw handle: building a Stream object costs ~5 us)
+            cur = torch.cuda.current_stream(device)
             _wait_event(cur, st["ev"])
             st["buf"].record_stream(cur)
             st["seen"].add(cur.cuda_stream)
@@ -493,7 +493,7 @@ def _prep_wait(device):
     """A batched refresh ran on the optimizer's stream: other streams order themselves behind it once."""
     ev = _prep_registry["event"]
     if ev is not None and not _capture["on"]:     # a capture is ordered behind the refresh as a whole
-        cur = torch.cuda.current_stream(device).cuda_stream
+        cur = _C.current_stream_handle()
         if cur != _prep_registry["stream"] and cur not in _prep_registry["waited"]:
             torch.cuda.current_stream(device).wait_event(ev)
             _prep_registry["waited"].add(cur)
