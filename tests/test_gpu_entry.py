@@ -256,3 +256,31 @@ def test_validate_entry_point_matches_reference_validate(dev, tag):
     va = [v for k, v, _ in wd["writer"].scalars if k == "valid_acc"][0]
     assert abs(vl - float(gold[tag + "_loss"])) <= 1e-4 * float(gold[tag + "_loss"])
     assert va == float(gold[tag + "_acc"])
+
+
+def test_flip_test_as_one_forward_equals_two_forwards(dev):
+    """validate() runs the flip test (reference function.py:213-236) as ONE forward over [crops | mirrored crops]: eval-mode
+    networks treat every image on its own, so the prediction table must equal the one from two forwards (to the rounding of
+    a split-K GEMM whose split count follows the batch: the channel-attention logits)."""
+    from oracle import recipes, core as oc
+    from buctd_amd import models
+    from buctd_amd.core import function
+    from buctd_amd.core.loss import JointsMSELoss
+    cfg = _cfg_for(False, True)
+    _, omodel, _, _ = recipes.build("coam_w16_96x64_colored")
+    net = models.pose_hrnet_coam.get_pose_net(cfg, is_train=False)
+    net.load_state_dict(omodel.state_dict(), strict=True)
+    net = net.cuda()
+    loader = _batches(cfg, 2, 2)
+    tables = []
+    old = function.PAIRED_FLIP_FORWARD
+    try:
+        for paired in (False, True):
+            function.PAIRED_FLIP_FORWARD = paired
+            ds = FakeDataset(4, [64, 96], oc.CROWDPOSE_FLIP_PAIRS, oc.CROWDPOSE_KPT_COLORS)
+            function.validate(cfg, loader, ds, net, JointsMSELoss(True).cuda(), "/tmp", "/tmp", None)
+            tables.append(ds.captured[0])
+    finally:
+        function.PAIRED_FLIP_FORWARD = old
+    assert np.abs(tables[0][:, :, :2] - tables[1][:, :, :2]).max() <= 1e-3      # image pixels
+    assert np.abs(tables[0][:, :, 2] - tables[1][:, :, 2]).max() <= 1e-5
