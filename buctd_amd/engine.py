@@ -133,6 +133,7 @@ class FusedAdam(torch.optim.Optimizer):
             ops.acc_pool.reset(self.flat.flat.device)  # BatchNorm accumulators of the step: one fill, every stream is joined here
 
     def zero_grad(self, set_to_none=True):
+        self.zeroed = getattr(self, "zeroed", 0) + 1      # (StepGraph: the gradient views a capture installed are gone)
         for p in self.flat.params:
             p.grad = None
 
@@ -227,6 +228,7 @@ class FusedSGD(torch.optim.Optimizer):
             ops.acc_pool.reset(self.flat.flat.device)
 
     def zero_grad(self, set_to_none=True):
+        self.zeroed = getattr(self, "zeroed", 0) + 1
         for p in self.flat.params:
             p.grad = None
 
@@ -584,14 +586,23 @@ class StepGraph:
                 flat.collect()                        # gradients autograd accumulated outside the arena are copied per replay
                 ops.acc_pool.zero_used(dev)           # a replay leaves its statistics accumulators zeroed for the next one
                 used = ops.acc_pool.used(dev)
-        finally:
+        except BaseException:
+            # a failed capture must not leave the pool ordered behind a captured event, nor gradient views of a graph that
+            # does not exist: the eager engine stays usable
             ops.set_stream_forks(*forks)
-            keep = ops.end_capture()
+            ops.end_capture()
+            ops.acc_pool.rebase(dev, ops.acc_pool.used(dev))
+            self.optimizer.zero_grad()
+            raise
+        ops.set_stream_forks(*forks)
+        keep = ops.end_capture()
         ops.acc_pool.rebase(dev, used)                # eager edge: zero before the first replay, fresh (uncaptured) event
+        grads = [(p, p.grad) for p in flat.params if p.grad is not None]
         counts = [(m, m._pending_batches - b) for m, b in zip(bns, before) if m._pending_batches != b]
         for m, b in zip(bns, before):
             m._pending_batches = b                    # the capture enqueued nothing: its batches are counted per replay
-        return {"graph": graph, "static": static, "out": out, "loss": loss, "bn_counts": counts, "keep": keep, "clocked": 0}
+        return {"graph": graph, "static": static, "out": out, "loss": loss, "bn_counts": counts, "keep": keep, "clocked": 0,
+                "grads": grads, "zeroed": getattr(self.optimizer, "zeroed", 0)}
 
     def __call__(self, x, target, weight):
         key = self._signature((x, target, weight))
@@ -627,6 +638,13 @@ class StepGraph:
         for m, c in g["bn_counts"]:
             m._pending_batches += c
         self.replays += 1
+        if getattr(self.optimizer, "zeroed", 0) != g["zeroed"]:
+            # somebody cleared the gradients since the capture (an eager step in between, the caller's own zero_grad): the
+            # replay wrote into the arena views the capture had installed - hand them to the parameters again, or the
+            # optimizer would take "no gradient" for "zero"
+            for p, gr in g["grads"]:
+                p.grad = gr
+            g["zeroed"] = getattr(self.optimizer, "zeroed", 0)
         self.optimizer.step()
         if clocked:
             torch.cuda.synchronize(x.device)

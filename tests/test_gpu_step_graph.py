@@ -103,6 +103,19 @@ def test_a_ragged_batch_runs_eager_and_the_graph_survives_it(dev):
         assert torch.equal(loss_e.detach(), loss_g.detach()), (i, float(loss_e), float(loss_g))
     assert step.replays == 4
     assert torch.equal(eopt.flat.flat, gopt.flat.flat)
+    # a caller that clears the gradients itself in front of a replayed step (the reference loop's habit) must not turn the
+    # replayed gradients into "no gradient"
+    x, t, w = _batch(cfg, 4, 399, dev)
+    engine.ops.set_grad_arena(eopt.flat)
+    loss_e = crit(eager(x), t, w)
+    eopt.zero_grad()
+    loss_e.backward()
+    eopt.step()
+    engine.ops.set_grad_arena(gopt.flat)
+    gopt.zero_grad()
+    _, loss_g = step(x, t, w)
+    assert torch.equal(loss_e.detach(), loss_g.detach())
+    assert torch.equal(eopt.flat.flat, gopt.flat.flat)
 
 
 def test_train_entry_point_takes_a_step_graph(dev):
