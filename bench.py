@@ -754,6 +754,11 @@ def main():
                     help="--gpus 1, models without train-mode dropout (train_c2 / train_c3): forward + loss + backward are captured "
                          "once as a hipGraph (engine.StepGraph) and replayed per step; the same kernels, bit-identical results, one "
                          "hipGraphLaunch instead of ~1000 host-side launches - the host-bound C2 step becomes GPU-bound")
+    ap.add_argument("--host-input", default="resident", choices=["resident", "copy", "prefetch"],
+                    help="where the batch is when a step starts: resident = in HBM (the contract of `value`); copy = pinned host "
+                         "memory, copied on the compute stream at the top of the step as the reference loop does; prefetch = pinned "
+                         "host memory through core.function.DevicePrefetch (what train() does: the next batch's copies beside the "
+                         "current step).  copy / prefetch give the PCIe-inclusive rate quoted in DESIGN.md - never the headline")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timer", action="store_true")
     args = ap.parse_args()
@@ -818,18 +823,35 @@ def main():
         graph_step = engine.StepGraph(model, criterion, optimizer, warmup=2)
         describe += " [forward + loss + backward replayed from a hipGraph]"
 
+    feed = None
+    if args.host_input != "resident":
+        from buctd_amd.core.function import DevicePrefetch
+        host = tuple(t.cpu().pin_memory() for t in (x, target, weight))
+        describe += f" [batch from pinned host memory every step: {args.host_input}]"
+
+        def endless():
+            while True:
+                yield host + ({},)
+        feed = iter(DevicePrefetch(endless(), True, device)) if args.host_input == "prefetch" else None
+
     def step():
-        if graph_step is not None:
-            out, loss = graph_step(x, target, weight)
+        if args.host_input == "prefetch":
+            x_, target_, weight_, _ = next(feed)
+        elif args.host_input == "copy":
+            x_, target_, weight_ = (t.cuda(non_blocking=True) for t in host)
         else:
-            out = model(x)
-            loss = criterion(out, target, weight)
+            x_, target_, weight_ = x, target, weight
+        if graph_step is not None:
+            out, loss = graph_step(x_, target_, weight_)
+        else:
+            out = model(x_)
+            loss = criterion(out, target_, weight_)
             optimizer.zero_grad()
             loss.backward()
             optimizer.step()
         if state["pending"] is not None:
             state["pending"].resolve(losses, acc)
-        state["pending"] = _DeferredStats(loss, out, target, args.batch)
+        state["pending"] = _DeferredStats(loss, out, target_, args.batch)
 
     def fence():
         if world > 1:
@@ -956,7 +978,7 @@ def main():
                        "params": sum(p.numel() for p in net.parameters()), "parallelism": f"dp{world}",
                        # HIP streams of this rank: main + branch / weight-gradient streams (+ communication under --gpus N)
                        "hip_streams": 1 + len(ops.compute_streams(device)) + (1 if world > 1 or args.one_rank_exchange else 0),
-                       "conv_math": args.conv_math, "loss": round(losses.avg, 6), "step_graph": bool(args.step_graph)},
+                       "conv_math": args.conv_math, "loss": round(losses.avg, 6), "step_graph": bool(args.step_graph), "host_input": args.host_input},
             # is a slow line a slow box or a slow build?  the spread of the timed steps (GPU time between one event per step
             # on the main stream) and what the SMU reported in the middle of the timed region
             "step_ms": {"min": round(step_ms[0], 3), "median": round(step_ms[len(step_ms) // 2], 3), "max": round(step_ms[-1], 3)},

@@ -103,6 +103,60 @@ def _train_line(epoch, i, total, batch_time, data_time, losses, acc, batch):
             f'Accuracy {acc.val:.3f} ({acc.avg:.3f})')
 
 
+PREFETCH_TO_DEVICE = True      # train(): host-to-device copies of the next batch beside the current step (DevicePrefetch)
+
+
+class DevicePrefetch:
+    """Iterates a loader of (input, target, target_weight, meta) host batches and yields them with the three tensors on the
+    device.  The reference loop copies a batch at the top of its iteration (function.py:118-125: .cuda(non_blocking=True)) -
+    on the compute stream, i.e. in front of the forward pass (85 MB per CoAM-W48 batch of 32: ~2 ms of every step).  Here
+    the copies of batch i + 1 are enqueued on the engine's weight-gradient stream BEFORE step i is enqueued: that stream is
+    idle during the forward pass, the copies run on the DMA engines beside it, and the main stream only waits for an event
+    that has long passed.  No new HIP stream (a fifth one costs 25-32 %: DESIGN.md 6).  Pinned host batches
+    (DataLoader(pin_memory=True), as the reference builds its loaders) make the copies asynchronous; pageable ones still work."""
+
+    def __init__(self, loader, conditional=True, device=None):
+        self.loader, self.conditional = loader, conditional
+        self.device = device if device is not None else torch.device('cuda', torch.cuda.current_device())
+
+    def __len__(self):
+        return len(self.loader)
+
+    def _enqueue(self, batch):
+        input, target, target_weight, meta = batch
+        if not self.conditional:
+            input = input[:, :3]
+        side = ops.copy_stream(self.device)
+        if side is None:
+            return (input.cuda(non_blocking=True), target.cuda(non_blocking=True), target_weight.cuda(non_blocking=True)), meta, None
+        with torch.cuda.stream(side):
+            dev = tuple(t.to(self.device, non_blocking=True) for t in (input, target, target_weight))
+            ev = torch.cuda.Event()
+            ev.record(side)
+        return dev, meta, ev
+
+    def _ready(self, item):
+        dev, meta, ev = item
+        if ev is not None:
+            main = torch.cuda.current_stream(self.device)
+            main.wait_event(ev)
+            for t in dev:
+                t.record_stream(main)
+        return dev[0], dev[1], dev[2], meta
+
+    def __iter__(self):
+        it = iter(self.loader)
+        try:
+            cur = self._enqueue(next(it))
+        except StopIteration:
+            return
+        for host in it:
+            nxt = self._enqueue(host)          # batch i + 1 goes on its way before step i is enqueued
+            yield self._ready(cur)
+            cur = nxt
+        yield self._ready(cur)
+
+
 def train(config, train_loader, model, criterion, optimizer, epoch, output_dir, tb_log_dir, writer_dict,
           print_prefix='', step_graph=None):
     """reference lib/core/function.py:102-175, same positional signature.  step_graph (an engine.StepGraph built on the same
@@ -113,11 +167,13 @@ def train(config, train_loader, model, criterion, optimizer, epoch, output_dir, 
     conditional = bool(config.MODEL.CONDITIONAL_TOPDOWN)
     tick = time.time()
     pending = None
-    for i, (input, target, target_weight, meta) in enumerate(train_loader):
+    batches = DevicePrefetch(train_loader, conditional) if PREFETCH_TO_DEVICE and torch.cuda.is_available() else train_loader
+    for i, (input, target, target_weight, meta) in enumerate(batches):
         data_time.update(time.time() - tick)
-        input = (input if conditional else input[:, :3]).cuda(non_blocking=True)
-        target = target.cuda(non_blocking=True)
-        target_weight = target_weight.cuda(non_blocking=True)
+        if not input.is_cuda:
+            input = (input if conditional else input[:, :3]).cuda(non_blocking=True)
+            target = target.cuda(non_blocking=True)
+            target_weight = target_weight.cuda(non_blocking=True)
         if step_graph is not None:
             output, loss = step_graph(input, target, target_weight)
         else:

@@ -895,6 +895,19 @@ def _side_stream(device):
     return st
 
 
+def copy_stream(device):
+    """The stream host-to-device copies of the NEXT batch go to (core.function.DevicePrefetch): the weight-gradient stream -
+    idle during the forward pass, and no additional HIP stream.  None where the engine forks no such stream."""
+    if not (_side["on"] and device.type == "cuda"):
+        return None
+    key = (device.index if device.index is not None else torch.cuda.current_device(), 0)
+    st = _side["streams"].get(key)
+    if st is None:
+        st = torch.cuda.Stream(device=device, priority=_SIDE_PRIO)
+        _side["streams"][key] = st
+    return st
+
+
 def side_streams(device):
     """The weight-gradient streams created so far on `device`."""
     return [st for (idx, _), st in _side["streams"].items() if idx == device.index]

@@ -284,3 +284,38 @@ def test_flip_test_as_one_forward_equals_two_forwards(dev):
         function.PAIRED_FLIP_FORWARD = old
     assert np.abs(tables[0][:, :, :2] - tables[1][:, :, :2]).max() <= 1e-3      # image pixels
     assert np.abs(tables[0][:, :, 2] - tables[1][:, :, 2]).max() <= 1e-5
+
+
+def test_train_with_device_prefetch_equals_the_plain_loop(dev):
+    """train() copies batch i + 1 to the device beside step i (core.function.DevicePrefetch, on the weight-gradient stream);
+    the reference loop copies at the top of the iteration (function.py:118-125).  Same batches, same order: the logged losses
+    and the parameters after the epoch are bit-identical, with pinned and with pageable host batches."""
+    import copy as _copy
+    from oracle import recipes
+    from buctd_amd import models, engine
+    from buctd_amd.core import function
+    from buctd_amd.core.loss import JointsMSELoss
+    cfg = _cfg_for(True, False)
+    _, omodel, _, _ = recipes.build("coam_w16_96x64_colored")
+    results = []
+    old = function.PREFETCH_TO_DEVICE
+    try:
+        for prefetch, pinned in ((False, False), (True, False), (True, True)):
+            function.PREFETCH_TO_DEVICE = prefetch
+            net = models.pose_hrnet_coam.get_pose_net(cfg, is_train=False)
+            net.load_state_dict(omodel.state_dict(), strict=True)
+            model = engine.DataParallel(net).cuda()
+            optimizer = engine.get_optimizer(cfg, model)
+            recipes.set_dropout(model, 0.0)
+            loader = _batches(cfg, 4, 2)
+            if pinned:
+                loader = [(x.pin_memory(), t.pin_memory(), w.pin_memory(), m) for x, t, w, m in loader]
+            wd = {"writer": Writer(), "train_global_steps": 0}
+            function.train(cfg, loader, model, JointsMSELoss(True).cuda(), optimizer, 1, "/tmp", "/tmp", wd)
+            losses = [v for k, v, _ in wd["writer"].scalars if k == "train_loss"]
+            results.append((losses, optimizer.flat.flat.detach().clone()))
+    finally:
+        function.PREFETCH_TO_DEVICE = old
+    for losses, params in results[1:]:
+        assert losses == results[0][0]
+        assert torch.equal(params, results[0][1])
