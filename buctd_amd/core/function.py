@@ -294,6 +294,22 @@ def _rank_batches(val_loader, rank, world):
         cursor += count
 
 
+def _prefetched(rank_batches, conditional):
+    """(i, row0, host batch) -> (i, row0, device batch): batch i + 1 is copied beside the forward of batch i (DevicePrefetch)."""
+    if not (PREFETCH_TO_DEVICE and torch.cuda.is_available()):
+        yield from rank_batches
+        return
+    pf = DevicePrefetch(None, conditional)
+    prev = None
+    for i, row0, batch in rank_batches:
+        item = (i, row0, pf._enqueue(batch))
+        if prev is not None:
+            yield prev[0], prev[1], pf._ready(prev[2])
+        prev = item
+    if prev is not None:
+        yield prev[0], prev[1], pf._ready(prev[2])
+
+
 def _mirrored_input(config, val_dataset, input, meta):
     """The input of the flip test (reference function.py:213-225): the mirrored crop, with the condition re-rendered from
     the mirrored condition key points."""
@@ -344,10 +360,11 @@ def validate(config, val_loader, val_dataset, model, criterion, output_dir, tb_l
 
     with torch.no_grad():
         tick = time.time()
-        for i, row0, (input, target, target_weight, meta) in _rank_batches(val_loader, rank, world):
+        for i, row0, (input, target, target_weight, meta) in _prefetched(_rank_batches(val_loader, rank, world), conditional):
             count = input.size(0)
             rows = slice(row0, row0 + count)
-            input = (input if conditional else input[:, :3]).cuda(non_blocking=True)
+            if not input.is_cuda:
+                input = (input if conditional else input[:, :3]).cuda(non_blocking=True)
             if config.TEST.FLIP_TEST:
                 output, flipped = _forward_with_flip(config, model, val_dataset, input, meta)
                 output = flip_merge_device(output.contiguous(), flipped.contiguous(), val_dataset.flip_pairs,
