@@ -509,6 +509,12 @@ def get_optimizer(cfg, model):
     return None       # the reference returns None for any other name (utils.py:259, 274)
 
 
+# Stream-capture error mode of the two graph classes: "thread_local" - a DataLoader's pin-memory thread (hipHostMalloc) or any
+# other thread of the process may call the runtime while a step is being captured; "global" would turn such a call into a
+# failed capture.  The kernels autograd's device thread launches into the capturing streams are captured either way.
+_CAPTURE_MODE = "thread_local"
+
+
 class StepGraph:
     """The device work of one training iteration - forward, loss, backward, gradient collection - captured ONCE as a hipGraph
     and replayed per step; the optimizer step stays an eager launch behind it (its bias corrections are launch arguments).
@@ -580,7 +586,7 @@ class StepGraph:
         ops.begin_capture(self._allow_seeds)
         forks = ops.set_stream_forks(self.streams == "engine")
         try:
-            with torch.cuda.graph(graph):
+            with torch.cuda.graph(graph, capture_error_mode=_CAPTURE_MODE):
                 ops.acc_pool.rebase(dev)              # the pool's ordering event becomes an edge of the graph
                 out, loss = self._forward_backward(*static)
                 flat.collect()                        # gradients autograd accumulated outside the arena are copied per replay
@@ -726,7 +732,7 @@ class ForwardGraph(torch.nn.Module):
         ops.begin_capture(allow_seeds=True)     # eval mode: the attention cores draw a seed but drop nothing (p = 0)
         forks = ops.set_stream_forks(False)
         try:
-            with torch.cuda.graph(graph):
+            with torch.cuda.graph(graph, capture_error_mode=_CAPTURE_MODE):
                 out = self.module(static)
         finally:
             ops.set_stream_forks(*forks)
