@@ -683,7 +683,8 @@ class ForwardGraph(torch.nn.Module):
     graph's static buffer and replay.  Outputs are copies by default (`static_output=True` hands out the graph's own output
     tensors: valid until the next call of the same signature).  Parameters are read at replay time, so a checkpoint loaded in
     place is picked up - but anything keyed on the weights (prepared filter images, folded BatchNorms) is rebuilt by the eager
-    engine, not by a replay: after changing weights call `reset()`; engine.FusedAdam steps are noticed automatically."""
+    engine, not by a replay: engine.FusedAdam steps and in-place rewrites (load_state_dict: a sample of tensor versions is
+    watched) drop the graphs automatically; `reset()` does it by hand."""
 
     def __init__(self, module, warmup=2, static_output=False, max_graphs=8, autoselect=True):
         super().__init__()
@@ -695,6 +696,7 @@ class ForwardGraph(torch.nn.Module):
         self.autoselect = bool(autoselect)
         self._seen, self._graphs = {}, {}
         self._epoch = None
+        self._probe = None
         self.replays = 0
 
     def reset(self):
@@ -703,8 +705,14 @@ class ForwardGraph(torch.nn.Module):
     def forward(self, x, *args, **kwargs):
         if (self.module.training or torch.is_grad_enabled() or args or kwargs or not torch.is_tensor(x) or not x.is_cuda):
             return self.module(x, *args, **kwargs)
-        epoch = ops.weights_epoch()
-        if epoch != self._epoch:          # an optimizer step rewrote the parameters: prepared images are refreshed eagerly
+        # an optimizer step (epoch) or an in-place rewrite of the parameters (tensor versions of a sample of them: a
+        # load_state_dict bumps every one) makes the eager engine rebuild prepared filter images and folded BatchNorms - a
+        # replay would not: drop the graphs
+        if self._probe is None:
+            ps = list(self.module.parameters()) + list(self.module.buffers())
+            self._probe = ps[::max(1, len(ps) // 16)]
+        epoch = (ops.weights_epoch(), tuple(p._version for p in self._probe))
+        if epoch != self._epoch:
             self.reset()
             self._epoch = epoch
         key = (tuple(x.shape), x.dtype, x.device, x.stride())

@@ -303,3 +303,25 @@ def test_autoselect_keeps_results_whichever_path_wins(dev):
             x, _, _ = _batch(cfg, 2, 1200 + i, dev)
             assert torch.equal(net(x), fg(x)), i
     assert len(fg._graphs) == 1
+
+
+def test_forward_graph_notices_a_checkpoint_loaded_in_place(dev):
+    """Prepared filter images and folded BatchNorms are rebuilt by the eager engine when the weights change; a replay would
+    keep the old ones - ForwardGraph watches the optimizer epoch and a sample of tensor versions and re-captures."""
+    from buctd_amd import engine, models
+    cfg = _prenet_cfg()
+    torch.manual_seed(31)
+    net = models.pose_hrnet.get_pose_net(cfg, is_train=False).to(dev).eval()
+    torch.manual_seed(32)
+    other = models.pose_hrnet.get_pose_net(cfg, is_train=False).to(dev).eval()
+    fg = engine.ForwardGraph(net, warmup=1, autoselect=False)
+    x, _, _ = _batch(cfg, 2, 1300, dev)
+    with torch.no_grad():
+        for _ in range(3):
+            assert torch.equal(fg(x), net(x))
+        assert fg.replays == 2
+        net.load_state_dict(other.state_dict())
+        want = other(x)
+        for _ in range(3):
+            assert torch.equal(fg(x), want)
+    assert fg.replays == 4
