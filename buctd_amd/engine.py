@@ -697,6 +697,7 @@ class ForwardGraph(torch.nn.Module):
         self._seen, self._graphs = {}, {}
         self._epoch = None
         self._probe = None
+        self._capture_streams = []
         self.replays = 0
 
     def reset(self):
@@ -734,17 +735,61 @@ class ForwardGraph(torch.nn.Module):
             return out
         return [o.clone() for o in out] if isinstance(out, list) else out.clone()
 
-    def _capture(self, x):
+    # ---- two lanes: independent requests beside each other -------------------------------------------------------------
+    def submit(self, x):
+        """Asynchronous forward for a serving loop: returns a handle at once, `handle.result()` makes the current stream wait
+        and returns the output (a copy).  Requests of a captured signature alternate between `LANES` graphs that replay on
+        the engine's two branch streams (no new HIP stream): the launch-bound kernels of independent requests run beside
+        each other - one person per call keeps ~180 kernels of a few microseconds each in flight, far from filling the
+        chip.  Submit a few requests before collecting the first.  Anything that cannot be replayed (train mode, gradients,
+        a signature still settling, autoselect preferring the eager engine) is computed on the spot."""
+        if (self.module.training or torch.is_grad_enabled() or not torch.is_tensor(x) or not x.is_cuda):
+            return _Ready(self.module(x))
+        key = (tuple(x.shape), x.dtype, x.device, x.stride())
+        g = self._graphs.get(key)
+        if g is None or not g["use"]:
+            return _Ready(self.forward(x))          # settles / captures lane 0 (and watches the weights)
+        probe = (ops.weights_epoch(), tuple(p._version for p in self._probe))
+        if probe != self._epoch:
+            return _Ready(self.forward(x))
+        lanes = g.setdefault("lanes", [g])
+        while len(lanes) < self.LANES:              # further lanes: their own graph, buffers and workspaces
+            lanes.append(self._capture(x, lane=len(lanes), clock=False))
+        k = g["next"] = (g.get("next", -1) + 1) % self.LANES
+        lane = lanes[k]
+        cur = torch.cuda.current_stream(x.device)
+        st = ops.lane_stream(x.device, k)
+        st.wait_stream(cur)                         # x is ready; the lane's previous request has been copied out (stream order)
+        with torch.cuda.stream(st):
+            lane["x"].copy_(x, non_blocking=True)
+            lane["graph"].replay()
+            out = lane["out"]
+            out = [o.clone() for o in out] if isinstance(out, list) else out.clone()
+            ev = torch.cuda.Event()
+            ev.record(st)
+        x.record_stream(st)
+        self.replays += 1
+        return _Pending(out, ev, x.device)
+
+    LANES = 2
+
+    def _capture(self, x, lane=0, clock=True):
         static = x.clone()
         graph = torch.cuda.CUDAGraph()
+        # every lane is captured on a stream of its own: the engine's scratch buffers are kept per stream, so two lanes that
+        # replay beside each other never share one (the capture streams themselves never execute anything)
+        if lane >= len(self._capture_streams):
+            self._capture_streams.extend(torch.cuda.Stream(device=x.device) for _ in range(lane + 1 - len(self._capture_streams)))
         ops.begin_capture(allow_seeds=True)     # eval mode: the attention cores draw a seed but drop nothing (p = 0)
         forks = ops.set_stream_forks(False)
         try:
-            with torch.cuda.graph(graph, capture_error_mode=_CAPTURE_MODE):
+            with torch.cuda.graph(graph, stream=self._capture_streams[lane], capture_error_mode=_CAPTURE_MODE):
                 out = self.module(static)
         finally:
             ops.set_stream_forks(*forks)
             keep = ops.end_capture()
+        if not clock:
+            return {"graph": graph, "x": static, "out": out, "keep": keep, "use": True}
         use = True
         if self.autoselect:
             import time
@@ -759,6 +804,30 @@ class ForwardGraph(torch.nn.Module):
                 return time.perf_counter() - t0
             use = clock(graph.replay) <= clock(lambda: self.module(static))
         return {"graph": graph, "x": static, "out": out, "keep": keep, "use": use}
+
+
+class _Ready:
+    """A result that is already enqueued on the current stream (ForwardGraph.submit when nothing was replayed)."""
+
+    def __init__(self, out):
+        self._out = out
+
+    def result(self):
+        return self._out
+
+
+class _Pending:
+    """A request replaying on a lane stream: result() orders the current stream behind it."""
+
+    def __init__(self, out, event, device):
+        self._out, self._event, self._device = out, event, device
+
+    def result(self):
+        cur = torch.cuda.current_stream(self._device)
+        cur.wait_event(self._event)
+        for o in (self._out if isinstance(self._out, list) else [self._out]):
+            o.record_stream(cur)
+        return self._out
 
 
 _comm_streams = {}      # device index -> the communication stream reserved by reserve_streams

@@ -989,6 +989,11 @@ def _branch_stream(device, i):
     return st
 
 
+def lane_stream(device, k):
+    """Branch stream k + 1 of `device` (engine.ForwardGraph.submit replays its k-th lane there)."""
+    return _branch_stream(device, k + 1)
+
+
 def _record(t, stream):
     if torch.is_tensor(t):
         if t.is_cuda:

@@ -325,3 +325,39 @@ def test_forward_graph_notices_a_checkpoint_loaded_in_place(dev):
         for _ in range(3):
             assert torch.equal(fg(x), want)
     assert fg.replays == 4
+
+
+@pytest.mark.parametrize("kind", ["prenet", "transpose"])
+def test_two_lanes_return_what_the_eager_forward_returns(dev, kind):
+    """ForwardGraph.submit: independent requests replay on two lanes (two graphs on the engine's two branch streams) beside
+    each other; every request must get exactly the eager forward's output, whatever is in flight next to it."""
+    from buctd_amd import engine, models
+    if kind == "prenet":
+        cfg = _prenet_cfg()
+        net = models.pose_hrnet.get_pose_net(cfg, is_train=False)
+    else:
+        from oracle import recipes
+        cfg, omodel, _, _ = recipes.build("transpose_w16_96x64")
+        net = models.transpose_h.get_pose_net(cfg, is_train=False)
+        net.load_state_dict(omodel.state_dict(), strict=True)
+    torch.manual_seed(41)
+    net = net.to(dev).eval()
+    fg = engine.ForwardGraph(net, warmup=1, autoselect=False)
+    w, h = cfg.MODEL.IMAGE_SIZE
+    g = torch.Generator().manual_seed(7)
+    xs = [torch.randn(2, 6, h, w, generator=g).to(dev) for _ in range(14)]
+    with torch.no_grad():
+        want = [net(x) for x in xs]
+        want = [y[-1] if isinstance(y, list) else y for y in want]
+        handles, got = [], []
+        for i, x in enumerate(xs):
+            handles.append(fg.submit(x))
+            if len(handles) == 3:                       # up to three requests in flight over two lanes
+                got.append(handles.pop(0).result())
+        got += [hd.result() for hd in handles]
+        torch.cuda.synchronize()
+    got = [y[-1] if isinstance(y, list) else y for y in got]
+    assert len(got) == len(want)
+    for i, (a, b) in enumerate(zip(want, got)):
+        assert torch.equal(a, b), i
+    assert fg.replays >= 11 and len(fg._graphs[next(iter(fg._graphs))]["lanes"]) == 2
