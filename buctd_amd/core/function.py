@@ -22,7 +22,7 @@ import torch.distributed as dist
 from .. import ops
 from ..utils.transforms import flip_hm, flip_merge_device
 from .evaluate import pck_from_coords
-from .inference import get_final_preds
+from .inference import DeferredFinalPreds, get_final_preds
 
 logger = logging.getLogger(__name__)
 
@@ -310,6 +310,22 @@ def _prefetched(rank_batches, conditional):
         yield prev[0], prev[1], pf._ready(prev[2])
 
 
+class _Enqueued:
+    """The result of a forward that is already enqueued on the current stream (a network without submit())."""
+
+    def __init__(self, out):
+        self.out = out
+
+    def result(self):
+        return self.out
+
+
+def _submit(model, x):
+    """-> handle with .result(): through the network's own submit() (engine.ForwardGraph: graph lanes) where it has one."""
+    submit = getattr(model, 'submit', None)
+    return submit(x) if callable(submit) else _Enqueued(model(x))
+
+
 def _mirrored_input(config, val_dataset, input, meta):
     """The input of the flip test (reference function.py:213-225): the mirrored crop, with the condition re-rendered from
     the mirrored condition key points."""
@@ -319,28 +335,11 @@ def _mirrored_input(config, val_dataset, input, meta):
     return input.flip(3)
 
 
-def _flip_test_forward(config, model, val_dataset, input, meta):
-    """Second forward on the mirrored input (reference function.py:213-236); returns the flipped output."""
-    out = model(_mirrored_input(config, val_dataset, input, meta))
-    return out[-1] if isinstance(out, list) else out
-
-
 # The flip test as ONE forward over [crops | mirrored crops]: eval-mode networks treat every image independently (running
 # BatchNorm statistics, per-image attention), so the two halves equal the reference's two forwards - one pass through the
 # launch sequence instead of two (validation at TEST.BATCH_SIZE <= 16 is bound by the host's ~7 ms per forward), twice the
 # rows per launch above that.  Off: two forwards, the reference's literal order.
 PAIRED_FLIP_FORWARD = True
-
-
-def _forward_with_flip(config, model, val_dataset, input, meta):
-    """-> (output, flipped output) of the flip test"""
-    n = input.size(0)
-    if PAIRED_FLIP_FORWARD and input.is_cuda:
-        out = model(torch.cat((input, _mirrored_input(config, val_dataset, input, meta)), dim=0))
-        out = out[-1] if isinstance(out, list) else out
-        return out[:n], out[n:]
-    out = model(input)
-    return (out[-1] if isinstance(out, list) else out), _flip_test_forward(config, model, val_dataset, input, meta)
 
 
 def validate(config, val_loader, val_dataset, model, criterion, output_dir, tb_log_dir, writer_dict=None, epoch=-1,
@@ -358,55 +357,95 @@ def validate(config, val_loader, val_dataset, model, criterion, output_dir, tb_l
     last = len(val_loader) - 1
     conditional = bool(config.MODEL.CONDITIONAL_TOPDOWN)
 
+    # The loop is a three-stage software pipeline over the batches (same results, same order as the reference's loop):
+    #   enqueue(i)      the forward of batch i (both halves of the flip test) - through model.submit() where the network offers
+    #                   one (engine.ForwardGraph: two graph lanes), so that it runs beside what follows
+    #   device_part(i)  flip merge, loss, accuracy decode, final-prediction decode + their copies into pinned memory
+    #   host_part(i)    waits for those few KB, fills the tables, logs
+    # in the order device_part(i - 1), enqueue(i), host_part(i - 1) (enqueue(i) first where the forward has a lane of its own):
+    # the host arithmetic of a batch runs while the GPU is busy with the next batch's forward.
+    def enqueue(i, row0, batch):
+        input, target, target_weight, meta = batch
+        if not input.is_cuda:
+            input = (input if conditional else input[:, :3]).cuda(non_blocking=True)
+        n = input.size(0)
+        if not config.TEST.FLIP_TEST:
+            handles = (_submit(model, input),)
+        elif PAIRED_FLIP_FORWARD:
+            handles = (_submit(model, torch.cat((input, _mirrored_input(config, val_dataset, input, meta)), dim=0)),)
+        else:
+            handles = (_submit(model, input), _submit(model, _mirrored_input(config, val_dataset, input, meta)))
+        return dict(i=i, rows=slice(row0, row0 + n), count=n, input=input, target=target, target_weight=target_weight,
+                    meta=meta, handles=handles)
+
+    def device_part(it):
+        outs = [h.result() for h in it.pop('handles')]
+        outs = [o[-1] if isinstance(o, list) else o for o in outs]
+        output = outs[0]
+        if config.TEST.FLIP_TEST:
+            n = it['count']
+            output, flipped = (output[:n], output[n:]) if len(outs) == 1 else (outs[0], outs[1])
+            output = flip_merge_device(output.contiguous(), flipped.contiguous(), val_dataset.flip_pairs,
+                                       bool(config.TEST.SHIFT_HEATMAP))
+        it['target'] = it['target'].cuda(non_blocking=True)
+        target_weight = it.pop('target_weight').cuda(non_blocking=True)
+        loss = criterion(output, it['target'], target_weight)
+        it['stats'] = _DeferredStats(loss, output, it['target'], it['count'])
+        it['decode'] = DeferredFinalPreds(config, output)
+        it['output'] = output
+
+    def host_part(it, tick):
+        i, rows, meta = it['i'], it['rows'], it['meta']
+        center = meta['center'].numpy()
+        scale = meta['scale'].numpy()
+        preds, maxvals = it['decode'].final_preds(center, scale)
+        pred = it['stats'].resolve(losses, acc)
+        now = time.time()
+        batch_time.update(now - tick)
+        all_preds[rows, :, 0:2] = preds[:, :, 0:2]
+        all_preds[rows, :, 2:3] = maxvals
+        all_boxes[rows, 0:2] = center[:, 0:2]
+        all_boxes[rows, 2:4] = scale[:, 0:2]
+        all_boxes[rows, 4] = np.prod(scale * 200, 1)
+        all_boxes[rows, 5] = meta['score'].numpy()
+        all_boxes[rows, 6] = meta['annotation_id'].numpy()
+        filled[rows] = True
+        if world > 1:
+            image_path[rows] = list(meta['image'])
+        else:
+            image_path.extend(meta['image'])
+        if i % config.PRINT_FREQ == 0 or i == last:
+            logger.info(f'Test: [{i}/{last}]\t'
+                        f'Time {batch_time.val:.3f} ({batch_time.avg:.3f})\t'
+                        f'Loss {losses.val:.6f} ({losses.avg:.6f})\t'
+                        f'Accuracy {acc.val:.3f} ({acc.avg:.3f})')
+            if config.DEBUG.DEBUG:
+                tag = '{}_epoch_{:09d}_iter_{}_{}'.format(os.path.join(output_dir, 'val'), epoch, i, print_prefix)
+                _save_debug_images(config, it['input'], meta, it['target'], pred * 4, it['output'], tag, output_dir=output_dir)
+        return now
+
     with torch.no_grad():
         tick = time.time()
-        for i, row0, (input, target, target_weight, meta) in _prefetched(_rank_batches(val_loader, rank, world), conditional):
-            count = input.size(0)
-            rows = slice(row0, row0 + count)
-            if not input.is_cuda:
-                input = (input if conditional else input[:, :3]).cuda(non_blocking=True)
-            if config.TEST.FLIP_TEST:
-                output, flipped = _forward_with_flip(config, model, val_dataset, input, meta)
-                output = flip_merge_device(output.contiguous(), flipped.contiguous(), val_dataset.flip_pairs,
-                                           bool(config.TEST.SHIFT_HEATMAP))
+        pending = None
+        lanes = callable(getattr(model, 'submit', None))
+        for i, row0, batch in _prefetched(_rank_batches(val_loader, rank, world), conditional):
+            if lanes:
+                # the forward runs on a lane stream of its own: enqueue it first, so that it overlaps the previous batch's
+                # forward on the other lane (a lane only waits for what the current stream holds at submit time)
+                cur = enqueue(i, row0, batch)
+                if pending is not None:
+                    device_part(pending)
             else:
-                out = model(input)
-                output = out[-1] if isinstance(out, list) else out
-            target = target.cuda(non_blocking=True)
-            target_weight = target_weight.cuda(non_blocking=True)
-            loss = criterion(output, target, target_weight)
-            stats = _DeferredStats(loss, output, target, count)
-
-            center = meta['center'].numpy()
-            scale = meta['scale'].numpy()
-            preds, maxvals = get_final_preds(config, output, center, scale)
-            pred = stats.resolve(losses, acc)
-
-            now = time.time()
-            batch_time.update(now - tick)
-            tick = now
-
-            all_preds[rows, :, 0:2] = preds[:, :, 0:2]
-            all_preds[rows, :, 2:3] = maxvals
-            all_boxes[rows, 0:2] = center[:, 0:2]
-            all_boxes[rows, 2:4] = scale[:, 0:2]
-            all_boxes[rows, 4] = np.prod(scale * 200, 1)
-            all_boxes[rows, 5] = meta['score'].numpy()
-            all_boxes[rows, 6] = meta['annotation_id'].numpy()
-            filled[rows] = True
-            if world > 1:
-                image_path[rows] = list(meta['image'])
-            else:
-                image_path.extend(meta['image'])
-
-            if i % config.PRINT_FREQ == 0 or i == last:
-                logger.info(f'Test: [{i}/{last}]\t'
-                            f'Time {batch_time.val:.3f} ({batch_time.avg:.3f})\t'
-                            f'Loss {losses.val:.6f} ({losses.avg:.6f})\t'
-                            f'Accuracy {acc.val:.3f} ({acc.avg:.3f})')
-                if config.DEBUG.DEBUG:
-                    tag = '{}_epoch_{:09d}_iter_{}_{}'.format(os.path.join(output_dir, 'val'), epoch, i, print_prefix)
-                    _save_debug_images(config, input, meta, target, pred * 4, output, tag, output_dir=output_dir)
+                # one stream: the previous batch's decode must sit in front of this forward, or the host would wait for it
+                if pending is not None:
+                    device_part(pending)
+                cur = enqueue(i, row0, batch)
+            if pending is not None:
+                tick = host_part(pending, tick)
+            pending = cur
+        if pending is not None:
+            device_part(pending)
+            tick = host_part(pending, tick)
 
         if world > 1:
             all_preds, all_boxes, image_path = gather_validation_shards(all_preds, all_boxes, image_path, filled)

@@ -46,16 +46,39 @@ def _quarter_offsets_host(heatmaps, coords):
     return np.stack([np.sign(dx), np.sign(dy)], axis=2) * 0.25 * inside[..., None]
 
 
+class DeferredFinalPreds:
+    """get_final_preds in two halves for a device tensor: the decode kernel and the copies of its K * 5 floats per person
+    into pinned host memory are enqueued here; final_preds(center, scale) waits for them and does the host arithmetic
+    (reference inference.py:51-87).  validate() enqueues the next batch's forward between the two halves."""
+
+    def __init__(self, config, batch_heatmaps):
+        self.hh, self.hw = batch_heatmaps.shape[2], batch_heatmaps.shape[3]
+        self.refine = bool(config.TEST.POST_PROCESS)
+        res = ops.argmax_decode(batch_heatmaps.contiguous(), refine=self.refine)
+        self.host = []
+        for t in (res[0], res[1]) + ((res[3],) if self.refine else ()):
+            h = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
+            h.copy_(t, non_blocking=True)
+            self.host.append(h)
+        self.event = torch.cuda.Event()
+        self.event.record()
+
+    def final_preds(self, center, scale):
+        self.event.synchronize()
+        coords, maxvals = self.host[0].numpy(), self.host[1].numpy()
+        if self.refine:
+            coords = coords + self.host[2].numpy()
+        preds = np.stack([transform_preds(coords[b], center[b], scale[b], [self.hw, self.hh]) for b in range(coords.shape[0])])
+        return preds.astype(coords.dtype), maxvals.copy()
+
+
 def get_final_preds(config, batch_heatmaps, center, scale, use_dark=False):
     if use_dark:
         raise NotImplementedError("the DARK decoder is dead code in the reference (use_dark=False default)")
     hh, hw = batch_heatmaps.shape[2], batch_heatmaps.shape[3]
     refine = bool(config.TEST.POST_PROCESS)
     if isinstance(batch_heatmaps, torch.Tensor):
-        res = ops.argmax_decode(batch_heatmaps.contiguous(), refine=refine)
-        coords, maxvals = res[0].cpu().numpy(), res[1].cpu().numpy()
-        if refine:
-            coords = coords + res[3].cpu().numpy()
+        return DeferredFinalPreds(config, batch_heatmaps).final_preds(center, scale)
     else:
         coords, maxvals = get_max_preds(batch_heatmaps)
         if refine:
